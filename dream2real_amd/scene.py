@@ -1,0 +1,231 @@
+"""Scene description for the render-and-score path: hash-grid metadata, NeRF parameter
+containers and the synthetic scenes used by the tests and by bench.py.
+
+The reference consumes trained instant-ngp snapshots (`fg_base.ingp`, `bg_base.ingp`,
+reference reconstruction/ngp_visual_model.py:20-29).  None is available offline, so the
+benchmarks and parity tests run on seeded synthetic models with the same structure
+(SURVEY.md §8(d)): a 16-level, 2-feature, 2^19-entry hash grid with fp16 tables, a
+32->64->16 density MLP, a 32->64->64->16 colour MLP, and a 128^3 occupancy bitfield.
+
+Nothing here is arithmetic of the hot path: it only builds *inputs* (tables, weights,
+bitfields, cameras) that are handed unchanged to both the HIP library and the oracle.
+"""
+from __future__ import annotations
+
+import dataclasses
+import math
+from typing import Optional
+
+import numpy as np
+
+GRID = 128          # occupancy grid side (instant-ngp NERF_GRIDSIZE)
+DT = np.float32(math.sqrt(3.0) / 1024.0)   # constant march step at aabb_scale 1
+
+
+@dataclasses.dataclass
+class GridLevels:
+    """Per-level constants of a tiny-cuda-nn style multiresolution hash grid."""
+    n_levels: int
+    n_features: int
+    log2_hashmap_size: int
+    base_resolution: int
+    per_level_scale: float
+    scale: np.ndarray      # [L] float32
+    res: np.ndarray        # [L] uint32
+    size: np.ndarray       # [L] uint32, entries per level
+    offset: np.ndarray     # [L] uint32, first entry of each level
+    n_entries: int
+
+    @property
+    def hashed(self) -> np.ndarray:
+        """True where the level needs the spatial hash (res^3 exceeds the level size)."""
+        return (self.res.astype(np.uint64) ** 3) > self.size.astype(np.uint64)
+
+
+def grid_levels(n_levels: int = 16, n_features: int = 2, log2_hashmap_size: int = 19,
+                base_resolution: int = 16, per_level_scale: Optional[float] = None,
+                aabb_scale: int = 1) -> GridLevels:
+    """Level table exactly as tiny-cuda-nn's GridEncoding constructor derives it
+    (float32 exp2f/ceilf; sizes rounded up to 8 and capped at 2^log2_hashmap_size)."""
+    if per_level_scale is None:
+        # instant-ngp: desired resolution 2048*aabb_scale at the finest level
+        per_level_scale = math.exp(math.log(2048.0 * aabb_scale / base_resolution) / (n_levels - 1))
+    log2_pls = np.float32(np.log2(np.float32(per_level_scale)))
+    scale = np.zeros(n_levels, np.float32)
+    res = np.zeros(n_levels, np.uint32)
+    size = np.zeros(n_levels, np.uint32)
+    offset = np.zeros(n_levels, np.uint32)
+    off = 0
+    for l in range(n_levels):
+        s = np.float32(np.exp2(np.float32(l) * log2_pls)) * np.float32(base_resolution) - np.float32(1.0)
+        r = int(math.ceil(float(s))) + 1
+        max_params = (2 ** 32 - 1) // 2
+        p = max_params if float(r) ** 3 > float(max_params) else r ** 3
+        p = (p + 7) // 8 * 8
+        p = min(p, 1 << log2_hashmap_size)
+        scale[l], res[l], size[l], offset[l] = s, r, p, off
+        off += p
+    return GridLevels(n_levels, n_features, log2_hashmap_size, base_resolution,
+                      float(per_level_scale), scale, res, size, offset, off)
+
+
+@dataclasses.dataclass
+class NerfModel:
+    """Host-side parameters of one NeRF (the state a pyngp.Testbed holds after
+    load_snapshot, reference reconstruction/ngp_visual_model.py:24-28)."""
+    levels: GridLevels
+    grid: np.ndarray       # [n_entries, F] float16
+    dw1: np.ndarray        # [64, 32] float16   density layer 1
+    dw2: np.ndarray        # [16, 64] float16   density layer 2
+    cw1: np.ndarray        # [64, 32] float16   colour layer 1 (in = [density out | SH])
+    cw2: np.ndarray        # [64, 64] float16
+    cw3: np.ndarray        # [16, 64] float16   rows 0..2 = rgb
+    occ_bits: np.ndarray   # [128^3/8] uint8, bit (x + 128*(y + 128*z)), LSB first
+
+    def occupancy_bool(self) -> np.ndarray:
+        """[z, y, x] boolean view of the bitfield."""
+        return np.unpackbits(self.occ_bits, bitorder="little").astype(bool).reshape(GRID, GRID, GRID)
+
+
+@dataclasses.dataclass
+class View:
+    """Camera/intrinsics state the path sets on a Testbed before render()
+    (reference reconstruction/combined_rendering.py:98-105,116,123-130)."""
+    width: int
+    height: int
+    focal: tuple            # pixels at (width, height): rel_focal * height
+    center: tuple           # principal point, relative (cx/w, cy/h)
+    scale: float = 1.0      # dataset scale  (configs/shopping_demo.json:63)
+    offset: tuple = (0.0, 0.3, 0.5)   # dataset offset (configs/shopping_demo.json:64)
+    background: tuple = (0.0, 0.0, 0.0, 1.0)
+    min_transmittance: float = 0.01
+    near_distance: float = 0.0
+
+    @staticmethod
+    def from_training_view(width: int, height: int, fx: float = 924.66912, fy: float = 926.49735,
+                           cx: float = 654.51953, cy: float = 355.18523, w0: int = 1280,
+                           h0: int = 720, **kw) -> "View":
+        """set_camera_to_training_view + render(w,h): relative focal length is taken over
+        the image *height* (fov axis 1) and re-applied at the render height.
+        Defaults are the RealSense intrinsics of configs/shopping_demo.json:49-60."""
+        rel = (fx / h0, fy / h0)
+        return View(width, height, (rel[0] * height, rel[1] * height), (cx / w0, cy / h0), **kw)
+
+
+def pack_bits(occ_zyx: np.ndarray) -> np.ndarray:
+    return np.packbits(occ_zyx.reshape(-1).astype(np.uint8), bitorder="little")
+
+
+def world_to_ngp(p, scale: float = 1.0, offset=(0.0, 0.3, 0.5)) -> np.ndarray:
+    """World point -> instant-ngp unit-cube coordinates: p*scale+offset, then (x,y,z)<-(y,z,x)."""
+    q = np.asarray(p, np.float64) * scale + np.asarray(offset, np.float64)
+    return np.stack([q[..., 1], q[..., 2], q[..., 0]], axis=-1)
+
+
+def _xavier(rng: np.random.Generator, n_out: int, n_in: int) -> np.ndarray:
+    lim = math.sqrt(6.0 / (n_in + n_out))
+    return rng.uniform(-lim, lim, size=(n_out, n_in)).astype(np.float32)
+
+
+def make_synthetic_nerf(occ_zyx: np.ndarray, *, seed_grid: int, seed_mlp: int,
+                        levels: Optional[GridLevels] = None, log_sigma: float = 5.0) -> NerfModel:
+    """Seeded random NeRF with a controllable opacity.
+
+    Tables are U(-0.5, 0.5) (PCG64); feature 0 of level 0 is pinned to 0.5 so that a
+    dedicated hidden unit carries a constant through the density MLP and
+    sigma = exp(out0) ~ exp(log_sigma): occupied space is opaque within ~8-20 samples,
+    as a trained object would be, while colour and fine structure stay random."""
+    levels = levels or grid_levels()
+    F = levels.n_features
+    rg = np.random.Generator(np.random.PCG64(seed_grid))
+    grid = rg.uniform(-0.5, 0.5, size=(levels.n_entries, F)).astype(np.float32)
+    grid[levels.offset[0]:levels.offset[0] + levels.size[0], 0] = 0.5
+    rm = np.random.Generator(np.random.PCG64(seed_mlp))
+    n_in = levels.n_levels * F
+    dw1 = _xavier(rm, 64, n_in)
+    dw2 = _xavier(rm, 16, 64)
+    cw1 = _xavier(rm, 64, 32)
+    cw2 = _xavier(rm, 64, 64)
+    cw3 = _xavier(rm, 16, 64)
+    dw1[0, :] = 0.0
+    dw1[0, 0] = 2.0            # hidden0 = relu(2 * 0.5) = 1
+    dw2[0, 0] = log_sigma      # out0 = log_sigma + noise
+    f16 = lambda a: a.astype(np.float16)
+    return NerfModel(levels, f16(grid), f16(dw1), f16(dw2), f16(cw1), f16(cw2), f16(cw3),
+                     pack_bits(occ_zyx))
+
+
+def _cell_centres():
+    c = (np.arange(GRID, dtype=np.float64) + 0.5) / GRID
+    z, y, x = np.meshgrid(c, c, c, indexing="ij")
+    return x, y, z
+
+
+def ellipsoid_occupancy(centre_ngp, radii_ngp) -> np.ndarray:
+    x, y, z = _cell_centres()
+    cx, cy, cz = centre_ngp
+    rx, ry, rz = radii_ngp
+    return ((x - cx) / rx) ** 2 + ((y - cy) / ry) ** 2 + ((z - cz) / rz) ** 2 <= 1.0
+
+
+def look_at_opencv(eye, target, up=(0.0, 0.0, 1.0)) -> np.ndarray:
+    """Camera-to-world 4x4 in the OpenCV convention (x right, y down, z forward) — the
+    convention of the reference's opt_cam_poses before utils/accio2ngp.py:133 flips it."""
+    eye = np.asarray(eye, np.float64)
+    fwd = np.asarray(target, np.float64) - eye
+    fwd /= np.linalg.norm(fwd)
+    right = np.cross(fwd, np.asarray(up, np.float64))
+    right /= np.linalg.norm(right)
+    down = np.cross(fwd, right)
+    T = np.eye(4)
+    T[:3, 0], T[:3, 1], T[:3, 2], T[:3, 3] = right, down, fwd, eye
+    return T
+
+
+@dataclasses.dataclass
+class SyntheticScene:
+    """Everything optimise_pose_grid needs from a TaskModel, for a seeded synthetic task."""
+    name: str
+    scene_type: int
+    scene_centre: np.ndarray      # world
+    fg: NerfModel
+    bg: NerfModel
+    obj_pose: np.ndarray          # T_WO_1, 4x4 world pose of the movable object now
+    cam_poses: np.ndarray         # [V,4,4] opt_cam_poses (OpenCV convention)
+    fg_background: tuple          # Testbed.background_color of the fg model
+
+    def view(self, width: int, height: int) -> View:
+        return View.from_training_view(width, height)
+
+
+def make_scene(kind: str = "shopping") -> SyntheticScene:
+    """Seeded scenes of SURVEY.md §8(d).  kind: 'shopping' (apple-sized ellipsoid, scene
+    type 3) or 'pool_triangle' (2.8 cm sphere, scene type 0)."""
+    levels = grid_levels()
+    scene_centre = np.array([0.5, 0.0, 0.035])          # configs/shopping_demo.json:29
+    if kind == "shopping":
+        scene_type, radii_w = 3, (0.04, 0.04, 0.05)
+        obj_t = scene_centre + np.array([-0.02, -0.05, 0.05])
+    elif kind == "pool_triangle":
+        scene_type, radii_w = 0, (0.028, 0.028, 0.028)
+        obj_t = scene_centre + np.array([-0.03, -0.02, 0.028])
+    else:
+        raise ValueError(kind)
+    obj_pose = np.eye(4)
+    obj_pose[:3, 3] = obj_t
+    # world radii (x,y,z) -> ngp axes (y,z,x)
+    radii_ngp = (radii_w[1], radii_w[2], radii_w[0])
+    fg_occ = ellipsoid_occupancy(world_to_ngp(obj_t), radii_ngp)
+    fg = make_synthetic_nerf(fg_occ, seed_grid=1, seed_mlp=3, levels=levels)
+    # background: table slab (6 cm under world z=0, i.e. ngp y in [0.44,0.5]) + three blobs
+    x, y, z = _cell_centres()
+    bg_occ = (y >= 0.44) & (y < 0.5)
+    for dx, dy, r in ((0.12, -0.10, 0.05), (-0.15, 0.08, 0.04), (0.05, 0.15, 0.045)):
+        c = world_to_ngp(scene_centre + np.array([dx, dy, r - 0.035]))
+        bg_occ |= ellipsoid_occupancy(c, (r, r, r))
+    bg = make_synthetic_nerf(bg_occ, seed_grid=2, seed_mlp=4, levels=levels)
+    eye = scene_centre + 0.6 * np.array([-0.35, -0.45, 0.82]) / np.linalg.norm([-0.35, -0.45, 0.82])
+    cams = np.stack([look_at_opencv(eye, scene_centre),
+                     look_at_opencv(eye + np.array([0.1, 0.0, 0.02]), scene_centre)])
+    return SyntheticScene(kind, scene_type, scene_centre, fg, bg, obj_pose, cams,
+                          fg_background=(0.0, 0.0, 0.0, 1.0))

@@ -1,0 +1,604 @@
+/*
+ * d2r_oracle.c — CPU restatement of Dream2Real's render-and-composite hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library, and only as the checker / the timed CPU baseline.
+ * The product path (dream2real_amd/ + libd2r.so) never links or calls it.
+ *
+ * What is restated, and from where (paths relative to /root/reference):
+ *   - fg/bg depth-test composite, un-premultiply, sRGB, uint8 quantise,
+ *     alpha threshold ............ reconstruction/combined_rendering.py:133-155
+ *   - linear_to_srgb ............. EXTERNAL instant-ngp scripts/common.py,
+ *                                  called at combined_rendering.py:150
+ *   - Testbed.render(w,h,1,True) in Shade and Depth mode
+ *                                  call sites combined_rendering.py:105,113,127,130
+ *     The arithmetic lives in NVlabs/instant-ngp (+ tiny-cuda-nn), an
+ *     un-vendored git submodule (.gitmodules:4-6, directory empty, pinned
+ *     commit unknown).  It is restated here from its published algorithm
+ *     (Mueller et al. 2022 and SURVEY.md Appendix A).  PARITY UNPINNED for
+ *     this part: no golden frame of the real renderer exists in the reference
+ *     tree, so this file is the specification the HIP kernels are held to.
+ *   - rot90 + CLIP image preprocessing (PIL antialiased bicubic resize in
+ *     fixed point, centre crop, rescale, normalise)
+ *                                  clip_scoring.py:145,177 (HF CLIPImageProcessor,
+ *                                  PIL backend; pinned against PIL here, see
+ *                                  tests/golden/make_goldens.py)
+ *
+ * Build: see oracle/Makefile (gcc -O2 -fopenmp -ffp-contract=off).
+ * All arithmetic is IEEE float32 unless stated; FMAs are written explicitly.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define D2R_ORACLE_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------ types */
+
+typedef struct {
+    /* multiresolution hash grid (tiny-cuda-nn GridEncoding, "Hash", linear interp) */
+    uint32_t n_levels;        /* L */
+    uint32_t n_features;      /* F per level (2 or 4) */
+    const float *level_scale;    /* [L] scale_l = exp2(l*log2(b))*N_min - 1 */
+    const uint32_t *level_res;   /* [L] ceil(scale_l)+1 */
+    const uint32_t *level_size;  /* [L] entries in level (hashmap_size) */
+    const uint32_t *level_offset;/* [L] first entry of level, in entries */
+    const uint16_t *grid;     /* fp16, [sum(level_size)][F] */
+    /* MLPs, fp16, row-major [out][in], no bias */
+    const uint16_t *dw1;      /* density 64 x 32 */
+    const uint16_t *dw2;      /* density 16 x 64 */
+    const uint16_t *cw1;      /* colour  64 x 32  (in = [density out 16 | SH 16]) */
+    const uint16_t *cw2;      /* colour  64 x 64 */
+    const uint16_t *cw3;      /* colour  16 x 64  (rows 0..2 used) */
+    /* occupancy, 128^3 bits, linear index x + 128*y + 128*128*z, LSB first */
+    const uint8_t *occ_bits;
+} d2r_oracle_nerf;
+
+typedef struct {
+    uint32_t width, height;
+    float focal[2];          /* pixels at this render size */
+    float center[2];         /* principal point, relative (cx/w, cy/h) */
+    float scale;             /* dataset scale   (nerf_matrix_to_ngp) */
+    float offset[3];         /* dataset offset  (nerf_matrix_to_ngp) */
+    float background[4];     /* Testbed.background_color RGBA */
+    float min_transmittance; /* nerf.render_min_transmittance (0.01) */
+    float near_distance;     /* 0 */
+} d2r_oracle_view;
+
+/* ------------------------------------------------------------- fp helpers */
+
+static float half_to_float(uint16_t h)
+{
+    uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t exp = (h >> 10) & 0x1fu;
+    uint32_t man = h & 0x3ffu;
+    uint32_t bits;
+    if (exp == 0) {
+        if (man == 0) {
+            bits = sign;
+        } else {
+            /* subnormal: normalise */
+            int e = -1;
+            do { man <<= 1; e++; } while (!(man & 0x400u));
+            man &= 0x3ffu;
+            bits = sign | ((uint32_t)(127 - 15 - e) << 23) | (man << 13);
+        }
+    } else if (exp == 31) {
+        bits = sign | 0x7f800000u | (man << 13);
+    } else {
+        bits = sign | ((exp + 127 - 15) << 23) | (man << 13);
+    }
+    float f;
+    memcpy(&f, &bits, 4);
+    return f;
+}
+
+static float srgb_to_linear(float x)
+{
+    return x <= 0.04045f ? x / 12.92f : powf((x + 0.055f) / 1.055f, 2.4f);
+}
+
+/* instant-ngp scripts/common.py linear_to_srgb, float32 numpy semantics */
+static float linear_to_srgb(float x)
+{
+    const float limit = 0.0031308f;
+    return x > limit ? 1.055f * powf(x, (float)(1.0 / 2.4)) - 0.055f : 12.92f * x;
+}
+
+/* ------------------------------------------------------ camera conventions */
+
+/* instant-ngp nerf_matrix_to_ngp: negate columns 1,2; t*scale+offset;
+ * cycle axes (x,y,z) <- (y,z,x).  in: 3x4 row-major; out: 3x4 row-major. */
+D2R_ORACLE_API void d2r_oracle_nerf_matrix_to_ngp(const float *m, float scale,
+                                                  const float *offset, float *out)
+{
+    float r[3][4];
+    for (int i = 0; i < 3; i++) {
+        r[i][0] = m[i * 4 + 0];
+        r[i][1] = -m[i * 4 + 1];
+        r[i][2] = -m[i * 4 + 2];
+        r[i][3] = m[i * 4 + 3] * scale + offset[i];
+    }
+    for (int c = 0; c < 4; c++) {
+        out[0 * 4 + c] = r[1][c];
+        out[1 * 4 + c] = r[2][c];
+        out[2 * 4 + c] = r[0][c];
+    }
+}
+
+/* -------------------------------------------------------- hash-grid encode */
+
+static inline uint32_t grid_index(uint32_t hashmap_size, uint32_t res, uint32_t x, uint32_t y,
+                                  uint32_t z)
+{
+    /* tiny-cuda-nn grid_index: dense while the running stride fits, else spatial hash */
+    uint32_t pos[3] = {x, y, z};
+    uint64_t stride = 1;
+    uint64_t index = 0;
+    for (int d = 0; d < 3 && stride <= hashmap_size; d++) {
+        index += (uint64_t)pos[d] * stride;
+        stride *= res;
+    }
+    if (hashmap_size < stride) {
+        index = (uint32_t)(x * 1u) ^ (uint32_t)(y * 2654435761u) ^ (uint32_t)(z * 805459861u);
+    }
+    return (uint32_t)(index % hashmap_size);
+}
+
+/* features out: [L*F] fp32, level-major */
+static void hashgrid_encode(const d2r_oracle_nerf *m, const float x[3], float *out)
+{
+    const uint32_t F = m->n_features;
+    for (uint32_t l = 0; l < m->n_levels; l++) {
+        const float scale = m->level_scale[l];
+        const uint32_t res = m->level_res[l];
+        const uint32_t size = m->level_size[l];
+        const uint16_t *tab = m->grid + (size_t)m->level_offset[l] * F;
+        float w[3];
+        uint32_t g[3];
+        for (int d = 0; d < 3; d++) {
+            float p = fmaf(scale, x[d], 0.5f);
+            float fl = floorf(p);
+            g[d] = (uint32_t)(int32_t)fl;
+            w[d] = p - fl;
+        }
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (uint32_t c = 0; c < 8; c++) {
+            float weight = 1.0f;
+            uint32_t gc[3];
+            for (int d = 0; d < 3; d++) {
+                if ((c & (1u << d)) == 0) {
+                    weight *= 1.0f - w[d];
+                    gc[d] = g[d];
+                } else {
+                    weight *= w[d];
+                    gc[d] = g[d] + 1;
+                }
+            }
+            uint32_t idx = grid_index(size, res, gc[0], gc[1], gc[2]);
+            for (uint32_t f = 0; f < F; f++)
+                acc[f] = fmaf(weight, half_to_float(tab[(size_t)idx * F + f]), acc[f]);
+        }
+        for (uint32_t f = 0; f < F; f++) out[l * F + f] = acc[f];
+    }
+}
+
+/* real spherical harmonics, degree 4 (16 coefficients), tiny-cuda-nn ordering */
+static void sh_encode4(const float d[3], float *o)
+{
+    float x = d[0], y = d[1], z = d[2];
+    float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+    o[0] = 0.28209479177387814f;
+    o[1] = -0.48860251190291987f * y;
+    o[2] = 0.48860251190291987f * z;
+    o[3] = -0.48860251190291987f * x;
+    o[4] = 1.0925484305920792f * xy;
+    o[5] = -1.0925484305920792f * yz;
+    o[6] = 0.94617469575755997f * z2 - 0.31539156525251999f;
+    o[7] = -1.0925484305920792f * xz;
+    o[8] = 0.54627421529603959f * x2 - 0.54627421529603959f * y2;
+    o[9] = 0.59004358992664352f * y * (-3.0f * x2 + y2);
+    o[10] = 2.8906114426405538f * xy * z;
+    o[11] = 0.45704579946446572f * y * (1.0f - 5.0f * z2);
+    o[12] = 0.3731763325901154f * z * (5.0f * z2 - 3.0f);
+    o[13] = 0.45704579946446572f * x * (1.0f - 5.0f * z2);
+    o[14] = 1.4453057213202769f * z * (x2 - y2);
+    o[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
+}
+
+static void matvec_f16(const uint16_t *w, int n_out, int n_in, const float *in, float *out,
+                       int relu)
+{
+    for (int o = 0; o < n_out; o++) {
+        float acc = 0.f;
+        for (int i = 0; i < n_in; i++) acc = fmaf(half_to_float(w[o * n_in + i]), in[i], acc);
+        out[o] = relu ? (acc > 0.f ? acc : 0.f) : acc;
+    }
+}
+
+/* sigma and rgb (network's sRGB-space prediction) at one sample */
+static void nerf_eval(const d2r_oracle_nerf *m, const float x[3], const float dir[3],
+                      float *sigma, float rgb[3])
+{
+    float feat[64];
+    float h[64], dout[16], cin[32], h2[64], cout[16];
+    hashgrid_encode(m, x, feat);
+    const int n_in = (int)(m->n_levels * m->n_features); /* 32 */
+    matvec_f16(m->dw1, 64, n_in, feat, h, 1);
+    matvec_f16(m->dw2, 16, 64, h, dout, 0);
+    *sigma = expf(dout[0]);
+    for (int i = 0; i < 16; i++) cin[i] = dout[i];
+    sh_encode4(dir, cin + 16);
+    matvec_f16(m->cw1, 64, 32, cin, h, 1);
+    matvec_f16(m->cw2, 64, 64, h, h2, 1);
+    matvec_f16(m->cw3, 16, 64, h2, cout, 0);
+    for (int i = 0; i < 3; i++) rgb[i] = 1.0f / (1.0f + expf(-cout[i]));
+}
+
+/* debug/parity hook: evaluate the field at n points */
+D2R_ORACLE_API void d2r_oracle_eval_points(const d2r_oracle_nerf *m, const float *xyz,
+                                           const float *dirs, uint32_t n, float *sigma_rgb)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < (int64_t)n; i++) {
+        float s, c[3];
+        nerf_eval(m, xyz + 3 * i, dirs + 3 * i, &s, c);
+        sigma_rgb[4 * i + 0] = s;
+        sigma_rgb[4 * i + 1] = c[0];
+        sigma_rgb[4 * i + 2] = c[1];
+        sigma_rgb[4 * i + 3] = c[2];
+    }
+}
+
+D2R_ORACLE_API void d2r_oracle_encode_points(const d2r_oracle_nerf *m, const float *xyz,
+                                             uint32_t n, float *feat)
+{
+    const uint32_t nf = m->n_levels * m->n_features;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < (int64_t)n; i++) hashgrid_encode(m, xyz + 3 * i, feat + nf * i);
+}
+
+/* ----------------------------------------------------------- ray marching */
+
+#define D2R_GRID 128
+#define D2R_DT 0.0016914558f /* sqrt(3)/1024, constant step: cone_angle 0 at aabb_scale 1 */
+
+static inline int occ_test(const uint8_t *bits, int cx, int cy, int cz)
+{
+    uint32_t idx = (uint32_t)cx + D2R_GRID * ((uint32_t)cy + D2R_GRID * (uint32_t)cz);
+    return (bits[idx >> 3] >> (idx & 7)) & 1;
+}
+
+static inline int cell_of(float p)
+{
+    int c = (int)(p * (float)D2R_GRID);
+    return c < 0 ? 0 : (c > D2R_GRID - 1 ? D2R_GRID - 1 : c);
+}
+
+/*
+ * One frame: Testbed.render(w, h, spp=1, linear=True) in Shade AND Depth mode at once.
+ *   cam_nerf : 3x4 row-major, the matrix handed to set_nerf_camera_matrix
+ *   rgba     : [h][w][4] Shade frame (premultiplied linear rgb, alpha) after background blend
+ *   depth    : [h][w]    channel 0 of the Depth frame (sum w*z, /A on saturation)
+ *   n_samples: optional, total network evaluations
+ */
+D2R_ORACLE_API void d2r_oracle_render(const d2r_oracle_nerf *m, const d2r_oracle_view *v,
+                                      const float *cam_nerf, float *rgba, float *depth,
+                                      uint64_t *n_samples)
+{
+    float cam[12];
+    d2r_oracle_nerf_matrix_to_ngp(cam_nerf, v->scale, v->offset, cam);
+    const int W = (int)v->width, H = (int)v->height;
+    const float inv_scale = 1.0f / v->scale;
+    uint64_t total = 0;
+
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : total)
+    for (int py = 0; py < H; py++) {
+        for (int px = 0; px < W; px++) {
+            float C[3] = {0.f, 0.f, 0.f}, A = 0.f, Z = 0.f;
+            /* pixel -> ray, pixel centre */
+            float u = ((float)px + 0.5f) / (float)W;
+            float vv = ((float)py + 0.5f) / (float)H;
+            float dc[3] = {(u - v->center[0]) * (float)W / v->focal[0],
+                           (vv - v->center[1]) * (float)H / v->focal[1], 1.0f};
+            float d[3], o[3];
+            for (int i = 0; i < 3; i++) {
+                d[i] = fmaf(cam[i * 4 + 2], dc[2],
+                            fmaf(cam[i * 4 + 1], dc[1], cam[i * 4 + 0] * dc[0]));
+                o[i] = cam[i * 4 + 3];
+            }
+            for (int i = 0; i < 3; i++) o[i] = fmaf(d[i], v->near_distance, o[i]);
+            float inv_len = 1.0f / sqrtf(fmaf(d[2], d[2], fmaf(d[1], d[1], d[0] * d[0])));
+            for (int i = 0; i < 3; i++) d[i] *= inv_len;
+            const float fwd[3] = {cam[2], cam[6], cam[10]};
+            const float org[3] = {cam[3], cam[7], cam[11]};
+
+            /* unit-cube AABB slab test */
+            float tmin = -INFINITY, tmax = INFINITY;
+            for (int i = 0; i < 3; i++) {
+                float inv = 1.0f / d[i];
+                float t0 = (0.0f - o[i]) * inv, t1 = (1.0f - o[i]) * inv;
+                float lo = fminf(t0, t1), hi = fmaxf(t0, t1);
+                tmin = fmaxf(tmin, lo);
+                tmax = fminf(tmax, hi);
+            }
+            if (tmax >= tmin && tmax > 0.f) {
+                const float t0 = fmaxf(tmin, 0.0f) + 1e-6f;
+                /* lattice t_k = t0 + k*dt; k runs until the sample leaves the cube */
+                for (uint32_t k = 0; k < 4096; k++) {
+                    float t = fmaf((float)k, D2R_DT, t0);
+                    float p[3];
+                    for (int i = 0; i < 3; i++) p[i] = fmaf(t, d[i], o[i]);
+                    if (p[0] < 0.f || p[0] > 1.f || p[1] < 0.f || p[1] > 1.f || p[2] < 0.f ||
+                        p[2] > 1.f)
+                        break;
+                    if (!occ_test(m->occ_bits, cell_of(p[0]), cell_of(p[1]), cell_of(p[2])))
+                        continue;
+                    float sigma, rgb[3];
+                    nerf_eval(m, p, d, &sigma, rgb);
+                    total++;
+                    float T = 1.0f - A;
+                    float alpha = 1.0f - expf(-sigma * D2R_DT);
+                    float wgt = alpha * T;
+                    float z = ((p[0] - org[0]) * fwd[0] + (p[1] - org[1]) * fwd[1] +
+                               (p[2] - org[2]) * fwd[2]) * inv_scale;
+                    for (int i = 0; i < 3; i++) C[i] = fmaf(wgt, rgb[i], C[i]);
+                    Z = fmaf(wgt, z, Z);
+                    A += wgt;
+                    if (A > 1.0f - v->min_transmittance) {
+                        float ia = 1.0f / A;
+                        for (int i = 0; i < 3; i++) C[i] *= ia;
+                        Z *= ia;
+                        A = 1.0f;
+                        break;
+                    }
+                }
+            }
+            /* shade: accumulated sRGB-space colour -> linear (premultiplied); tonemap: blend
+             * background_color, linear=True so no output curve */
+            float *out = rgba + ((size_t)py * W + px) * 4;
+            for (int i = 0; i < 3; i++) {
+                float lin = srgb_to_linear(C[i]);
+                out[i] = fmaf((1.0f - A) * v->background[3], v->background[i], lin);
+            }
+            out[3] = fmaf(1.0f - A, v->background[3], A);
+            depth[(size_t)py * W + px] = Z;
+        }
+    }
+    if (n_samples) *n_samples = total;
+}
+
+/* ------------------------------------- combined_rendering.py:133-155 composite */
+
+static inline uint8_t quant_u8(float x)
+{
+    float c = x < 0.f ? 0.f : (x > 1.f ? 1.f : x);
+    return (uint8_t)(c * 255.0f + 0.5f);
+}
+
+/* fg_depth / bg_depth are channel 0 of the depth frames; out: [h][w][3] uint8 */
+D2R_ORACLE_API void d2r_oracle_composite(const float *fg_rgba, const float *fg_depth,
+                                         const float *bg_rgba, const float *bg_depth,
+                                         uint32_t w, uint32_t h, uint8_t *out)
+{
+    const size_t n = (size_t)w * h;
+    for (size_t i = 0; i < n; i++) {
+        float fd = fg_depth[i], bd = bg_depth[i];
+        if (fd < 0.05f) fd = 100.f; /* :134 */
+        if (bd < 0.05f) bd = 100.f; /* :135 */
+        const float *src = (fd < bd) ? fg_rgba + 4 * i : bg_rgba + 4 * i; /* :136,:144 */
+        float a = src[3];
+        uint8_t q[4];
+        for (int c = 0; c < 3; c++) {
+            float x = (a != 0.f) ? src[c] / a : 0.f; /* :148 */
+            q[c] = quant_u8(linear_to_srgb(x));      /* :150-151 */
+        }
+        q[3] = quant_u8(a);
+        if (q[3] < 130) q[0] = q[1] = q[2] = 0; /* :153 */
+        out[3 * i + 0] = q[0];
+        out[3 * i + 1] = q[1];
+        out[3 * i + 2] = q[2];
+    }
+}
+
+/* --------------------------------- clip_scoring.py:145 rot90 + CLIP preprocess */
+
+/* Pillow ImagingResample (Resample.c) bicubic, antialiased, 8 bits per channel */
+#define PRECISION_BITS (32 - 8 - 2)
+
+static double bicubic_filter(double x)
+{
+    const double a = -0.5;
+    if (x < 0.0) x = -x;
+    if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
+    if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
+    return 0.0;
+}
+
+static int precompute_coeffs(int in_size, int out_size, int **bounds_out, int32_t **kk_out)
+{
+    double support = 2.0, scale, filterscale;
+    filterscale = scale = (double)in_size / out_size;
+    if (filterscale < 1.0) filterscale = 1.0;
+    support = support * filterscale;
+    int ksize = (int)ceil(support) * 2 + 1;
+    double *prekk = (double *)malloc(sizeof(double) * out_size * ksize);
+    int *bounds = (int *)malloc(sizeof(int) * out_size * 2);
+    int32_t *kk = (int32_t *)malloc(sizeof(int32_t) * out_size * ksize);
+    for (int xx = 0; xx < out_size; xx++) {
+        double center = (xx + 0.5) * scale;
+        double ww = 0.0;
+        double ss = 1.0 / filterscale;
+        int xmin = (int)(center - support + 0.5);
+        if (xmin < 0) xmin = 0;
+        int xmax = (int)(center + support + 0.5);
+        if (xmax > in_size) xmax = in_size;
+        xmax -= xmin;
+        double *k = &prekk[xx * ksize];
+        int x;
+        for (x = 0; x < xmax; x++) {
+            double w = bicubic_filter((x + xmin - center + 0.5) * ss);
+            k[x] = w;
+            ww += w;
+        }
+        for (x = 0; x < xmax; x++)
+            if (ww != 0.0) k[x] /= ww;
+        for (; x < ksize; x++) k[x] = 0;
+        bounds[xx * 2 + 0] = xmin;
+        bounds[xx * 2 + 1] = xmax;
+    }
+    for (int i = 0; i < out_size * ksize; i++) {
+        if (prekk[i] < 0)
+            kk[i] = (int32_t)(-0.5 + prekk[i] * (1 << PRECISION_BITS));
+        else
+            kk[i] = (int32_t)(0.5 + prekk[i] * (1 << PRECISION_BITS));
+    }
+    free(prekk);
+    *bounds_out = bounds;
+    *kk_out = kk;
+    return ksize;
+}
+
+static inline uint8_t clip8(int32_t in)
+{
+    int32_t v = in >> PRECISION_BITS;
+    return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+
+/* export the fixed-point tables so the product's host side can be checked against them */
+D2R_ORACLE_API int d2r_oracle_resample_coeffs(int in_size, int out_size, int *bounds,
+                                              int32_t *kk, int kk_capacity)
+{
+    int *b;
+    int32_t *k;
+    int ksize = precompute_coeffs(in_size, out_size, &b, &k);
+    if (out_size * ksize <= kk_capacity) {
+        memcpy(bounds, b, sizeof(int) * 2 * out_size);
+        memcpy(kk, k, sizeof(int32_t) * out_size * ksize);
+    }
+    free(b);
+    free(k);
+    return ksize;
+}
+
+/* src [sh][sw][3] u8 -> dst [dh][dw][3] u8, Image.resize((dw,dh), BICUBIC) */
+static void pil_resize_rgb(const uint8_t *src, int sw, int sh, uint8_t *dst, int dw, int dh)
+{
+    int *bh, *bv;
+    int32_t *kh, *kv;
+    int ksh = precompute_coeffs(sw, dw, &bh, &kh);
+    int ksv = precompute_coeffs(sh, dh, &bv, &kv);
+    int need_h = dw != sw, need_v = dh != sh;
+    int ybox_first = bv[0];
+    int ybox_last = bv[dh * 2 - 2] + bv[dh * 2 - 1];
+    const uint8_t *cur = src;
+    int cur_w = sw, cur_h = sh;
+    uint8_t *tmp = NULL;
+    if (need_h) {
+        int th = ybox_last - ybox_first;
+        tmp = (uint8_t *)malloc((size_t)th * dw * 3);
+        for (int yy = 0; yy < th; yy++) {
+            const uint8_t *row = src + (size_t)(yy + ybox_first) * sw * 3;
+            for (int xx = 0; xx < dw; xx++) {
+                int xmin = bh[xx * 2], xmax = bh[xx * 2 + 1];
+                const int32_t *k = &kh[xx * ksh];
+                for (int c = 0; c < 3; c++) {
+                    int32_t ss = 1 << (PRECISION_BITS - 1);
+                    for (int x = 0; x < xmax; x++) ss += row[(x + xmin) * 3 + c] * k[x];
+                    tmp[((size_t)yy * dw + xx) * 3 + c] = clip8(ss);
+                }
+            }
+        }
+        for (int i = 0; i < dh; i++) bv[i * 2] -= ybox_first;
+        cur = tmp;
+        cur_w = dw;
+        cur_h = th;
+    }
+    (void)cur_h;
+    if (need_v) {
+        for (int yy = 0; yy < dh; yy++) {
+            int ymin = bv[yy * 2], ymax = bv[yy * 2 + 1];
+            const int32_t *k = &kv[yy * ksv];
+            for (int xx = 0; xx < cur_w; xx++)
+                for (int c = 0; c < 3; c++) {
+                    int32_t ss = 1 << (PRECISION_BITS - 1);
+                    for (int y = 0; y < ymax; y++)
+                        ss += cur[((size_t)(y + ymin) * cur_w + xx) * 3 + c] * k[y];
+                    dst[((size_t)yy * cur_w + xx) * 3 + c] = clip8(ss);
+                }
+        }
+    } else {
+        memcpy(dst, cur, (size_t)dh * dw * 3);
+    }
+    free(tmp);
+    free(bh);
+    free(bv);
+    free(kh);
+    free(kv);
+}
+
+/*
+ * frame [h][w][3] u8  --rot90 CCW (clip_scoring.py:145)-->  [w][h][3]
+ *   --resize shortest edge -> S (bicubic), centre crop SxS, /255, (x-mean)/std-->
+ * pixel_values [3][S][S] fp32 (HF CLIPImageProcessor, clip_scoring.py:177)
+ * optional u8_out [S][S][3] receives the cropped uint8 image.
+ */
+D2R_ORACLE_API void d2r_oracle_clip_preprocess(const uint8_t *frame, uint32_t w, uint32_t h,
+                                               uint32_t S, int do_rot90, float *pixel_values,
+                                               uint8_t *u8_out)
+{
+    int iw, ih;
+    uint8_t *img;
+    if (do_rot90) {
+        iw = (int)h;
+        ih = (int)w;
+        img = (uint8_t *)malloc((size_t)iw * ih * 3);
+        for (int i = 0; i < ih; i++)
+            for (int j = 0; j < iw; j++)
+                memcpy(img + ((size_t)i * iw + j) * 3,
+                       frame + ((size_t)j * w + (w - 1 - (uint32_t)i)) * 3, 3);
+    } else {
+        iw = (int)w;
+        ih = (int)h;
+        img = (uint8_t *)malloc((size_t)iw * ih * 3);
+        memcpy(img, frame, (size_t)iw * ih * 3);
+    }
+    /* HF get_resize_output_image_size, shortest_edge=S, default_to_square=False */
+    int short_e = iw < ih ? iw : ih, long_e = iw < ih ? ih : iw;
+    int new_short = (int)S, new_long = (int)((double)S * long_e / short_e);
+    int rw = iw <= ih ? new_short : new_long;
+    int rh = iw <= ih ? new_long : new_short;
+    uint8_t *res = (uint8_t *)malloc((size_t)rw * rh * 3);
+    if (rw == iw && rh == ih)
+        memcpy(res, img, (size_t)rw * rh * 3);
+    else
+        pil_resize_rgb(img, iw, ih, res, rw, rh);
+    int top = (rh - (int)S) / 2, left = (rw - (int)S) / 2;
+    static const float mean[3] = {0.48145466f, 0.4578275f, 0.40821073f};
+    static const float stdv[3] = {0.26862954f, 0.26130258f, 0.27577711f};
+    for (uint32_t y = 0; y < S; y++)
+        for (uint32_t x = 0; x < S; x++)
+            for (int c = 0; c < 3; c++) {
+                uint8_t p = res[((size_t)(y + top) * rw + (x + left)) * 3 + c];
+                if (u8_out) u8_out[((size_t)y * S + x) * 3 + c] = p;
+                float f = (float)((double)p * (1.0 / 255.0)); /* HF rescale: f64 mul -> f32 */
+                pixel_values[((size_t)c * S + y) * S + x] = (f - mean[c]) / stdv[c];
+            }
+    free(res);
+    free(img);
+}
+
+D2R_ORACLE_API int d2r_oracle_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

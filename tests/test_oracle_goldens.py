@@ -1,0 +1,90 @@
+"""The oracle (oracle/) pinned against the committed golden vectors that were produced by
+the real reference code / Hugging Face / Pillow (tests/golden/make_goldens.py)."""
+import numpy as np
+
+from oracle import clip_ref, host_ref, render_ref
+from tests.golden.frames import seeded_render_frames
+from dream2real_amd.clip_model import CLIP_CONFIGS, random_clip_state_dict
+
+
+def test_g1_converter(goldens):
+    np.testing.assert_array_equal(host_ref.converter(goldens["g1_in"]), goldens["g1_out"])
+
+
+def test_g2_convert_virtual_pose(goldens):
+    for (a, b, c), want in zip(goldens["g2_in"], goldens["g2_out"]):
+        np.testing.assert_allclose(host_ref.convert_virtual_pose(a, b, c), want, rtol=0, atol=1e-12)
+
+
+def test_g3_renderer_render_composite(goldens):
+    """reference renderer.render (combined_rendering.py:73-163) with fake Testbeds ==
+    oracle camera chain + oracle composite, bit-exact uint8 frames."""
+    H, W = goldens["g3_hw"]
+    T_WO_1 = host_ref.converter(goldens["g3_obj_pose"][None].astype(np.float32))   # [1,4,4] f32, :82
+    valid = host_ref.converter(goldens["g3_valid"])
+    rp = host_ref.converter(goldens["g3_render_poses"])
+    bg_rgba, bg_depth = seeded_render_frames(2 * 100 + int(abs(goldens["g3_bg_cam"][0, 3]) * 1000) % 7, H, W)
+    for i in range(valid.shape[0]):
+        cam = host_ref.convert_virtual_pose(T_WO_1, valid[i], rp[0])[0, :3]
+        np.testing.assert_array_equal(cam, goldens["g3_fg_cams"][i])
+        fg_rgba, fg_depth = seeded_render_frames(1 * 100 + int(abs(cam[0, 3]) * 1000) % 7, H, W)
+        got = render_ref.composite(fg_rgba, fg_depth, bg_rgba, bg_depth)
+        want = goldens["g3_frames"][i]
+        assert got.shape == want.shape
+        np.testing.assert_array_equal(got, want)
+
+
+def test_g4_clip_image_processor(goldens):
+    """HF CLIPImageProcessor (PIL bicubic, centre crop, rescale, normalise) == oracle."""
+    n = 0
+    for key in goldens.files:
+        if not key.startswith("g4_") or not key.endswith("_u8"):
+            continue
+        _, tag, hw, _ = key.split("_")
+        S = int(tag)
+        hh, ww = map(int, hw.split("x"))
+        r = np.random.Generator(np.random.PCG64(1000 + hh + ww))
+        img = r.integers(0, 256, size=(hh, ww, 3), dtype=np.uint8)
+        yy, xx = np.mgrid[0:hh, 0:ww]
+        img[: hh // 2] = np.stack([(yy * 255 // hh), (xx * 255 // ww), ((yy + xx) % 256)], -1)[: hh // 2]
+        pv, u8 = render_ref.clip_preprocess(img, S, rot90=False)
+        np.testing.assert_array_equal(u8, goldens[key])
+        base = key[:-3]
+        np.testing.assert_allclose(pv[:, :8, :8], goldens[base + "_pv_slice"], rtol=0, atol=2e-7)
+        assert abs(pv.astype(np.float64).sum() - goldens[base + "_pv_sum"][0]) < 1e-2
+        n += 1
+    assert n >= 9
+
+
+def test_rot90_matches_numpy():
+    r = np.random.Generator(np.random.PCG64(5))
+    img = r.integers(0, 256, size=(36, 64, 3), dtype=np.uint8)
+    # S equal to the short edge of the rotated frame and square crop -> no resampling
+    _, u8 = render_ref.clip_preprocess(img, 36, rot90=True)
+    rot = np.rot90(img, k=1, axes=(0, 1))          # clip_scoring.py:145
+    top = (64 - 36) // 2
+    np.testing.assert_array_equal(u8, rot[top:top + 36])
+
+
+def _check_clip(goldens, name, pv, tol):
+    cfg = CLIP_CONFIGS[name]
+    sd = random_clip_state_dict(cfg, seed=6)
+    hs = []
+    ie = clip_ref.vision_embeds(pv, sd, cfg, hidden_out=hs)
+    te = clip_ref.text_embeds(goldens[f"g5_{name}_ids"], sd, cfg)
+    np.testing.assert_allclose(ie, goldens[f"g5_{name}_image_embeds"], rtol=0, atol=tol)
+    np.testing.assert_allclose(te, goldens[f"g5_{name}_text_embeds"], rtol=0, atol=tol)
+    lg = clip_ref.logits_per_image(ie, te, sd["logit_scale"])
+    np.testing.assert_allclose(lg, goldens[f"g5_{name}_logits"], rtol=0, atol=100 * tol)
+    np.testing.assert_allclose(hs[-1][:, :3, :16], goldens[f"g5_{name}_hlast_slice"], rtol=0, atol=50 * tol)
+
+
+def test_g5_clip_tiny(goldens):
+    _check_clip(goldens, "vit_tiny", goldens["g5_vit_tiny_pv"], 2e-6)
+
+
+def test_g5_clip_vit_b16(goldens):
+    cfg = CLIP_CONFIGS["vit_b16"]
+    r = np.random.Generator(np.random.PCG64(77))
+    pv = r.standard_normal((2, 3, cfg["image_size"], cfg["image_size"]), dtype=np.float32)
+    _check_clip(goldens, "vit_b16", pv, 2e-5)
