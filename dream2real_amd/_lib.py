@@ -1,0 +1,94 @@
+"""ctypes binding of libd2r.so (include/d2r.h).  Fails loudly when the library is missing or
+there is no gfx950 device: this package has no CPU compute path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libd2r.so")
+
+EXPORTS = [
+    "d2r_abi_version", "d2r_ctx_create", "d2r_ctx_destroy", "d2r_ctx_set_stream", "d2r_ctx_synchronize",
+    "d2r_last_error", "d2r_nerf_create", "d2r_nerf_destroy", "d2r_render", "d2r_nerf_eval_points",
+    "d2r_set_background", "d2r_render_composite", "d2r_clip_create", "d2r_clip_destroy",
+    "d2r_clip_score_frames", "d2r_clip_preprocess", "d2r_clip_embed_pixels", "d2r_render_score",
+    "d2r_get_render_stats", "d2r_collect_render_stats", "d2r_ctx_set_option",
+]
+
+
+class D2RError(RuntimeError):
+    pass
+
+
+class NerfDesc(C.Structure):
+    _fields_ = [("n_levels", C.c_uint32), ("n_features", C.c_uint32), ("level_scale", C.c_void_p),
+                ("level_res", C.c_void_p), ("level_size", C.c_void_p), ("level_offset", C.c_void_p),
+                ("n_entries", C.c_uint32), ("grid_fp16", C.c_void_p), ("dw1_fp16", C.c_void_p),
+                ("dw2_fp16", C.c_void_p), ("cw1_fp16", C.c_void_p), ("cw2_fp16", C.c_void_p),
+                ("cw3_fp16", C.c_void_p), ("occupancy_bits", C.c_void_p)]
+
+
+class ViewC(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("focal", C.c_float * 2),
+                ("center", C.c_float * 2), ("scale", C.c_float), ("offset", C.c_float * 3),
+                ("background", C.c_float * 4), ("min_transmittance", C.c_float),
+                ("near_distance", C.c_float)]
+
+
+class ClipDesc(C.Structure):
+    _fields_ = [("image_size", C.c_uint32), ("patch_size", C.c_uint32), ("hidden_size", C.c_uint32),
+                ("num_layers", C.c_uint32), ("num_heads", C.c_uint32), ("mlp_size", C.c_uint32),
+                ("proj_dim", C.c_uint32)]
+
+
+class RenderStats(C.Structure):
+    _fields_ = [("rays_total", C.c_uint64), ("rays_alive", C.c_uint64), ("samples", C.c_uint64)]
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """dlopen libd2r.so and declare prototypes.  Raises if the library has not been built
+    (`python -c "import __graft_entry__ as g; g.build()"`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise D2RError(f"{LIB_PATH} is missing: build it with __graft_entry__.build() "
+                       "(make -C dream2real_amd/csrc); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    lib.d2r_last_error.restype = C.c_char_p
+    lib.d2r_last_error.argtypes = [C.c_void_p]
+    lib.d2r_ctx_destroy.restype = None
+    lib.d2r_nerf_destroy.restype = None
+    lib.d2r_clip_destroy.restype = None
+    for name in EXPORTS:
+        getattr(lib, name)          # every declared symbol must be exported
+    if lib.d2r_abi_version() != 1:
+        raise D2RError("libd2r.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, ctx=None):
+    if rc != 0:
+        msg = load().d2r_last_error(ctx)
+        raise D2RError(f"libd2r error {rc}: {msg.decode() if msg else '?'}")
+
+
+def ptr(a) -> C.c_void_p:
+    """Host pointer of a C-contiguous numpy array (or None)."""
+    if a is None:
+        return C.c_void_p(0)
+    assert a.flags["C_CONTIGUOUS"]
+    return C.c_void_p(a.ctypes.data)
+
+
+def view_c(v) -> ViewC:
+    return ViewC(v.width, v.height, (C.c_float * 2)(*v.focal), (C.c_float * 2)(*v.center), v.scale,
+                 (C.c_float * 3)(*v.offset), (C.c_float * 4)(*v.background), v.min_transmittance,
+                 v.near_distance)

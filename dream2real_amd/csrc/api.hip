@@ -1,0 +1,553 @@
+// api.hip — the C ABI of libd2r.so (see include/d2r.h).  Host-side glue only: argument
+// checking, device memory, and the order in which the kernels of nerf.hip / clip.hip run.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "d2r_internal.h"
+
+// implemented in clip.hip / nerf.hip
+struct d2r_clip;
+int d2r_launch_preprocess(d2r_ctx *, d2r_clip *, const uint8_t *frames_dev, uint32_t n, uint32_t w, uint32_t h,
+                          int rot90, uint16_t *patches_dev, float *pixel_values_dev);
+int d2r_clip_forward(d2r_ctx *, const d2r_clip *, const uint16_t *patches_dev, uint32_t n, const float *text_dev,
+                     uint32_t C, float logit_scale, float *logits_dev, float *embeds_dev);
+int d2r_launch_patchify(d2r_ctx *, const d2r_clip *, const float *pv_dev, uint32_t n, uint16_t *patches_dev);
+size_t d2r_clip_patch_bytes(const d2r_clip *, uint32_t n);
+int d2r_launch_eval_points(d2r_ctx *, const d2r_nerf *, const float *xyz, const float *dirs, uint32_t n, float *out);
+uint32_t d2r_clip_image_size(const d2r_clip *);
+uint32_t d2r_clip_proj_dim(const d2r_clip *);
+
+static thread_local std::string g_err;
+
+int d2r_fail(d2r_ctx *ctx, int code, const std::string &msg)
+{
+    if (ctx) ctx->err = msg;
+    g_err = msg;
+    return code;
+}
+
+int d2r_reserve(d2r_ctx *ctx, d2r_ctx::Buf &b, size_t bytes)
+{
+    if (bytes <= b.cap) return D2R_OK;
+    if (b.p) {
+        hipStreamSynchronize(ctx->stream);
+        hipFree(b.p);
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    size_t want = bytes + bytes / 8 + 256;
+    if (hipMalloc(&b.p, want) != hipSuccess) {
+        b.p = nullptr;
+        return d2r_fail(ctx, D2R_ERR_MEMORY, "hipMalloc(" + std::to_string(want) + ") failed");
+    }
+    b.cap = want;
+    hipMemsetAsync(b.p, 0, want, ctx->stream);   // padded rows/columns of GEMM operands must be finite
+    return D2R_OK;
+}
+
+extern "C" {
+
+int d2r_abi_version(void) { return D2R_ABI_VERSION; }
+
+const char *d2r_last_error(d2r_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+int d2r_ctx_create(int device, d2r_ctx **out)
+{
+    if (!out) return d2r_fail(nullptr, D2R_ERR_INVALID, "null out pointer");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return d2r_fail(nullptr, D2R_ERR_DEVICE, "no HIP device: libd2r has no CPU path");
+    if (device < 0 || device >= n) return d2r_fail(nullptr, D2R_ERR_INVALID, "device index out of range");
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess)
+        return d2r_fail(nullptr, D2R_ERR_DEVICE, "hipGetDeviceProperties failed");
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return d2r_fail(nullptr, D2R_ERR_DEVICE, std::string("libd2r is built for gfx950 only, found ") + prop.gcnArchName);
+    if (hipSetDevice(device) != hipSuccess) return d2r_fail(nullptr, D2R_ERR_DEVICE, "hipSetDevice failed");
+    d2r_ctx *c = new d2r_ctx();
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return d2r_fail(nullptr, D2R_ERR_DEVICE, "hipStreamCreate failed");
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return D2R_OK;
+}
+
+void d2r_ctx_destroy(d2r_ctx *c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    d2r_ctx::Buf *bufs[] = {&c->cams, &c->queue, &c->counters, &c->frames, &c->rgba, &c->depth, &c->poses,
+                            &c->text, &c->logits, &c->pix, &c->bg_rgba, &c->bg_depth, &c->bg_u8};
+    for (auto *b : bufs)
+        if (b->p) hipFree(b->p);
+    for (auto &b : c->clipws)
+        if (b.p) hipFree(b.p);
+    hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int d2r_ctx_set_stream(d2r_ctx *ctx, void *s)
+{
+    if (!ctx) return d2r_fail(nullptr, D2R_ERR_INVALID, "null ctx");
+    hipStreamSynchronize(ctx->stream);
+    ctx->stream = s ? (hipStream_t)s : ctx->own_stream;
+    return D2R_OK;
+}
+
+int d2r_ctx_synchronize(d2r_ctx *ctx)
+{
+    if (!ctx) return d2r_fail(nullptr, D2R_ERR_INVALID, "null ctx");
+    D2R_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return D2R_OK;
+}
+
+int d2r_ctx_set_option(d2r_ctx *ctx, const char *key, int64_t value)
+{
+    if (!ctx || !key) return d2r_fail(ctx, D2R_ERR_INVALID, "null argument");
+    if (!strcmp(key, "chunk")) {
+        if (value < 1 || value > 4096) return d2r_fail(ctx, D2R_ERR_INVALID, "chunk must be in [1, 4096]");
+        ctx->chunk = value;
+    } else if (!strcmp(key, "march_blocks")) {
+        if (value < 0 || value > 65535) return d2r_fail(ctx, D2R_ERR_INVALID, "march_blocks out of range");
+        ctx->march_blocks = value;
+    } else {
+        return d2r_fail(ctx, D2R_ERR_INVALID, std::string("unknown option ") + key);
+    }
+    return D2R_OK;
+}
+
+int d2r_get_render_stats(d2r_ctx *ctx, d2r_render_stats *out)
+{
+    if (!ctx || !out) return d2r_fail(ctx, D2R_ERR_INVALID, "null argument");
+    *out = ctx->stats;
+    return D2R_OK;
+}
+
+// ------------------------------------------------------------------- NeRF
+
+static float half_to_float(uint16_t h)
+{
+    uint32_t sign = (uint32_t)(h & 0x8000u) << 16, exp = (h >> 10) & 0x1fu, man = h & 0x3ffu, bits;
+    if (exp == 0) {
+        if (man == 0) bits = sign;
+        else {
+            int e = -1;
+            do { man <<= 1; e++; } while (!(man & 0x400u));
+            bits = sign | ((uint32_t)(127 - 15 - e) << 23) | ((man & 0x3ffu) << 13);
+        }
+    } else if (exp == 31) bits = sign | 0x7f800000u | (man << 13);
+    else bits = sign | ((exp + 127 - 15) << 23) | (man << 13);
+    float f;
+    memcpy(&f, &bits, 4);
+    return f;
+}
+
+static uint16_t float_to_bf16(float f)
+{
+    uint32_t b;
+    memcpy(&b, &f, 4);
+    if ((b & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((b >> 16) | 0x40);
+    b += 0x7fffu + ((b >> 16) & 1u);
+    return (uint16_t)(b >> 16);
+}
+
+// MFMA A-operand fragments of the five weight matrices (nerf.hip mlp_tile).
+//   kind 0: k index is a network INPUT in natural order   col = 16*s + 8*hi + j
+//   kind 1: k index comes from a previous layer's C layout col = 16*s + 8*(j>>2) + 4*hi + (j&3)
+static void build_frag(std::vector<uint16_t> &dst, int frag, const uint16_t *w, int n_out, int n_in, int mtile,
+                       int s, int kind, int col_base = 0)
+{
+    for (int lane = 0; lane < 64; lane++) {
+        int i = lane & 31, hi = lane >> 5, row = mtile * 32 + i;
+        for (int j = 0; j < 8; j++) {
+            int col = col_base + (kind == 0 ? 16 * s + 8 * hi + j : 16 * s + 8 * (j >> 2) + 4 * hi + (j & 3));
+            float v = (row < n_out && col < n_in) ? half_to_float(w[row * n_in + col]) : 0.f;
+            dst[((size_t)frag * 64 + lane) * 8 + j] = float_to_bf16(v);
+        }
+    }
+}
+
+int d2r_nerf_create(d2r_ctx *ctx, const d2r_nerf_desc *d, d2r_nerf **out)
+{
+    if (!ctx || !d || !out) return d2r_fail(ctx, D2R_ERR_INVALID, "null argument");
+    if (d->n_levels != 16 || d->n_features != 2)
+        return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "only the L=16, F=2 hash grid layout is implemented");
+    if (!d->level_scale || !d->level_res || !d->level_size || !d->level_offset || !d->grid_fp16 || !d->dw1_fp16 ||
+        !d->dw2_fp16 || !d->cw1_fp16 || !d->cw2_fp16 || !d->cw3_fp16 || !d->occupancy_bits)
+        return d2r_fail(ctx, D2R_ERR_INVALID, "null field in d2r_nerf_desc");
+    hipSetDevice(ctx->device);
+    d2r_nerf *m = new d2r_nerf();
+    m->ctx = ctx;
+    NerfParams &P = m->P;
+    P.n_levels = d->n_levels;
+    for (uint32_t l = 0; l < d->n_levels; l++) {
+        LevelMeta &lm = P.lv[l];
+        lm.scale = d->level_scale[l];
+        lm.res = d->level_res[l];
+        lm.size = d->level_size[l];
+        lm.offset = d->level_offset[l];
+        uint64_t r3 = (uint64_t)lm.res * lm.res * lm.res;
+        lm.hashed = r3 > lm.size;
+        if (lm.hashed && (lm.size & (lm.size - 1))) {
+            delete m;
+            return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "hashed levels must have a power-of-two size");
+        }
+        if ((uint64_t)lm.offset + lm.size > d->n_entries) {
+            delete m;
+            return d2r_fail(ctx, D2R_ERR_INVALID, "level table exceeds n_entries");
+        }
+    }
+    // occupancy -> 4x4x4 bricks + bounding box of occupied cells
+    std::vector<uint64_t> bricks(32 * 32 * 32, 0);
+    int lo[3] = {D2R_GRID, D2R_GRID, D2R_GRID}, hi[3] = {-1, -1, -1};
+    for (int z = 0; z < D2R_GRID; z++)
+        for (int y = 0; y < D2R_GRID; y++)
+            for (int x = 0; x < D2R_GRID; x++) {
+                uint32_t idx = x + D2R_GRID * (y + D2R_GRID * z);
+                if ((d->occupancy_bits[idx >> 3] >> (idx & 7)) & 1) {
+                    bricks[(x >> 2) + 32 * ((y >> 2) + 32 * (z >> 2))] |= 1ull << ((x & 3) + 4 * (y & 3) + 16 * (z & 3));
+                    int c[3] = {x, y, z};
+                    for (int a = 0; a < 3; a++) {
+                        lo[a] = std::min(lo[a], c[a]);
+                        hi[a] = std::max(hi[a], c[a]);
+                    }
+                }
+            }
+    for (int a = 0; a < 3; a++) {
+        if (hi[a] < 0) {          // nothing occupied: empty box
+            P.bbox_lo[a] = 2.f;
+            P.bbox_hi[a] = -2.f;
+        } else {
+            P.bbox_lo[a] = (float)lo[a] / D2R_GRID - 1e-4f;
+            P.bbox_hi[a] = (float)(hi[a] + 1) / D2R_GRID + 1e-4f;
+        }
+    }
+    // weight fragments
+    std::vector<uint16_t> wf((size_t)D2R_N_WFRAG * 64 * 8);
+    const int n_in = (int)(d->n_levels * d->n_features);
+    for (int mt = 0; mt < 2; mt++)
+        for (int s = 0; s < 2; s++) build_frag(wf, 0 + mt * 2 + s, d->dw1_fp16, 64, n_in, mt, s, 0);
+    for (int q = 0; q < 4; q++) build_frag(wf, 4 + q, d->dw2_fp16, 16, 64, 0, q, 1);
+    for (int mt = 0; mt < 2; mt++) {
+        build_frag(wf, 8 + mt * 2 + 0, d->cw1_fp16, 64, 32, mt, 0, 1);          // density outputs (C layout)
+        build_frag(wf, 8 + mt * 2 + 1, d->cw1_fp16, 64, 32, mt, 0, 0, 16);      // SH, natural order at col 16
+    }
+    for (int mt = 0; mt < 2; mt++)
+        for (int q = 0; q < 4; q++) build_frag(wf, 12 + mt * 4 + q, d->cw2_fp16, 64, 64, mt, q, 1);
+    for (int q = 0; q < 4; q++) build_frag(wf, 20 + q, d->cw3_fp16, 16, 64, 0, q, 1);
+
+    const size_t grid_bytes = (size_t)d->n_entries * 4;
+    if (grid_bytes >= (1ull << 32)) {
+        delete m;
+        return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "grid larger than 4 GiB");
+    }
+    bool ok = hipMalloc(&m->d_grid, grid_bytes) == hipSuccess &&
+              hipMalloc(&m->d_bricks, bricks.size() * 8) == hipSuccess &&
+              hipMalloc(&m->d_wfrag, wf.size() * 2) == hipSuccess;
+    ok = ok && hipMemcpy(m->d_grid, d->grid_fp16, grid_bytes, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(m->d_bricks, bricks.data(), bricks.size() * 8, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(m->d_wfrag, wf.data(), wf.size() * 2, hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) {
+        d2r_nerf_destroy(m);
+        return d2r_fail(ctx, D2R_ERR_MEMORY, "device allocation/upload failed for the NeRF model");
+    }
+    P.grid = (const uint32_t *)m->d_grid;
+    P.grid_bytes = (uint32_t)grid_bytes;
+    P.bricks = (const uint64_t *)m->d_bricks;
+    P.wfrag = (const uint4 *)m->d_wfrag;
+    *out = m;
+    return D2R_OK;
+}
+
+void d2r_nerf_destroy(d2r_nerf *m)
+{
+    if (!m) return;
+    if (m->d_grid) hipFree(m->d_grid);
+    if (m->d_bricks) hipFree(m->d_bricks);
+    if (m->d_wfrag) hipFree(m->d_wfrag);
+    delete m;
+}
+
+static int check_view(d2r_ctx *ctx, const d2r_view *v)
+{
+    if (!v) return d2r_fail(ctx, D2R_ERR_INVALID, "null view");
+    if (v->width == 0 || v->height == 0 || v->width > 8192 || v->height > 8192)
+        return d2r_fail(ctx, D2R_ERR_INVALID, "bad view size");
+    if (!(v->scale > 0.f)) return d2r_fail(ctx, D2R_ERR_INVALID, "view.scale must be positive");
+    return D2R_OK;
+}
+
+static int fetch_stats(d2r_ctx *ctx, uint64_t rays_total, bool accumulate)
+{
+    uint32_t c[4];
+    D2R_HIP(ctx, hipMemcpyAsync(c, ctx->counters.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+    D2R_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    uint64_t samples;
+    memcpy(&samples, &c[2], 8);
+    if (!accumulate) ctx->stats = d2r_render_stats{0, 0, 0};
+    ctx->stats.rays_total += rays_total;
+    ctx->stats.rays_alive += c[0];
+    ctx->stats.samples += samples;
+    return D2R_OK;
+}
+
+int d2r_render(d2r_ctx *ctx, const d2r_nerf *model, const d2r_view *view, const float *cams_nerf, uint32_t n,
+               float *rgba_out, float *depth_out, uint64_t *n_samples_out)
+{
+    if (!ctx || !model || !cams_nerf) return d2r_fail(ctx, D2R_ERR_INVALID, "null argument");
+    int rc = check_view(ctx, view);
+    if (rc) return rc;
+    if (n == 0) return D2R_OK;
+    hipSetDevice(ctx->device);
+    const ViewParams V = d2r_view_params(view);
+    const size_t px = (size_t)V.W * V.H;
+    ctx->stats = d2r_render_stats{0, 0, 0};
+    // bound the pass size: 2^31 rays and ~1 GiB of fp32 frames
+    uint32_t per = (uint32_t)std::max<size_t>(1, std::min<size_t>(n, (64u << 20) / px + 1));
+    for (uint32_t c0 = 0; c0 < n; c0 += per) {
+        uint32_t nc = std::min(per, n - c0);
+        if ((rc = d2r_reserve(ctx, ctx->poses, (size_t)nc * 12 * 4))) return rc;
+        if ((rc = d2r_reserve(ctx, ctx->cams, (size_t)nc * 12 * 4))) return rc;
+        if ((rc = d2r_reserve(ctx, ctx->rgba, (size_t)nc * px * 16))) return rc;
+        if ((rc = d2r_reserve(ctx, ctx->depth, (size_t)nc * px * 4))) return rc;
+        D2R_HIP(ctx, hipMemcpyAsync(ctx->poses.p, cams_nerf + (size_t)c0 * 12, (size_t)nc * 48, hipMemcpyHostToDevice, ctx->stream));
+        if ((rc = d2r_launch_cameras_direct(ctx, V, (const float *)ctx->poses.p, nc, (float *)ctx->cams.p))) return rc;
+        if ((rc = d2r_launch_render(ctx, model, V, (const float *)ctx->cams.p, nc, false, (float *)ctx->rgba.p,
+                                    (float *)ctx->depth.p, nullptr)))
+            return rc;
+        if (rgba_out)
+            D2R_HIP(ctx, hipMemcpyAsync(rgba_out + (size_t)c0 * px * 4, ctx->rgba.p, (size_t)nc * px * 16, hipMemcpyDeviceToHost, ctx->stream));
+        if (depth_out)
+            D2R_HIP(ctx, hipMemcpyAsync(depth_out + (size_t)c0 * px, ctx->depth.p, (size_t)nc * px * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if ((rc = fetch_stats(ctx, (uint64_t)nc * px, true))) return rc;
+    }
+    if (n_samples_out) *n_samples_out = ctx->stats.samples;
+    return D2R_OK;
+}
+
+int d2r_nerf_eval_points(d2r_ctx *ctx, const d2r_nerf *model, const float *xyz, const float *dirs, uint32_t n,
+                         float *sigma_rgb_out)
+{
+    if (!ctx || !model || !xyz || !dirs || !sigma_rgb_out) return d2r_fail(ctx, D2R_ERR_INVALID, "null argument");
+    if (n == 0) return D2R_OK;
+    hipSetDevice(ctx->device);
+    int rc;
+    if ((rc = d2r_reserve(ctx, ctx->rgba, (size_t)n * 16))) return rc;
+    if ((rc = d2r_reserve(ctx, ctx->depth, (size_t)n * 12))) return rc;
+    if ((rc = d2r_reserve(ctx, ctx->pix, (size_t)n * 12))) return rc;
+    D2R_HIP(ctx, hipMemcpyAsync(ctx->depth.p, xyz, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
+    D2R_HIP(ctx, hipMemcpyAsync(ctx->pix.p, dirs, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = d2r_launch_eval_points(ctx, model, (const float *)ctx->depth.p, (const float *)ctx->pix.p, n, (float *)ctx->rgba.p)))
+        return rc;
+    D2R_HIP(ctx, hipMemcpyAsync(sigma_rgb_out, ctx->rgba.p, (size_t)n * 16, hipMemcpyDeviceToHost, ctx->stream));
+    D2R_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return D2R_OK;
+}
+
+int d2r_set_background(d2r_ctx *ctx, const d2r_view *view, const float *bg_rgba, const float *bg_depth)
+{
+    if (!ctx || !bg_rgba || !bg_depth) return d2r_fail(ctx, D2R_ERR_INVALID, "null argument");
+    int rc = check_view(ctx, view);
+    if (rc) return rc;
+    hipSetDevice(ctx->device);
+    const size_t px = (size_t)view->width * view->height;
+    if ((rc = d2r_reserve(ctx, ctx->bg_rgba, px * 16))) return rc;
+    if ((rc = d2r_reserve(ctx, ctx->bg_depth, px * 4))) return rc;
+    if ((rc = d2r_reserve(ctx, ctx->bg_u8, px * 3 + 16))) return rc;
+    D2R_HIP(ctx, hipMemcpyAsync(ctx->bg_rgba.p, bg_rgba, px * 16, hipMemcpyHostToDevice, ctx->stream));
+    D2R_HIP(ctx, hipMemcpyAsync(ctx->bg_depth.p, bg_depth, px * 4, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = d2r_launch_bg_quantize(ctx, view->width, view->height))) return rc;
+    D2R_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->bg_w = view->width;
+    ctx->bg_h = view->height;
+    return D2R_OK;
+}
+
+int d2r_render_composite(d2r_ctx *ctx, const d2r_nerf *fg, const d2r_view *view, const float *obj_pose_now,
+                         const float *cam_pose, const float *obj_poses, uint32_t K, uint8_t *frames_out)
+{
+    if (!ctx || !fg || !obj_pose_now || !cam_pose || !obj_poses || !frames_out)
+        return d2r_fail(ctx, D2R_ERR_INVALID, "null argument");
+    int rc = check_view(ctx, view);
+    if (rc) return rc;
+    hipSetDevice(ctx->device);
+    const ViewParams V = d2r_view_params(view);
+    const size_t px = (size_t)V.W * V.H;
+    ctx->stats = d2r_render_stats{0, 0, 0};
+    const uint32_t per = (uint32_t)std::max<int64_t>(1, ctx->chunk);
+    for (uint32_t c0 = 0; c0 < K; c0 += per) {
+        uint32_t nc = std::min(per, K - c0);
+        if ((rc = d2r_reserve(ctx, ctx->poses, (size_t)nc * 64))) return rc;
+        if ((rc = d2r_reserve(ctx, ctx->cams, (size_t)nc * 48))) return rc;
+        if ((rc = d2r_reserve(ctx, ctx->frames, (size_t)nc * px * 3))) return rc;
+        D2R_HIP(ctx, hipMemcpyAsync(ctx->poses.p, obj_poses + (size_t)c0 * 16, (size_t)nc * 64, hipMemcpyHostToDevice, ctx->stream));
+        if ((rc = d2r_launch_cameras_virtual(ctx, V, obj_pose_now, cam_pose, (const float *)ctx->poses.p, nc, (float *)ctx->cams.p)))
+            return rc;
+        if ((rc = d2r_launch_render(ctx, fg, V, (const float *)ctx->cams.p, nc, true, nullptr, nullptr, (uint8_t *)ctx->frames.p)))
+            return rc;
+        D2R_HIP(ctx, hipMemcpyAsync(frames_out + (size_t)c0 * px * 3, ctx->frames.p, (size_t)nc * px * 3, hipMemcpyDeviceToHost, ctx->stream));
+        if ((rc = fetch_stats(ctx, (uint64_t)nc * px, true))) return rc;
+    }
+    return D2R_OK;
+}
+
+// -------------------------------------------------------------------- CLIP
+
+static int upload_text(d2r_ctx *ctx, const d2r_clip *clip, const float *text, uint32_t C)
+{
+    if (!text || C == 0 || C > 1024) return d2r_fail(ctx, D2R_ERR_INVALID, "bad text embeddings");
+    size_t bytes = (size_t)C * d2r_clip_proj_dim(clip) * 4;
+    int rc = d2r_reserve(ctx, ctx->text, bytes);
+    if (rc) return rc;
+    D2R_HIP(ctx, hipMemcpyAsync(ctx->text.p, text, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return D2R_OK;
+}
+
+int d2r_clip_score_frames(d2r_ctx *ctx, const d2r_clip *clip, const uint8_t *frames, uint32_t n, uint32_t w,
+                          uint32_t h, int rot90, const float *text_embeds, uint32_t C, float logit_scale,
+                          float *logits_out, float *embeds_out)
+{
+    if (!ctx || !clip || !frames || !logits_out) return d2r_fail(ctx, D2R_ERR_INVALID, "null argument");
+    hipSetDevice(ctx->device);
+    int rc = upload_text(ctx, clip, text_embeds, C);
+    if (rc) return rc;
+    const size_t px = (size_t)w * h;
+    const uint32_t D = d2r_clip_proj_dim(clip);
+    const uint32_t per = (uint32_t)std::max<int64_t>(1, ctx->chunk);
+    for (uint32_t c0 = 0; c0 < n; c0 += per) {
+        uint32_t nc = std::min(per, n - c0);
+        if ((rc = d2r_reserve(ctx, ctx->frames, (size_t)nc * px * 3))) return rc;
+        if ((rc = d2r_reserve(ctx, ctx->clipws[6], d2r_clip_patch_bytes(clip, nc)))) return rc;
+        if ((rc = d2r_reserve(ctx, ctx->logits, (size_t)nc * (C + D) * 4))) return rc;
+        float *lg = (float *)ctx->logits.p, *em = lg + (size_t)nc * C;
+        D2R_HIP(ctx, hipMemcpyAsync(ctx->frames.p, frames + (size_t)c0 * px * 3, (size_t)nc * px * 3, hipMemcpyHostToDevice, ctx->stream));
+        if ((rc = d2r_launch_preprocess(ctx, (d2r_clip *)clip, (const uint8_t *)ctx->frames.p, nc, w, h, rot90,
+                                        (uint16_t *)ctx->clipws[6].p, nullptr)))
+            return rc;
+        if ((rc = d2r_clip_forward(ctx, clip, (const uint16_t *)ctx->clipws[6].p, nc, (const float *)ctx->text.p, C,
+                                   logit_scale, lg, em)))
+            return rc;
+        D2R_HIP(ctx, hipMemcpyAsync(logits_out + (size_t)c0 * C, lg, (size_t)nc * C * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (embeds_out)
+            D2R_HIP(ctx, hipMemcpyAsync(embeds_out + (size_t)c0 * D, em, (size_t)nc * D * 4, hipMemcpyDeviceToHost, ctx->stream));
+        D2R_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return D2R_OK;
+}
+
+int d2r_clip_preprocess(d2r_ctx *ctx, const d2r_clip *clip, const uint8_t *frames, uint32_t n, uint32_t w,
+                        uint32_t h, int rot90, float *pixel_values_out)
+{
+    if (!ctx || !clip || !frames || !pixel_values_out) return d2r_fail(ctx, D2R_ERR_INVALID, "null argument");
+    hipSetDevice(ctx->device);
+    const size_t px = (size_t)w * h, S = d2r_clip_image_size(clip);
+    int rc;
+    if ((rc = d2r_reserve(ctx, ctx->frames, (size_t)n * px * 3))) return rc;
+    if ((rc = d2r_reserve(ctx, ctx->pix, (size_t)n * 3 * S * S * 4))) return rc;
+    D2R_HIP(ctx, hipMemcpyAsync(ctx->frames.p, frames, (size_t)n * px * 3, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = d2r_launch_preprocess(ctx, (d2r_clip *)clip, (const uint8_t *)ctx->frames.p, n, w, h, rot90, nullptr,
+                                    (float *)ctx->pix.p)))
+        return rc;
+    D2R_HIP(ctx, hipMemcpyAsync(pixel_values_out, ctx->pix.p, (size_t)n * 3 * S * S * 4, hipMemcpyDeviceToHost, ctx->stream));
+    D2R_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return D2R_OK;
+}
+
+int d2r_clip_embed_pixels(d2r_ctx *ctx, const d2r_clip *clip, const float *pixel_values, uint32_t n,
+                          float *embeds_out)
+{
+    if (!ctx || !clip || !pixel_values || !embeds_out) return d2r_fail(ctx, D2R_ERR_INVALID, "null argument");
+    hipSetDevice(ctx->device);
+    const size_t S = d2r_clip_image_size(clip);
+    const uint32_t D = d2r_clip_proj_dim(clip);
+    int rc;
+    const uint32_t per = (uint32_t)std::max<int64_t>(1, ctx->chunk);
+    for (uint32_t c0 = 0; c0 < n; c0 += per) {
+        uint32_t nc = std::min(per, n - c0);
+        if ((rc = d2r_reserve(ctx, ctx->pix, (size_t)nc * 3 * S * S * 4))) return rc;
+        if ((rc = d2r_reserve(ctx, ctx->clipws[6], d2r_clip_patch_bytes(clip, nc)))) return rc;
+        if ((rc = d2r_reserve(ctx, ctx->logits, (size_t)nc * D * 4))) return rc;
+        if ((rc = d2r_reserve(ctx, ctx->text, (size_t)D * 4))) return rc;
+        D2R_HIP(ctx, hipMemcpyAsync(ctx->pix.p, pixel_values + (size_t)c0 * 3 * S * S, (size_t)nc * 3 * S * S * 4, hipMemcpyHostToDevice, ctx->stream));
+        if ((rc = d2r_launch_patchify(ctx, clip, (const float *)ctx->pix.p, nc, (uint16_t *)ctx->clipws[6].p))) return rc;
+        if ((rc = d2r_clip_forward(ctx, clip, (const uint16_t *)ctx->clipws[6].p, nc, (const float *)ctx->text.p, 0, 1.0f,
+                                   nullptr, (float *)ctx->logits.p)))
+            return rc;
+        D2R_HIP(ctx, hipMemcpyAsync(embeds_out + (size_t)c0 * D, ctx->logits.p, (size_t)nc * D * 4, hipMemcpyDeviceToHost, ctx->stream));
+        D2R_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return D2R_OK;
+}
+
+// ------------------------------------------------------------ fused hot path
+
+int d2r_render_score(d2r_ctx *ctx, const d2r_nerf *fg, const d2r_clip *clip, const d2r_view *view,
+                     const float *obj_pose_now, const float *cam_pose, const float *obj_poses_dev, uint32_t K,
+                     const float *text_embeds, uint32_t C, float logit_scale, float *logits_dev, uint8_t *frames_out)
+{
+    if (!ctx || !fg || !clip || !obj_pose_now || !cam_pose || !obj_poses_dev || !logits_dev)
+        return d2r_fail(ctx, D2R_ERR_INVALID, "null argument");
+    int rc = check_view(ctx, view);
+    if (rc) return rc;
+    hipSetDevice(ctx->device);
+    if ((rc = upload_text(ctx, clip, text_embeds, C))) return rc;
+    const ViewParams V = d2r_view_params(view);
+    const size_t px = (size_t)V.W * V.H;
+    const uint32_t per = (uint32_t)std::max<int64_t>(1, ctx->chunk);
+    // workspaces are sized once for a full chunk so that no allocation happens inside the loop
+    const uint32_t cap = std::min(per, K);
+    if ((rc = d2r_reserve(ctx, ctx->cams, (size_t)cap * 48))) return rc;
+    if ((rc = d2r_reserve(ctx, ctx->frames, (size_t)cap * px * 3))) return rc;
+    if ((rc = d2r_reserve(ctx, ctx->clipws[6], d2r_clip_patch_bytes(clip, cap)))) return rc;
+    if ((rc = d2r_reserve(ctx, ctx->counters, 64 + 16 * (size_t)((K + per - 1) / per)))) return rc;
+    ctx->stats = d2r_render_stats{0, 0, 0};
+    for (uint32_t c0 = 0; c0 < K; c0 += per) {
+        uint32_t nc = std::min(per, K - c0);
+        if ((rc = d2r_launch_cameras_virtual(ctx, V, obj_pose_now, cam_pose, obj_poses_dev + (size_t)c0 * 16, nc, (float *)ctx->cams.p)))
+            return rc;
+        if ((rc = d2r_launch_render(ctx, fg, V, (const float *)ctx->cams.p, nc, true, nullptr, nullptr, (uint8_t *)ctx->frames.p)))
+            return rc;
+        // keep this chunk's counters for the stats read-back at the end
+        D2R_HIP(ctx, hipMemcpyAsync((uint8_t *)ctx->counters.p + 64 + 16 * (size_t)(c0 / per), ctx->counters.p, 16,
+                                    hipMemcpyDeviceToDevice, ctx->stream));
+        if (frames_out)
+            D2R_HIP(ctx, hipMemcpyAsync(frames_out + (size_t)c0 * px * 3, ctx->frames.p, (size_t)nc * px * 3, hipMemcpyDeviceToHost, ctx->stream));
+        if ((rc = d2r_launch_preprocess(ctx, (d2r_clip *)clip, (const uint8_t *)ctx->frames.p, nc, V.W, V.H, 1,
+                                        (uint16_t *)ctx->clipws[6].p, nullptr)))
+            return rc;
+        if ((rc = d2r_clip_forward(ctx, clip, (const uint16_t *)ctx->clipws[6].p, nc, (const float *)ctx->text.p, C,
+                                   logit_scale, logits_dev + (size_t)c0 * C, nullptr)))
+            return rc;
+    }
+    if (frames_out) D2R_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stats.rays_total = (uint64_t)K * px;
+    return D2R_OK;
+}
+
+// Reads back the per-chunk counters of the last d2r_render_score (synchronises the stream).
+int d2r_collect_render_stats(d2r_ctx *ctx, uint32_t K)
+{
+    if (!ctx) return d2r_fail(nullptr, D2R_ERR_INVALID, "null ctx");
+    const uint32_t per = (uint32_t)std::max<int64_t>(1, ctx->chunk);
+    const uint32_t nchunks = (K + per - 1) / per;
+    std::vector<uint32_t> c((size_t)nchunks * 4);
+    D2R_HIP(ctx, hipMemcpyAsync(c.data(), (uint8_t *)ctx->counters.p + 64, c.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    D2R_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stats.rays_alive = 0;
+    ctx->stats.samples = 0;
+    for (uint32_t i = 0; i < nchunks; i++) {
+        uint64_t s;
+        memcpy(&s, &c[i * 4 + 2], 8);
+        ctx->stats.rays_alive += c[i * 4];
+        ctx->stats.samples += s;
+    }
+    return D2R_OK;
+}
+
+}  // extern "C"

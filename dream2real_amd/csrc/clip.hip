@@ -1,0 +1,902 @@
+// clip.hip — CLIP image scoring for gfx950 (MI355X), hand-written HIP.
+//
+// Replaces np.rot90 + CLIPProcessor + CLIPModel (vision tower, projection, logits) of
+// reference clip_scoring.py:145,177-181.  Specification: oracle/d2r_oracle.c
+// (d2r_oracle_clip_preprocess) and oracle/clip_ref.py.
+//
+//   k_preprocess   rot90 + Pillow antialiased bicubic resize (both passes in 22-bit fixed
+//                  point with the uint8 intermediate staged in LDS) + centre crop +
+//                  rescale/normalise, written patch-major in bf16 so patch embedding is a
+//                  plain GEMM; optional fp32 pixel_values for parity
+//   k_gemm         C = A[M,K] * W[N,K]^T on v_mfma_f32_32x32x16_bf16, 128x128x64 tiles,
+//                  XOR-swizzled LDS (conflict-free ds_read_b128), register-staged double
+//                  buffering, XCD-aware tile order, fused epilogues (bias, quick_gelu,
+//                  fp32 residual accumulate)
+//   k_embed_ln     [class | patches] + position embedding + pre_layrnorm -> fp32 residual
+//   k_layernorm    fp32 residual -> bf16 GEMM operand, one wave per token
+//   k_attention    flash-style attention per (image, head): S^T = K Q^T so each query's
+//                  scores are lane-local, online softmax, P fed back as the MFMA B operand
+//                  without leaving registers, V^T staged in LDS
+//   k_head         post_layernorm(CLS) -> visual_projection -> L2 normalise -> logits
+#include "d2r_internal.h"
+
+#include <math.h>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ClipWeights {
+    // bf16 GEMM operands, row-major [N][K]
+    const uint16_t *w_patch;   // [d][Kp_pad]
+    const float *cls, *pos;    // [d], [T][d]
+    const float *pre_w, *pre_b;
+    struct Layer {
+        const float *ln1_w, *ln1_b, *ln2_w, *ln2_b;
+        const uint16_t *w_qkv, *w_o, *w_fc1, *w_fc2;
+        const float *b_qkv, *b_o, *b_fc1, *b_fc2;
+    };
+    const float *post_w, *post_b;
+    const float *proj;         // fp32 [D][d]
+};
+
+struct ResampleTables {
+    const int *bounds_h;     // [rw][2]  (xmin, count) in rotated-source columns
+    const int *kk_h;         // [rw][ks_h]
+    const int *bounds_v;     // [rh][2]
+    const int *kk_v;         // [rh][ks_v]
+    int ks_h, ks_v;
+    int need_h, need_v;
+    int iw, ih;              // (rotated) source size
+    int rw, rh;              // resized size
+    int left, top;           // crop offset in the resized image
+    int max_rows;            // LDS rows per band
+};
+
+struct PrepCache {
+    uint32_t w, h;
+    int rot90;
+    ResampleTables R;
+};
+
+struct d2r_clip {
+    d2r_ctx *ctx;
+    d2r_clip_desc desc;
+    uint32_t T, Kp, Kp_pad;
+    std::vector<void *> allocs;
+    ClipWeights w;
+    std::vector<ClipWeights::Layer> layers;
+    std::vector<PrepCache> prep;     // resampling tables per (w, h, rot90), built on first use
+};
+
+__device__ __forceinline__ uint16_t f2bf(float x)
+{
+    union { __bf16 b; uint16_t u; } c;
+    c.b = (__bf16)x;
+    return c.u;
+}
+__device__ __forceinline__ uint32_t pack2(float a, float b)
+{
+    return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);
+}
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ------------------------------------------------------------ preprocess
+
+#define PRECISION_BITS 22
+__device__ __forceinline__ uint32_t clip8(int v)
+{
+    v >>= PRECISION_BITS;
+    return (uint32_t)min(max(v, 0), 255);
+}
+
+// grid (S/band_rows... bands, n); block 256.  dynamic LDS: max_rows * S * 3 bytes.
+__global__ __launch_bounds__(256) void k_preprocess(const uint8_t *__restrict__ frames, uint32_t w, uint32_t h,
+                                                    int rot90, ResampleTables R, uint32_t S, uint32_t P,
+                                                    uint32_t band, uint16_t *__restrict__ patches,
+                                                    uint32_t Kp_pad, float *__restrict__ pixel_values)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t tmp[];
+    const uint32_t img = blockIdx.y;
+    const uint32_t row0 = blockIdx.x * band;                 // first output row (cropped coords)
+    const uint32_t nrows = min(band, S - row0);
+    const uint8_t *src = frames + (size_t)img * w * h * 3;
+    // rows of the horizontally-resampled image this band needs
+    int y_first, y_last;
+    if (R.need_v) {
+        y_first = R.bounds_v[2 * (R.top + row0)];
+        int lastrow = R.top + row0 + nrows - 1;
+        y_last = R.bounds_v[2 * lastrow] + R.bounds_v[2 * lastrow + 1];
+    } else {
+        y_first = R.top + row0;
+        y_last = y_first + nrows;
+    }
+    const int trows = y_last - y_first;
+    // pass 1: horizontal filter (or copy) into LDS, columns [left, left+S)
+    for (uint32_t i = threadIdx.x; i < (uint32_t)trows * S; i += blockDim.x) {
+        int ty = i / S, tx = i % S;
+        int sy = y_first + ty;                 // row in rotated source
+        int ox = R.left + tx;                  // column in resized image
+        uint32_t o[3];
+        if (R.need_h) {
+            int xmin = R.bounds_h[2 * ox], cnt = R.bounds_h[2 * ox + 1];
+            const int *k = R.kk_h + (size_t)ox * R.ks_h;
+            int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0;
+            for (int x = 0; x < cnt; x++) {
+                int sx = xmin + x;
+                const uint8_t *p = rot90 ? src + ((size_t)sx * w + (w - 1 - sy)) * 3
+                                         : src + ((size_t)sy * w + sx) * 3;
+                int kv = k[x];
+                s0 += p[0] * kv;
+                s1 += p[1] * kv;
+                s2 += p[2] * kv;
+            }
+            o[0] = clip8(s0); o[1] = clip8(s1); o[2] = clip8(s2);
+        } else {
+            const uint8_t *p = rot90 ? src + ((size_t)ox * w + (w - 1 - sy)) * 3
+                                     : src + ((size_t)sy * w + ox) * 3;
+            o[0] = p[0]; o[1] = p[1]; o[2] = p[2];
+        }
+        uint8_t *d = tmp + ((size_t)ty * S + tx) * 3;
+        d[0] = (uint8_t)o[0]; d[1] = (uint8_t)o[1]; d[2] = (uint8_t)o[2];
+    }
+    __syncthreads();
+    // pass 2: vertical filter, normalise, scatter patch-major
+    const float mean[3] = {0.48145466f, 0.4578275f, 0.40821073f};
+    const float stdv[3] = {0.26862954f, 0.26130258f, 0.27577711f};
+    const uint32_t g = S / P;
+    for (uint32_t i = threadIdx.x; i < nrows * S; i += blockDim.x) {
+        uint32_t ry = i / S, rx = i % S;
+        uint32_t oy = row0 + ry;
+        uint32_t q[3];
+        if (R.need_v) {
+            int ymin = R.bounds_v[2 * (R.top + oy)] - y_first, cnt = R.bounds_v[2 * (R.top + oy) + 1];
+            const int *k = R.kk_v + (size_t)(R.top + oy) * R.ks_v;
+            int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0;
+            for (int y = 0; y < cnt; y++) {
+                const uint8_t *p = tmp + ((size_t)(ymin + y) * S + rx) * 3;
+                int kv = k[y];
+                s0 += p[0] * kv;
+                s1 += p[1] * kv;
+                s2 += p[2] * kv;
+            }
+            q[0] = clip8(s0); q[1] = clip8(s1); q[2] = clip8(s2);
+        } else {
+            const uint8_t *p = tmp + ((size_t)ry * S + rx) * 3;
+            q[0] = p[0]; q[1] = p[1]; q[2] = p[2];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            float f = (float)((double)q[c] * (1.0 / 255.0));
+            float v = (f - mean[c]) / stdv[c];
+            if (pixel_values) pixel_values[(((size_t)img * 3 + c) * S + oy) * S + rx] = v;
+            if (patches) {
+                uint32_t pr = oy / P, pc = rx / P, iy = oy % P, ix = rx % P;
+                size_t rowi = (size_t)img * g * g + pr * g + pc;
+                patches[rowi * Kp_pad + (c * P + iy) * P + ix] = f2bf(v);
+            }
+        }
+    }
+}
+
+// pixel_values [n][3][S][S] fp32 -> patch-major bf16 (parity entry for the ViT alone)
+__global__ void k_patchify(const float *__restrict__ pv, uint32_t n, uint32_t S, uint32_t P,
+                           uint16_t *__restrict__ patches, uint32_t Kp_pad)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = (size_t)n * 3 * S * S;
+    if (i >= total) return;
+    uint32_t x = i % S, y = (i / S) % S, c = (i / ((size_t)S * S)) % 3, img = i / ((size_t)3 * S * S);
+    uint32_t g = S / P;
+    size_t rowi = (size_t)img * g * g + (y / P) * g + (x / P);
+    patches[rowi * Kp_pad + (c * P + (y % P)) * P + (x % P)] = f2bf(pv[i]);
+}
+
+// ------------------------------------------------------------------ GEMM
+
+enum { EPI_F32 = 0, EPI_BIAS_BF16 = 1, EPI_BIAS_GELU_BF16 = 2, EPI_BIAS_RESID_F32 = 3 };
+
+#define BM 128
+#define BN 128
+#define BK 64
+
+__device__ __forceinline__ uint32_t lds_off(uint32_t row, uint32_t chunk)
+{
+    return row * 128u + ((chunk ^ ((row >> 1) & 7u)) << 4);
+}
+
+// A [M_pad][K] bf16, W [N][K] bf16, M_pad % 128 == 0, N % 128 == 0, K % 64 == 0
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void k_gemm(const uint16_t *__restrict__ A, const uint16_t *__restrict__ W,
+                                                 const float *__restrict__ bias, void *__restrict__ Cout,
+                                                 uint32_t M_pad, uint32_t N, uint32_t K, uint32_t M_real)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *As = smem;                 // 2 x 16 KB
+    uint8_t *Bs = smem + 2 * BM * BK * 2;
+    // XCD-aware tile order (bijective): blocks b, b+8, ... share an L2; give each XCD a
+    // contiguous run of tiles, n fastest so neighbours reuse the same A row panel.
+    const uint32_t nwg = gridDim.x, tiles_n = N / BN;
+    const uint32_t xcd = blockIdx.x & 7u, loc = blockIdx.x >> 3, q = nwg >> 3, rr = nwg & 7u;
+    const uint32_t tile = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
+    const uint32_t m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const uint32_t li = lane & 31, hi = lane >> 5;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    const uint32_t lrow = tid >> 3, lchunk = tid & 7;    // 32 rows x 8 chunks per pass
+    const uint16_t *Ag = A + (size_t)(m0 + lrow) * K + lchunk * 8;
+    const uint16_t *Wg = W + (size_t)(n0 + lrow) * K + lchunk * 8;
+    uint4 ra[4], rb[4];
+    const uint32_t nk = K / BK;
+
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        ra[p] = *(const uint4 *)(Ag + (size_t)p * 32 * K);
+        rb[p] = *(const uint4 *)(Wg + (size_t)p * 32 * K);
+    }
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        *(uint4 *)(As + lds_off(lrow + p * 32, lchunk)) = ra[p];
+        *(uint4 *)(Bs + lds_off(lrow + p * 32, lchunk)) = rb[p];
+    }
+    __syncthreads();
+
+    for (uint32_t kt = 0; kt < nk; kt++) {
+        const uint32_t cur = kt & 1;
+        if (kt + 1 < nk) {
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                ra[p] = *(const uint4 *)(Ag + (size_t)p * 32 * K + (size_t)(kt + 1) * BK);
+                rb[p] = *(const uint4 *)(Wg + (size_t)p * 32 * K + (size_t)(kt + 1) * BK);
+            }
+        }
+        const uint8_t *Ab = As + cur * (BM * BK * 2);
+        const uint8_t *Bb = Bs + cur * (BN * BK * 2);
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            uint4 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                fa[i] = *(const uint4 *)(Ab + lds_off(wm + i * 32 + li, 2 * s + hi));
+                fb[i] = *(const uint4 *)(Bb + lds_off(wn + i * 32 + li, 2 * s + hi));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    union { uint4 u; bf16x8 v; } a, b;
+                    a.u = fa[i];
+                    b.u = fb[j];
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc[i][j], 0, 0, 0);
+                }
+        }
+        if (kt + 1 < nk) {
+            uint8_t *An = As + (cur ^ 1) * (BM * BK * 2);
+            uint8_t *Bn = Bs + (cur ^ 1) * (BN * BK * 2);
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                *(uint4 *)(An + lds_off(lrow + p * 32, lchunk)) = ra[p];
+                *(uint4 *)(Bn + lds_off(lrow + p * 32, lchunk)) = rb[p];
+            }
+        }
+        __syncthreads();
+    }
+
+    // epilogue: acc[i][j][r] -> row m0+wm+32i+(r&3)+8(r>>2)+4hi, col n0+wn+32j+li
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const uint32_t col = n0 + wn + j * 32 + li;
+            const float bv = (EPI == EPI_F32) ? 0.f : bias[col];
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const uint32_t row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (row >= M_real) continue;
+                float v = acc[i][j][r] + bv;
+                const size_t o = (size_t)row * N + col;
+                if (EPI == EPI_F32) {
+                    ((float *)Cout)[o] = v;
+                } else if (EPI == EPI_BIAS_BF16) {
+                    ((uint16_t *)Cout)[o] = f2bf(v);
+                } else if (EPI == EPI_BIAS_GELU_BF16) {
+                    v = v / (1.0f + __expf(-1.702f * v));
+                    ((uint16_t *)Cout)[o] = f2bf(v);
+                } else {
+                    ((float *)Cout)[o] += v;
+                }
+            }
+        }
+}
+
+// -------------------------------------------------------- embeddings + LN
+
+// X[b*T + t] = pre_layrnorm( (t==0 ? class_embedding : patch_out[b*(T-1)+t-1]) + position[t] )
+__global__ __launch_bounds__(256) void k_embed_ln(const float *__restrict__ patch_out, const float *__restrict__ cls,
+                                                  const float *__restrict__ pos, const float *__restrict__ w,
+                                                  const float *__restrict__ b, float *__restrict__ X, uint32_t rows,
+                                                  uint32_t T, uint32_t d)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const uint32_t bi = row / T, t = row % T;
+    const float *src = t == 0 ? cls : patch_out + ((size_t)bi * (T - 1) + (t - 1)) * d;
+    float4 v[4], o[4];
+    for (int i = 0; i < 4; i++) {
+        uint32_t c0 = (lane + 64 * i) * 4;
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c0 < d) {
+            float4 a = *(const float4 *)(src + c0), p = *(const float4 *)(pos + (size_t)t * d + c0);
+            v[i] = make_float4(a.x + p.x, a.y + p.y, a.z + p.z, a.w + p.w);
+        }
+    }
+    // padded lanes hold zeros but must not bias the variance: handle via masked deviation
+    float s = 0.f;
+    for (int i = 0; i < 4; i++) s += v[i].x + v[i].y + v[i].z + v[i].w;
+    const float mu = wave_sum(s) / (float)d;
+    float q = 0.f;
+    for (int i = 0; i < 4; i++) {
+        uint32_t c0 = (lane + 64 * i) * 4;
+        if (c0 < d) {
+            float a = v[i].x - mu, bb = v[i].y - mu, c = v[i].z - mu, e = v[i].w - mu;
+            q += a * a + bb * bb + c * c + e * e;
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + 1e-5f);
+    for (int i = 0; i < 4; i++) {
+        uint32_t c0 = (lane + 64 * i) * 4;
+        if (c0 < d) {
+            float4 ww = *(const float4 *)(w + c0), bb = *(const float4 *)(b + c0);
+            o[i].x = (v[i].x - mu) * rstd * ww.x + bb.x;
+            o[i].y = (v[i].y - mu) * rstd * ww.y + bb.y;
+            o[i].z = (v[i].z - mu) * rstd * ww.z + bb.z;
+            o[i].w = (v[i].w - mu) * rstd * ww.w + bb.w;
+            *(float4 *)(X + (size_t)row * d + c0) = o[i];
+        }
+    }
+}
+
+// Y(bf16) = LayerNorm(X fp32), one wave per row
+__global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ X, const float *__restrict__ w,
+                                                   const float *__restrict__ b, uint16_t *__restrict__ Y,
+                                                   uint32_t rows, uint32_t d)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float4 v[4];
+    for (int i = 0; i < 4; i++) {
+        uint32_t c0 = (lane + 64 * i) * 4;
+        v[i] = c0 < d ? *(const float4 *)(X + (size_t)row * d + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float s = 0.f;
+    for (int i = 0; i < 4; i++) s += v[i].x + v[i].y + v[i].z + v[i].w;
+    const float mu = wave_sum(s) / (float)d;
+    float q = 0.f;
+    for (int i = 0; i < 4; i++) {
+        uint32_t c0 = (lane + 64 * i) * 4;
+        if (c0 < d) {
+            float a = v[i].x - mu, bb = v[i].y - mu, c = v[i].z - mu, e = v[i].w - mu;
+            q += a * a + bb * bb + c * c + e * e;
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + 1e-5f);
+    for (int i = 0; i < 4; i++) {
+        uint32_t c0 = (lane + 64 * i) * 4;
+        if (c0 < d) {
+            float4 ww = *(const float4 *)(w + c0), bb = *(const float4 *)(b + c0);
+            uint2 o;
+            o.x = pack2((v[i].x - mu) * rstd * ww.x + bb.x, (v[i].y - mu) * rstd * ww.y + bb.y);
+            o.y = pack2((v[i].z - mu) * rstd * ww.z + bb.z, (v[i].w - mu) * rstd * ww.w + bb.w);
+            *(uint2 *)(Y + (size_t)row * d + c0) = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------- attention
+
+// QKV [rows][3d] bf16 (q | k | v, head h at columns h*64), out AO [rows][d] bf16.
+// grid (heads, images); block 256; dynamic LDS: K [T_pad][64] swizzled + Vt [64][T_pad+4].
+__global__ __launch_bounds__(256, 2) void k_attention(const uint16_t *__restrict__ QKV, uint16_t *__restrict__ AO,
+                                                      uint32_t T, uint32_t T_pad, uint32_t d)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *Ks = smem;                                  // T_pad * 128 B
+    uint16_t *Vt = (uint16_t *)(smem + (size_t)T_pad * 128);
+    const uint32_t vstride = T_pad + 4;
+    const uint32_t head = blockIdx.x, img = blockIdx.y;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, hi = lane >> 5;
+    const size_t row_base = (size_t)img * T;
+    const uint32_t ld = 3 * d;
+    const uint16_t *Qg = QKV + row_base * ld + head * 64;
+    const uint16_t *Kg = Qg + d;
+    const uint16_t *Vg = Qg + 2 * d;
+
+    // stage K (row-major, swizzled 16-B chunks) and V^T; rows >= T are zero
+    for (uint32_t i = tid; i < T_pad * 8; i += 256) {
+        uint32_t key = i >> 3, c = i & 7;
+        uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+        if (key < T) {
+            kv = *(const uint4 *)(Kg + (size_t)key * ld + c * 8);
+            vv = *(const uint4 *)(Vg + (size_t)key * ld + c * 8);
+        }
+        *(uint4 *)(Ks + lds_off(key, c)) = kv;
+        const uint16_t *ve = (const uint16_t *)&vv;
+#pragma unroll
+        for (int e = 0; e < 8; e++) Vt[(c * 8 + e) * vstride + key] = ve[e];
+    }
+    __syncthreads();
+
+    const float scale = 0.125f;   // head_dim^-0.5, head_dim = 64
+    const uint32_t n_qt = (T + 31) / 32, n_kt = T_pad / 32;
+    for (uint32_t qt = wave; qt < n_qt; qt += 4) {
+        const uint32_t qrow = qt * 32 + li;
+        // B operand of S^T = K Q^T: lane (q, hi) holds Q[q][16s + 8hi .. +8)
+        uint4 qf[4];
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+            qf[s] = qrow < T ? *(const uint4 *)(Qg + (size_t)qrow * ld + 16 * s + 8 * hi) : make_uint4(0, 0, 0, 0);
+        f32x16 o0, o1;
+#pragma unroll
+        for (int r = 0; r < 16; r++) o0[r] = o1[r] = 0.f;
+        float m_run = -INFINITY, l_run = 0.f;
+        for (uint32_t kt = 0; kt < n_kt; kt++) {
+            f32x16 sacc;
+#pragma unroll
+            for (int r = 0; r < 16; r++) sacc[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                union { uint4 u; bf16x8 v; } a, b;
+                a.u = *(const uint4 *)(Ks + lds_off(kt * 32 + li, 2 * s + hi));
+                b.u = qf[s];
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, sacc, 0, 0, 0);
+            }
+            // lane (q, hi), reg r  <->  key kt*32 + (r&3) + 8*(r>>2) + 4*hi
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                uint32_t key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                float sv = key < T ? sacc[r] * scale : -INFINITY;
+                sacc[r] = sv;
+                tmax = fmaxf(tmax, sv);
+            }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+            const float m_new = fmaxf(m_run, tmax);
+            const float alpha = __expf(m_run - m_new);      // m_run = -inf on the first tile -> 0
+            float psum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                float p = __expf(sacc[r] - m_new);
+                sacc[r] = p;
+                psum += p;
+            }
+            l_run = l_run * alpha + psum;
+            m_run = m_new;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                o0[r] *= alpha;
+                o1[r] *= alpha;
+            }
+            // O^T[d][q] += V^T[d][key] P^T[key][q]; P regs 8s..8s+7 are the B fragment of k-step s
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                union { uint4 u; bf16x8 v; } pb, va0, va1;
+                pb.u.x = pack2(sacc[8 * s + 0], sacc[8 * s + 1]);
+                pb.u.y = pack2(sacc[8 * s + 2], sacc[8 * s + 3]);
+                pb.u.z = pack2(sacc[8 * s + 4], sacc[8 * s + 5]);
+                pb.u.w = pack2(sacc[8 * s + 6], sacc[8 * s + 7]);
+                // A slot (hi, j) <-> key kt*32 + 16s + 8(j>>2) + 4hi + (j&3)
+                const uint32_t kb = kt * 32 + 16 * s + 4 * hi;
+                const uint2 a00 = *(const uint2 *)(Vt + (size_t)li * vstride + kb);
+                const uint2 a01 = *(const uint2 *)(Vt + (size_t)li * vstride + kb + 8);
+                const uint2 a10 = *(const uint2 *)(Vt + (size_t)(32 + li) * vstride + kb);
+                const uint2 a11 = *(const uint2 *)(Vt + (size_t)(32 + li) * vstride + kb + 8);
+                va0.u = make_uint4(a00.x, a00.y, a01.x, a01.y);
+                va1.u = make_uint4(a10.x, a10.y, a11.x, a11.y);
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va0.v, pb.v, o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va1.v, pb.v, o1, 0, 0, 0);
+            }
+        }
+        const float l_tot = l_run + __shfl_xor(l_run, 32);
+        const float inv_l = 1.0f / l_tot;
+        if (qrow < T) {
+            uint16_t *dst = AO + (row_base + qrow) * d + head * 64;
+            // lane (q, hi), reg r of o{0,1} <-> dim 32*{0,1} + (r&3) + 8*(r>>2) + 4*hi
+#pragma unroll
+            for (int g4 = 0; g4 < 4; g4++) {
+                uint2 w0, w1;
+                w0.x = pack2(o0[4 * g4 + 0] * inv_l, o0[4 * g4 + 1] * inv_l);
+                w0.y = pack2(o0[4 * g4 + 2] * inv_l, o0[4 * g4 + 3] * inv_l);
+                w1.x = pack2(o1[4 * g4 + 0] * inv_l, o1[4 * g4 + 1] * inv_l);
+                w1.y = pack2(o1[4 * g4 + 2] * inv_l, o1[4 * g4 + 3] * inv_l);
+                *(uint2 *)(dst + 8 * g4 + 4 * hi) = w0;
+                *(uint2 *)(dst + 32 + 8 * g4 + 4 * hi) = w1;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ head
+
+// one block per image: post_layernorm(X[b*T]) -> proj -> L2 normalise -> logits
+__global__ __launch_bounds__(256) void k_head(const float *__restrict__ X, uint32_t T, uint32_t d,
+                                              const float *__restrict__ lw, const float *__restrict__ lb,
+                                              const float *__restrict__ proj, uint32_t D,
+                                              const float *__restrict__ text, uint32_t C, float logit_scale,
+                                              float *__restrict__ logits, float *__restrict__ embeds)
+{
+    __shared__ float xs[1024];
+    __shared__ float es[1024];
+    __shared__ float red[8];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *x = X + (size_t)blockIdx.x * T * d;
+    float s = 0.f;
+    for (uint32_t i = tid; i < d; i += 256) s += x[i];
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    const float mu = (red[0] + red[1] + red[2] + red[3]) / (float)d;
+    __syncthreads();
+    float q = 0.f;
+    for (uint32_t i = tid; i < d; i += 256) {
+        float a = x[i] - mu;
+        q += a * a;
+    }
+    q = wave_sum(q);
+    if (lane == 0) red[wave] = q;
+    __syncthreads();
+    const float rstd = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)d + 1e-5f);
+    for (uint32_t i = tid; i < d; i += 256) xs[i] = (x[i] - mu) * rstd * lw[i] + lb[i];
+    __syncthreads();
+    // projection: one wave per output row, lanes stride the dot product
+    float nrm = 0.f;
+    for (uint32_t o = wave; o < D; o += 4) {
+        const float *pr = proj + (size_t)o * d;
+        float a = 0.f;
+        for (uint32_t i = lane; i < d; i += 64) a = fmaf(pr[i], xs[i], a);
+        a = wave_sum(a);
+        if (lane == 0) es[o] = a;
+        nrm += a * a;     // identical in every lane of the wave
+    }
+    __syncthreads();
+    if (lane == 0) red[4 + wave] = nrm;
+    __syncthreads();
+    const float inv = 1.0f / sqrtf(red[4] + red[5] + red[6] + red[7]);
+    for (uint32_t i = tid; i < D; i += 256) {
+        es[i] *= inv;
+        if (embeds) embeds[(size_t)blockIdx.x * D + i] = es[i];
+    }
+    __syncthreads();
+    for (uint32_t c = wave; c < C; c += 4) {
+        float a = 0.f;
+        for (uint32_t i = lane; i < D; i += 64) a = fmaf(es[i], text[(size_t)c * D + i], a);
+        a = wave_sum(a);
+        if (lane == 0 && logits) logits[(size_t)blockIdx.x * C + c] = logit_scale * a;
+    }
+}
+
+// fp32 -> bf16 weight conversion with optional K padding
+__global__ void k_convert_bf16(const float *__restrict__ src, uint16_t *__restrict__ dst, uint32_t rows,
+                               uint32_t K, uint32_t K_pad)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)rows * K_pad) return;
+    uint32_t r = i / K_pad, c = i % K_pad;
+    dst[i] = c < K ? f2bf(src[(size_t)r * K + c]) : (uint16_t)0;
+}
+
+// ---------------------------------------------------------------- host side
+
+static inline uint32_t round_up(uint32_t a, uint32_t b) { return (a + b - 1) / b * b; }
+
+static double bicubic_filter(double x)
+{
+    const double a = -0.5;
+    if (x < 0.0) x = -x;
+    if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
+    if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
+    return 0.0;
+}
+
+// Pillow's antialiased bicubic coefficient tables (Resample.c precompute_coeffs +
+// normalize_coeffs_8bpc), restated; oracle counterpart: d2r_oracle_resample_coeffs
+static int resample_coeffs(int in_size, int out_size, std::vector<int> &bounds, std::vector<int> &kk)
+{
+    double scale = (double)in_size / out_size, filterscale = scale < 1.0 ? 1.0 : scale;
+    double support = 2.0 * filterscale;
+    int ksize = (int)ceil(support) * 2 + 1;
+    bounds.assign((size_t)out_size * 2, 0);
+    kk.assign((size_t)out_size * ksize, 0);
+    std::vector<double> k(ksize);
+    for (int xx = 0; xx < out_size; xx++) {
+        double center = (xx + 0.5) * scale, ww = 0.0, ss = 1.0 / filterscale;
+        int xmin = (int)(center - support + 0.5);
+        if (xmin < 0) xmin = 0;
+        int xmax = (int)(center + support + 0.5);
+        if (xmax > in_size) xmax = in_size;
+        xmax -= xmin;
+        for (int x = 0; x < xmax; x++) {
+            k[x] = bicubic_filter((x + xmin - center + 0.5) * ss);
+            ww += k[x];
+        }
+        for (int x = 0; x < ksize; x++) {
+            double v = x < xmax ? (ww != 0.0 ? k[x] / ww : k[x]) : 0.0;
+            kk[(size_t)xx * ksize + x] = v < 0 ? (int)(-0.5 + v * (1 << PRECISION_BITS))
+                                               : (int)(0.5 + v * (1 << PRECISION_BITS));
+        }
+        bounds[xx * 2] = xmin;
+        bounds[xx * 2 + 1] = xmax;
+    }
+    return ksize;
+}
+
+// Resampling geometry + Pillow coefficient tables for one frame size, uploaded once.
+static int prep_tables(d2r_ctx *ctx, d2r_clip *clip, uint32_t w, uint32_t h, int rot90, const PrepCache **out)
+{
+    for (const PrepCache &pc : clip->prep)
+        if (pc.w == w && pc.h == h && pc.rot90 == rot90) {
+            *out = &pc;
+            return D2R_OK;
+        }
+    const uint32_t S = clip->desc.image_size, P = clip->desc.patch_size;
+    ResampleTables R{};
+    R.iw = rot90 ? (int)h : (int)w;
+    R.ih = rot90 ? (int)w : (int)h;
+    // HF get_resize_output_image_size(shortest_edge=S, default_to_square=False)
+    int short_e = R.iw < R.ih ? R.iw : R.ih, long_e = R.iw < R.ih ? R.ih : R.iw;
+    int new_long = (int)((double)S * long_e / short_e);
+    R.rw = R.iw <= R.ih ? (int)S : new_long;
+    R.rh = R.iw <= R.ih ? new_long : (int)S;
+    R.need_h = R.rw != R.iw;
+    R.need_v = R.rh != R.ih;
+    R.left = (R.rw - (int)S) / 2;
+    R.top = (R.rh - (int)S) / 2;
+    std::vector<int> bh, kh, bv, kv;
+    R.ks_h = resample_coeffs(R.iw, R.rw, bh, kh);
+    R.ks_v = resample_coeffs(R.ih, R.rh, bv, kv);
+    const uint32_t band = P;
+    int max_rows = (int)band;
+    if (R.need_v) {
+        max_rows = 0;
+        for (uint32_t r0 = 0; r0 < S; r0 += band) {
+            uint32_t last = std::min(r0 + band, S) - 1;
+            int y0 = bv[2 * (R.top + r0)], y1 = bv[2 * (R.top + last)] + bv[2 * (R.top + last) + 1];
+            max_rows = std::max(max_rows, y1 - y0);
+        }
+    }
+    R.max_rows = max_rows;
+    std::vector<int> all;
+    size_t o_bh = 0, o_kh = o_bh + bh.size(), o_bv = o_kh + kh.size(), o_kv = o_bv + bv.size();
+    all.insert(all.end(), bh.begin(), bh.end());
+    all.insert(all.end(), kh.begin(), kh.end());
+    all.insert(all.end(), bv.begin(), bv.end());
+    all.insert(all.end(), kv.begin(), kv.end());
+    int *dev = nullptr;
+    if (hipMalloc(&dev, all.size() * sizeof(int)) != hipSuccess) return d2r_fail(ctx, D2R_ERR_MEMORY, "hipMalloc failed");
+    clip->allocs.push_back(dev);
+    D2R_HIP(ctx, hipMemcpy(dev, all.data(), all.size() * sizeof(int), hipMemcpyHostToDevice));
+    R.bounds_h = dev + o_bh;
+    R.kk_h = dev + o_kh;
+    R.bounds_v = dev + o_bv;
+    R.kk_v = dev + o_kv;
+    clip->prep.push_back(PrepCache{w, h, rot90, R});
+    *out = &clip->prep.back();
+    return D2R_OK;
+}
+
+// frames (device, [n][h][w][3] u8) -> patches (bf16 [n*g*g][Kp_pad]) and/or pixel_values
+int d2r_launch_preprocess(d2r_ctx *ctx, d2r_clip *clip, const uint8_t *frames_dev, uint32_t n, uint32_t w,
+                          uint32_t h, int rot90, uint16_t *patches_dev, float *pixel_values_dev)
+{
+    const uint32_t S = clip->desc.image_size, P = clip->desc.patch_size;
+    const PrepCache *pc = nullptr;
+    int rc = prep_tables(ctx, clip, w, h, rot90, &pc);
+    if (rc) return rc;
+    const ResampleTables &R = pc->R;
+    const uint32_t band = P;
+    size_t lds = (size_t)R.max_rows * S * 3;
+    if (lds > 150 * 1024) return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "preprocess band does not fit in LDS");
+    if (lds > 64 * 1024)
+        hipFuncSetAttribute((const void *)k_preprocess, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    hipLaunchKernelGGL(k_preprocess, dim3((S + band - 1) / band, n), dim3(256), lds, ctx->stream, frames_dev, w, h,
+                       rot90, R, S, P, band, patches_dev, clip->Kp_pad, pixel_values_dev);
+    D2R_HIP(ctx, hipGetLastError());
+    return D2R_OK;
+}
+
+template <int EPI>
+static int launch_gemm(d2r_ctx *ctx, const uint16_t *A, const uint16_t *W, const float *bias, void *C,
+                       uint32_t M_real, uint32_t N, uint32_t K)
+{
+    const uint32_t M_pad = round_up(M_real, BM);
+    if (N % BN || K % BK) return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "GEMM N must be a multiple of 128 and K of 64");
+    const uint32_t nwg = (M_pad / BM) * (N / BN);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void *)k_gemm<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_gemm<EPI>, dim3(nwg), dim3(256), 65536, ctx->stream, A, W, bias, C, M_pad, N, K, M_real);
+    D2R_HIP(ctx, hipGetLastError());
+    return D2R_OK;
+}
+
+// patches (bf16 [n*(T-1) padded to 128][Kp_pad]) -> logits/embeds.  Workspaces:
+//  clipws[0] patch_out f32, [1] X f32, [2] Xn bf16, [3] QKV bf16, [4] AO bf16, [5] H bf16
+int d2r_clip_forward(d2r_ctx *ctx, const d2r_clip *clip, const uint16_t *patches_dev, uint32_t n,
+                     const float *text_dev, uint32_t C, float logit_scale, float *logits_dev, float *embeds_dev)
+{
+    const d2r_clip_desc &D = clip->desc;
+    const uint32_t d = D.hidden_size, T = clip->T, mlp = D.mlp_size;
+    const uint32_t rows = n * T, rows_pad = round_up(rows, BM);
+    const uint32_t prow = n * (T - 1);
+    int rc;
+    if ((rc = d2r_reserve(ctx, ctx->clipws[0], (size_t)round_up(prow, BM) * d * 4))) return rc;
+    if ((rc = d2r_reserve(ctx, ctx->clipws[1], (size_t)rows_pad * d * 4))) return rc;
+    if ((rc = d2r_reserve(ctx, ctx->clipws[2], (size_t)rows_pad * d * 2))) return rc;
+    if ((rc = d2r_reserve(ctx, ctx->clipws[3], (size_t)rows_pad * 3 * d * 2))) return rc;
+    if ((rc = d2r_reserve(ctx, ctx->clipws[4], (size_t)rows_pad * d * 2))) return rc;
+    if ((rc = d2r_reserve(ctx, ctx->clipws[5], (size_t)rows_pad * mlp * 2))) return rc;
+    float *patch_out = (float *)ctx->clipws[0].p, *X = (float *)ctx->clipws[1].p;
+    uint16_t *Xn = (uint16_t *)ctx->clipws[2].p, *QKV = (uint16_t *)ctx->clipws[3].p;
+    uint16_t *AO = (uint16_t *)ctx->clipws[4].p, *H = (uint16_t *)ctx->clipws[5].p;
+
+    if ((rc = launch_gemm<EPI_F32>(ctx, patches_dev, clip->w.w_patch, nullptr, patch_out, prow, d, clip->Kp_pad)))
+        return rc;
+    hipLaunchKernelGGL(k_embed_ln, dim3((rows + 3) / 4), dim3(256), 0, ctx->stream, patch_out, clip->w.cls,
+                       clip->w.pos, clip->w.pre_w, clip->w.pre_b, X, rows, T, d);
+    const uint32_t T_pad = round_up(T, 32);
+    const size_t attn_lds = (size_t)T_pad * 128 + (size_t)64 * (T_pad + 4) * 2;
+    static bool attn_attr = false;
+    if (!attn_attr) {
+        hipFuncSetAttribute((const void *)k_attention, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attn_attr = true;
+    }
+    if (attn_lds > 160 * 1024) return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "sequence too long for the attention LDS layout");
+    for (uint32_t l = 0; l < D.num_layers; l++) {
+        const ClipWeights::Layer &L = clip->layers[l];
+        hipLaunchKernelGGL(k_layernorm, dim3((rows + 3) / 4), dim3(256), 0, ctx->stream, X, L.ln1_w, L.ln1_b, Xn,
+                           rows, d);
+        if ((rc = launch_gemm<EPI_BIAS_BF16>(ctx, Xn, L.w_qkv, L.b_qkv, QKV, rows, 3 * d, d))) return rc;
+        hipLaunchKernelGGL(k_attention, dim3(D.num_heads, n), dim3(256), attn_lds, ctx->stream, QKV, AO, T, T_pad, d);
+        if ((rc = launch_gemm<EPI_BIAS_RESID_F32>(ctx, AO, L.w_o, L.b_o, X, rows, d, d))) return rc;
+        hipLaunchKernelGGL(k_layernorm, dim3((rows + 3) / 4), dim3(256), 0, ctx->stream, X, L.ln2_w, L.ln2_b, Xn,
+                           rows, d);
+        if ((rc = launch_gemm<EPI_BIAS_GELU_BF16>(ctx, Xn, L.w_fc1, L.b_fc1, H, rows, mlp, d))) return rc;
+        if ((rc = launch_gemm<EPI_BIAS_RESID_F32>(ctx, H, L.w_fc2, L.b_fc2, X, rows, d, mlp))) return rc;
+    }
+    hipLaunchKernelGGL(k_head, dim3(n), dim3(256), 0, ctx->stream, X, T, d, clip->w.post_w, clip->w.post_b,
+                       clip->w.proj, D.proj_dim, text_dev, C, logit_scale, logits_dev, embeds_dev);
+    D2R_HIP(ctx, hipGetLastError());
+    return D2R_OK;
+}
+
+int d2r_launch_patchify(d2r_ctx *ctx, const d2r_clip *clip, const float *pv_dev, uint32_t n, uint16_t *patches_dev)
+{
+    size_t total = (size_t)n * 3 * clip->desc.image_size * clip->desc.image_size;
+    hipLaunchKernelGGL(k_patchify, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, ctx->stream, pv_dev, n,
+                       clip->desc.image_size, clip->desc.patch_size, patches_dev, clip->Kp_pad);
+    D2R_HIP(ctx, hipGetLastError());
+    return D2R_OK;
+}
+
+size_t d2r_clip_patch_bytes(const d2r_clip *clip, uint32_t n)
+{
+    return (size_t)round_up(n * (clip->T - 1), BM) * clip->Kp_pad * 2;
+}
+
+// ------------------------------------------------------------ create/destroy
+
+extern "C" int d2r_clip_create(d2r_ctx *ctx, const d2r_clip_desc *desc, const float *weights, size_t n_floats,
+                               d2r_clip **out)
+{
+    if (!ctx || !desc || !weights || !out) return d2r_fail(ctx, D2R_ERR_INVALID, "null argument");
+    const uint32_t d = desc->hidden_size, P = desc->patch_size, S = desc->image_size, mlp = desc->mlp_size;
+    if (d % 128 || mlp % 128 || d > 1024 || desc->proj_dim > 1024 || d / desc->num_heads != 64 || S % P)
+        return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "unsupported CLIP geometry (need head_dim 64, d,mlp % 128 == 0, d <= 1024)");
+    hipSetDevice(ctx->device);
+    d2r_clip *c = new d2r_clip();
+    c->ctx = ctx;
+    c->desc = *desc;
+    c->T = (S / P) * (S / P) + 1;
+    c->Kp = 3 * P * P;
+    c->Kp_pad = round_up(c->Kp, BK);
+    const uint32_t T = c->T, Dp = desc->proj_dim;
+    size_t expect = (size_t)d * c->Kp + d + (size_t)T * d + 2 * d +
+                    (size_t)desc->num_layers * (4 * (size_t)d + 4 * ((size_t)d * d + d) + (size_t)mlp * d + mlp + (size_t)d * mlp + d) +
+                    2 * d + (size_t)Dp * d;
+    if (n_floats != expect) {
+        delete c;
+        return d2r_fail(ctx, D2R_ERR_INVALID, "weight blob size does not match the descriptor");
+    }
+    // stage the whole blob on the device once, then carve fp32 views and bf16 copies
+    float *blob = nullptr;
+    if (hipMalloc(&blob, n_floats * 4) != hipSuccess) {
+        delete c;
+        return d2r_fail(ctx, D2R_ERR_MEMORY, "hipMalloc failed for CLIP weights");
+    }
+    c->allocs.push_back(blob);
+    if (hipMemcpy(blob, weights, n_floats * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        d2r_clip_destroy(c);
+        return d2r_fail(ctx, D2R_ERR_DEVICE, "weight upload failed");
+    }
+    size_t off = 0;
+    auto f32 = [&](size_t n) { const float *p = blob + off; off += n; return p; };
+    bool ok = true;
+    auto bf16 = [&](const float *src, uint32_t rows, uint32_t K, uint32_t K_pad) -> const uint16_t * {
+        uint16_t *p = nullptr;
+        if (hipMalloc(&p, (size_t)rows * K_pad * 2) != hipSuccess) { ok = false; return nullptr; }
+        c->allocs.push_back(p);
+        size_t tot = (size_t)rows * K_pad;
+        hipLaunchKernelGGL(k_convert_bf16, dim3((uint32_t)((tot + 255) / 256)), dim3(256), 0, ctx->stream, src, p, rows, K, K_pad);
+        return p;
+    };
+    c->w.w_patch = bf16(f32((size_t)d * c->Kp), d, c->Kp, c->Kp_pad);
+    c->w.cls = f32(d);
+    c->w.pos = f32((size_t)T * d);
+    c->w.pre_w = f32(d);
+    c->w.pre_b = f32(d);
+    c->layers.resize(desc->num_layers);
+    for (uint32_t l = 0; l < desc->num_layers && ok; l++) {
+        ClipWeights::Layer &L = c->layers[l];
+        L.ln1_w = f32(d);
+        L.ln1_b = f32(d);
+        // q, k, v are consecutive [d][d] + [d] pairs: fuse into one [3d][d] operand and one [3d] bias
+        uint16_t *wqkv = nullptr;
+        float *bqkv = nullptr;
+        if (hipMalloc(&wqkv, (size_t)3 * d * d * 2) != hipSuccess || hipMalloc(&bqkv, (size_t)3 * d * 4) != hipSuccess) { ok = false; break; }
+        c->allocs.push_back(wqkv);
+        c->allocs.push_back(bqkv);
+        for (int j = 0; j < 3; j++) {
+            const float *wj = f32((size_t)d * d), *bj = f32(d);
+            size_t tot = (size_t)d * d;
+            hipLaunchKernelGGL(k_convert_bf16, dim3((uint32_t)((tot + 255) / 256)), dim3(256), 0, ctx->stream, wj,
+                               wqkv + (size_t)j * d * d, d, d, d);
+            hipMemcpyAsync(bqkv + (size_t)j * d, bj, (size_t)d * 4, hipMemcpyDeviceToDevice, ctx->stream);
+        }
+        L.w_qkv = wqkv;
+        L.b_qkv = bqkv;
+        L.w_o = bf16(f32((size_t)d * d), d, d, d);
+        L.b_o = f32(d);
+        L.ln2_w = f32(d);
+        L.ln2_b = f32(d);
+        L.w_fc1 = bf16(f32((size_t)mlp * d), mlp, d, d);
+        L.b_fc1 = f32(mlp);
+        L.w_fc2 = bf16(f32((size_t)d * mlp), d, mlp, mlp);
+        L.b_fc2 = f32(d);
+    }
+    c->w.post_w = f32(d);
+    c->w.post_b = f32(d);
+    c->w.proj = f32((size_t)Dp * d);
+    if (!ok || hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess) {
+        d2r_clip_destroy(c);
+        return d2r_fail(ctx, D2R_ERR_DEVICE, "CLIP weight conversion failed");
+    }
+    *out = c;
+    return D2R_OK;
+}
+
+extern "C" void d2r_clip_destroy(d2r_clip *c)
+{
+    if (!c) return;
+    for (void *p : c->allocs) hipFree(p);
+    delete c;
+}
+
+uint32_t d2r_clip_image_size(const d2r_clip *c) { return c->desc.image_size; }
+uint32_t d2r_clip_proj_dim(const d2r_clip *c) { return c->desc.proj_dim; }

@@ -1,0 +1,89 @@
+// Internal declarations shared by the HIP translation units of libd2r.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/d2r.h"
+
+#define D2R_MAX_LEVELS 16
+#define D2R_GRID 128
+#define D2R_DT 0.0016914558f           // sqrt(3)/1024
+#define D2R_INV_DT (1.0f / D2R_DT)
+#define D2R_N_WFRAG 24                 // MLP weight fragments (see nerf.hip)
+
+struct LevelMeta {
+    float scale;
+    uint32_t res;
+    uint32_t size;
+    uint32_t offset;
+    uint32_t hashed;
+};
+
+struct NerfParams {
+    const uint32_t *grid;      // [n_entries] half2 packed
+    uint32_t grid_bytes;
+    uint32_t n_levels;
+    LevelMeta lv[D2R_MAX_LEVELS];
+    const uint64_t *bricks;    // [32^3] 4x4x4-cell occupancy bricks
+    const uint4 *wfrag;        // [24][64] MFMA A-operand fragments of the MLPs
+    float bbox_lo[3], bbox_hi[3];  // bounding box of occupied cells (+margin), unit-cube units
+};
+
+struct ViewParams {
+    uint32_t W, H;
+    float focal[2], center[2];
+    float scale, inv_scale;
+    float offset[3];
+    float background[4];
+    float min_transmittance, near_distance;
+};
+
+struct ClipParams;   // clip.hip
+
+struct d2r_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // growable device workspaces (one per role so sizes are independent)
+    struct Buf { void *p = nullptr; size_t cap = 0; };
+    Buf cams, queue, counters, frames, rgba, depth, poses, clipws[8], text, logits, pix;
+    // background of the current view
+    Buf bg_rgba, bg_depth, bg_u8;
+    uint32_t bg_w = 0, bg_h = 0;
+    d2r_render_stats stats{};
+    int64_t chunk = 128;       // candidates per pass of the fused path
+    int64_t march_blocks = 0;  // 0 = auto
+};
+
+struct d2r_nerf {
+    d2r_ctx *ctx;
+    NerfParams P{};
+    void *d_grid = nullptr, *d_bricks = nullptr, *d_wfrag = nullptr;
+};
+
+int d2r_fail(d2r_ctx *ctx, int code, const std::string &msg);
+int d2r_reserve(d2r_ctx *ctx, d2r_ctx::Buf &b, size_t bytes);
+
+#define D2R_HIP(ctx, expr)                                                              \
+    do {                                                                                \
+        hipError_t e_ = (expr);                                                         \
+        if (e_ != hipSuccess)                                                           \
+            return d2r_fail(ctx, D2R_ERR_DEVICE,                                        \
+                            std::string(#expr) + ": " + hipGetErrorString(e_));         \
+    } while (0)
+
+// nerf.hip launchers
+int d2r_launch_cameras_direct(d2r_ctx *, const ViewParams &, const float *cams_nerf_dev, uint32_t n,
+                              float *cams_out);
+int d2r_launch_cameras_virtual(d2r_ctx *, const ViewParams &, const float *obj_now16,
+                               const float *cam16, const float *obj_poses_dev, uint32_t n,
+                               float *cams_out);
+int d2r_launch_render(d2r_ctx *, const d2r_nerf *, const ViewParams &, const float *cams_dev,
+                      uint32_t n, bool composite, float *rgba_dev, float *depth_dev,
+                      uint8_t *frames_dev);
+int d2r_launch_bg_quantize(d2r_ctx *, uint32_t w, uint32_t h);
+ViewParams d2r_view_params(const d2r_view *v);

@@ -1,0 +1,258 @@
+"""Python handles over libd2r.so: Context (one per GPU), Testbed (the pyngp.Testbed surface the
+path uses) and ClipScorer (the CLIPModel/CLIPProcessor surface the path uses).
+
+Reference surfaces mirrored here:
+  pyngp.Testbed  — reconstruction/combined_rendering.py:98-105,112-113,116,123-130 and
+                   reconstruction/ngp_visual_model.py:24-28
+  CLIPModel / CLIPProcessor — clip_scoring.py:150-151,177-181
+"""
+from __future__ import annotations
+
+import ctypes as C
+import dataclasses
+
+import numpy as np
+
+from . import _lib
+from .clip_model import pack_vision_weights
+from .scene import NerfModel, View
+
+Shade = "Shade"     # pyngp.Shade
+Depth = "Depth"     # pyngp.Depth
+
+
+class Context:
+    """d2r_ctx: one per GPU; owns the HIP stream and workspaces."""
+
+    def __init__(self, device: int = 0):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(self.lib.d2r_ctx_create(C.c_int(device), C.byref(h)))
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.d2r_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc):
+        _lib.check(rc, self.h)
+
+    def set_stream(self, hip_stream_ptr: int):
+        self.check(self.lib.d2r_ctx_set_stream(self.h, C.c_void_p(hip_stream_ptr)))
+
+    def synchronize(self):
+        self.check(self.lib.d2r_ctx_synchronize(self.h))
+
+    def set_option(self, key: str, value: int):
+        self.check(self.lib.d2r_ctx_set_option(self.h, key.encode(), C.c_int64(value)))
+
+    def render_stats(self, collect_K: int | None = None) -> dict:
+        if collect_K is not None:
+            self.check(self.lib.d2r_collect_render_stats(self.h, C.c_uint32(collect_K)))
+        s = _lib.RenderStats()
+        self.check(self.lib.d2r_get_render_stats(self.h, C.byref(s)))
+        return {"rays_total": s.rays_total, "rays_alive": s.rays_alive, "samples": s.samples}
+
+    def set_background(self, view: View, bg_rgba: np.ndarray, bg_depth: np.ndarray):
+        a = np.ascontiguousarray(bg_rgba, np.float32)
+        d = np.ascontiguousarray(bg_depth, np.float32)
+        assert a.shape == (view.height, view.width, 4) and d.shape == (view.height, view.width)
+        v = _lib.view_c(view)
+        self.check(self.lib.d2r_set_background(self.h, C.byref(v), _lib.ptr(a), _lib.ptr(d)))
+
+
+class _Nerf:
+    """`testbed.nerf` namespace (render_min_transmittance lives there in pyngp)."""
+
+    def __init__(self):
+        self.render_min_transmittance = 0.01
+
+
+class Testbed:
+    """The slice of pyngp.Testbed that Dream2Real's render path touches, backed by libd2r.
+
+    `training_views` is the per-view metadata a snapshot carries (intrinsics at the training
+    resolution); `dataset_scale` / `dataset_offset` are the values nerf_matrix_to_ngp uses.
+    """
+
+    def __init__(self, ctx: Context, model: NerfModel, training_views=None, dataset_scale: float = 1.0,
+                 dataset_offset=(0.0, 0.3, 0.5)):
+        self.ctx = ctx
+        self.model = model
+        lv = model.levels
+        self._keep = dict(
+            scale=np.ascontiguousarray(lv.scale, np.float32), res=np.ascontiguousarray(lv.res, np.uint32),
+            size=np.ascontiguousarray(lv.size, np.uint32), offset=np.ascontiguousarray(lv.offset, np.uint32),
+            grid=np.ascontiguousarray(model.grid, np.float16), dw1=np.ascontiguousarray(model.dw1, np.float16),
+            dw2=np.ascontiguousarray(model.dw2, np.float16), cw1=np.ascontiguousarray(model.cw1, np.float16),
+            cw2=np.ascontiguousarray(model.cw2, np.float16), cw3=np.ascontiguousarray(model.cw3, np.float16),
+            occ=np.ascontiguousarray(model.occ_bits, np.uint8))
+        k = self._keep
+        desc = _lib.NerfDesc(lv.n_levels, lv.n_features, _lib.ptr(k["scale"]), _lib.ptr(k["res"]),
+                             _lib.ptr(k["size"]), _lib.ptr(k["offset"]), lv.n_entries, _lib.ptr(k["grid"]),
+                             _lib.ptr(k["dw1"]), _lib.ptr(k["dw2"]), _lib.ptr(k["cw1"]), _lib.ptr(k["cw2"]),
+                             _lib.ptr(k["cw3"]), _lib.ptr(k["occ"]))
+        h = C.c_void_p()
+        ctx.check(ctx.lib.d2r_nerf_create(ctx.h, C.byref(desc), C.byref(h)))
+        self.h = h
+        # pyngp.Testbed attributes the path reads/writes
+        self.background_color = [0.0, 0.0, 0.0, 1.0]
+        self.render_ground_truth = False
+        self.render_mode = Shade
+        self.snap_to_pixel_centers = True
+        self.shall_train = False
+        self.nerf = _Nerf()
+        self.training_views = training_views or [dict(fx=924.66912, fy=926.49735, cx=654.51953, cy=355.18523,
+                                                      w=1280, h=720)]
+        self.dataset_scale = dataset_scale
+        self.dataset_offset = tuple(dataset_offset)
+        self._view_idx = 0
+        self._cam = np.eye(4, dtype=np.float32)[:3]
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.d2r_nerf_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # --- pyngp.Testbed surface -------------------------------------------------
+    def set_camera_to_training_view(self, idx: int):
+        self._view_idx = int(idx) % len(self.training_views)
+
+    def set_nerf_camera_matrix(self, m):
+        self._cam = np.ascontiguousarray(np.asarray(m, np.float64)[:3, :4], np.float32)
+
+    def view(self, width: int, height: int) -> View:
+        tv = self.training_views[self._view_idx]
+        return View.from_training_view(width, height, tv["fx"], tv["fy"], tv["cx"], tv["cy"], tv["w"], tv["h"],
+                                       scale=self.dataset_scale, offset=self.dataset_offset,
+                                       background=tuple(self.background_color),
+                                       min_transmittance=self.nerf.render_min_transmittance)
+
+    def render(self, width: int, height: int, spp: int = 1, linear: bool = True) -> np.ndarray:
+        """float32 [h,w,4]; Shade -> premultiplied linear RGBA, Depth -> depth in every colour
+        channel (reference combined_rendering.py:127,130 read channel 0 only)."""
+        if spp != 1 or not linear:
+            raise NotImplementedError("the path renders with spp=1, linear=True only")
+        rgba, depth = self.render_batch(self._cam[None], width, height)
+        if self.render_mode == Shade:
+            return rgba[0]
+        out = np.zeros((height, width, 4), np.float32)
+        out[..., 0] = out[..., 1] = out[..., 2] = depth[0]
+        out[..., 3] = rgba[0][..., 3]
+        return out
+
+    # --- batched form ----------------------------------------------------------
+    def render_batch(self, cams_nerf, width: int, height: int):
+        """n cameras (each the 3x4 handed to set_nerf_camera_matrix) -> (rgba [n,h,w,4], depth [n,h,w])."""
+        cams = np.ascontiguousarray(np.asarray(cams_nerf, np.float64)[:, :3, :4], np.float32)
+        n = cams.shape[0]
+        rgba = np.empty((n, height, width, 4), np.float32)
+        depth = np.empty((n, height, width), np.float32)
+        v = _lib.view_c(self.view(width, height))
+        ns = C.c_uint64(0)
+        self.ctx.check(self.ctx.lib.d2r_render(self.ctx.h, self.h, C.byref(v), _lib.ptr(cams), C.c_uint32(n),
+                                               _lib.ptr(rgba), _lib.ptr(depth), C.byref(ns)))
+        self.last_samples = int(ns.value)
+        return rgba, depth
+
+    def eval_points(self, xyz, dirs) -> np.ndarray:
+        p = np.ascontiguousarray(xyz, np.float32)
+        d = np.ascontiguousarray(dirs, np.float32)
+        out = np.empty((p.shape[0], 4), np.float32)
+        self.ctx.check(self.ctx.lib.d2r_nerf_eval_points(self.ctx.h, self.h, _lib.ptr(p), _lib.ptr(d),
+                                                         C.c_uint32(p.shape[0]), _lib.ptr(out)))
+        return out
+
+    def render_composite(self, view: View, obj_pose_now, cam_pose, obj_poses) -> np.ndarray:
+        """K candidate poses -> uint8 [K,h,w,3] (needs Context.set_background for this view)."""
+        a = np.ascontiguousarray(np.asarray(obj_pose_now, np.float64).reshape(16), np.float32)
+        c = np.ascontiguousarray(np.asarray(cam_pose, np.float64).reshape(16), np.float32)
+        p = np.ascontiguousarray(np.asarray(obj_poses, np.float64).reshape(-1, 16), np.float32)
+        K = p.shape[0]
+        frames = np.empty((K, view.height, view.width, 3), np.uint8)
+        v = _lib.view_c(view)
+        self.ctx.check(self.ctx.lib.d2r_render_composite(self.ctx.h, self.h, C.byref(v), _lib.ptr(a), _lib.ptr(c),
+                                                         _lib.ptr(p), C.c_uint32(K), _lib.ptr(frames)))
+        return frames
+
+
+class ClipScorer:
+    """CLIPModel + CLIPProcessor as the path uses them: images in, logits_per_image out, text
+    embeddings computed once and cached by the caller."""
+
+    def __init__(self, ctx: Context, cfg: dict, state_dict: dict):
+        self.ctx, self.cfg = ctx, cfg
+        blob = pack_vision_weights(state_dict, cfg)
+        desc = _lib.ClipDesc(cfg["image_size"], cfg["patch_size"], cfg["hidden_size"], cfg["num_layers"],
+                             cfg["num_heads"], cfg["mlp"], cfg["proj"])
+        h = C.c_void_p()
+        ctx.check(ctx.lib.d2r_clip_create(ctx.h, C.byref(desc), _lib.ptr(blob), C.c_size_t(blob.size), C.byref(h)))
+        self.h = h
+        self.logit_scale = float(np.exp(np.float32(state_dict.get("logit_scale", 4.6052))))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.d2r_clip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def score_frames(self, frames_u8, text_embeds, rot90: bool = True, return_embeds: bool = False):
+        f = np.ascontiguousarray(frames_u8, np.uint8)
+        n, h, w, _ = f.shape
+        t = np.ascontiguousarray(text_embeds, np.float32)
+        Cn = t.shape[0]
+        logits = np.empty((n, Cn), np.float32)
+        emb = np.empty((n, self.cfg["proj"]), np.float32) if return_embeds else None
+        self.ctx.check(self.ctx.lib.d2r_clip_score_frames(
+            self.ctx.h, self.h, _lib.ptr(f), C.c_uint32(n), C.c_uint32(w), C.c_uint32(h), C.c_int(int(rot90)),
+            _lib.ptr(t), C.c_uint32(Cn), C.c_float(self.logit_scale), _lib.ptr(logits), _lib.ptr(emb)))
+        return (logits, emb) if return_embeds else logits
+
+    def preprocess(self, frames_u8, rot90: bool = True) -> np.ndarray:
+        f = np.ascontiguousarray(frames_u8, np.uint8)
+        n, h, w, _ = f.shape
+        S = self.cfg["image_size"]
+        pv = np.empty((n, 3, S, S), np.float32)
+        self.ctx.check(self.ctx.lib.d2r_clip_preprocess(self.ctx.h, self.h, _lib.ptr(f), C.c_uint32(n), C.c_uint32(w),
+                                                        C.c_uint32(h), C.c_int(int(rot90)), _lib.ptr(pv)))
+        return pv
+
+    def embed_pixels(self, pixel_values) -> np.ndarray:
+        pv = np.ascontiguousarray(pixel_values, np.float32)
+        n = pv.shape[0]
+        emb = np.empty((n, self.cfg["proj"]), np.float32)
+        self.ctx.check(self.ctx.lib.d2r_clip_embed_pixels(self.ctx.h, self.h, _lib.ptr(pv), C.c_uint32(n), _lib.ptr(emb)))
+        return emb
+
+
+def render_score_device(ctx: Context, fg: Testbed, scorer: ClipScorer, view: View, obj_pose_now, cam_pose,
+                        obj_poses_dev_ptr: int, K: int, text_embeds, logits_dev_ptr: int, frames_out=None):
+    """The fused hot path on device pointers (d2r_render_score): candidate poses already in
+    HBM, logits written to HBM, asynchronous on the context's stream."""
+    a = np.ascontiguousarray(np.asarray(obj_pose_now, np.float64).reshape(16), np.float32)
+    c = np.ascontiguousarray(np.asarray(cam_pose, np.float64).reshape(16), np.float32)
+    t = np.ascontiguousarray(text_embeds, np.float32)
+    v = _lib.view_c(view)
+    ctx.check(ctx.lib.d2r_render_score(ctx.h, fg.h, scorer.h, C.byref(v), _lib.ptr(a), _lib.ptr(c),
+                                       C.c_void_p(obj_poses_dev_ptr), C.c_uint32(K), _lib.ptr(t),
+                                       C.c_uint32(t.shape[0]), C.c_float(scorer.logit_scale),
+                                       C.c_void_p(logits_dev_ptr), _lib.ptr(frames_out)))

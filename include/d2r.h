@@ -1,0 +1,230 @@
+/*
+ * d2r.h — C ABI of libd2r.so: the MI355X (gfx950) render-and-score path of Dream2Real.
+ *
+ * The reference has no C ABI in tree; its two native seams on this path are Python
+ * extension surfaces:
+ *   (1) pyngp.Testbed  — load_snapshot / set_camera_to_training_view /
+ *       set_nerf_camera_matrix / background_color / render_mode / render(w,h,spp,linear)
+ *       used at reference reconstruction/combined_rendering.py:98-105,112-113,116,123-130
+ *       and reconstruction/ngp_visual_model.py:24-28;
+ *   (2) transformers.CLIPModel / CLIPProcessor used at reference clip_scoring.py:150-151,
+ *       177-181.
+ * Each entry point below names the reference interface it replaces.  The Python host
+ * (dream2real_amd/) binds these with ctypes; INTEGRATION.md shows the binding a
+ * reference maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative d2r_status; the message is
+ *     available from d2r_last_error(ctx) (or d2r_last_error(NULL) for create failures);
+ *   - no C++ exception crosses the ABI, nothing calls abort();
+ *   - "host" pointers are read/written before the call returns; "dev" pointers are HIP
+ *     device pointers on the context's device, used on the context's stream;
+ *   - the library owns its handles; parameter blobs are copied to the device at create;
+ *   - one context per GPU; calls on one context must be serialised by the caller;
+ *   - there is NO CPU fallback: every compute entry point needs a gfx950 device.
+ */
+#ifndef D2R_H
+#define D2R_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define D2R_API __attribute__((visibility("default")))
+#define D2R_ABI_VERSION 1
+
+typedef enum {
+    D2R_OK = 0,
+    D2R_ERR_INVALID = -1,   /* bad argument */
+    D2R_ERR_DEVICE = -2,    /* HIP error, or no gfx950 device */
+    D2R_ERR_MEMORY = -3,    /* allocation failed */
+    D2R_ERR_UNSUPPORTED = -4
+} d2r_status;
+
+typedef struct d2r_ctx d2r_ctx;
+typedef struct d2r_nerf d2r_nerf;
+typedef struct d2r_clip d2r_clip;
+
+/* ------------------------------------------------------------------ context */
+
+D2R_API int d2r_abi_version(void);
+/* One context per GPU.  Owns a HIP stream and a workspace that grows on demand. */
+D2R_API int d2r_ctx_create(int device, d2r_ctx **out);
+D2R_API void d2r_ctx_destroy(d2r_ctx *ctx);
+/* Run on a caller-owned hipStream_t (e.g. torch's current stream); NULL restores the
+ * context's own stream. */
+D2R_API int d2r_ctx_set_stream(d2r_ctx *ctx, void *hip_stream);
+D2R_API int d2r_ctx_synchronize(d2r_ctx *ctx);
+D2R_API const char *d2r_last_error(d2r_ctx *ctx);
+
+/* --------------------------------------------------------------- NeRF model */
+
+/* State a pyngp.Testbed holds after load_snapshot (reference ngp_visual_model.py:24-28):
+ * tiny-cuda-nn hash grid + density/colour MLPs + 128^3 occupancy bitfield. */
+typedef struct {
+    uint32_t n_levels;          /* L (16) */
+    uint32_t n_features;        /* F (2) */
+    const float *level_scale;   /* host [L]: exp2(l*log2(b))*N_min - 1 */
+    const uint32_t *level_res;  /* host [L]: ceil(scale)+1 */
+    const uint32_t *level_size; /* host [L]: entries per level */
+    const uint32_t *level_offset; /* host [L]: first entry of each level */
+    uint32_t n_entries;         /* sum(level_size) */
+    const uint16_t *grid_fp16;  /* host [n_entries][F] */
+    const uint16_t *dw1_fp16;   /* host [64][L*F]  density layer 1, row-major [out][in] */
+    const uint16_t *dw2_fp16;   /* host [16][64]   density layer 2 */
+    const uint16_t *cw1_fp16;   /* host [64][32]   colour layer 1, in = [density out 16 | SH 16] */
+    const uint16_t *cw2_fp16;   /* host [64][64] */
+    const uint16_t *cw3_fp16;   /* host [16][64]   rows 0..2 = rgb */
+    const uint8_t *occupancy_bits; /* host [128^3/8], bit x+128*(y+128*z), LSB first */
+} d2r_nerf_desc;
+
+/* replaces Testbed(mode=Nerf) + load_snapshot */
+D2R_API int d2r_nerf_create(d2r_ctx *ctx, const d2r_nerf_desc *desc, d2r_nerf **out);
+D2R_API void d2r_nerf_destroy(d2r_nerf *m);
+
+/* Camera state set on a Testbed before render(): set_camera_to_training_view (intrinsics),
+ * background_color, nerf.render_min_transmittance, dataset scale/offset used by
+ * set_nerf_camera_matrix (reference combined_rendering.py:98-105,116,123-127). */
+typedef struct {
+    uint32_t width, height;
+    float focal[2];          /* pixels at this render size (rel. focal length * height) */
+    float center[2];         /* principal point, relative (cx/w, cy/h) */
+    float scale;             /* dataset scale */
+    float offset[3];         /* dataset offset */
+    float background[4];     /* Testbed.background_color RGBA */
+    float min_transmittance; /* 0.01 */
+    float near_distance;     /* 0 */
+} d2r_view;
+
+/*
+ * replaces n x { set_nerf_camera_matrix(cam); render_mode=Shade; render(w,h,1,True);
+ *                render_mode=Depth; render(w,h,1,True) }   (combined_rendering.py:123-130)
+ * in one pass.  cams_nerf: host [n][12], row-major 3x4, the matrix handed to
+ * set_nerf_camera_matrix.  rgba_out: host [n][h][w][4] Shade frames; depth_out: host
+ * [n][h][w] channel 0 of the Depth frames.  Either output may be NULL.
+ * n_samples_out (optional): network evaluations performed.
+ */
+D2R_API int d2r_render(d2r_ctx *ctx, const d2r_nerf *model, const d2r_view *view,
+                       const float *cams_nerf, uint32_t n, float *rgba_out, float *depth_out,
+                       uint64_t *n_samples_out);
+
+/* Field evaluation at arbitrary unit-cube points (parity hook for the hash-grid encode and
+ * both MLPs): xyz, dirs host [n][3] (dirs unit length); out host [n][4] = sigma, r, g, b
+ * with rgb the network's sRGB-space prediction. */
+D2R_API int d2r_nerf_eval_points(d2r_ctx *ctx, const d2r_nerf *model, const float *xyz,
+                                 const float *dirs, uint32_t n, float *sigma_rgb_out);
+
+/* ------------------------------------------------- background + compositing */
+
+/* Fixes the per-view background the candidates are composited over: bg_image / bg_depth
+ * of reference combined_rendering.py:105-113 (host [h][w][4] and [h][w]; depth is
+ * channel 0, already rectified/masked if it came from depths_gt). */
+D2R_API int d2r_set_background(d2r_ctx *ctx, const d2r_view *view, const float *bg_rgba,
+                               const float *bg_depth);
+
+/*
+ * replaces the body of renderer.render's loop over valid poses
+ * (reference combined_rendering.py:118-155 with convert_virtual_pose :250-263):
+ *   obj_pose_now  host [16]    T_WO_1, row-major 4x4, NGP convention (after converter)
+ *   cam_pose      host [16]    T_WC_1 of the render view, NGP convention
+ *   obj_poses     host [K][16] candidate poses T_WO_2, NGP convention
+ *   frames_out    host [K][h][w][3] uint8 composited sRGB frames
+ */
+D2R_API int d2r_render_composite(d2r_ctx *ctx, const d2r_nerf *fg, const d2r_view *view,
+                                 const float *obj_pose_now, const float *cam_pose,
+                                 const float *obj_poses, uint32_t K, uint8_t *frames_out);
+
+/* -------------------------------------------------------------------- CLIP */
+
+typedef struct {
+    uint32_t image_size;   /* S: 224 / 336 */
+    uint32_t patch_size;   /* P: 16 / 14 */
+    uint32_t hidden_size;  /* d: 768 / 1024 */
+    uint32_t num_layers;   /* 12 / 24 */
+    uint32_t num_heads;    /* 12 / 16 (head dim must be 64) */
+    uint32_t mlp_size;     /* 3072 / 4096 */
+    uint32_t proj_dim;     /* D: 512 / 768 */
+} d2r_clip_desc;
+
+/*
+ * replaces CLIPModel.from_pretrained(...).to(device) (vision tower + visual projection,
+ * reference clip_scoring.py:150).  weights: host fp32 blob, tensors concatenated in this
+ * order (Hugging Face names; Linear weights row-major [out][in]):
+ *   patch_embedding.weight [d][3*P*P], class_embedding [d], position_embedding [T][d],
+ *   pre_layrnorm.{weight,bias},
+ *   per layer: layer_norm1.{weight,bias}, q_proj.{weight,bias}, k_proj.{weight,bias},
+ *              v_proj.{weight,bias}, out_proj.{weight,bias}, layer_norm2.{weight,bias},
+ *              fc1.{weight,bias}, fc2.{weight,bias},
+ *   post_layernorm.{weight,bias}, visual_projection.weight [D][d]
+ * n_floats must equal the size this order implies.
+ */
+D2R_API int d2r_clip_create(d2r_ctx *ctx, const d2r_clip_desc *desc, const float *weights,
+                            size_t n_floats, d2r_clip **out);
+D2R_API void d2r_clip_destroy(d2r_clip *clip);
+
+/*
+ * replaces np.rot90 (clip_scoring.py:145) + CLIPProcessor(images=...) (:177) +
+ * CLIPModel vision forward and logits_per_image (:180-181) for frames already on the host:
+ *   frames       host [n][h][w][3] uint8
+ *   rot90        non-zero: rotate each frame 90 degrees CCW first
+ *   text_embeds  host [C][D], L2-normalised text embeddings (cached, computed once)
+ *   logit_scale  exp(logit_scale) of the checkpoint (100 for OpenAI CLIP)
+ *   logits_out   host [n][C]   logits_per_image
+ *   embeds_out   host [n][D]   optional, L2-normalised image embeddings
+ */
+D2R_API int d2r_clip_score_frames(d2r_ctx *ctx, const d2r_clip *clip, const uint8_t *frames,
+                                  uint32_t n, uint32_t w, uint32_t h, int rot90,
+                                  const float *text_embeds, uint32_t C, float logit_scale,
+                                  float *logits_out, float *embeds_out);
+
+/* CLIPProcessor(images=...) alone: pixel_values host [n][3][S][S] fp32 (parity hook). */
+D2R_API int d2r_clip_preprocess(d2r_ctx *ctx, const d2r_clip *clip, const uint8_t *frames,
+                                uint32_t n, uint32_t w, uint32_t h, int rot90,
+                                float *pixel_values_out);
+
+/* CLIPModel vision forward on given pixel_values host [n][3][S][S] -> embeds [n][D]
+ * (parity hook for the ViT alone). */
+D2R_API int d2r_clip_embed_pixels(d2r_ctx *ctx, const d2r_clip *clip, const float *pixel_values,
+                                  uint32_t n, float *embeds_out);
+
+/* --------------------------------------------------- the fused hot path */
+
+/*
+ * Pose batch in, logits out: HOT LOOP A + HOT LOOP B of reference clip_scoring.py:136-185
+ * with nothing but poses and logits crossing PCIe.  Needs d2r_set_background first.
+ *   obj_poses_dev  DEVICE [K][16] fp32 candidate poses T_WO_2 (NGP convention)
+ *   text_embeds    host [C][D]
+ *   logits_dev     DEVICE [K][C] fp32
+ *   frames_out     host [K][h][w][3] uint8, optional (NULL in benchmark mode)
+ * Asynchronous on the context's stream when frames_out is NULL; call
+ * d2r_ctx_synchronize (or synchronise the caller-owned stream) before reading logits_dev.
+ */
+D2R_API int d2r_render_score(d2r_ctx *ctx, const d2r_nerf *fg, const d2r_clip *clip,
+                             const d2r_view *view, const float *obj_pose_now,
+                             const float *cam_pose, const float *obj_poses_dev, uint32_t K,
+                             const float *text_embeds, uint32_t C, float logit_scale,
+                             float *logits_dev, uint8_t *frames_out);
+
+/* Counters of the last d2r_render / d2r_render_composite / d2r_render_score call, for
+ * roofline accounting (bench.py): rays generated, rays that reached occupied space,
+ * network evaluations (hash-grid samples). */
+typedef struct {
+    uint64_t rays_total;
+    uint64_t rays_alive;
+    uint64_t samples;
+} d2r_render_stats;
+D2R_API int d2r_get_render_stats(d2r_ctx *ctx, d2r_render_stats *out);
+/* After an asynchronous d2r_render_score over K poses: synchronises the stream and gathers
+ * the per-chunk device counters into the stats d2r_get_render_stats returns. */
+D2R_API int d2r_collect_render_stats(d2r_ctx *ctx, uint32_t K);
+
+/* Tunables (chunk size of the candidate loop etc.); unknown keys return D2R_ERR_INVALID. */
+D2R_API int d2r_ctx_set_option(d2r_ctx *ctx, const char *key, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* D2R_H */

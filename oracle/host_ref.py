@@ -38,8 +38,10 @@ _BOUNDS = {  # vision_3d/obj_pose_opt.py:16-36  (lo, hi) offsets from scene_cent
 
 
 def _linspace_f32(lo, hi, n):
-    """torch.linspace(float32): step=(hi-lo)/(n-1); first half lo+i*step, second half
-    hi-(n-1-i)*step (ATen RangeFactoriesKernel)."""
+    """torch.linspace on float32 (ATen CPU RangeFactoriesKernel): step = (hi-lo)/(n-1) in
+    float32; first half fma(step, i, lo), second half fma(-step, n-1-i, hi).  The fused
+    multiply-add is emulated through float64 (the product of two float32 is exact there);
+    checked against torch.linspace in tests/test_host_logic.py."""
     lo, hi = np.float32(lo), np.float32(hi)
     if n == 1:
         return np.array([lo], np.float32)
@@ -47,9 +49,9 @@ def _linspace_f32(lo, hi, n):
     out = np.zeros(n, np.float32)
     for i in range(n):
         if i < n // 2:
-            out[i] = np.float32(lo + np.float32(step * np.float32(i)))
+            out[i] = np.float32(np.float64(lo) + np.float64(step) * i)
         else:
-            out[i] = np.float32(hi - np.float32(step * np.float32(n - 1 - i)))
+            out[i] = np.float32(np.float64(hi) - np.float64(step) * (n - 1 - i))
     return out
 
 
