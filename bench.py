@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py — candidate renders scored per second on MI355X (BASELINE.json metric).
+
+A "step" is one pass of the hot path over one batch of candidate poses: pose batch in
+(resident in HBM) -> virtual cameras -> hash-grid NeRF ray march -> composite over the fixed
+background -> rot90 + CLIP preprocess -> ViT forward -> logits against the cached text
+embeddings, then (N>1) ONE all-gather of logits, ratio, smoothing, argmax.
+
+Workload (config.workload): BASELINE.json configs[1] — synthetic "shopping" scene (seeded,
+SURVEY.md §8(d)), 4 096 candidate poses per GPU, 640x360 renders, ViT-B/16, bf16 MFMA with
+fp32 accumulation.  N>1: one process per GPU (torchrun), every rank renders+scores its own
+contiguous 4 096-pose block of a [64,64,N] grid (weak scaling), no data-path collective
+except the all-gather of scores.
+
+python bench.py [--gpus N] [--steps K] [--warmup W]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+ALGO_BYTES_PER_SAMPLE = 512          # L*8*F*2 B = 16*8*2*2
+HBM_PEAK_GBPS = 8000.0               # MI355X_MICROARCH.md: 8.0 TB/s spec
+MFMA_BF16_PEAK_TFLOPS = 2500.0       # dense bf16
+VIT_B16_GFLOP = 35.1                 # per image
+MLP_FLOP_PER_SAMPLE = 20480
+
+
+def cpu_baseline(scene, W, H, cfg, sd, text, poses_world, n_sample):
+    """The oracle (CPU restatement) timed on the host cores on a bounded sample of the same
+    workload.  Checker code used here ONLY as the reported CPU baseline."""
+    from oracle import render_ref
+    from tests.parity_utils import OraclePipeline, oracle_logits
+    pipe = OraclePipeline(scene, W, H)
+    bg = pipe.background()                       # setup, not timed (once per view)
+    idx = np.linspace(0, len(poses_world) - 1, n_sample).astype(int)
+    t0 = time.time()
+    frames = pipe.frames(poses_world[idx].reshape(-1, 4, 4), bg=bg)
+    t_render = time.time() - t0
+    t1 = time.time()
+    lg, _ = oracle_logits(frames, cfg, sd, text)
+    t_clip = time.time() - t1
+    dt = time.time() - t0
+    return {"value": round(n_sample / dt, 4), "unit": "candidates/s", "cores": os.cpu_count(),
+            "kind": "port",
+            "sample": f"{n_sample} of the {len(poses_world)} candidates at {W}x{H}: oracle C render+composite "
+                      f"(OpenMP, {render_ref.num_threads()} threads, {t_render:.1f}s) + numpy fp32 ViT-B/16 "
+                      f"(BLAS threads, {t_clip:.1f}s)"}, frames, lg, idx
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=360)
+    ap.add_argument("--poses-per-gpu", type=int, default=4096)
+    ap.add_argument("--clip", default="vit_b16")
+    ap.add_argument("--scene", default="shopping")
+    ap.add_argument("--chunk", type=int, default=128)
+    ap.add_argument("--cpu-sample", type=int, default=6, help="candidates in the CPU-baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    from dream2real_amd import dist as d2r_dist
+    from dream2real_amd import engine, obj_pose_opt
+    from dream2real_amd.accio2ngp import converter
+    from dream2real_amd.clip_model import CLIP_CONFIGS, random_clip_state_dict
+    from dream2real_amd.clip_scoring import reduce_logits
+    from dream2real_amd.geometry_utils import spatially_smooth_heatmap
+    from dream2real_amd.scene import make_scene
+    from tests.parity_utils import make_task, seeded_text_embeds
+
+    rank, world, local = d2r_dist.init_from_env()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    # ---------------- setup (untimed): scene, models, background, poses in HBM
+    W, H = args.width, args.height
+    scene = make_scene(args.scene)
+    cfg = CLIP_CONFIGS[args.clip]
+    sd = random_clip_state_dict(cfg, seed=6)
+    text = seeded_text_embeds(cfg, sd)                       # cached text embeddings (goal, norm)
+    ctx = engine.Context(local)
+    ctx.set_option("chunk", args.chunk)
+    fg, bg = engine.Testbed(ctx, scene.fg), engine.Testbed(ctx, scene.bg)
+    fg.background_color = list(scene.fg_background)
+    scorer = engine.ClipScorer(ctx, cfg, sd)
+    side = int(round(np.sqrt(args.poses_per_gpu)))
+    assert side * side == args.poses_per_gpu
+    sample_res = [side, side, world, 1, 1, 1]
+    task = make_task(scene)
+    pose_batch = obj_pose_opt.sample_poses_grid(task, sample_res, scene.scene_type)       # [N,16] world
+    N = pose_batch.shape[0]
+    lo, hi = d2r_dist.shard_range(N, rank, world)
+    # contiguous in (x, y, z) order means z interleaves: shard by z-slice so every rank gets a full
+    # (x, y) sheet -> permute to z-major for sharding, remember the inverse for the gather
+    order = np.arange(N).reshape(side, side, world).transpose(2, 0, 1).reshape(-1)
+    my_idx = order[lo:hi]
+    poses_ngp = converter(pose_batch[my_idx].reshape(-1, 4, 4)).reshape(-1, 16).astype(np.float32)
+    poses_dev = torch.from_numpy(poses_ngp).to(dev)
+    K_local = poses_dev.shape[0]
+    logits_dev = torch.zeros((K_local, text.shape[0]), dtype=torch.float32, device=dev)
+    cam_ngp = converter(np.asarray(scene.cam_poses, np.float32))[0]
+    bg_rgba, bg_depth = bg.render_batch(cam_ngp[None, :3], W, H)
+    view = fg.view(W, H)
+    ctx.set_background(view, bg_rgba[0], bg_depth[0])
+    T1 = converter(np.asarray(scene.obj_pose, np.float32)[None])[0]
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+
+    def step():
+        engine.render_score_device(ctx, fg, scorer, view, T1, cam_ngp, poses_dev.data_ptr(), K_local, text,
+                                   logits_dev.data_ptr())
+        full = d2r_dist.allgather_logits(logits_dev, N, rank, world)      # one RCCL all-gather (N>1)
+        lg = full.cpu().numpy()                                            # [N, C], z-major order
+        scores = np.zeros(N, np.float32)
+        scores[order] = reduce_logits(lg, 1, True)
+        scores = spatially_smooth_heatmap(scores, sample_res)
+        return int(np.argmax(scores)), scores
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    ctx.set_option("timing", 1)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        best, scores = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    timing = ctx.timing()
+    ctx.set_option("timing", 0)
+    stats = ctx.render_stats(collect_K=K_local)          # counters of the last step
+
+    if rank == 0:
+        total = N * args.steps
+        value = total / elapsed
+        samples_per_launch = stats["samples"] / max(1, -(-K_local // args.chunk))
+        march_avg_s = timing["march_ms"] / max(1, timing["march_launches"]) * 1e-3
+        achieved = samples_per_launch * ALGO_BYTES_PER_SAMPLE / march_avg_s / 1e9 if march_avg_s > 0 else 0.0
+        n_img = K_local * args.steps
+        clip_tflops = VIT_B16_GFLOP * 1e9 * n_img / (timing["clip_ms"] * 1e-3) / 1e12 if args.clip == "vit_b16" and timing["clip_ms"] > 0 else None
+        out = {
+            "metric": "candidate renders scored/sec (640x360)", "value": round(value, 2), "unit": "candidates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"BASELINE.json configs[1]: {args.scene} scene, {args.poses_per_gpu} candidate poses per GPU, "
+                                   f"{W}x{H}, bf16 MLP + {args.clip}", "poses_total": N, "chunk": args.chunk,
+                       "parallelism": f"pose-shard x{world}" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "kernel": "k_march (hash-grid fetch + fused MLP + compositing)",
+                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+                         "samples_per_launch": int(samples_per_launch),
+                         "avg_launch_ms": round(march_avg_s * 1e3, 4),
+                         "mlp_tflops": round(samples_per_launch * MLP_FLOP_PER_SAMPLE / march_avg_s / 1e12, 3) if march_avg_s > 0 else None},
+            "roofline_vit": {"bound": "mfma", "achieved": round(clip_tflops, 2) if clip_tflops else None,
+                             "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(clip_tflops / MFMA_BF16_PEAK_TFLOPS, 5) if clip_tflops else None},
+            "device_ms_per_step": {k.replace("_ms", ""): round(v / args.steps, 3) for k, v in timing.items() if k.endswith("_ms")},
+            "render_stats_per_step": stats,
+            "argmax_pose": best,
+        }
+        if world == 1 and args.cpu_sample > 0:
+            cb, frames_o, lg_o, idx = cpu_baseline(scene, W, H, cfg, sd, text, pose_batch, args.cpu_sample)
+            out["cpu_baseline"] = cb
+            # same candidates through the GPU path: parity of the benchmark itself
+            lg_gpu = logits_dev.cpu().numpy()[np.searchsorted(my_idx, idx)] if world == 1 else None
+            if lg_gpu is not None:
+                out["parity_vs_oracle"] = {"max_cosine_err": float(np.abs(lg_gpu - lg_o).max() / scorer.logit_scale),
+                                           "n": int(len(idx))}
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

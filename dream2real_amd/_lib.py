@@ -15,7 +15,7 @@ EXPORTS = [
     "d2r_last_error", "d2r_nerf_create", "d2r_nerf_destroy", "d2r_render", "d2r_nerf_eval_points",
     "d2r_set_background", "d2r_render_composite", "d2r_clip_create", "d2r_clip_destroy",
     "d2r_clip_score_frames", "d2r_clip_preprocess", "d2r_clip_embed_pixels", "d2r_render_score",
-    "d2r_get_render_stats", "d2r_collect_render_stats", "d2r_ctx_set_option",
+    "d2r_get_render_stats", "d2r_collect_render_stats", "d2r_ctx_set_option", "d2r_get_timing",
 ]
 
 
@@ -46,6 +46,12 @@ class ClipDesc(C.Structure):
 
 class RenderStats(C.Structure):
     _fields_ = [("rays_total", C.c_uint64), ("rays_alive", C.c_uint64), ("samples", C.c_uint64)]
+
+
+class Timing(C.Structure):
+    _fields_ = [("march_ms", C.c_double), ("march_launches", C.c_uint64), ("raygen_ms", C.c_double),
+                ("raygen_launches", C.c_uint64), ("prep_ms", C.c_double), ("prep_launches", C.c_uint64),
+                ("clip_ms", C.c_double), ("clip_launches", C.c_uint64)]
 
 
 _lib = None

@@ -47,9 +47,52 @@ int d2r_reserve(d2r_ctx *ctx, d2r_ctx::Buf &b, size_t bytes)
     return D2R_OK;
 }
 
+size_t d2r_ctx::timing_begin(int kind)
+{
+    if (!timing) return (size_t)-1;
+    while (ev_pool.size() < ev_used + 2) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return (size_t)-1;
+        ev_pool.push_back(e);
+    }
+    size_t b = ev_used, e = ev_used + 1;
+    ev_used += 2;
+    ev_pairs.push_back({kind, {b, e}});
+    (void)hipEventRecord(ev_pool[b], stream);
+    return ev_pairs.size() - 1;
+}
+
+void d2r_ctx::timing_end(size_t pair)
+{
+    if (pair == (size_t)-1) return;
+    (void)hipEventRecord(ev_pool[ev_pairs[pair].second.second], stream);
+}
+
 extern "C" {
 
 int d2r_abi_version(void) { return D2R_ABI_VERSION; }
+
+int d2r_get_timing(d2r_ctx *ctx, d2r_timing *out)
+{
+    if (!ctx || !out) return d2r_fail(ctx, D2R_ERR_INVALID, "null argument");
+    D2R_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    double ms[D2R_T_KINDS] = {0, 0, 0, 0};
+    uint64_t n[D2R_T_KINDS] = {0, 0, 0, 0};
+    for (auto &p : ctx->ev_pairs) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, ctx->ev_pool[p.second.first], ctx->ev_pool[p.second.second]) == hipSuccess) {
+            ms[p.first] += t;
+            n[p.first]++;
+        }
+    }
+    out->march_ms = ms[D2R_T_MARCH];   out->march_launches = n[D2R_T_MARCH];
+    out->raygen_ms = ms[D2R_T_RAYGEN]; out->raygen_launches = n[D2R_T_RAYGEN];
+    out->prep_ms = ms[D2R_T_PREP];     out->prep_launches = n[D2R_T_PREP];
+    out->clip_ms = ms[D2R_T_CLIP];     out->clip_launches = n[D2R_T_CLIP];
+    ctx->ev_used = 0;
+    ctx->ev_pairs.clear();
+    return D2R_OK;
+}
 
 const char *d2r_last_error(d2r_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
 
@@ -88,7 +131,8 @@ void d2r_ctx_destroy(d2r_ctx *c)
         if (b->p) hipFree(b->p);
     for (auto &b : c->clipws)
         if (b.p) hipFree(b.p);
-    hipStreamDestroy(c->own_stream);
+    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
 
@@ -116,6 +160,10 @@ int d2r_ctx_set_option(d2r_ctx *ctx, const char *key, int64_t value)
     } else if (!strcmp(key, "march_blocks")) {
         if (value < 0 || value > 65535) return d2r_fail(ctx, D2R_ERR_INVALID, "march_blocks out of range");
         ctx->march_blocks = value;
+    } else if (!strcmp(key, "timing")) {
+        ctx->timing = value != 0;
+        ctx->ev_used = 0;
+        ctx->ev_pairs.clear();
     } else {
         return d2r_fail(ctx, D2R_ERR_INVALID, std::string("unknown option ") + key);
     }
@@ -518,12 +566,16 @@ int d2r_render_score(d2r_ctx *ctx, const d2r_nerf *fg, const d2r_clip *clip, con
                                     hipMemcpyDeviceToDevice, ctx->stream));
         if (frames_out)
             D2R_HIP(ctx, hipMemcpyAsync(frames_out + (size_t)c0 * px * 3, ctx->frames.p, (size_t)nc * px * 3, hipMemcpyDeviceToHost, ctx->stream));
+        size_t tp = ctx->timing_begin(D2R_T_PREP);
         if ((rc = d2r_launch_preprocess(ctx, (d2r_clip *)clip, (const uint8_t *)ctx->frames.p, nc, V.W, V.H, 1,
                                         (uint16_t *)ctx->clipws[6].p, nullptr)))
             return rc;
+        ctx->timing_end(tp);
+        size_t tc = ctx->timing_begin(D2R_T_CLIP);
         if ((rc = d2r_clip_forward(ctx, clip, (const uint16_t *)ctx->clipws[6].p, nc, (const float *)ctx->text.p, C,
                                    logit_scale, logits_dev + (size_t)c0 * C, nullptr)))
             return rc;
+        ctx->timing_end(tc);
     }
     if (frames_out) D2R_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->stats.rays_total = (uint64_t)K * px;

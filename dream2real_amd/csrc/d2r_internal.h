@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/d2r.h"
@@ -57,7 +58,15 @@ struct d2r_ctx {
     d2r_render_stats stats{};
     int64_t chunk = 128;       // candidates per pass of the fused path
     int64_t march_blocks = 0;  // 0 = auto
+    // optional per-kernel timing (HIP events on the launch stream), see d2r_get_timing
+    int64_t timing = 0;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    std::vector<std::pair<int, std::pair<size_t, size_t>>> ev_pairs;   // (kind, (begin, end))
+    size_t timing_begin(int kind);          // returns pair index, records the begin event
+    void timing_end(size_t pair);
 };
+enum { D2R_T_MARCH = 0, D2R_T_RAYGEN = 1, D2R_T_CLIP = 2, D2R_T_PREP = 3, D2R_T_KINDS = 4 };
 
 struct d2r_nerf {
     d2r_ctx *ctx;

@@ -721,9 +721,12 @@ int d2r_launch_render(d2r_ctx *ctx, const d2r_nerf *m, const ViewParams &V, cons
                            (const uint4 *)ctx->bg_u8.p, (uint4 *)frames_dev, n_vec, n);
     }
     const uint32_t tiles = ((V.W + 15) / 16) * ((V.H + 15) / 16);
+    size_t tr = ctx->timing_begin(D2R_T_RAYGEN);
     hipLaunchKernelGGL(k_raygen, dim3(tiles, n), dim3(256), 0, ctx->stream, m->P, V, cams_dev,
                        (uint2 *)ctx->queue.p, cnt, composite ? nullptr : rgba_dev,
                        composite ? nullptr : depth_dev);
+    ctx->timing_end(tr);
+    size_t tm = ctx->timing_begin(D2R_T_MARCH);
     int blocks = ctx->march_blocks > 0 ? (int)ctx->march_blocks : 256 * 2;
     if (composite)
         hipLaunchKernelGGL(k_march<true>, dim3(blocks), dim3(256), 0, ctx->stream, m->P, V, cams_dev,
@@ -733,6 +736,7 @@ int d2r_launch_render(d2r_ctx *ctx, const d2r_nerf *m, const ViewParams &V, cons
         hipLaunchKernelGGL(k_march<false>, dim3(blocks), dim3(256), 0, ctx->stream, m->P, V, cams_dev,
                            (const uint2 *)ctx->queue.p, cnt, cnt + 1, rgba_dev, depth_dev, nullptr, nullptr,
                            (unsigned long long *)(cnt + 2));
+    ctx->timing_end(tm);
     D2R_HIP(ctx, hipGetLastError());
     return D2R_OK;
 }

@@ -1,0 +1,86 @@
+"""Pose-shard data parallelism for the render-and-score path: one process per GPU, candidate
+poses split in contiguous blocks, ONE all-gather of the fp32 logits (RCCL over xGMI on GPUs,
+gloo in the CPU tests), after which ratio / smoothing / argmax run identically on every rank.
+
+The reference is single-GPU (README.md:27); candidates are independent through render,
+composite and CLIP (reference combined_rendering.py:118-155, clip_scoring.py:175-183), and
+only spatially_smooth_heatmap (geometry_utils.py:252-269) needs neighbouring grid cells —
+hence gather first, smooth after."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+
+def shard_range(n_items: int, rank: int, world: int):
+    """Contiguous block [lo, hi) of rank `rank`; blocks differ in size by at most one."""
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def init_from_env(backend: str | None = None):
+    """torch.distributed process group from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*.
+    Returns (rank, world, local_rank); a no-op (0, 1, 0) outside a launcher."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"    # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def allgather_logits(local_logits, n_total: int, rank: int, world: int):
+    """local_logits: torch tensor [n_local, C] (cuda for nccl, cpu for gloo) -> [n_total, C] on
+    every rank.  Shards may be ragged by one row: rows are padded to the largest shard for the
+    single all_gather_into_tensor and the padding dropped afterwards."""
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return local_logits
+    C = local_logits.shape[1]
+    n_max = -(-n_total // world)
+    pad = torch.zeros((n_max, C), dtype=local_logits.dtype, device=local_logits.device)
+    pad[: local_logits.shape[0]] = local_logits
+    out = torch.empty((world * n_max, C), dtype=local_logits.dtype, device=local_logits.device)
+    dist.all_gather_into_tensor(out, pad)
+    parts = []
+    for r in range(world):
+        lo, hi = shard_range(n_total, r, world)
+        parts.append(out[r * n_max: r * n_max + (hi - lo)])
+    return torch.cat(parts, 0)
+
+
+def score_sharded(pose_batch: np.ndarray, score_fn, sample_res, has_norm: bool, n_goal: int = 1,
+                  smoothing: bool = True, rank: int = 0, world: int = 1, is_valid=None):
+    """The multi-GPU form of optimise_pose_grid's scoring half.
+
+    score_fn(poses [k,16]) -> torch tensor [k, C] of logits for this rank's block.
+    Returns (best_pose_idx, pose_scores [N]) — identical on every rank."""
+    import torch
+    from .clip_scoring import reduce_logits
+    from .geometry_utils import spatially_smooth_heatmap
+    N = pose_batch.shape[0]
+    valid = np.ones(N, bool) if is_valid is None else np.asarray(is_valid, bool)
+    valid_idxs = np.nonzero(valid)[0]
+    K = len(valid_idxs)
+    if K == 0:
+        raise Exception
+    lo, hi = shard_range(K, rank, world)
+    local = score_fn(pose_batch[valid_idxs[lo:hi]])
+    full = allgather_logits(local, K, rank, world)
+    logits = reduce_logits(full.detach().cpu().numpy(), n_goal, has_norm)
+    scores = np.zeros(N, np.float32)
+    scores[valid_idxs] = logits
+    if smoothing:
+        scores = spatially_smooth_heatmap(scores, sample_res)
+    return int(np.argmax(scores)), scores

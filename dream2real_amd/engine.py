@@ -61,6 +61,12 @@ class Context:
         self.check(self.lib.d2r_get_render_stats(self.h, C.byref(s)))
         return {"rays_total": s.rays_total, "rays_alive": s.rays_alive, "samples": s.samples}
 
+    def timing(self) -> dict:
+        """Device time per kernel family since set_option("timing", 1) (synchronises)."""
+        t = _lib.Timing()
+        self.check(self.lib.d2r_get_timing(self.h, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in t._fields_}
+
     def set_background(self, view: View, bg_rgba: np.ndarray, bg_depth: np.ndarray):
         a = np.ascontiguousarray(bg_rgba, np.float32)
         d = np.ascontiguousarray(bg_depth, np.float32)

@@ -221,7 +221,20 @@ D2R_API int d2r_get_render_stats(d2r_ctx *ctx, d2r_render_stats *out);
  * the per-chunk device counters into the stats d2r_get_render_stats returns. */
 D2R_API int d2r_collect_render_stats(d2r_ctx *ctx, uint32_t K);
 
-/* Tunables (chunk size of the candidate loop etc.); unknown keys return D2R_ERR_INVALID. */
+/* Per-kernel device time of the calls made since timing was switched on with
+ * d2r_ctx_set_option(ctx, "timing", 1): HIP events recorded on the launch stream around the
+ * ray-march kernel, the ray-generation kernel, the CLIP preprocess kernel and the CLIP
+ * forward (all its kernels).  d2r_get_timing synchronises the stream, sums the elapsed
+ * times and resets the event list. */
+typedef struct {
+    double march_ms;   uint64_t march_launches;
+    double raygen_ms;  uint64_t raygen_launches;
+    double prep_ms;    uint64_t prep_launches;
+    double clip_ms;    uint64_t clip_launches;   /* one "launch" = one forward over a chunk */
+} d2r_timing;
+D2R_API int d2r_get_timing(d2r_ctx *ctx, d2r_timing *out);
+
+/* Tunables ("chunk", "march_blocks", "timing"); unknown keys return D2R_ERR_INVALID. */
 D2R_API int d2r_ctx_set_option(d2r_ctx *ctx, const char *key, int64_t value);
 
 #ifdef __cplusplus

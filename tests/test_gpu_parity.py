@@ -1,0 +1,323 @@
+"""Parity tests proper: the HIP path (through the C ABI, via dream2real_amd.engine) against
+the oracle on the same seeded inputs.  Run on the MI355X box:  pytest -m gpu.
+
+Tolerances (measured headroom in tools/gpu_diag.py, gpurun_out/diag1.log):
+  field      sigma within 1e-2 relative, rgb within 1e-2 absolute   (bf16 MLP vs fp32 oracle)
+  frames     fp32 RGBA within 5e-3, identical hit-pixel sets, uint8 frames within 1 LSB with
+             at most 2% of pixels off by that 1 LSB
+  preprocess bit-exact uint8 resampling (integer arithmetic), pixel_values within 1e-6
+  scores     cosine error <= 1e-3 (north_star), i.e. |dlogit| <= 0.1 at logit scale 100
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from dream2real_amd.clip_model import CLIP_CONFIGS, random_clip_state_dict
+from dream2real_amd.scene import make_scene
+from oracle import clip_ref, host_ref, render_ref
+from tests.parity_utils import (OraclePipeline, cosine, make_task, oracle_logits, random_unit_text_embeds,
+                                seeded_text_embeds)
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    from dream2real_amd import engine
+    scene = make_scene("shopping")
+    ctx = engine.Context(0)
+    fg = engine.Testbed(ctx, scene.fg)
+    fg.background_color = list(scene.fg_background)
+    bg = engine.Testbed(ctx, scene.bg)
+    yield dict(engine=engine, scene=scene, ctx=ctx, fg=fg, bg=bg)
+    fg.close()
+    bg.close()
+    ctx.close()
+
+
+def _loaded_native():
+    maps = open("/proc/self/maps").read()
+    return "libd2r.so" in maps
+
+
+def test_native_library_is_loaded(gpu):
+    assert _loaded_native()
+
+
+def test_field_eval_matches_oracle(gpu):
+    scene, fg = gpu["scene"], gpu["fg"]
+    r = np.random.Generator(np.random.PCG64(0))
+    n = 5000     # not a multiple of 64: exercises partially filled waves
+    occ = np.argwhere(scene.fg.occupancy_bool())
+    cells = occ[r.integers(0, len(occ), n)]
+    xyz = ((cells[:, ::-1] + r.random((n, 3))) / 128.0).astype(np.float32)
+    xyz[:8] = r.random((8, 3)).astype(np.float32)          # anywhere in the cube
+    xyz[8] = (0.0, 0.0, 0.0)
+    xyz[9] = (1.0, 1.0, 1.0)                               # upper corner: dense-level index wrap
+    d = r.standard_normal((n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    got = fg.eval_points(xyz, d)
+    want = render_ref.eval_points(render_ref.OracleNerf(scene.fg), xyz, d)
+    assert np.isfinite(got).all()
+    np.testing.assert_allclose(got[:, 0], want[:, 0], rtol=1e-2, atol=1e-3)
+    np.testing.assert_allclose(got[:, 1:], want[:, 1:], rtol=0, atol=1e-2)
+
+
+@pytest.mark.parametrize("W,H", [(160, 90), (70, 50)])
+def test_render_matches_oracle(gpu, W, H):
+    """Testbed.render (Shade + Depth) for a batch of virtual cameras, incl. one that misses."""
+    scene, fg = gpu["scene"], gpu["fg"]
+    pipe = OraclePipeline(scene, W, H)
+    poses = host_ref.sample_poses_grid(scene.scene_centre, [3, 2, 1, 1, 1, 1], scene.scene_type).reshape(-1, 4, 4)
+    cams = np.stack([pipe.fg_camera(p) for p in poses])
+    rgba, depth = fg.render_batch(cams, W, H)
+    total_hits = 0
+    for i, p in enumerate(poses):
+        orgba, odepth = pipe.fg_render(p)
+        assert ((depth[i] > 0) == (odepth > 0)).all(), "hit-pixel sets differ"
+        total_hits += int((odepth > 0).sum())
+        np.testing.assert_allclose(rgba[i], orgba, rtol=0, atol=5e-3)
+        np.testing.assert_allclose(depth[i], odepth, rtol=0, atol=2e-3)
+    assert total_hits > 500
+    # sample counts agree up to early-termination jitter
+    assert abs(fg.last_samples - pipe.n_samples) <= 0.01 * pipe.n_samples
+
+
+def test_background_render_matches_oracle(gpu):
+    scene, bg = gpu["scene"], gpu["bg"]
+    W, H = 160, 90
+    pipe = OraclePipeline(scene, W, H)
+    cam = host_ref.converter(np.asarray(scene.cam_poses, np.float32))[0]
+    rgba, depth = bg.render_batch(cam[None, :3], W, H)
+    orgba, odepth = pipe.background()
+    assert ((depth[0] > 0) == (odepth > 0)).all()
+    np.testing.assert_allclose(rgba[0], orgba, rtol=0, atol=5e-3)
+    np.testing.assert_allclose(depth[0], odepth, rtol=0, atol=2e-3)
+
+
+def test_testbed_surface_shade_and_depth(gpu):
+    """pyngp-style stateful calls return the same frames as the batched entry point."""
+    scene, fg, engine = gpu["scene"], gpu["fg"], gpu["engine"]
+    W, H = 64, 36
+    pipe = OraclePipeline(scene, W, H)
+    cam = pipe.fg_camera(scene.obj_pose)
+    fg.set_camera_to_training_view(0)
+    fg.set_nerf_camera_matrix(cam)
+    fg.render_mode = engine.Shade
+    shade = fg.render(W, H, 1, True)
+    fg.render_mode = engine.Depth
+    dep = fg.render(W, H, 1, True)
+    fg.render_mode = engine.Shade
+    orgba, odepth = pipe.fg_render(scene.obj_pose)
+    np.testing.assert_allclose(shade, orgba, rtol=0, atol=5e-3)
+    np.testing.assert_allclose(dep[..., 0], odepth, rtol=0, atol=2e-3)
+    with pytest.raises(NotImplementedError):
+        fg.render(W, H, 4, True)
+
+
+def test_composited_frames_match_oracle(gpu):
+    """renderer.render: K candidates -> uint8 frames (depth test, un-premultiply, sRGB,
+    quantise, alpha threshold), same background on both sides."""
+    scene, fg, ctx = gpu["scene"], gpu["fg"], gpu["ctx"]
+    W, H = 160, 90
+    pipe = OraclePipeline(scene, W, H)
+    poses = host_ref.sample_poses_grid(scene.scene_centre, [4, 3, 2, 1, 1, 1], scene.scene_type).reshape(-1, 4, 4)
+    obg = pipe.background()
+    view = fg.view(W, H)
+    ctx.set_background(view, obg[0], obg[1])
+    T1 = host_ref.converter(np.asarray(scene.obj_pose, np.float32)[None])[0]
+    TC = host_ref.converter(np.asarray(scene.cam_poses, np.float32))[0]
+    ctx.set_option("chunk", 5)          # ragged chunking: 24 poses in passes of 5
+    frames = fg.render_composite(view, T1, TC, host_ref.converter(poses.astype(np.float32)))
+    ctx.set_option("chunk", 128)
+    want = pipe.frames(poses, bg=obg)
+    diff = np.abs(frames.astype(int) - want.astype(int)).max(-1)
+    assert diff.max() <= 1
+    assert (diff > 0).mean() < 0.02
+    st = ctx.render_stats()
+    assert st["rays_total"] == len(poses) * W * H and st["samples"] > 0
+
+
+def test_alpha_threshold_and_transparent_fg(gpu):
+    """fg background alpha 0 (in-process trained models): semi-transparent
+    silhouette pixels fall under the 130/255 alpha threshold and turn black."""
+    import dataclasses
+    scene, fg, ctx = gpu["scene"], gpu["fg"], gpu["ctx"]
+    W, H = 96, 54
+    pipe = OraclePipeline(scene, W, H)
+    pipe.view_fg = dataclasses.replace(pipe.view_fg, background=(0.0, 0.0, 0.0, 0.0), min_transmittance=1e-4)
+    fg.background_color = [0.0, 0.0, 0.0, 0.0]
+    fg.nerf.render_min_transmittance = 1e-4
+    try:
+        obg = pipe.background()
+        view = fg.view(W, H)
+        ctx.set_background(view, obg[0], obg[1])
+        T1 = host_ref.converter(np.asarray(scene.obj_pose, np.float32)[None])[0]
+        TC = host_ref.converter(np.asarray(scene.cam_poses, np.float32))[0]
+        poses = np.asarray(scene.obj_pose, np.float32)[None]
+        frames = fg.render_composite(view, T1, TC, host_ref.converter(poses))
+        want = pipe.frames(poses, bg=obg)
+    finally:
+        fg.background_color = list(scene.fg_background)
+        fg.nerf.render_min_transmittance = 0.01
+    diff = np.abs(frames.astype(int) - want.astype(int)).max(-1)
+    # a pixel whose alpha sits exactly at the threshold may flip to/from black
+    assert (diff > 1).mean() < 2e-3
+
+
+@pytest.mark.parametrize("hw", [(360, 640), (90, 160), (336, 336), (224, 224), (50, 70)])
+def test_preprocess_bit_exact(gpu, hw):
+    engine, ctx = gpu["engine"], gpu["ctx"]
+    cfg = dict(CLIP_CONFIGS["vit_b16"], num_layers=1)
+    sc = engine.ClipScorer(ctx, cfg, random_clip_state_dict(cfg, seed=6, text=False))
+    r = np.random.Generator(np.random.PCG64(hw[0]))
+    f = r.integers(0, 256, size=(3, hw[0], hw[1], 3), dtype=np.uint8)
+    for rot in (True, False):
+        got = sc.preprocess(f, rot90=rot)
+        want = np.stack([render_ref.clip_preprocess(x, cfg["image_size"], rot)[0] for x in f])
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-6)
+    sc.close()
+
+
+@pytest.mark.parametrize("name,n", [("vit_tiny", 9), ("vit_b16", 5)])
+def test_vit_embeddings_match_oracle(gpu, name, n):
+    engine, ctx = gpu["engine"], gpu["ctx"]
+    cfg = CLIP_CONFIGS[name]
+    sd = random_clip_state_dict(cfg, seed=6, text=False)
+    sc = engine.ClipScorer(ctx, cfg, sd)
+    r = np.random.Generator(np.random.PCG64(3))
+    pv = r.standard_normal((n, 3, cfg["image_size"], cfg["image_size"]), dtype=np.float32)
+    got = sc.embed_pixels(pv)
+    want = clip_ref.vision_embeds(pv, sd, cfg)
+    assert (1.0 - cosine(got, want)).max() < 1e-4
+    np.testing.assert_allclose(np.linalg.norm(got, axis=1), 1.0, atol=1e-5)
+    # logits against cached text embeddings: cosine error <= 1e-3
+    text = random_unit_text_embeds(cfg["proj"], 3)
+    frames = r.integers(0, 256, size=(n, 90, 160, 3), dtype=np.uint8)
+    lg = sc.score_frames(frames, text)
+    olg, _ = oracle_logits(frames, cfg, sd, text)
+    assert np.abs(lg - olg).max() / sc.logit_scale <= 1e-3
+    sc.close()
+
+
+def test_vit_golden_image_embeds(gpu, goldens):
+    """HIP ViT-B/16 against the committed Hugging Face golden embeddings."""
+    engine, ctx = gpu["engine"], gpu["ctx"]
+    cfg = CLIP_CONFIGS["vit_b16"]
+    sd = random_clip_state_dict(cfg, seed=6, text=False)
+    sc = engine.ClipScorer(ctx, cfg, sd)
+    r = np.random.Generator(np.random.PCG64(77))
+    pv = r.standard_normal((2, 3, 224, 224), dtype=np.float32)
+    got = sc.embed_pixels(pv)
+    assert (1.0 - cosine(got, goldens["g5_vit_b16_image_embeds"])).max() < 1e-4
+    sc.close()
+
+
+def test_optimise_pose_grid_end_to_end(gpu, tmp_path):
+    """Pose batch in, scores out through the reference-shaped Python API (config 0 shapes:
+    32 poses, 160x90), against the oracle pipeline; argmax pose identical."""
+    from dream2real_amd import clip_scoring, combined_rendering
+    engine, ctx, scene, fg, bg = gpu["engine"], gpu["ctx"], gpu["scene"], gpu["fg"], gpu["bg"]
+    cfg = CLIP_CONFIGS["vit_tiny"]
+    sd = random_clip_state_dict(cfg, seed=6)
+    text = seeded_text_embeds(cfg, sd)
+    sc = engine.ClipScorer(ctx, cfg, sd)
+    task = make_task(scene, fg, bg)
+    task.text_embeds = text
+    W, H = 160, 90
+    sample_res = [8, 4, 1, 1, 1, 1]
+    rend = combined_rendering.renderer(str(tmp_path), task, resolution=(W, H))
+
+    def phys_check(pose_batch, task_model, valid_so_far):
+        v = valid_so_far.clone()
+        v[5] = False                      # one pose fails the physics pre-filter
+        return v
+
+    best, pose_batch, scores = clip_scoring.optimise_pose_grid(
+        rend, None, [0], task, str(tmp_path), sample_res=sample_res, phys_check=phys_check,
+        scene_type=scene.scene_type, smoothing=True, scorer=sc)
+    assert tuple(best.shape) == (4, 4) and tuple(pose_batch.shape) == (32, 16) and tuple(scores.shape) == (32,)
+    np.testing.assert_array_equal(pose_batch.numpy(), host_ref.sample_poses_grid(scene.scene_centre, sample_res, 3))
+    # oracle side
+    pipe = OraclePipeline(scene, W, H)
+    valid = np.ones(32, bool)
+    valid[5] = False
+    frames = pipe.frames(pose_batch.numpy()[valid])
+    lg, _ = oracle_logits(frames, cfg, sd, text)
+    want = np.zeros(32, np.float32)
+    want[valid] = host_ref.score_logits(lg, True)
+    want = host_ref.spatially_smooth_heatmap(want, sample_res)
+    got = scores.numpy()
+    assert got[5] == 0.0
+    np.testing.assert_allclose(got, want, rtol=0, atol=5e-3)
+    assert int(np.argmax(got)) == int(np.argmax(want))
+    np.testing.assert_array_equal(best.numpy().reshape(16), pose_batch.numpy()[int(np.argmax(want))])
+    assert (tmp_path / "best_render.png").exists()
+    # zero valid poses -> bare Exception, like the reference (clip_scoring.py:115-117)
+    with pytest.raises(Exception):
+        clip_scoring.optimise_pose_grid(rend, None, [0], task, str(tmp_path), sample_res=sample_res,
+                                        phys_check=lambda p, t, v: v & False, scene_type=3, scorer=sc)
+    sc.close()
+
+
+def test_fused_render_score_device_path(gpu):
+    """d2r_render_score on device pointers == render_composite + score_frames."""
+    import torch
+    engine, ctx, scene, fg = gpu["engine"], gpu["ctx"], gpu["scene"], gpu["fg"]
+    cfg = CLIP_CONFIGS["vit_tiny"]
+    sd = random_clip_state_dict(cfg, seed=6, text=False)
+    sc = engine.ClipScorer(ctx, cfg, sd)
+    text = random_unit_text_embeds(cfg["proj"], 2)
+    W, H = 160, 90
+    pipe = OraclePipeline(scene, W, H)
+    obg = pipe.background()
+    view = fg.view(W, H)
+    ctx.set_background(view, obg[0], obg[1])
+    poses = host_ref.sample_poses_grid(scene.scene_centre, [5, 3, 1, 1, 1, 1], scene.scene_type)
+    poses_ngp = host_ref.converter(poses.reshape(-1, 4, 4)).reshape(-1, 16)
+    T1 = host_ref.converter(np.asarray(scene.obj_pose, np.float32)[None])[0]
+    TC = host_ref.converter(np.asarray(scene.cam_poses, np.float32))[0]
+    dev = torch.device("cuda:0")
+    p_dev = torch.from_numpy(poses_ngp).to(dev)
+    lg_dev = torch.zeros((len(poses), 2), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    ctx.set_option("chunk", 4)
+    frames = np.zeros((len(poses), H, W, 3), np.uint8)
+    engine.render_score_device(ctx, fg, sc, view, T1, TC, p_dev.data_ptr(), len(poses), text, lg_dev.data_ptr(), frames)
+    ctx.synchronize()
+    st = ctx.render_stats(collect_K=len(poses))
+    ctx.set_option("chunk", 128)
+    got = lg_dev.cpu().numpy()
+    frames2 = fg.render_composite(view, T1, TC, poses_ngp.reshape(-1, 4, 4))
+    np.testing.assert_array_equal(frames, frames2)
+    np.testing.assert_allclose(got, sc.score_frames(frames2, text), rtol=0, atol=2e-3)
+    olg, _ = oracle_logits(pipe.frames(poses.reshape(-1, 4, 4), bg=obg), cfg, sd, text)
+    assert np.abs(got - olg).max() / sc.logit_scale <= 1e-3
+    assert st["samples"] > 0 and st["rays_alive"] > 0
+    sc.close()
+
+
+def test_full_size_properties(gpu):
+    """BASELINE.json config-1 frame size (640x360): size-independent properties instead of the
+    (slow) oracle — determinism, candidates only differ where the object is, a pose outside
+    the view leaves the pure background, and translation equivariance of the hit mask."""
+    scene, fg, bg, ctx = gpu["scene"], gpu["fg"], gpu["bg"], gpu["ctx"]
+    W, H = 640, 360
+    cam_bg = host_ref.converter(np.asarray(scene.cam_poses, np.float32))[0]
+    brgba, bdepth = bg.render_batch(cam_bg[None, :3], W, H)
+    view = fg.view(W, H)
+    ctx.set_background(view, brgba[0], bdepth[0])
+    T1 = host_ref.converter(np.asarray(scene.obj_pose, np.float32)[None])[0]
+    far = np.array(scene.obj_pose, np.float32)
+    far[:3, 3] += (5.0, 5.0, 0.0)                      # far outside the frustum
+    poses = host_ref.sample_poses_grid(scene.scene_centre, [4, 4, 1, 1, 1, 1], scene.scene_type).reshape(-1, 4, 4)
+    poses = np.concatenate([poses, far[None]])
+    pn = host_ref.converter(poses)
+    a = fg.render_composite(view, T1, cam_bg, pn)
+    b = fg.render_composite(view, T1, cam_bg, pn)
+    np.testing.assert_array_equal(a, b)                               # deterministic
+    bg_only = a[-1]
+    changed = (a[:-1] != bg_only[None]).any(-1).reshape(len(poses) - 1, -1).mean(1)
+    assert (changed < 0.05).all() and changed.max() > 0.001           # sparse fg footprint
+    st = ctx.render_stats()
+    assert st["rays_total"] == len(poses) * W * H
+    assert 5 < st["samples"] / max(st["rays_alive"], 1) < 60          # ~18 samples per hit ray

@@ -1,0 +1,126 @@
+"""Host-side steps of the path (product, numpy) against the oracle restatements, torch and
+hand-derived known answers.  CPU only."""
+import numpy as np
+import pytest
+import types
+
+from dream2real_amd import accio2ngp, clip_scoring, combined_rendering, geometry_utils, obj_pose_opt
+from dream2real_amd.scene import grid_levels, make_scene
+from oracle import host_ref
+
+
+def _task(centre):
+    return types.SimpleNamespace(scene_model=types.SimpleNamespace(scene_centre=np.asarray(centre, np.float32)))
+
+
+def test_converter_golden(goldens):
+    np.testing.assert_array_equal(accio2ngp.converter(goldens["g1_in"]), goldens["g1_out"])
+    x = goldens["g1_in"].copy()
+    accio2ngp.converter(x)
+    np.testing.assert_array_equal(x, goldens["g1_in"])            # input untouched
+
+
+def test_convert_virtual_pose_golden(goldens):
+    for (a, b, c), want in zip(goldens["g2_in"], goldens["g2_out"]):
+        np.testing.assert_allclose(combined_rendering.convert_virtual_pose(a, b, c), want, rtol=0, atol=1e-12)
+
+
+def test_linspace_matches_torch():
+    import torch
+    for lo, hi in ((0.31, 0.65), (-0.25, 0.10), (0.035, 0.175), (-np.pi, np.pi / 2)):
+        for n in (1, 2, 3, 7, 8, 40, 64, 100, 128, 150):
+            want = torch.linspace(float(np.float32(lo)), float(np.float32(hi)), n).numpy()
+            np.testing.assert_array_equal(obj_pose_opt.linspace_f32(lo, hi, n), want)
+            np.testing.assert_array_equal(host_ref._linspace_f32(lo, hi, n), want)
+
+
+@pytest.mark.parametrize("scene_type,res", [(3, [8, 4, 1, 1, 1, 1]), (0, [5, 3, 2, 1, 1, 1]), (1, [2, 2, 2, 2, 3, 2])])
+def test_sample_poses_grid(scene_type, res):
+    centre = [0.5, 0.0, 0.035]
+    got = obj_pose_opt.sample_poses_grid(_task(centre), res, scene_type)
+    want = host_ref.sample_poses_grid(centre, res, scene_type)
+    assert got.shape == (int(np.prod(res)), 16) and got.dtype == np.float32
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-6)
+    np.testing.assert_array_equal(got[:, [3, 7, 11]], want[:, [3, 7, 11]])      # translations exact
+    # known answers: grid endpoints from obj_pose_opt.py:16-36
+    b = obj_pose_opt.SCENE_BOUNDS[scene_type]
+    assert got[0, 3] == np.float32(np.float32(b[0][0]) + np.float32(centre[0]))
+    assert got[-1, 3] == np.float32(np.float32(b[0][1]) + np.float32(centre[0]))
+    z_end = b[2][1] if res[2] > 1 else b[2][0]                     # linspace(lo, hi, 1) == [lo]
+    assert got[-1, 11] == np.float32(np.float32(z_end) + np.float32(centre[2]))
+    R = got[:, [0, 1, 2, 4, 5, 6, 8, 9, 10]].reshape(-1, 3, 3)
+    np.testing.assert_allclose(R @ R.transpose(0, 2, 1), np.tile(np.eye(3), (len(R), 1, 1)), atol=1e-6)
+    with pytest.raises(NotImplementedError):
+        obj_pose_opt.sample_poses_grid(_task(centre), res, 2)
+
+
+def test_euler_matches_scipy():
+    from scipy.spatial.transform import Rotation
+    e = np.random.default_rng(0).uniform(-3, 3, (50, 3)).astype(np.float32)
+    # pytorch3d 'XYZ' = Rx @ Ry @ Rz = scipy intrinsic 'XYZ'
+    want = Rotation.from_euler("XYZ", e.astype(np.float64)).as_matrix()
+    np.testing.assert_allclose(obj_pose_opt.euler_xyz_to_matrix(e), want, atol=2e-6)
+
+
+def test_gaussian_kernel_known_answer():
+    k = geometry_utils.gaussian_kernel_3(0.7)
+    k1 = np.array([0.209454, 0.581093, 0.209454])
+    np.testing.assert_allclose(k, np.outer(k1, k1), atol=2e-6)
+    np.testing.assert_allclose(host_ref.gaussian_kernel_1d(0.7), k1, atol=1e-6)
+
+
+def test_smoothing_matches_torch_conv_and_oracle():
+    import torch
+    rng = np.random.default_rng(1)
+    res = [7, 5, 3, 2, 1, 1]
+    s = rng.uniform(0.9, 1.1, int(np.prod(res))).astype(np.float32)
+    s[rng.random(s.size) < 0.2] = 0
+    got = geometry_utils.spatially_smooth_heatmap(s, res)
+    want = host_ref.spatially_smooth_heatmap(s, res)
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-6)
+    assert ((got == 0) == (s == 0)).all()
+    # independent check through torch conv2d with the reference's reshaping
+    t = torch.from_numpy(s.copy())
+    mn = t[t != 0].min()
+    zero = t == 0
+    t[zero] = mn
+    R = int(np.prod(res[2:]))
+    img = t.view(res[0] * res[1], R).swapaxes(0, 1).reshape(R, 1, res[0], res[1])
+    img = torch.nn.functional.pad(img, (1, 1, 1, 1), value=float(mn))
+    k = torch.from_numpy(geometry_utils.gaussian_kernel_3(0.7))[None, None]
+    out = torch.nn.functional.conv2d(img, k).reshape(R, res[0] * res[1]).swapaxes(0, 1).reshape(-1)
+    out[zero] = 0
+    np.testing.assert_allclose(got, out.numpy(), rtol=0, atol=1e-6)
+    # constant map stays constant; a single spike spreads with the kernel weights
+    c = np.full(25, 2.0, np.float32)
+    np.testing.assert_allclose(geometry_utils.spatially_smooth_heatmap(c, [5, 5, 1, 1, 1, 1]), c, atol=1e-6)
+
+
+def test_reduce_logits_and_captions():
+    a = np.random.default_rng(2).uniform(10, 30, (6, 3)).astype(np.float32)
+    np.testing.assert_allclose(clip_scoring.reduce_logits(a, 1, True), host_ref.score_logits(a, True), rtol=1e-6)
+    np.testing.assert_allclose(clip_scoring.reduce_logits(a[:, :1], 1, False), host_ref.score_logits(a[:, :1], False))
+    caps, n_goal = clip_scoring.build_captions("g", ["n1", "n2"], False)
+    assert caps == ["g", "n1", "n2"] and n_goal == 1
+    caps, n_goal = clip_scoring.build_captions("g", ["n"], True)
+    assert len(caps) == 18 and n_goal == 9 and caps[1] == "a photo of g" and caps[9] == "n"
+    b = np.random.default_rng(3).uniform(10, 30, (4, 18)).astype(np.float32)
+    np.testing.assert_allclose(clip_scoring.reduce_logits(b, 9, True), host_ref.score_logits_templates(b, 9, True), rtol=1e-6)
+
+
+def test_grid_levels_known_answers():
+    lv = grid_levels()
+    assert lv.n_entries == 6098120
+    assert list(lv.res[:6]) == [16, 23, 31, 43, 59, 81] and lv.res[-1] == 2048
+    assert abs(lv.per_level_scale - 1.3819) < 1e-4
+    assert list(lv.hashed) == [False] * 5 + [True] * 11
+    assert lv.size[0] == 4096 and lv.size[-1] == 1 << 19
+    assert (lv.size % 8 == 0).all()
+
+
+def test_synthetic_scene_is_deterministic():
+    a, b = make_scene("shopping"), make_scene("shopping")
+    np.testing.assert_array_equal(a.fg.grid, b.fg.grid)
+    np.testing.assert_array_equal(a.fg.occ_bits, b.fg.occ_bits)
+    assert 300 < a.fg.occupancy_bool().sum() < 2000
+    assert make_scene("pool_triangle").scene_type == 0
