@@ -114,7 +114,10 @@ def main():
     view = fg.view(W, H)
     ctx.set_background(view, bg_rgba[0], bg_depth[0])
     T1 = converter(np.asarray(scene.obj_pose, np.float32)[None])[0]
-    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    # run the library on a torch-owned (non-null) stream so torch copies/collectives order after it
+    stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(stream)
+    ctx.set_stream(stream.cuda_stream)
 
     def step():
         engine.render_score_device(ctx, fg, scorer, view, T1, cam_ngp, poses_dev.data_ptr(), K_local, text,

@@ -209,6 +209,24 @@ __device__ __forceinline__ uint32_t lds_off(uint32_t row, uint32_t chunk)
     return row * 128u + ((chunk ^ ((row >> 1) & 7u)) << 4);
 }
 
+// Direct global->LDS copy of one 16-byte chunk per lane (1 KiB per wave instruction).  The LDS
+// destination is wave-uniform base (M0) + lane*16, so the XOR swizzle is applied on the SOURCE
+// side.  Issued from inline asm so that hipcc does not see an in-flight LDS write and drain it
+// (vmcnt(0)) in front of every ds_read of the tile being computed; the waits are placed by hand
+// (cdna_hip_programming.md 5.7).  lds_byte_addr must be wave-uniform.
+__device__ __forceinline__ void glds16(const void *g, uint32_t lds_byte_addr)
+{
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(g), "s"(lds_byte_addr)
+                 : "memory");
+}
+__device__ __forceinline__ uint32_t lds_addr(const void *p)
+{
+    return (uint32_t)(size_t)(__attribute__((address_space(3))) const void *)p;
+}
+
 // A [M_pad][K] bf16, W [N][K] bf16, M_pad % 128 == 0, N % 128 == 0, K % 64 == 0
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void k_gemm(const uint16_t *__restrict__ A, const uint16_t *__restrict__ W,
@@ -225,7 +243,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm(const uint16_t *__restrict__ A,
     const uint32_t tile = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
     const uint32_t m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
 
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
     const uint32_t li = lane & 31, hi = lane >> 5;
 
@@ -237,33 +256,36 @@ __global__ __launch_bounds__(256, 2) void k_gemm(const uint16_t *__restrict__ A,
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-    const uint32_t lrow = tid >> 3, lchunk = tid & 7;    // 32 rows x 8 chunks per pass
-    const uint16_t *Ag = A + (size_t)(m0 + lrow) * K + lchunk * 8;
-    const uint16_t *Wg = W + (size_t)(n0 + lrow) * K + lchunk * 8;
-    uint4 ra[4], rb[4];
+    // staging: wave w copies row blocks {4w..4w+3} (8 rows x 128 B each) of both operands.
+    // lane -> (row in block, physical chunk); the logical chunk it fetches is the swizzle inverse
+    const uint32_t r_in = lane >> 3, pc = lane & 7;
+    const uint16_t *ag[4], *wg[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t row = (wave * 4 + i) * 8 + r_in;
+        const uint32_t lc = pc ^ ((row >> 1) & 7u);
+        ag[i] = A + (size_t)(m0 + row) * K + lc * 8;
+        wg[i] = W + (size_t)(n0 + row) * K + lc * 8;
+    }
     const uint32_t nk = K / BK;
+    const uint32_t as_base = __builtin_amdgcn_readfirstlane(lds_addr(As));
+    const uint32_t bs_base = __builtin_amdgcn_readfirstlane(lds_addr(Bs));
+    auto stage = [&](uint32_t buf, uint32_t kt) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t boff = buf * (BM * BK * 2) + (wave * 4 + i) * 1024;
+            glds16(ag[i] + (size_t)kt * BK, as_base + boff);
+            glds16(wg[i] + (size_t)kt * BK, bs_base + boff);
+        }
+    };
 
-#pragma unroll
-    for (int p = 0; p < 4; p++) {
-        ra[p] = *(const uint4 *)(Ag + (size_t)p * 32 * K);
-        rb[p] = *(const uint4 *)(Wg + (size_t)p * 32 * K);
-    }
-#pragma unroll
-    for (int p = 0; p < 4; p++) {
-        *(uint4 *)(As + lds_off(lrow + p * 32, lchunk)) = ra[p];
-        *(uint4 *)(Bs + lds_off(lrow + p * 32, lchunk)) = rb[p];
-    }
-    __syncthreads();
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();          // tile 0 landed and is visible to every wave
 
     for (uint32_t kt = 0; kt < nk; kt++) {
         const uint32_t cur = kt & 1;
-        if (kt + 1 < nk) {
-#pragma unroll
-            for (int p = 0; p < 4; p++) {
-                ra[p] = *(const uint4 *)(Ag + (size_t)p * 32 * K + (size_t)(kt + 1) * BK);
-                rb[p] = *(const uint4 *)(Wg + (size_t)p * 32 * K + (size_t)(kt + 1) * BK);
-            }
-        }
+        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);       // next tile streams in under the MFMAs
         const uint8_t *Ab = As + cur * (BM * BK * 2);
         const uint8_t *Bb = Bs + cur * (BN * BK * 2);
 #pragma unroll
@@ -284,19 +306,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm(const uint16_t *__restrict__ A,
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc[i][j], 0, 0, 0);
                 }
         }
-        if (kt + 1 < nk) {
-            uint8_t *An = As + (cur ^ 1) * (BM * BK * 2);
-            uint8_t *Bn = Bs + (cur ^ 1) * (BN * BK * 2);
-#pragma unroll
-            for (int p = 0; p < 4; p++) {
-                *(uint4 *)(An + lds_off(lrow + p * 32, lchunk)) = ra[p];
-                *(uint4 *)(Bn + lds_off(lrow + p * 32, lchunk)) = rb[p];
-            }
-        }
-        __syncthreads();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's share of the next tile landed
+        __syncthreads();                                     // ... everyone's did, and `cur` is free
     }
 
     // epilogue: acc[i][j][r] -> row m0+wm+32i+(r&3)+8(r>>2)+4hi, col n0+wn+32j+li
+    const bool full = m0 + BM <= M_real;      // block-uniform: only the last row panel is ragged
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -306,7 +321,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm(const uint16_t *__restrict__ A,
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const uint32_t row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if (row >= M_real) continue;
+                if (!full && row >= M_real) continue;
                 float v = acc[i][j][r] + bv;
                 const size_t o = (size_t)row * N + col;
                 if (EPI == EPI_F32) {
