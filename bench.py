@@ -76,7 +76,7 @@ def main():
     from dream2real_amd.clip_scoring import reduce_logits
     from dream2real_amd.geometry_utils import spatially_smooth_heatmap
     from dream2real_amd.scene import make_scene
-    from tests.parity_utils import make_task, seeded_text_embeds
+    from tests.parity_utils import make_task, scene_text_embeds
 
     rank, world, local = d2r_dist.init_from_env()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
@@ -88,7 +88,6 @@ def main():
     scene = make_scene(args.scene)
     cfg = CLIP_CONFIGS[args.clip]
     sd = random_clip_state_dict(cfg, seed=6)
-    text = seeded_text_embeds(cfg, sd)                       # cached text embeddings (goal, norm)
     ctx = engine.Context(local)
     ctx.set_option("chunk", args.chunk)
     fg, bg = engine.Testbed(ctx, scene.fg), engine.Testbed(ctx, scene.bg)
@@ -108,12 +107,17 @@ def main():
     poses_ngp = converter(pose_batch[my_idx].reshape(-1, 4, 4)).reshape(-1, 16).astype(np.float32)
     poses_dev = torch.from_numpy(poses_ngp).to(dev)
     K_local = poses_dev.shape[0]
-    logits_dev = torch.zeros((K_local, text.shape[0]), dtype=torch.float32, device=dev)
     cam_ngp = converter(np.asarray(scene.cam_poses, np.float32))[0]
     bg_rgba, bg_depth = bg.render_batch(cam_ngp[None, :3], W, H)
     view = fg.view(W, H)
     ctx.set_background(view, bg_rgba[0], bg_depth[0])
     T1 = converter(np.asarray(scene.obj_pose, np.float32)[None])[0]
+    # cached text embeddings (goal, normalising): seeded unit vectors correlated with the embedding
+    # of the un-moved scene, standing in for the text tower output of a real caption pair
+    frame0 = fg.render_composite(view, T1, cam_ngp, T1[None])
+    _, e0 = scorer.score_frames(frame0, np.zeros((1, cfg["proj"]), np.float32), return_embeds=True)
+    text = scene_text_embeds(e0[0])
+    logits_dev = torch.zeros((K_local, text.shape[0]), dtype=torch.float32, device=dev)
     # run the library on a torch-owned (non-null) stream so torch copies/collectives order after it
     stream = torch.cuda.Stream(dev)
     torch.cuda.set_stream(stream)

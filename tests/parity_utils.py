@@ -29,6 +29,16 @@ def random_unit_text_embeds(D, n_caps=2, seed=5):
     return t / np.linalg.norm(t, axis=-1, keepdims=True)
 
 
+def scene_text_embeds(image_embed, n_caps=2, seed=5, noise=0.8):
+    """Cached "caption" embeddings for a synthetic task: unit vectors positively correlated with
+    an image embedding of the scene (as a real goal/normalising caption pair would be), so
+    logits are positive and the goal/norm ratio is well conditioned."""
+    e = np.asarray(image_embed, np.float64).reshape(-1)
+    r = np.random.Generator(np.random.PCG64(seed))
+    t = e[None] + noise * r.standard_normal((n_caps, e.size)) / np.sqrt(e.size) * np.linalg.norm(e)
+    return (t / np.linalg.norm(t, axis=-1, keepdims=True)).astype(np.float32)
+
+
 def make_task(scene, fg_tb=None, bg_tb=None):
     """Duck-typed TaskModel (reference scene_model.py:45-130) for a synthetic scene."""
     import torch
@@ -103,7 +113,9 @@ def run_smoke():
     W, H = 96, 54
     cfg = CLIP_CONFIGS["vit_tiny"]
     sd = random_clip_state_dict(cfg, seed=6)
-    text = seeded_text_embeds(cfg, sd)
+    pipe = OraclePipeline(scene, W, H)
+    _, e0 = oracle_logits(pipe.frames(np.asarray(scene.obj_pose, np.float32)[None]), cfg, sd, np.zeros((1, cfg["proj"])))
+    text = scene_text_embeds(e0[0])
     ctx = engine.Context(0)
     fg_tb, bg_tb = engine.Testbed(ctx, scene.fg), engine.Testbed(ctx, scene.bg)
     fg_tb.background_color = list(scene.fg_background)
@@ -117,11 +129,12 @@ def run_smoke():
         best, pose_batch, scores = clip_scoring.optimise_pose_grid(
             rend, None, [0], task, td, sample_res=sample_res, phys_check=all_valid, scene_type=scene.scene_type,
             smoothing=False, scorer=scorer)
-    pipe = OraclePipeline(scene, W, H)
     frames = pipe.frames(pose_batch.numpy())
     lg, _ = oracle_logits(frames, cfg, sd, text)
     want = host_ref.score_logits(lg, True)
     got = scores.numpy()
     err = np.abs(got - want).max()
-    print(f"smoke: {len(want)} candidates, max |score - oracle| = {err:.2e}, samples(oracle) = {pipe.n_samples}")
-    assert np.isfinite(got).all() and err < 2e-2, (got, want)
+    tol = float((0.1 * (1.0 + np.abs(want)) / np.abs(lg[:, 1])).max())    # 1e-3 cosine per logit, propagated
+    print(f"smoke: {len(want)} candidates, max |score - oracle| = {err:.2e} (tol {tol:.2e}), "
+          f"oracle samples = {pipe.n_samples}, libd2r loaded = {'libd2r.so' in open('/proc/self/maps').read()}")
+    assert np.isfinite(got).all() and err <= tol, (got, want)
