@@ -66,6 +66,13 @@ def load() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise D2RError(f"{LIB_PATH} is missing: build it with __graft_entry__.build() "
                        "(make -C dream2real_amd/csrc); there is no CPU fallback")
+    # torch wheels bundle their own libamdhip64.so.7; whichever copy of that soname is mapped first
+    # serves the whole process.  Load torch's first so libd2r, torch tensors/streams and RCCL all
+    # share ONE HIP runtime (with /opt/rocm's copy mapped first, torch finds no GPU afterwards).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     lib.d2r_last_error.restype = C.c_char_p
     lib.d2r_last_error.argtypes = [C.c_void_p]
