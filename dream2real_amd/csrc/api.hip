@@ -206,6 +206,7 @@ static uint16_t float_to_bf16(float f)
 }
 
 // MFMA A-operand fragments of the five weight matrices (nerf.hip mlp_tile).
+//   kind 2: hash-grid features in slot order              col = 2*(2*(4*s + (j>>1)) + hi) + (j&1)
 //   kind 0: k index is a network INPUT in natural order   col = 16*s + 8*hi + j
 //   kind 1: k index comes from a previous layer's C layout col = 16*s + 8*(j>>2) + 4*hi + (j&3)
 static void build_frag(std::vector<uint16_t> &dst, int frag, const uint16_t *w, int n_out, int n_in, int mtile,
@@ -214,7 +215,9 @@ static void build_frag(std::vector<uint16_t> &dst, int frag, const uint16_t *w, 
     for (int lane = 0; lane < 64; lane++) {
         int i = lane & 31, hi = lane >> 5, row = mtile * 32 + i;
         for (int j = 0; j < 8; j++) {
-            int col = col_base + (kind == 0 ? 16 * s + 8 * hi + j : 16 * s + 8 * (j >> 2) + 4 * hi + (j & 3));
+            int col = col_base + (kind == 0   ? 16 * s + 8 * hi + j
+                                  : kind == 1 ? 16 * s + 8 * (j >> 2) + 4 * hi + (j & 3)
+                                              : 2 * (2 * (4 * s + (j >> 1)) + hi) + (j & 1));
             float v = (row < n_out && col < n_in) ? half_to_float(w[row * n_in + col]) : 0.f;
             dst[((size_t)frag * 64 + lane) * 8 + j] = float_to_bf16(v);
         }
@@ -234,8 +237,12 @@ int d2r_nerf_create(d2r_ctx *ctx, const d2r_nerf_desc *d, d2r_nerf **out)
     m->ctx = ctx;
     NerfParams &P = m->P;
     P.n_levels = d->n_levels;
+    LevelMeta lv[D2R_MAX_LEVELS];
+    int n_dense = 0;
+    bool prefix = true;
+    uint32_t hash_size = 0;
     for (uint32_t l = 0; l < d->n_levels; l++) {
-        LevelMeta &lm = P.lv[l];
+        LevelMeta &lm = lv[l];
         lm.scale = d->level_scale[l];
         lm.res = d->level_res[l];
         lm.size = d->level_size[l];
@@ -246,10 +253,39 @@ int d2r_nerf_create(d2r_ctx *ctx, const d2r_nerf_desc *d, d2r_nerf **out)
             delete m;
             return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "hashed levels must have a power-of-two size");
         }
+        if (lm.hashed) {
+            if (hash_size && hash_size != lm.size) {
+                delete m;
+                return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "hashed levels must share one table size");
+            }
+            hash_size = lm.size;
+        }
         if ((uint64_t)lm.offset + lm.size > d->n_entries) {
             delete m;
             return d2r_fail(ctx, D2R_ERR_INVALID, "level table exceeds n_entries");
         }
+        if (!lm.hashed && prefix) n_dense++;
+        if (lm.hashed) prefix = false;
+        if (!lm.hashed && !prefix && (int)l >= n_dense) n_dense = -1000;   // dense after hashed: irregular
+    }
+    P.n_dense = n_dense < 0 ? -1 : n_dense;
+    // interleaved slot tables: entry e of level 2i+h at word 2e+h of slot i
+    std::vector<uint32_t> tab;
+    const uint32_t *src = (const uint32_t *)d->grid_fp16;       // half2 per entry
+    for (uint32_t i = 0; i < d->n_levels / 2; i++) {
+        const LevelMeta &a = lv[2 * i], &b = lv[2 * i + 1];
+        SlotMeta &sm = P.slot[i];
+        sm.scale[0] = a.scale; sm.scale[1] = b.scale;
+        sm.res[0] = a.res; sm.res[1] = b.res;
+        sm.size[0] = a.size; sm.size[1] = b.size;
+        sm.hashed[0] = a.hashed; sm.hashed[1] = b.hashed;
+        sm.mask8 = hash_size ? (((hash_size - 1u) << 3) | 4u) : 0u;
+        sm.off = (uint32_t)(tab.size() * 4);
+        const uint32_t n = std::max(a.size, b.size);
+        const size_t base = tab.size();
+        tab.resize(base + (size_t)n * 2, 0u);
+        for (uint32_t e = 0; e < a.size; e++) tab[base + 2 * (size_t)e] = src[a.offset + e];
+        for (uint32_t e = 0; e < b.size; e++) tab[base + 2 * (size_t)e + 1] = src[b.offset + e];
     }
     // occupancy -> 4x4x4 bricks + bounding box of occupied cells
     std::vector<uint64_t> bricks(32 * 32 * 32, 0);
@@ -280,7 +316,7 @@ int d2r_nerf_create(d2r_ctx *ctx, const d2r_nerf_desc *d, d2r_nerf **out)
     std::vector<uint16_t> wf((size_t)D2R_N_WFRAG * 64 * 8);
     const int n_in = (int)(d->n_levels * d->n_features);
     for (int mt = 0; mt < 2; mt++)
-        for (int s = 0; s < 2; s++) build_frag(wf, 0 + mt * 2 + s, d->dw1_fp16, 64, n_in, mt, s, 0);
+        for (int s = 0; s < 2; s++) build_frag(wf, 0 + mt * 2 + s, d->dw1_fp16, 64, n_in, mt, s, 2);
     for (int q = 0; q < 4; q++) build_frag(wf, 4 + q, d->dw2_fp16, 16, 64, 0, q, 1);
     for (int mt = 0; mt < 2; mt++) {
         build_frag(wf, 8 + mt * 2 + 0, d->cw1_fp16, 64, 32, mt, 0, 1);          // density outputs (C layout)
@@ -290,7 +326,7 @@ int d2r_nerf_create(d2r_ctx *ctx, const d2r_nerf_desc *d, d2r_nerf **out)
         for (int q = 0; q < 4; q++) build_frag(wf, 12 + mt * 4 + q, d->cw2_fp16, 64, 64, mt, q, 1);
     for (int q = 0; q < 4; q++) build_frag(wf, 20 + q, d->cw3_fp16, 16, 64, 0, q, 1);
 
-    const size_t grid_bytes = (size_t)d->n_entries * 4;
+    const size_t grid_bytes = tab.size() * 4;
     if (grid_bytes >= (1ull << 32)) {
         delete m;
         return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "grid larger than 4 GiB");
@@ -298,7 +334,7 @@ int d2r_nerf_create(d2r_ctx *ctx, const d2r_nerf_desc *d, d2r_nerf **out)
     bool ok = hipMalloc(&m->d_grid, grid_bytes) == hipSuccess &&
               hipMalloc(&m->d_bricks, bricks.size() * 8) == hipSuccess &&
               hipMalloc(&m->d_wfrag, wf.size() * 2) == hipSuccess;
-    ok = ok && hipMemcpy(m->d_grid, d->grid_fp16, grid_bytes, hipMemcpyHostToDevice) == hipSuccess &&
+    ok = ok && hipMemcpy(m->d_grid, tab.data(), grid_bytes, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(m->d_bricks, bricks.data(), bricks.size() * 8, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(m->d_wfrag, wf.data(), wf.size() * 2, hipMemcpyHostToDevice) == hipSuccess;
     if (!ok) {

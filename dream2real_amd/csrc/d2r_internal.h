@@ -23,11 +23,24 @@ struct LevelMeta {
     uint32_t hashed;
 };
 
+// One "slot" = the pair of hash-grid levels (2i, 2i+1) that the two lanes (l, l^32) of a lane
+// pair evaluate.  Their tables are stored INTERLEAVED in HBM: entry e of level 2i+h lives at
+// byte  slot_off + 8*e + 4*h, so a corner address is (index << 3) | (h << 2) plus an SGPR offset.
+struct SlotMeta {
+    float scale[2];
+    uint32_t res[2];
+    uint32_t size[2];
+    uint32_t hashed[2];
+    uint32_t mask8;      // (hash table size - 1) << 3 | 4   (hashed levels share one size)
+    uint32_t off;        // byte offset of the slot's interleaved table
+};
+
 struct NerfParams {
-    const uint32_t *grid;      // [n_entries] half2 packed
+    const uint32_t *grid;      // interleaved slot tables, half2 entries
     uint32_t grid_bytes;
     uint32_t n_levels;
-    LevelMeta lv[D2R_MAX_LEVELS];
+    int32_t n_dense;           // leading dense levels (slot kinds follow from it), -1 = irregular
+    SlotMeta slot[D2R_MAX_LEVELS / 2];
     const uint64_t *bricks;    // [32^3] 4x4x4-cell occupancy bricks
     const uint4 *wfrag;        // [24][64] MFMA A-operand fragments of the MLPs
     float bbox_lo[3], bbox_hi[3];  // bounding box of occupied cells (+margin), unit-cube units

@@ -202,7 +202,8 @@ __device__ __forceinline__ bool make_ray(const NerfParams &P, const ViewParams &
 __device__ __forceinline__ bool next_sample(const NerfParams &P, const Ray &r, uint32_t &k, float &px,
                                             float &py, float &pz)
 {
-    float ix = 1.0f / r.dx, iy = 1.0f / r.dy, iz = 1.0f / r.dz;
+    // approximate reciprocals are enough: they only size the conservative skip below
+    float ix = __builtin_amdgcn_rcpf(r.dx), iy = __builtin_amdgcn_rcpf(r.dy), iz = __builtin_amdgcn_rcpf(r.dz);
     while (k <= r.k_hi) {
         float t = fmaf((float)k, D2R_DT, r.t0);
         px = fmaf(t, r.dx, r.ox);
@@ -293,52 +294,102 @@ __device__ __forceinline__ f32x16 mfma(const uint4 &a, const uint4 &b, f32x16 c)
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v, fb.v, c, 0, 0, 0);
 }
 
-// four consecutive levels (two features each) of one sample -> 8 fp32 features
-__device__ __forceinline__ void encode4(const NerfParams &P, const __amdgpu_buffer_rsrc_t &rs, int lvl0,
-                                        bool hi, float x, float y, float z, float *f)
+enum { K_DENSE = 0, K_HASH = 1, K_MIXED = 2 };
+
+// kind of slot i when the first ND levels are dense (ND < 0: treat every slot as mixed)
+template <int ND>
+__device__ __host__ constexpr int slot_kind(int i)
 {
+    return ND < 0 ? K_MIXED : (2 * i + 1 < ND ? K_DENSE : (2 * i >= ND ? K_HASH : K_MIXED));
+}
+
+// One slot (this lane's level of the pair) of one sample -> 2 fp32 features.
+// Arithmetic per corner: 1 address op + 1 load + weight product + 2 fma; the slot table base
+// rides in the SGPR soffset of the buffer load.  Matches oracle hashgrid_encode().
+template <int KIND>
+__device__ __forceinline__ void encode_slot(const NerfParams &P, const __amdgpu_buffer_rsrc_t &rs, int slot,
+                                            bool hi, float x, float y, float z, float &o0, float &o1)
+{
+    const SlotMeta &m = P.slot[slot];
+    const float scale = hi ? m.scale[1] : m.scale[0];
+    float p0 = fmaf(scale, x, 0.5f), p1 = fmaf(scale, y, 0.5f), p2 = fmaf(scale, z, 0.5f);
+    float f0 = floorf(p0), f1 = floorf(p1), f2 = floorf(p2);
+    float wx = p0 - f0, wy = p1 - f1, wz = p2 - f2;
+    uint32_t gx = (uint32_t)(int)f0, gy = (uint32_t)(int)f1, gz = (uint32_t)(int)f2;
+    const uint32_t h4 = hi ? 4u : 0u;
+    uint32_t off[8];
+    if (KIND == K_HASH) {
+        // everything pre-shifted by 3: ((a<<3) ^ (b<<3)) & (mask<<3|4) == ((a^b)&mask)<<3 | h4
+        const uint32_t x0 = (gx << 3) | h4, x1 = x0 + 8u;
+        const uint32_t y0 = gy * (2654435761u << 3), y1 = y0 + (2654435761u << 3);
+        const uint32_t z0 = gz * (805459861u << 3), z1 = z0 + (805459861u << 3);
+        const uint32_t yz[4] = {y0 ^ z0, y1 ^ z0, y0 ^ z1, y1 ^ z1};
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const LevelMeta &ma = P.lv[lvl0 + q];
-        const LevelMeta &mb = P.lv[lvl0 + 4 + q];
-        const float scale = hi ? mb.scale : ma.scale;
-        const uint32_t res = hi ? mb.res : ma.res;
-        const uint32_t size = hi ? mb.size : ma.size;
-        const uint32_t offset = hi ? mb.offset : ma.offset;
-        const bool hashed = (hi ? mb.hashed : ma.hashed) != 0;
-        float p0 = fmaf(scale, x, 0.5f), p1 = fmaf(scale, y, 0.5f), p2 = fmaf(scale, z, 0.5f);
-        float f0 = floorf(p0), f1 = floorf(p1), f2 = floorf(p2);
-        float wx = p0 - f0, wy = p1 - f1, wz = p2 - f2;
-        uint32_t gx = (uint32_t)(int)f0, gy = (uint32_t)(int)f1, gz = (uint32_t)(int)f2;
+        for (int c = 0; c < 8; c++) off[c] = (((c & 1) ? x1 : x0) ^ yz[c >> 1]) & m.mask8;
+    } else {
+        const uint32_t res = hi ? m.res[1] : m.res[0];
+        const uint32_t size = hi ? m.size[1] : m.size[0];
+        const bool hashed = KIND == K_MIXED && ((hi ? m.hashed[1] : m.hashed[0]) != 0);
         const uint32_t my = hashed ? 2654435761u : res;
         const uint32_t mz = hashed ? 805459861u : res * res;
-        uint32_t ix[2] = {gx, gx + 1u};
-        uint32_t iy[2] = {gy * my, (gy + 1u) * my};
-        uint32_t iz[2] = {gz * mz, (gz + 1u) * mz};
-        float wxs[2] = {1.0f - wx, wx}, wys[2] = {1.0f - wy, wy}, wzs[2] = {1.0f - wz, wz};
-        uint32_t raw[8];
+        const uint32_t y0 = gy * my, y1 = y0 + my, z0 = gz * mz, z1 = z0 + mz;
+        if (KIND == K_DENSE) {
+            const uint32_t x0 = (gx << 3) | h4, x1 = x0 + 8u;
+            const uint32_t yz[4] = {(y0 + z0) << 3, (y1 + z0) << 3, (y0 + z1) << 3, (y1 + z1) << 3};
 #pragma unroll
-        for (int c = 0; c < 8; c++) {
-            uint32_t a = ix[c & 1], b = iy[(c >> 1) & 1], d = iz[c >> 2];
-            uint32_t ih = (a ^ b ^ d) & (size - 1u);       // hashed levels have power-of-two sizes
-            uint32_t id = a + b + d;
-            id = id >= size ? id - size : id;              // dense: idx % size (one wrap at most)
-            uint32_t idx = hashed ? ih : id;
-            raw[c] = __builtin_amdgcn_raw_buffer_load_b32(rs, (offset + idx) * 4u, 0, 0);
-        }
-        float a0 = 0.f, a1 = 0.f;
+            for (int c = 0; c < 8; c++) off[c] = ((c & 1) ? x1 : x0) + yz[c >> 1];
+        } else {
 #pragma unroll
-        for (int c = 0; c < 8; c++) {
-            float w = wxs[c & 1] * wys[(c >> 1) & 1] * wzs[c >> 2];
-            // oracle order: weight = prod over dims (x, then y, then z) starting from 1
-            union { uint32_t u; _Float16 h[2]; } cv;
-            cv.u = raw[c];
-            a0 = fmaf(w, (float)cv.h[0], a0);
-            a1 = fmaf(w, (float)cv.h[1], a1);
+            for (int c = 0; c < 8; c++) {
+                uint32_t a = gx + (c & 1), b = (c & 2) ? y1 : y0, d = (c & 4) ? z1 : z0;
+                uint32_t idx = hashed ? ((a ^ b ^ d) & (size - 1u)) : (a + b + d);
+                off[c] = (idx << 3) | h4;
+            }
         }
-        f[2 * q + 0] = a0;
-        f[2 * q + 1] = a1;
+        // dense index can reach `size` only on the far faces of the cube (x, y or z == 1):
+        // tiny-cuda-nn wraps with % size there
+        const bool edge = !hashed && (gx + 1u >= res || gy + 1u >= res || gz + 1u >= res);
+        if (__builtin_expect(edge, 0)) {
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                uint32_t idx = (gx + (c & 1)) + ((c & 2) ? y1 : y0) + ((c & 4) ? z1 : z0);
+                idx = idx >= size ? idx - size : idx;
+                off[c] = (idx << 3) | h4;
+            }
+        }
     }
+    uint32_t raw[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++) raw[c] = __builtin_amdgcn_raw_buffer_load_b32(rs, off[c], m.off, 0);
+    // corner weights in the oracle's order: ((wx_c * wy_c) * wz_c)
+    const float ux = 1.0f - wx, uy = 1.0f - wy, uz = 1.0f - wz;
+    const float xy[4] = {ux * uy, wx * uy, ux * wy, wx * wy};
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        const float w = xy[c & 3] * ((c & 4) ? wz : uz);
+        union { uint32_t u; _Float16 h[2]; } cv;
+        cv.u = raw[c];
+        a0 = fmaf(w, (float)cv.h[0], a0);
+        a1 = fmaf(w, (float)cv.h[1], a1);
+    }
+    o0 = a0;
+    o1 = a1;
+}
+
+// all 8 slots of one sample: f[2*i], f[2*i+1] = features of slot i (this lane's level of the pair)
+template <int ND>
+__device__ __forceinline__ void encode_sample(const NerfParams &P, const __amdgpu_buffer_rsrc_t &rs, bool hi,
+                                              float x, float y, float z, float *f)
+{
+    encode_slot<slot_kind<ND>(0)>(P, rs, 0, hi, x, y, z, f[0], f[1]);
+    encode_slot<slot_kind<ND>(1)>(P, rs, 1, hi, x, y, z, f[2], f[3]);
+    encode_slot<slot_kind<ND>(2)>(P, rs, 2, hi, x, y, z, f[4], f[5]);
+    encode_slot<slot_kind<ND>(3)>(P, rs, 3, hi, x, y, z, f[6], f[7]);
+    encode_slot<slot_kind<ND>(4)>(P, rs, 4, hi, x, y, z, f[8], f[9]);
+    encode_slot<slot_kind<ND>(5)>(P, rs, 5, hi, x, y, z, f[10], f[11]);
+    encode_slot<slot_kind<ND>(6)>(P, rs, 6, hi, x, y, z, f[12], f[13]);
+    encode_slot<slot_kind<ND>(7)>(P, rs, 7, hi, x, y, z, f[14], f[15]);
 }
 
 __device__ __forceinline__ void sh16(float x, float y, float z, float *o)
@@ -362,14 +413,22 @@ __device__ __forceinline__ void sh16(float x, float y, float z, float *o)
     o[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
 }
 
+// ReLU on the raw bits: max as signed integers against 0 maps every negative float (sign bit
+// set) to +0 and keeps the others — one v_max_i32, and none of the canonicalising v_max_f32
+// hipcc puts in front of fmaxf() on MFMA results.
+__device__ __forceinline__ float relu_bits(float x)
+{
+    return __int_as_float(max(__float_as_int(x), 0));
+}
+
 // relu + pack registers [r0, r0+8) of an accumulator as the next layer's B fragment
 __device__ __forceinline__ uint4 relu_pack(const f32x16 &a, int r0)
 {
     uint4 o;
-    o.x = pack2(fmaxf(a[r0 + 0], 0.f), fmaxf(a[r0 + 1], 0.f));
-    o.y = pack2(fmaxf(a[r0 + 2], 0.f), fmaxf(a[r0 + 3], 0.f));
-    o.z = pack2(fmaxf(a[r0 + 4], 0.f), fmaxf(a[r0 + 5], 0.f));
-    o.w = pack2(fmaxf(a[r0 + 6], 0.f), fmaxf(a[r0 + 7], 0.f));
+    o.x = pack2(relu_bits(a[r0 + 0]), relu_bits(a[r0 + 1]));
+    o.y = pack2(relu_bits(a[r0 + 2]), relu_bits(a[r0 + 3]));
+    o.z = pack2(relu_bits(a[r0 + 4]), relu_bits(a[r0 + 5]));
+    o.w = pack2(relu_bits(a[r0 + 6]), relu_bits(a[r0 + 7]));
     return o;
 }
 
@@ -430,6 +489,7 @@ __device__ __forceinline__ void mlp_tile(const uint4 *__restrict__ sw, uint32_t 
 
 // Evaluate the wave's 64 samples (one per lane; `valid` marks lanes that have one).
 // On return every valid lane holds sigma and the network rgb of ITS OWN sample.
+template <int ND>
 __device__ __forceinline__ void eval_wave(const NerfParams &P, const __amdgpu_buffer_rsrc_t &rs,
                                           const uint4 *__restrict__ sw, uint32_t lane, bool valid, float x,
                                           float y, float z, float dx, float dy, float dz, float &sigma,
@@ -450,15 +510,9 @@ __device__ __forceinline__ void eval_wave(const NerfParams &P, const __amdgpu_bu
     float fa[16], fb[16], sa[16], sb[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) fa[i] = fb[i] = 0.f;
-    // this lane's levels: {4hi .. 4hi+3} and {8+4hi .. 8+4hi+3}
-    if (av) {
-        encode4(P, rs, 0, hi, ax, ay, az, fa);
-        encode4(P, rs, 8, hi, ax, ay, az, fa + 8);
-    }
-    if (bv) {
-        encode4(P, rs, 0, hi, bx, by, bz, fb);
-        encode4(P, rs, 8, hi, bx, by, bz, fb + 8);
-    }
+    // this lane's levels: 2i + hi for every slot i (slots 0..3 -> k-step 0, 4..7 -> k-step 1)
+    if (av) encode_sample<ND>(P, rs, hi, ax, ay, az, fa);
+    if (bv) encode_sample<ND>(P, rs, hi, bx, by, bz, fb);
     sh16(adx, ady, adz, sa);
     sh16(bdx, bdy, bdz, sb);
     float sha[8], shb[8];
@@ -480,6 +534,7 @@ __device__ __forceinline__ void eval_wave(const NerfParams &P, const __amdgpu_bu
 }
 
 // field evaluation at arbitrary points (parity hook used by tests through d2r_eval_points)
+template <int ND>
 __global__ __launch_bounds__(256) void k_eval_points(NerfParams P, const float *__restrict__ xyz,
                                                      const float *__restrict__ dirs, uint32_t n,
                                                      float *__restrict__ out)
@@ -497,13 +552,13 @@ __global__ __launch_bounds__(256) void k_eval_points(NerfParams P, const float *
         dx = dirs[3 * i]; dy = dirs[3 * i + 1]; dz = dirs[3 * i + 2];
     }
     float s, r, g, b;
-    eval_wave(P, rs, sw, lane, valid, x, y, z, dx, dy, dz, s, r, g, b);
+    eval_wave<ND>(P, rs, sw, lane, valid, x, y, z, dx, dy, dz, s, r, g, b);
     if (valid) *(float4 *)(out + 4 * (size_t)i) = make_float4(s, r, g, b);
 }
 
 // ------------------------------------------------------------------ marcher
 
-template <bool COMPOSITE>
+template <bool COMPOSITE, int ND>
 __global__ __launch_bounds__(256, 2) void k_march(NerfParams P, ViewParams V, const float *__restrict__ cams,
                                                   const uint2 *__restrict__ queue,
                                                   const uint32_t *__restrict__ qcount,
@@ -565,7 +620,7 @@ __global__ __launch_bounds__(256, 2) void k_march(NerfParams P, ViewParams V, co
 
         // ---- evaluate this wave's samples
         float sigma, cr, cg, cb;
-        eval_wave(P, rs, sw, lane, alive, px, py, pz, ray.dx, ray.dy, ray.dz, sigma, cr, cg, cb);
+        eval_wave<ND>(P, rs, sw, lane, alive, px, py, pz, ray.dx, ray.dy, ray.dz, sigma, cr, cg, cb);
 
         // ---- composite + advance
         if (alive) {
@@ -728,14 +783,21 @@ int d2r_launch_render(d2r_ctx *ctx, const d2r_nerf *m, const ViewParams &V, cons
     ctx->timing_end(tr);
     size_t tm = ctx->timing_begin(D2R_T_MARCH);
     int blocks = ctx->march_blocks > 0 ? (int)ctx->march_blocks : 256 * 2;
-    if (composite)
-        hipLaunchKernelGGL(k_march<true>, dim3(blocks), dim3(256), 0, ctx->stream, m->P, V, cams_dev,
-                           (const uint2 *)ctx->queue.p, cnt, cnt + 1, nullptr, nullptr,
-                           (const float *)ctx->bg_depth.p, frames_dev, (unsigned long long *)(cnt + 2));
-    else
-        hipLaunchKernelGGL(k_march<false>, dim3(blocks), dim3(256), 0, ctx->stream, m->P, V, cams_dev,
-                           (const uint2 *)ctx->queue.p, cnt, cnt + 1, rgba_dev, depth_dev, nullptr, nullptr,
-                           (unsigned long long *)(cnt + 2));
+    const float *bgd = (const float *)ctx->bg_depth.p;
+    unsigned long long *sc = (unsigned long long *)(cnt + 2);
+    const uint2 *q = (const uint2 *)ctx->queue.p;
+#define D2R_MARCH(COMP, ND)                                                                                   \
+    hipLaunchKernelGGL((k_march<COMP, ND>), dim3(blocks), dim3(256), 0, ctx->stream, m->P, V, cams_dev, q, cnt, \
+                       cnt + 1, COMP ? nullptr : rgba_dev, COMP ? nullptr : depth_dev, COMP ? bgd : nullptr,   \
+                       COMP ? frames_dev : nullptr, sc)
+    // compile-time slot kinds for the usual tables (5 leading dense levels); anything else
+    // takes the generic (every slot mixed) instantiation
+    if (composite) {
+        if (m->P.n_dense == 5) D2R_MARCH(true, 5); else D2R_MARCH(true, -1);
+    } else {
+        if (m->P.n_dense == 5) D2R_MARCH(false, 5); else D2R_MARCH(false, -1);
+    }
+#undef D2R_MARCH
     ctx->timing_end(tm);
     D2R_HIP(ctx, hipGetLastError());
     return D2R_OK;
@@ -753,7 +815,10 @@ int d2r_launch_bg_quantize(d2r_ctx *ctx, uint32_t w, uint32_t h)
 int d2r_launch_eval_points(d2r_ctx *ctx, const d2r_nerf *m, const float *xyz, const float *dirs, uint32_t n,
                            float *out)
 {
-    hipLaunchKernelGGL(k_eval_points, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, m->P, xyz, dirs, n, out);
+    if (m->P.n_dense == 5)
+        hipLaunchKernelGGL(k_eval_points<5>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, m->P, xyz, dirs, n, out);
+    else
+        hipLaunchKernelGGL(k_eval_points<-1>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, m->P, xyz, dirs, n, out);
     D2R_HIP(ctx, hipGetLastError());
     return D2R_OK;
 }
