@@ -303,21 +303,21 @@ __device__ __host__ constexpr int slot_kind(int i)
     return ND < 0 ? K_MIXED : (2 * i + 1 < ND ? K_DENSE : (2 * i >= ND ? K_HASH : K_MIXED));
 }
 
-// One slot (this lane's level of the pair) of one sample -> 2 fp32 features.
-// Arithmetic per corner: 1 address op + 1 load + weight product + 2 fma; the slot table base
-// rides in the SGPR soffset of the buffer load.  Matches oracle hashgrid_encode().
+// Addresses + interpolation fractions of one slot (this lane's level of the pair) of one sample.
+// One address op per corner; the slot table base rides in the SGPR soffset of the buffer load.
 template <int KIND>
-__device__ __forceinline__ void encode_slot(const NerfParams &P, const __amdgpu_buffer_rsrc_t &rs, int slot,
-                                            bool hi, float x, float y, float z, float &o0, float &o1)
+__device__ __forceinline__ void slot_addr(const NerfParams &P, int slot, bool hi, float x, float y, float z,
+                                          uint32_t *off, float *w)
 {
     const SlotMeta &m = P.slot[slot];
     const float scale = hi ? m.scale[1] : m.scale[0];
     float p0 = fmaf(scale, x, 0.5f), p1 = fmaf(scale, y, 0.5f), p2 = fmaf(scale, z, 0.5f);
     float f0 = floorf(p0), f1 = floorf(p1), f2 = floorf(p2);
-    float wx = p0 - f0, wy = p1 - f1, wz = p2 - f2;
+    w[0] = p0 - f0;
+    w[1] = p1 - f1;
+    w[2] = p2 - f2;
     uint32_t gx = (uint32_t)(int)f0, gy = (uint32_t)(int)f1, gz = (uint32_t)(int)f2;
     const uint32_t h4 = hi ? 4u : 0u;
-    uint32_t off[8];
     if (KIND == K_HASH) {
         // everything pre-shifted by 3: ((a<<3) ^ (b<<3)) & (mask<<3|4) == ((a^b)&mask)<<3 | h4
         const uint32_t x0 = (gx << 3) | h4, x1 = x0 + 8u;
@@ -333,63 +333,65 @@ __device__ __forceinline__ void encode_slot(const NerfParams &P, const __amdgpu_
         const uint32_t my = hashed ? 2654435761u : res;
         const uint32_t mz = hashed ? 805459861u : res * res;
         const uint32_t y0 = gy * my, y1 = y0 + my, z0 = gz * mz, z1 = z0 + mz;
-        if (KIND == K_DENSE) {
-            const uint32_t x0 = (gx << 3) | h4, x1 = x0 + 8u;
-            const uint32_t yz[4] = {(y0 + z0) << 3, (y1 + z0) << 3, (y0 + z1) << 3, (y1 + z1) << 3};
+        const uint32_t yzd[4] = {y0 + z0, y1 + z0, y0 + z1, y1 + z1};
+        const uint32_t yzh[4] = {y0 ^ z0, y1 ^ z0, y0 ^ z1, y1 ^ z1};
 #pragma unroll
-            for (int c = 0; c < 8; c++) off[c] = ((c & 1) ? x1 : x0) + yz[c >> 1];
-        } else {
-#pragma unroll
-            for (int c = 0; c < 8; c++) {
-                uint32_t a = gx + (c & 1), b = (c & 2) ? y1 : y0, d = (c & 4) ? z1 : z0;
-                uint32_t idx = hashed ? ((a ^ b ^ d) & (size - 1u)) : (a + b + d);
-                off[c] = (idx << 3) | h4;
-            }
-        }
-        // dense index can reach `size` only on the far faces of the cube (x, y or z == 1):
-        // tiny-cuda-nn wraps with % size there
-        const bool edge = !hashed && (gx + 1u >= res || gy + 1u >= res || gz + 1u >= res);
-        if (__builtin_expect(edge, 0)) {
-#pragma unroll
-            for (int c = 0; c < 8; c++) {
-                uint32_t idx = (gx + (c & 1)) + ((c & 2) ? y1 : y0) + ((c & 4) ? z1 : z0);
-                idx = idx >= size ? idx - size : idx;
-                off[c] = (idx << 3) | h4;
-            }
+        for (int c = 0; c < 8; c++) {
+            const uint32_t a = gx + (c & 1);
+            // dense: tiny-cuda-nn's idx % size (the index reaches `size` only on the far cube faces)
+            uint32_t idx = a + yzd[c >> 1];
+            idx = min(idx, idx - size);        // unsigned: idx - size wraps huge unless idx >= size
+            if (KIND == K_MIXED) idx = hashed ? ((a ^ yzh[c >> 1]) & (size - 1u)) : idx;
+            off[c] = (idx << 3) | h4;
         }
     }
-    uint32_t raw[8];
-#pragma unroll
-    for (int c = 0; c < 8; c++) raw[c] = __builtin_amdgcn_raw_buffer_load_b32(rs, off[c], m.off, 0);
-    // corner weights in the oracle's order: ((wx_c * wy_c) * wz_c)
-    const float ux = 1.0f - wx, uy = 1.0f - wy, uz = 1.0f - wz;
-    const float xy[4] = {ux * uy, wx * uy, ux * wy, wx * wy};
+}
+
+// trilinear blend of the 8 corner entries, corner weights in the oracle's order ((wx*wy)*wz)
+__device__ __forceinline__ void slot_blend(const uint32_t *raw, const float *w, float &o0, float &o1)
+{
+    const float ux = 1.0f - w[0], uy = 1.0f - w[1], uz = 1.0f - w[2];
+    const float xy[4] = {ux * uy, w[0] * uy, ux * w[1], w[0] * w[1]};
     float a0 = 0.f, a1 = 0.f;
 #pragma unroll
     for (int c = 0; c < 8; c++) {
-        const float w = xy[c & 3] * ((c & 4) ? wz : uz);
+        const float wc = xy[c & 3] * ((c & 4) ? w[2] : uz);
         union { uint32_t u; _Float16 h[2]; } cv;
         cv.u = raw[c];
-        a0 = fmaf(w, (float)cv.h[0], a0);
-        a1 = fmaf(w, (float)cv.h[1], a1);
+        a0 = fmaf(wc, (float)cv.h[0], a0);
+        a1 = fmaf(wc, (float)cv.h[1], a1);
     }
     o0 = a0;
     o1 = a1;
 }
 
-// all 8 slots of one sample: f[2*i], f[2*i+1] = features of slot i (this lane's level of the pair)
+// All 8 slots of one sample in three phases — 64 addresses, then all 64 gathers issued
+// back-to-back (memory-level parallelism is what bounds this kernel), then the blends.
+// f[2*i], f[2*i+1] = features of slot i (this lane's level of the pair).  Matches oracle
+// hashgrid_encode().
 template <int ND>
 __device__ __forceinline__ void encode_sample(const NerfParams &P, const __amdgpu_buffer_rsrc_t &rs, bool hi,
                                               float x, float y, float z, float *f)
 {
-    encode_slot<slot_kind<ND>(0)>(P, rs, 0, hi, x, y, z, f[0], f[1]);
-    encode_slot<slot_kind<ND>(1)>(P, rs, 1, hi, x, y, z, f[2], f[3]);
-    encode_slot<slot_kind<ND>(2)>(P, rs, 2, hi, x, y, z, f[4], f[5]);
-    encode_slot<slot_kind<ND>(3)>(P, rs, 3, hi, x, y, z, f[6], f[7]);
-    encode_slot<slot_kind<ND>(4)>(P, rs, 4, hi, x, y, z, f[8], f[9]);
-    encode_slot<slot_kind<ND>(5)>(P, rs, 5, hi, x, y, z, f[10], f[11]);
-    encode_slot<slot_kind<ND>(6)>(P, rs, 6, hi, x, y, z, f[12], f[13]);
-    encode_slot<slot_kind<ND>(7)>(P, rs, 7, hi, x, y, z, f[14], f[15]);
+    uint32_t off[8][8];
+    float w[8][3];
+    slot_addr<slot_kind<ND>(0)>(P, 0, hi, x, y, z, off[0], w[0]);
+    slot_addr<slot_kind<ND>(1)>(P, 1, hi, x, y, z, off[1], w[1]);
+    slot_addr<slot_kind<ND>(2)>(P, 2, hi, x, y, z, off[2], w[2]);
+    slot_addr<slot_kind<ND>(3)>(P, 3, hi, x, y, z, off[3], w[3]);
+    slot_addr<slot_kind<ND>(4)>(P, 4, hi, x, y, z, off[4], w[4]);
+    slot_addr<slot_kind<ND>(5)>(P, 5, hi, x, y, z, off[5], w[5]);
+    slot_addr<slot_kind<ND>(6)>(P, 6, hi, x, y, z, off[6], w[6]);
+    slot_addr<slot_kind<ND>(7)>(P, 7, hi, x, y, z, off[7], w[7]);
+    __builtin_amdgcn_sched_barrier(0);
+    uint32_t raw[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int c = 0; c < 8; c++) raw[i][c] = __builtin_amdgcn_raw_buffer_load_b32(rs, off[i][c], P.slot[i].off, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 8; i++) slot_blend(raw[i], w[i], f[2 * i], f[2 * i + 1]);
 }
 
 __device__ __forceinline__ void sh16(float x, float y, float z, float *o)
