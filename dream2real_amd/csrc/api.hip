@@ -160,6 +160,8 @@ int d2r_ctx_set_option(d2r_ctx *ctx, const char *key, int64_t value)
     } else if (!strcmp(key, "march_blocks")) {
         if (value < 0 || value > 65535) return d2r_fail(ctx, D2R_ERR_INVALID, "march_blocks out of range");
         ctx->march_blocks = value;
+    } else if (!strcmp(key, "bricks")) {
+        ctx->use_bricks = value != 0;
     } else if (!strcmp(key, "timing")) {
         ctx->timing = value != 0;
         ctx->ev_used = 0;
@@ -312,6 +314,59 @@ int d2r_nerf_create(d2r_ctx *ctx, const d2r_nerf_desc *d, d2r_nerf **out)
             P.bbox_hi[a] = (float)(hi[a] + 1) / D2R_GRID + 1e-4f;
         }
     }
+    // De-hashed, bounding-box-local dense bricks of the leading levels (small objects): the
+    // vertices a sample inside an occupied cell can touch, with the table value (incl. tiny-cuda-nn's
+    // index wrap) resolved here once.  Served from LDS by k_march; values identical to the tables.
+    std::vector<uint32_t> brick_tab;
+    P.n_brick_slots = 0;
+    P.brick_words = 0;
+    if (hi[0] >= 0 && P.n_dense >= 0) {
+        const size_t budget_words = (160 * 1024 - (size_t)D2R_N_WFRAG * 64 * 16) / 4;
+        std::vector<uint32_t> words;
+        uint32_t slots_ok = 0;
+        for (uint32_t i = 0; i < d->n_levels / 2; i++) {
+            SlotMeta &sm = P.slot[i];
+            std::vector<uint32_t> add;
+            bool ok = true;
+            for (int h = 0; h < 2 && ok; h++) {
+                const LevelMeta &L = lv[2 * i + h];
+                int g0[3], n[3];
+                for (int a = 0; a < 3; a++) {
+                    // same correctly-rounded fma the kernels use: monotone, so these bound every sample
+                    float plo = fmaf(L.scale, (float)lo[a] / (float)D2R_GRID, 0.5f);
+                    float phi = fmaf(L.scale, (float)(hi[a] + 1) / (float)D2R_GRID, 0.5f);
+                    g0[a] = (int)floorf(plo);
+                    n[a] = (int)floorf(phi) + 1 - g0[a] + 1;
+                }
+                const size_t cnt = (size_t)n[0] * n[1] * n[2];
+                if (words.size() + add.size() + cnt > budget_words) { ok = false; break; }
+                const size_t base = words.size() + add.size();
+                sm.bnx[h] = (uint32_t)n[0];
+                sm.bnxy[h] = (uint32_t)(n[0] * n[1]);
+                sm.bbase[h] = (int32_t)base - (g0[0] + n[0] * g0[1] + n[0] * n[1] * g0[2]);
+                for (int z = 0; z < n[2]; z++)
+                    for (int y = 0; y < n[1]; y++)
+                        for (int x = 0; x < n[0]; x++) {
+                            uint32_t gx = (uint32_t)(g0[0] + x), gy = (uint32_t)(g0[1] + y), gz = (uint32_t)(g0[2] + z);
+                            uint64_t idx;
+                            if (L.hashed)
+                                idx = (uint32_t)(gx ^ (gy * 2654435761u) ^ (gz * 805459861u));
+                            else
+                                idx = (uint64_t)gx + (uint64_t)gy * L.res + (uint64_t)gz * L.res * L.res;
+                            add.push_back(src[L.offset + (uint32_t)(idx % L.size)]);
+                        }
+            }
+            if (!ok) break;
+            words.insert(words.end(), add.begin(), add.end());
+            slots_ok = i + 1;
+            if (slots_ok == 4 || slots_ok == 5) {          // instantiated kernel variants
+                P.n_brick_slots = slots_ok;
+                P.brick_words = (uint32_t)words.size();
+            }
+            if (slots_ok == 5) break;
+        }
+        brick_tab.assign(words.begin(), words.begin() + P.brick_words);
+    }
     // weight fragments
     std::vector<uint16_t> wf((size_t)D2R_N_WFRAG * 64 * 8);
     const int n_in = (int)(d->n_levels * d->n_features);
@@ -333,10 +388,12 @@ int d2r_nerf_create(d2r_ctx *ctx, const d2r_nerf_desc *d, d2r_nerf **out)
     }
     bool ok = hipMalloc(&m->d_grid, grid_bytes) == hipSuccess &&
               hipMalloc(&m->d_bricks, bricks.size() * 8) == hipSuccess &&
-              hipMalloc(&m->d_wfrag, wf.size() * 2) == hipSuccess;
+              hipMalloc(&m->d_wfrag, wf.size() * 2) == hipSuccess &&
+              hipMalloc(&m->d_brick_tab, std::max<size_t>(brick_tab.size(), 1) * 4) == hipSuccess;
     ok = ok && hipMemcpy(m->d_grid, tab.data(), grid_bytes, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(m->d_bricks, bricks.data(), bricks.size() * 8, hipMemcpyHostToDevice) == hipSuccess &&
-         hipMemcpy(m->d_wfrag, wf.data(), wf.size() * 2, hipMemcpyHostToDevice) == hipSuccess;
+         hipMemcpy(m->d_wfrag, wf.data(), wf.size() * 2, hipMemcpyHostToDevice) == hipSuccess &&
+         (brick_tab.empty() || hipMemcpy(m->d_brick_tab, brick_tab.data(), brick_tab.size() * 4, hipMemcpyHostToDevice) == hipSuccess);
     if (!ok) {
         d2r_nerf_destroy(m);
         return d2r_fail(ctx, D2R_ERR_MEMORY, "device allocation/upload failed for the NeRF model");
@@ -345,6 +402,7 @@ int d2r_nerf_create(d2r_ctx *ctx, const d2r_nerf_desc *d, d2r_nerf **out)
     P.grid_bytes = (uint32_t)grid_bytes;
     P.bricks = (const uint64_t *)m->d_bricks;
     P.wfrag = (const uint4 *)m->d_wfrag;
+    P.brick_tab = (const uint32_t *)m->d_brick_tab;
     *out = m;
     return D2R_OK;
 }
@@ -355,6 +413,7 @@ void d2r_nerf_destroy(d2r_nerf *m)
     if (m->d_grid) hipFree(m->d_grid);
     if (m->d_bricks) hipFree(m->d_bricks);
     if (m->d_wfrag) hipFree(m->d_wfrag);
+    if (m->d_brick_tab) hipFree(m->d_brick_tab);
     delete m;
 }
 

@@ -33,6 +33,10 @@ struct SlotMeta {
     uint32_t hashed[2];
     uint32_t mask8;      // (hash table size - 1) << 3 | 4   (hashed levels share one size)
     uint32_t off;        // byte offset of the slot's interleaved table
+    // bounding-box-local dense brick of each level (served from LDS when the slot is bricked):
+    // vertex (gx,gy,gz) at LDS word  bbase + gx + bnx*gy + bnxy*gz
+    uint32_t bnx[2], bnxy[2];
+    int32_t bbase[2];
 };
 
 struct NerfParams {
@@ -41,6 +45,9 @@ struct NerfParams {
     uint32_t n_levels;
     int32_t n_dense;           // leading dense levels (slot kinds follow from it), -1 = irregular
     SlotMeta slot[D2R_MAX_LEVELS / 2];
+    uint32_t n_brick_slots;    // leading slots whose levels are de-hashed into LDS bricks (0, 4 or 5)
+    uint32_t brick_words;      // total words of those bricks
+    const uint32_t *brick_tab; // [brick_words] half2 entries, copied to LDS by every workgroup
     const uint64_t *bricks;    // [32^3] 4x4x4-cell occupancy bricks
     const uint4 *wfrag;        // [24][64] MFMA A-operand fragments of the MLPs
     float bbox_lo[3], bbox_hi[3];  // bounding box of occupied cells (+margin), unit-cube units
@@ -71,6 +78,7 @@ struct d2r_ctx {
     d2r_render_stats stats{};
     int64_t chunk = 128;       // candidates per pass of the fused path
     int64_t march_blocks = 0;  // 0 = auto
+    int64_t use_bricks = 1;    // serve de-hashed coarse levels from LDS when the model has them
     // optional per-kernel timing (HIP events on the launch stream), see d2r_get_timing
     int64_t timing = 0;
     std::vector<hipEvent_t> ev_pool;
@@ -84,7 +92,7 @@ enum { D2R_T_MARCH = 0, D2R_T_RAYGEN = 1, D2R_T_CLIP = 2, D2R_T_PREP = 3, D2R_T_
 struct d2r_nerf {
     d2r_ctx *ctx;
     NerfParams P{};
-    void *d_grid = nullptr, *d_bricks = nullptr, *d_wfrag = nullptr;
+    void *d_grid = nullptr, *d_bricks = nullptr, *d_wfrag = nullptr, *d_brick_tab = nullptr;
 };
 
 int d2r_fail(d2r_ctx *ctx, int code, const std::string &msg);

@@ -294,13 +294,14 @@ __device__ __forceinline__ f32x16 mfma(const uint4 &a, const uint4 &b, f32x16 c)
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v, fb.v, c, 0, 0, 0);
 }
 
-enum { K_DENSE = 0, K_HASH = 1, K_MIXED = 2 };
+enum { K_DENSE = 0, K_HASH = 1, K_MIXED = 2, K_BRICK = 3 };
 
-// kind of slot i when the first ND levels are dense (ND < 0: treat every slot as mixed)
-template <int ND>
+// kind of slot i: the first NB slots are LDS bricks; otherwise dense/hashed/mixed from the number
+// of leading dense levels ND (ND < 0: treat every slot as mixed)
+template <int NB, int ND>
 __device__ __host__ constexpr int slot_kind(int i)
 {
-    return ND < 0 ? K_MIXED : (2 * i + 1 < ND ? K_DENSE : (2 * i >= ND ? K_HASH : K_MIXED));
+    return i < NB ? K_BRICK : (ND < 0 ? K_MIXED : (2 * i + 1 < ND ? K_DENSE : (2 * i >= ND ? K_HASH : K_MIXED)));
 }
 
 // Addresses + interpolation fractions of one slot (this lane's level of the pair) of one sample.
@@ -318,7 +319,14 @@ __device__ __forceinline__ void slot_addr(const NerfParams &P, int slot, bool hi
     w[2] = p2 - f2;
     uint32_t gx = (uint32_t)(int)f0, gy = (uint32_t)(int)f1, gz = (uint32_t)(int)f2;
     const uint32_t h4 = hi ? 4u : 0u;
-    if (KIND == K_HASH) {
+    if (KIND == K_BRICK) {
+        // bounding-box-local dense brick in LDS: byte offset of corner (0,0,0), then +x, +y, +z strides
+        const uint32_t nx = hi ? m.bnx[1] : m.bnx[0], nxy = hi ? m.bnxy[1] : m.bnxy[0];
+        const int32_t base = hi ? m.bbase[1] : m.bbase[0];
+        const uint32_t b = (uint32_t)((int32_t)(gx + nx * gy + nxy * gz) + base) << 2;
+#pragma unroll
+        for (int c = 0; c < 8; c++) off[c] = b + ((c & 1) ? 4u : 0u) + ((c & 2) ? nx << 2 : 0u) + ((c & 4) ? nxy << 2 : 0u);
+    } else if (KIND == K_HASH) {
         // everything pre-shifted by 3: ((a<<3) ^ (b<<3)) & (mask<<3|4) == ((a^b)&mask)<<3 | h4
         const uint32_t x0 = (gx << 3) | h4, x1 = x0 + 8u;
         const uint32_t y0 = gy * (2654435761u << 3), y1 = y0 + (2654435761u << 3);
@@ -369,26 +377,32 @@ __device__ __forceinline__ void slot_blend(const uint32_t *raw, const float *w, 
 // back-to-back (memory-level parallelism is what bounds this kernel), then the blends.
 // f[2*i], f[2*i+1] = features of slot i (this lane's level of the pair).  Matches oracle
 // hashgrid_encode().
-template <int ND>
-__device__ __forceinline__ void encode_sample(const NerfParams &P, const __amdgpu_buffer_rsrc_t &rs, bool hi,
-                                              float x, float y, float z, float *f)
+template <int NB, int ND>
+__device__ __forceinline__ void encode_sample(const NerfParams &P, const __amdgpu_buffer_rsrc_t &rs,
+                                              const uint8_t *__restrict__ lds_bricks, bool hi, float x, float y,
+                                              float z, float *f)
 {
     uint32_t off[8][8];
     float w[8][3];
-    slot_addr<slot_kind<ND>(0)>(P, 0, hi, x, y, z, off[0], w[0]);
-    slot_addr<slot_kind<ND>(1)>(P, 1, hi, x, y, z, off[1], w[1]);
-    slot_addr<slot_kind<ND>(2)>(P, 2, hi, x, y, z, off[2], w[2]);
-    slot_addr<slot_kind<ND>(3)>(P, 3, hi, x, y, z, off[3], w[3]);
-    slot_addr<slot_kind<ND>(4)>(P, 4, hi, x, y, z, off[4], w[4]);
-    slot_addr<slot_kind<ND>(5)>(P, 5, hi, x, y, z, off[5], w[5]);
-    slot_addr<slot_kind<ND>(6)>(P, 6, hi, x, y, z, off[6], w[6]);
-    slot_addr<slot_kind<ND>(7)>(P, 7, hi, x, y, z, off[7], w[7]);
+    slot_addr<slot_kind<NB, ND>(0)>(P, 0, hi, x, y, z, off[0], w[0]);
+    slot_addr<slot_kind<NB, ND>(1)>(P, 1, hi, x, y, z, off[1], w[1]);
+    slot_addr<slot_kind<NB, ND>(2)>(P, 2, hi, x, y, z, off[2], w[2]);
+    slot_addr<slot_kind<NB, ND>(3)>(P, 3, hi, x, y, z, off[3], w[3]);
+    slot_addr<slot_kind<NB, ND>(4)>(P, 4, hi, x, y, z, off[4], w[4]);
+    slot_addr<slot_kind<NB, ND>(5)>(P, 5, hi, x, y, z, off[5], w[5]);
+    slot_addr<slot_kind<NB, ND>(6)>(P, 6, hi, x, y, z, off[6], w[6]);
+    slot_addr<slot_kind<NB, ND>(7)>(P, 7, hi, x, y, z, off[7], w[7]);
     __builtin_amdgcn_sched_barrier(0);
     uint32_t raw[8][8];
+    // global gathers first (longest latency), then the LDS-resident bricks
 #pragma unroll
-    for (int i = 0; i < 8; i++)
+    for (int i = NB; i < 8; i++)
 #pragma unroll
         for (int c = 0; c < 8; c++) raw[i][c] = __builtin_amdgcn_raw_buffer_load_b32(rs, off[i][c], P.slot[i].off, 0);
+#pragma unroll
+    for (int i = 0; i < NB; i++)
+#pragma unroll
+        for (int c = 0; c < 8; c++) raw[i][c] = *(const uint32_t *)(lds_bricks + off[i][c]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < 8; i++) slot_blend(raw[i], w[i], f[2 * i], f[2 * i + 1]);
@@ -491,9 +505,9 @@ __device__ __forceinline__ void mlp_tile(const uint4 *__restrict__ sw, uint32_t 
 
 // Evaluate the wave's 64 samples (one per lane; `valid` marks lanes that have one).
 // On return every valid lane holds sigma and the network rgb of ITS OWN sample.
-template <int ND>
+template <int NB, int ND>
 __device__ __forceinline__ void eval_wave(const NerfParams &P, const __amdgpu_buffer_rsrc_t &rs,
-                                          const uint4 *__restrict__ sw, uint32_t lane, bool valid, float x,
+                                          const uint4 *__restrict__ sw, const uint8_t *__restrict__ lds_bricks, uint32_t lane, bool valid, float x,
                                           float y, float z, float dx, float dy, float dz, float &sigma,
                                           float &r, float &g, float &b)
 {
@@ -513,8 +527,8 @@ __device__ __forceinline__ void eval_wave(const NerfParams &P, const __amdgpu_bu
 #pragma unroll
     for (int i = 0; i < 16; i++) fa[i] = fb[i] = 0.f;
     // this lane's levels: 2i + hi for every slot i (slots 0..3 -> k-step 0, 4..7 -> k-step 1)
-    if (av) encode_sample<ND>(P, rs, hi, ax, ay, az, fa);
-    if (bv) encode_sample<ND>(P, rs, hi, bx, by, bz, fb);
+    if (av) encode_sample<NB, ND>(P, rs, lds_bricks, hi, ax, ay, az, fa);
+    if (bv) encode_sample<NB, ND>(P, rs, lds_bricks, hi, bx, by, bz, fb);
     sh16(adx, ady, adz, sa);
     sh16(bdx, bdy, bdz, sb);
     float sha[8], shb[8];
@@ -554,14 +568,14 @@ __global__ __launch_bounds__(256) void k_eval_points(NerfParams P, const float *
         dx = dirs[3 * i]; dy = dirs[3 * i + 1]; dz = dirs[3 * i + 2];
     }
     float s, r, g, b;
-    eval_wave<ND>(P, rs, sw, lane, valid, x, y, z, dx, dy, dz, s, r, g, b);
+    eval_wave<0, ND>(P, rs, sw, nullptr, lane, valid, x, y, z, dx, dy, dz, s, r, g, b);   // arbitrary points: no bricks
     if (valid) *(float4 *)(out + 4 * (size_t)i) = make_float4(s, r, g, b);
 }
 
 // ------------------------------------------------------------------ marcher
 
-template <bool COMPOSITE, int ND>
-__global__ __launch_bounds__(256, 2) void k_march(NerfParams P, ViewParams V, const float *__restrict__ cams,
+template <bool COMPOSITE, int NB, int ND>
+__global__ __launch_bounds__(512, 2) void k_march(NerfParams P, ViewParams V, const float *__restrict__ cams,
                                                   const uint2 *__restrict__ queue,
                                                   const uint32_t *__restrict__ qcount,
                                                   uint32_t *__restrict__ qhead, float *__restrict__ rgba_out,
@@ -570,8 +584,13 @@ __global__ __launch_bounds__(256, 2) void k_march(NerfParams P, ViewParams V, co
                                                   uint8_t *__restrict__ frames,
                                                   unsigned long long *__restrict__ sample_counter)
 {
-    __shared__ uint4 sw[D2R_N_WFRAG * 64];
+    // one 8-wave workgroup per CU: [0, 24 KiB) MLP fragments, then the de-hashed level bricks
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint4 *sw = (uint4 *)smem;
+    uint8_t *lds_bricks = smem + D2R_N_WFRAG * 64 * 16;
     for (uint32_t i = threadIdx.x; i < D2R_N_WFRAG * 64; i += blockDim.x) sw[i] = P.wfrag[i];
+    if (NB > 0)
+        for (uint32_t i = threadIdx.x; i < P.brick_words; i += blockDim.x) ((uint32_t *)lds_bricks)[i] = P.brick_tab[i];
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t n_q = *qcount;
@@ -622,7 +641,7 @@ __global__ __launch_bounds__(256, 2) void k_march(NerfParams P, ViewParams V, co
 
         // ---- evaluate this wave's samples
         float sigma, cr, cg, cb;
-        eval_wave<ND>(P, rs, sw, lane, alive, px, py, pz, ray.dx, ray.dy, ray.dz, sigma, cr, cg, cb);
+        eval_wave<NB, ND>(P, rs, sw, lds_bricks, lane, alive, px, py, pz, ray.dx, ray.dy, ray.dz, sigma, cr, cg, cb);
 
         // ---- composite + advance
         if (alive) {
@@ -784,20 +803,35 @@ int d2r_launch_render(d2r_ctx *ctx, const d2r_nerf *m, const ViewParams &V, cons
                        composite ? nullptr : depth_dev);
     ctx->timing_end(tr);
     size_t tm = ctx->timing_begin(D2R_T_MARCH);
-    int blocks = ctx->march_blocks > 0 ? (int)ctx->march_blocks : 256 * 2;
+    int blocks = ctx->march_blocks > 0 ? (int)ctx->march_blocks : 256;     // persistent: one per CU
     const float *bgd = (const float *)ctx->bg_depth.p;
     unsigned long long *sc = (unsigned long long *)(cnt + 2);
     const uint2 *q = (const uint2 *)ctx->queue.p;
-#define D2R_MARCH(COMP, ND)                                                                                   \
-    hipLaunchKernelGGL((k_march<COMP, ND>), dim3(blocks), dim3(256), 0, ctx->stream, m->P, V, cams_dev, q, cnt, \
-                       cnt + 1, COMP ? nullptr : rgba_dev, COMP ? nullptr : depth_dev, COMP ? bgd : nullptr,   \
-                       COMP ? frames_dev : nullptr, sc)
-    // compile-time slot kinds for the usual tables (5 leading dense levels); anything else
-    // takes the generic (every slot mixed) instantiation
+    const uint32_t nb = (ctx->use_bricks && m->P.n_dense == 5) ? m->P.n_brick_slots : 0;
+    const size_t lds = (size_t)D2R_N_WFRAG * 64 * 16 + (nb ? (size_t)m->P.brick_words * 4 : 0);
+#define D2R_MARCH(COMP, NB, ND)                                                                                   \
+    do {                                                                                                          \
+        static bool attr = false;                                                                                 \
+        if (!attr) {                                                                                              \
+            (void)hipFuncSetAttribute((const void *)k_march<COMP, NB, ND>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            attr = true;                                                                                          \
+        }                                                                                                         \
+        hipLaunchKernelGGL((k_march<COMP, NB, ND>), dim3(blocks), dim3(512), lds, ctx->stream, m->P, V, cams_dev, q, \
+                           cnt, cnt + 1, COMP ? nullptr : rgba_dev, COMP ? nullptr : depth_dev,                   \
+                           COMP ? bgd : nullptr, COMP ? frames_dev : nullptr, sc);                                \
+    } while (0)
+    // compile-time slot kinds: the usual tables have 5 leading dense levels; small objects get 4 or
+    // 5 LDS-bricked slots; anything else takes the generic (every slot mixed) instantiation
     if (composite) {
-        if (m->P.n_dense == 5) D2R_MARCH(true, 5); else D2R_MARCH(true, -1);
+        if (m->P.n_dense != 5) D2R_MARCH(true, 0, -1);
+        else if (nb == 5) D2R_MARCH(true, 5, 5);
+        else if (nb == 4) D2R_MARCH(true, 4, 5);
+        else D2R_MARCH(true, 0, 5);
     } else {
-        if (m->P.n_dense == 5) D2R_MARCH(false, 5); else D2R_MARCH(false, -1);
+        if (m->P.n_dense != 5) D2R_MARCH(false, 0, -1);
+        else if (nb == 5) D2R_MARCH(false, 5, 5);
+        else if (nb == 4) D2R_MARCH(false, 4, 5);
+        else D2R_MARCH(false, 0, 5);
     }
 #undef D2R_MARCH
     ctx->timing_end(tm);

@@ -234,7 +234,9 @@ typedef struct {
 } d2r_timing;
 D2R_API int d2r_get_timing(d2r_ctx *ctx, d2r_timing *out);
 
-/* Tunables ("chunk", "march_blocks", "timing"); unknown keys return D2R_ERR_INVALID. */
+/* Tunables ("chunk", "march_blocks", "timing", "bricks"); unknown keys return D2R_ERR_INVALID.
+ * "bricks" (default 1): serve the de-hashed coarse levels of small models from LDS; 0 forces
+ * every level through the global tables (results are bit-identical either way). */
 D2R_API int d2r_ctx_set_option(d2r_ctx *ctx, const char *key, int64_t value);
 
 #ifdef __cplusplus

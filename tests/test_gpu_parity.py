@@ -137,6 +137,25 @@ def test_composited_frames_match_oracle(gpu):
     assert st["rays_total"] == len(poses) * W * H and st["samples"] > 0
 
 
+def test_lds_bricks_are_bit_identical_to_global_tables(gpu):
+    """The de-hashed bounding-box bricks served from LDS hold exactly the table values: frames and
+    sample counts with and without them are bit-identical."""
+    scene, fg, ctx = gpu["scene"], gpu["fg"], gpu["ctx"]
+    W, H = 200, 120
+    pipe = OraclePipeline(scene, 64, 36)
+    poses = host_ref.sample_poses_grid(scene.scene_centre, [4, 4, 2, 1, 1, 1], scene.scene_type).reshape(-1, 4, 4)
+    cams = np.stack([pipe.fg_camera(p) for p in poses])
+    out = {}
+    for flag in (1, 0):
+        ctx.set_option("bricks", flag)
+        rgba, depth = fg.render_batch(cams, W, H)
+        out[flag] = (rgba, depth, fg.last_samples)
+    ctx.set_option("bricks", 1)
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+    assert out[0][2] == out[1][2] > 10000
+
+
 def test_alpha_threshold_and_transparent_fg(gpu):
     """fg background alpha 0 (in-process trained models): semi-transparent
     silhouette pixels fall under the 130/255 alpha threshold and turn black."""
