@@ -382,30 +382,38 @@ __device__ __forceinline__ void encode_sample(const NerfParams &P, const __amdgp
                                               const uint8_t *__restrict__ lds_bricks, bool hi, float x, float y,
                                               float z, float *f)
 {
-    uint32_t off[8][8];
-    float w[8][3];
-    slot_addr<slot_kind<NB, ND>(0)>(P, 0, hi, x, y, z, off[0], w[0]);
-    slot_addr<slot_kind<NB, ND>(1)>(P, 1, hi, x, y, z, off[1], w[1]);
-    slot_addr<slot_kind<NB, ND>(2)>(P, 2, hi, x, y, z, off[2], w[2]);
-    slot_addr<slot_kind<NB, ND>(3)>(P, 3, hi, x, y, z, off[3], w[3]);
-    slot_addr<slot_kind<NB, ND>(4)>(P, 4, hi, x, y, z, off[4], w[4]);
-    slot_addr<slot_kind<NB, ND>(5)>(P, 5, hi, x, y, z, off[5], w[5]);
-    slot_addr<slot_kind<NB, ND>(6)>(P, 6, hi, x, y, z, off[6], w[6]);
-    slot_addr<slot_kind<NB, ND>(7)>(P, 7, hi, x, y, z, off[7], w[7]);
-    __builtin_amdgcn_sched_barrier(0);
-    uint32_t raw[8][8];
-    // global gathers first (longest latency), then the LDS-resident bricks
-#pragma unroll
-    for (int i = NB; i < 8; i++)
-#pragma unroll
-        for (int c = 0; c < 8; c++) raw[i][c] = __builtin_amdgcn_raw_buffer_load_b32(rs, off[i][c], P.slot[i].off, 0);
-#pragma unroll
-    for (int i = 0; i < NB; i++)
-#pragma unroll
-        for (int c = 0; c < 8; c++) raw[i][c] = *(const uint32_t *)(lds_bricks + off[i][c]);
+    // Global (table) slots: all addresses, then all gathers back-to-back (memory-level parallelism),
+    // LDS-brick slots are evaluated underneath while those are in flight, then the global blends.
+    constexpr int NG = 8 - NB;
+    uint32_t off[NG > 0 ? NG : 1][8];
+    float w[NG > 0 ? NG : 1][3];
+    uint32_t raw[NG > 0 ? NG : 1][8];
+    if (NB <= 0) slot_addr<slot_kind<NB, ND>(0)>(P, 0, hi, x, y, z, off[0 - (NB <= 0 ? NB : 0)], w[0 - (NB <= 0 ? NB : 0)]);
+    if (NB <= 1) slot_addr<slot_kind<NB, ND>(1)>(P, 1, hi, x, y, z, off[NB <= 1 ? 1 - NB : 0], w[NB <= 1 ? 1 - NB : 0]);
+    if (NB <= 2) slot_addr<slot_kind<NB, ND>(2)>(P, 2, hi, x, y, z, off[NB <= 2 ? 2 - NB : 0], w[NB <= 2 ? 2 - NB : 0]);
+    if (NB <= 3) slot_addr<slot_kind<NB, ND>(3)>(P, 3, hi, x, y, z, off[NB <= 3 ? 3 - NB : 0], w[NB <= 3 ? 3 - NB : 0]);
+    if (NB <= 4) slot_addr<slot_kind<NB, ND>(4)>(P, 4, hi, x, y, z, off[NB <= 4 ? 4 - NB : 0], w[NB <= 4 ? 4 - NB : 0]);
+    if (NB <= 5) slot_addr<slot_kind<NB, ND>(5)>(P, 5, hi, x, y, z, off[NB <= 5 ? 5 - NB : 0], w[NB <= 5 ? 5 - NB : 0]);
+    if (NB <= 6) slot_addr<slot_kind<NB, ND>(6)>(P, 6, hi, x, y, z, off[NB <= 6 ? 6 - NB : 0], w[NB <= 6 ? 6 - NB : 0]);
+    if (NB <= 7) slot_addr<slot_kind<NB, ND>(7)>(P, 7, hi, x, y, z, off[NB <= 7 ? 7 - NB : 0], w[NB <= 7 ? 7 - NB : 0]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 0; i < 8; i++) slot_blend(raw[i], w[i], f[2 * i], f[2 * i + 1]);
+    for (int i = 0; i < NG; i++)
+#pragma unroll
+        for (int c = 0; c < 8; c++)
+            raw[i][c] = __builtin_amdgcn_raw_buffer_load_b32(rs, off[i][c], P.slot[NB + i].off, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NB; i++) {
+        uint32_t bo[8], br[8];
+        float bw[3];
+        slot_addr<K_BRICK>(P, i, hi, x, y, z, bo, bw);
+#pragma unroll
+        for (int c = 0; c < 8; c++) br[c] = *(const uint32_t *)(lds_bricks + bo[c]);
+        slot_blend(br, bw, f[2 * i], f[2 * i + 1]);
+    }
+#pragma unroll
+    for (int i = 0; i < NG; i++) slot_blend(raw[i], w[i], f[2 * (NB + i)], f[2 * (NB + i) + 1]);
 }
 
 __device__ __forceinline__ void sh16(float x, float y, float z, float *o)
@@ -448,59 +456,68 @@ __device__ __forceinline__ uint4 relu_pack(const f32x16 &a, int r0)
     return o;
 }
 
-// One tile (32 samples: sample n lives in lanes n and n+32, which hold half of its
-// features each).  Returns raw density-net output 0 and colour-net outputs 0..2 in
-// lanes 0..31 (hi == 0).
-__device__ __forceinline__ void mlp_tile(const uint4 *__restrict__ sw, uint32_t lane, const float *feat,
-                                         const float *sh, float &s_raw, float &c0, float &c1, float &c2)
+// Both tiles of the wave through both MLPs, layer by layer.  Tile t = 32 samples: sample n lives
+// in lanes n and n+32, which hold half of its features each.  The two tiles' accumulator chains
+// are independent, so their MFMAs are interleaved to fill each other's dependent-accumulate
+// latency.  Returns raw density-net output 0 and colour-net outputs 0..2 in lanes 0..31.
+__device__ __forceinline__ void mlp_tiles(const uint4 *__restrict__ sw, uint32_t lane, const float *featA,
+                                          const float *featB, const float *shA, const float *shB, float *outA,
+                                          float *outB)
 {
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    uint4 b0, b1;
-    b0.x = pack2(feat[0], feat[1]); b0.y = pack2(feat[2], feat[3]);
-    b0.z = pack2(feat[4], feat[5]); b0.w = pack2(feat[6], feat[7]);
-    b1.x = pack2(feat[8], feat[9]); b1.y = pack2(feat[10], feat[11]);
-    b1.z = pack2(feat[12], feat[13]); b1.w = pack2(feat[14], feat[15]);
-    // density layer 1: 64 x 32
-    f32x16 h0 = mfma(sw[0 * 64 + lane], b0, zero);
-    h0 = mfma(sw[1 * 64 + lane], b1, h0);
-    f32x16 h1 = mfma(sw[2 * 64 + lane], b0, zero);
-    h1 = mfma(sw[3 * 64 + lane], b1, h1);
-    uint4 hq0 = relu_pack(h0, 0), hq1 = relu_pack(h0, 8), hq2 = relu_pack(h1, 0), hq3 = relu_pack(h1, 8);
+    uint4 a0, a1, b0, b1;
+    a0.x = pack2(featA[0], featA[1]); a0.y = pack2(featA[2], featA[3]);
+    a0.z = pack2(featA[4], featA[5]); a0.w = pack2(featA[6], featA[7]);
+    a1.x = pack2(featA[8], featA[9]); a1.y = pack2(featA[10], featA[11]);
+    a1.z = pack2(featA[12], featA[13]); a1.w = pack2(featA[14], featA[15]);
+    b0.x = pack2(featB[0], featB[1]); b0.y = pack2(featB[2], featB[3]);
+    b0.z = pack2(featB[4], featB[5]); b0.w = pack2(featB[6], featB[7]);
+    b1.x = pack2(featB[8], featB[9]); b1.y = pack2(featB[10], featB[11]);
+    b1.z = pack2(featB[12], featB[13]); b1.w = pack2(featB[14], featB[15]);
+    // density layer 1: 64 x 32  (4 independent accumulators)
+    uint4 w0 = sw[0 * 64 + lane], w1 = sw[1 * 64 + lane], w2 = sw[2 * 64 + lane], w3 = sw[3 * 64 + lane];
+    f32x16 hA0 = mfma(w0, a0, zero), hB0 = mfma(w0, b0, zero), hA1 = mfma(w2, a0, zero), hB1 = mfma(w2, b0, zero);
+    hA0 = mfma(w1, a1, hA0); hB0 = mfma(w1, b1, hB0); hA1 = mfma(w3, a1, hA1); hB1 = mfma(w3, b1, hB1);
+    uint4 pA0 = relu_pack(hA0, 0), pA1 = relu_pack(hA0, 8), pA2 = relu_pack(hA1, 0), pA3 = relu_pack(hA1, 8);
+    uint4 pB0 = relu_pack(hB0, 0), pB1 = relu_pack(hB0, 8), pB2 = relu_pack(hB1, 0), pB3 = relu_pack(hB1, 8);
     // density layer 2: 16 (padded 32) x 64
-    f32x16 dd = mfma(sw[4 * 64 + lane], hq0, zero);
-    dd = mfma(sw[5 * 64 + lane], hq1, dd);
-    dd = mfma(sw[6 * 64 + lane], hq2, dd);
-    dd = mfma(sw[7 * 64 + lane], hq3, dd);
-    s_raw = dd[0];
+    w0 = sw[4 * 64 + lane]; w1 = sw[5 * 64 + lane]; w2 = sw[6 * 64 + lane]; w3 = sw[7 * 64 + lane];
+    f32x16 dA = mfma(w0, pA0, zero), dB = mfma(w0, pB0, zero);
+    dA = mfma(w1, pA1, dA); dB = mfma(w1, pB1, dB);
+    dA = mfma(w2, pA2, dA); dB = mfma(w2, pB2, dB);
+    dA = mfma(w3, pA3, dA); dB = mfma(w3, pB3, dB);
+    outA[0] = dA[0];
+    outB[0] = dB[0];
     // colour layer 1: 64 x 32, input = [density out (no activation) | SH]
-    uint4 bd, bs;
-    bd.x = pack2(dd[0], dd[1]); bd.y = pack2(dd[2], dd[3]);
-    bd.z = pack2(dd[4], dd[5]); bd.w = pack2(dd[6], dd[7]);
-    bs.x = pack2(sh[0], sh[1]); bs.y = pack2(sh[2], sh[3]);
-    bs.z = pack2(sh[4], sh[5]); bs.w = pack2(sh[6], sh[7]);
-    f32x16 g0 = mfma(sw[8 * 64 + lane], bd, zero);
-    g0 = mfma(sw[9 * 64 + lane], bs, g0);
-    f32x16 g1 = mfma(sw[10 * 64 + lane], bd, zero);
-    g1 = mfma(sw[11 * 64 + lane], bs, g1);
-    uint4 gq0 = relu_pack(g0, 0), gq1 = relu_pack(g0, 8), gq2 = relu_pack(g1, 0), gq3 = relu_pack(g1, 8);
+    uint4 cA, sA, cB, sB;
+    cA.x = pack2(dA[0], dA[1]); cA.y = pack2(dA[2], dA[3]); cA.z = pack2(dA[4], dA[5]); cA.w = pack2(dA[6], dA[7]);
+    cB.x = pack2(dB[0], dB[1]); cB.y = pack2(dB[2], dB[3]); cB.z = pack2(dB[4], dB[5]); cB.w = pack2(dB[6], dB[7]);
+    sA.x = pack2(shA[0], shA[1]); sA.y = pack2(shA[2], shA[3]); sA.z = pack2(shA[4], shA[5]); sA.w = pack2(shA[6], shA[7]);
+    sB.x = pack2(shB[0], shB[1]); sB.y = pack2(shB[2], shB[3]); sB.z = pack2(shB[4], shB[5]); sB.w = pack2(shB[6], shB[7]);
+    w0 = sw[8 * 64 + lane]; w1 = sw[9 * 64 + lane]; w2 = sw[10 * 64 + lane]; w3 = sw[11 * 64 + lane];
+    f32x16 gA0 = mfma(w0, cA, zero), gB0 = mfma(w0, cB, zero), gA1 = mfma(w2, cA, zero), gB1 = mfma(w2, cB, zero);
+    gA0 = mfma(w1, sA, gA0); gB0 = mfma(w1, sB, gB0); gA1 = mfma(w3, sA, gA1); gB1 = mfma(w3, sB, gB1);
+    pA0 = relu_pack(gA0, 0); pA1 = relu_pack(gA0, 8); pA2 = relu_pack(gA1, 0); pA3 = relu_pack(gA1, 8);
+    pB0 = relu_pack(gB0, 0); pB1 = relu_pack(gB0, 8); pB2 = relu_pack(gB1, 0); pB3 = relu_pack(gB1, 8);
     // colour layer 2: 64 x 64
-    f32x16 e0 = mfma(sw[12 * 64 + lane], gq0, zero);
-    e0 = mfma(sw[13 * 64 + lane], gq1, e0);
-    e0 = mfma(sw[14 * 64 + lane], gq2, e0);
-    e0 = mfma(sw[15 * 64 + lane], gq3, e0);
-    f32x16 e1 = mfma(sw[16 * 64 + lane], gq0, zero);
-    e1 = mfma(sw[17 * 64 + lane], gq1, e1);
-    e1 = mfma(sw[18 * 64 + lane], gq2, e1);
-    e1 = mfma(sw[19 * 64 + lane], gq3, e1);
-    uint4 eq0 = relu_pack(e0, 0), eq1 = relu_pack(e0, 8), eq2 = relu_pack(e1, 0), eq3 = relu_pack(e1, 8);
+    f32x16 eA0 = zero, eB0 = zero, eA1 = zero, eB1 = zero;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint4 u0 = sw[(12 + q) * 64 + lane], u1 = sw[(16 + q) * 64 + lane];
+        const uint4 xa = q == 0 ? pA0 : q == 1 ? pA1 : q == 2 ? pA2 : pA3;
+        const uint4 xb = q == 0 ? pB0 : q == 1 ? pB1 : q == 2 ? pB2 : pB3;
+        eA0 = mfma(u0, xa, eA0); eB0 = mfma(u0, xb, eB0); eA1 = mfma(u1, xa, eA1); eB1 = mfma(u1, xb, eB1);
+    }
+    pA0 = relu_pack(eA0, 0); pA1 = relu_pack(eA0, 8); pA2 = relu_pack(eA1, 0); pA3 = relu_pack(eA1, 8);
+    pB0 = relu_pack(eB0, 0); pB1 = relu_pack(eB0, 8); pB2 = relu_pack(eB1, 0); pB3 = relu_pack(eB1, 8);
     // colour layer 3: 16 (padded 32) x 64
-    f32x16 cc = mfma(sw[20 * 64 + lane], eq0, zero);
-    cc = mfma(sw[21 * 64 + lane], eq1, cc);
-    cc = mfma(sw[22 * 64 + lane], eq2, cc);
-    cc = mfma(sw[23 * 64 + lane], eq3, cc);
-    c0 = cc[0];
-    c1 = cc[1];
-    c2 = cc[2];
+    w0 = sw[20 * 64 + lane]; w1 = sw[21 * 64 + lane]; w2 = sw[22 * 64 + lane]; w3 = sw[23 * 64 + lane];
+    f32x16 oA = mfma(w0, pA0, zero), oB = mfma(w0, pB0, zero);
+    oA = mfma(w1, pA1, oA); oB = mfma(w1, pB1, oB);
+    oA = mfma(w2, pA2, oA); oB = mfma(w2, pB2, oB);
+    oA = mfma(w3, pA3, oA); oB = mfma(w3, pB3, oB);
+    outA[1] = oA[0]; outA[2] = oA[1]; outA[3] = oA[2];
+    outB[1] = oB[0]; outB[2] = oB[1]; outB[3] = oB[2];
 }
 
 // Evaluate the wave's 64 samples (one per lane; `valid` marks lanes that have one).
@@ -537,9 +554,10 @@ __device__ __forceinline__ void eval_wave(const NerfParams &P, const __amdgpu_bu
         sha[j] = hi ? sa[8 + j] : sa[j];
         shb[j] = hi ? sb[8 + j] : sb[j];
     }
-    float s0, r0, g0, b0, s1, r1, g1, b1;
-    mlp_tile(sw, lane, fa, sha, s0, r0, g0, b0);
-    mlp_tile(sw, lane, fb, shb, s1, r1, g1, b1);
+    float oa[4], ob[4];
+    mlp_tiles(sw, lane, fa, fb, sha, shb, oa, ob);
+    const float s0 = oa[0], r0 = oa[1], g0 = oa[2], b0 = oa[3];
+    const float s1 = ob[0], r1 = ob[1], g1 = ob[2], b1 = ob[3];
     // tile-1 results live in lanes 0..31; their owners are lanes 32..63
     float ts = __shfl_xor(s1, 32), tr = __shfl_xor(r1, 32), tg = __shfl_xor(g1, 32), tb = __shfl_xor(b1, 32);
     float sr = hi ? ts : s0;
@@ -574,8 +592,11 @@ __global__ __launch_bounds__(256) void k_eval_points(NerfParams P, const float *
 
 // ------------------------------------------------------------------ marcher
 
+#ifndef D2R_MARCH_THREADS
+#define D2R_MARCH_THREADS 1024
+#endif
 template <bool COMPOSITE, int NB, int ND>
-__global__ __launch_bounds__(512, 2) void k_march(NerfParams P, ViewParams V, const float *__restrict__ cams,
+__global__ __launch_bounds__(D2R_MARCH_THREADS) void k_march(NerfParams P, ViewParams V, const float *__restrict__ cams,
                                                   const uint2 *__restrict__ queue,
                                                   const uint32_t *__restrict__ qcount,
                                                   uint32_t *__restrict__ qhead, float *__restrict__ rgba_out,
@@ -816,7 +837,7 @@ int d2r_launch_render(d2r_ctx *ctx, const d2r_nerf *m, const ViewParams &V, cons
             (void)hipFuncSetAttribute((const void *)k_march<COMP, NB, ND>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             attr = true;                                                                                          \
         }                                                                                                         \
-        hipLaunchKernelGGL((k_march<COMP, NB, ND>), dim3(blocks), dim3(512), lds, ctx->stream, m->P, V, cams_dev, q, \
+        hipLaunchKernelGGL((k_march<COMP, NB, ND>), dim3(blocks), dim3(D2R_MARCH_THREADS), lds, ctx->stream, m->P, V, cams_dev, q, \
                            cnt, cnt + 1, COMP ? nullptr : rgba_dev, COMP ? nullptr : depth_dev,                   \
                            COMP ? bgd : nullptr, COMP ? frames_dev : nullptr, sc);                                \
     } while (0)
