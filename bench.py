@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--clip", default="vit_b16")
     ap.add_argument("--scene", default="shopping")
     ap.add_argument("--chunk", type=int, default=128)
+    ap.add_argument("--opt", action="append", default=[], help="library tunable key=value (repeatable)")
     ap.add_argument("--cpu-sample", type=int, default=6, help="candidates in the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -90,6 +91,9 @@ def main():
     sd = random_clip_state_dict(cfg, seed=6)
     ctx = engine.Context(local)
     ctx.set_option("chunk", args.chunk)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        ctx.set_option(k, int(v))
     fg, bg = engine.Testbed(ctx, scene.fg), engine.Testbed(ctx, scene.bg)
     fg.background_color = list(scene.fg_background)
     scorer = engine.ClipScorer(ctx, cfg, sd)
@@ -176,6 +180,7 @@ def main():
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
                          "samples_per_launch": int(samples_per_launch),
+                         "lane_utilisation": round(stats["samples"] / max(1, 64 * stats["wave_iters"]), 4),
                          "avg_launch_ms": round(march_avg_s * 1e3, 4),
                          "mlp_tflops": round(samples_per_launch * MLP_FLOP_PER_SAMPLE / march_avg_s / 1e12, 3) if march_avg_s > 0 else None},
             "roofline_vit": {"bound": "mfma", "achieved": round(clip_tflops, 2) if clip_tflops else None,

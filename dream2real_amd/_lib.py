@@ -45,7 +45,8 @@ class ClipDesc(C.Structure):
 
 
 class RenderStats(C.Structure):
-    _fields_ = [("rays_total", C.c_uint64), ("rays_alive", C.c_uint64), ("samples", C.c_uint64)]
+    _fields_ = [("rays_total", C.c_uint64), ("rays_alive", C.c_uint64), ("samples", C.c_uint64),
+                ("wave_iters", C.c_uint64)]
 
 
 class Timing(C.Structure):

@@ -160,6 +160,12 @@ int d2r_ctx_set_option(d2r_ctx *ctx, const char *key, int64_t value)
     } else if (!strcmp(key, "march_blocks")) {
         if (value < 0 || value > 65535) return d2r_fail(ctx, D2R_ERR_INVALID, "march_blocks out of range");
         ctx->march_blocks = value;
+    } else if (!strcmp(key, "refill_min")) {
+        if (value < 1 || value > 64) return d2r_fail(ctx, D2R_ERR_INVALID, "refill_min must be in [1, 64]");
+        ctx->refill_min = value;
+    } else if (!strcmp(key, "gbrick_slots")) {
+        if (value < 0 || value > 3) return d2r_fail(ctx, D2R_ERR_INVALID, "gbrick_slots must be in [0, 3]");
+        ctx->gbrick_slots = value;
     } else if (!strcmp(key, "bricks")) {
         ctx->use_bricks = value != 0;
     } else if (!strcmp(key, "timing")) {
@@ -317,55 +323,64 @@ int d2r_nerf_create(d2r_ctx *ctx, const d2r_nerf_desc *d, d2r_nerf **out)
     // De-hashed, bounding-box-local dense bricks of the leading levels (small objects): the
     // vertices a sample inside an occupied cell can touch, with the table value (incl. tiny-cuda-nn's
     // index wrap) resolved here once.  Served from LDS by k_march; values identical to the tables.
-    std::vector<uint32_t> brick_tab;
+    std::vector<uint32_t> brick_tab, gbrick_tab;
     P.n_brick_slots = 0;
     P.brick_words = 0;
+    P.n_gbrick_slots = 0;
+    // appends the brick of level 2i+h to `words`; false when it would exceed `budget_words`
+    auto add_level_brick = [&](uint32_t i, int h, std::vector<uint32_t> &words, size_t budget_words, size_t word0) -> bool {
+        SlotMeta &sm = P.slot[i];
+        const LevelMeta &L = lv[2 * i + h];
+        int g0[3], n[3];
+        for (int a = 0; a < 3; a++) {
+            // same correctly-rounded fma the kernels use: monotone, so these bound every sample
+            float plo = fmaf(L.scale, (float)lo[a] / (float)D2R_GRID, 0.5f);
+            float phi = fmaf(L.scale, (float)(hi[a] + 1) / (float)D2R_GRID, 0.5f);
+            g0[a] = (int)floorf(plo);
+            n[a] = (int)floorf(phi) + 1 - g0[a] + 1;
+        }
+        const size_t cnt = (size_t)n[0] * n[1] * n[2];
+        if (words.size() + cnt > budget_words) return false;
+        const size_t base = word0 + words.size();
+        sm.bnx[h] = (uint32_t)n[0];
+        sm.bnxy[h] = (uint32_t)(n[0] * n[1]);
+        sm.bbase[h] = (int32_t)((int64_t)base - ((int64_t)g0[0] + (int64_t)n[0] * g0[1] + (int64_t)n[0] * n[1] * g0[2]));
+        for (int z = 0; z < n[2]; z++)
+            for (int y = 0; y < n[1]; y++)
+                for (int x = 0; x < n[0]; x++) {
+                    uint32_t gx = (uint32_t)(g0[0] + x), gy = (uint32_t)(g0[1] + y), gz = (uint32_t)(g0[2] + z);
+                    uint64_t idx;
+                    if (L.hashed)
+                        idx = (uint32_t)(gx ^ (gy * 2654435761u) ^ (gz * 805459861u));
+                    else
+                        idx = (uint64_t)gx + (uint64_t)gy * L.res + (uint64_t)gz * L.res * L.res;
+                    words.push_back(src[L.offset + (uint32_t)(idx % L.size)]);
+                }
+        return true;
+    };
     if (hi[0] >= 0 && P.n_dense >= 0) {
         const size_t budget_words = (160 * 1024 - (size_t)D2R_N_WFRAG * 64 * 16) / 4;
         std::vector<uint32_t> words;
-        uint32_t slots_ok = 0;
-        for (uint32_t i = 0; i < d->n_levels / 2; i++) {
-            SlotMeta &sm = P.slot[i];
-            std::vector<uint32_t> add;
-            bool ok = true;
-            for (int h = 0; h < 2 && ok; h++) {
-                const LevelMeta &L = lv[2 * i + h];
-                int g0[3], n[3];
-                for (int a = 0; a < 3; a++) {
-                    // same correctly-rounded fma the kernels use: monotone, so these bound every sample
-                    float plo = fmaf(L.scale, (float)lo[a] / (float)D2R_GRID, 0.5f);
-                    float phi = fmaf(L.scale, (float)(hi[a] + 1) / (float)D2R_GRID, 0.5f);
-                    g0[a] = (int)floorf(plo);
-                    n[a] = (int)floorf(phi) + 1 - g0[a] + 1;
-                }
-                const size_t cnt = (size_t)n[0] * n[1] * n[2];
-                if (words.size() + add.size() + cnt > budget_words) { ok = false; break; }
-                const size_t base = words.size() + add.size();
-                sm.bnx[h] = (uint32_t)n[0];
-                sm.bnxy[h] = (uint32_t)(n[0] * n[1]);
-                sm.bbase[h] = (int32_t)base - (g0[0] + n[0] * g0[1] + n[0] * n[1] * g0[2]);
-                for (int z = 0; z < n[2]; z++)
-                    for (int y = 0; y < n[1]; y++)
-                        for (int x = 0; x < n[0]; x++) {
-                            uint32_t gx = (uint32_t)(g0[0] + x), gy = (uint32_t)(g0[1] + y), gz = (uint32_t)(g0[2] + z);
-                            uint64_t idx;
-                            if (L.hashed)
-                                idx = (uint32_t)(gx ^ (gy * 2654435761u) ^ (gz * 805459861u));
-                            else
-                                idx = (uint64_t)gx + (uint64_t)gy * L.res + (uint64_t)gz * L.res * L.res;
-                            add.push_back(src[L.offset + (uint32_t)(idx % L.size)]);
-                        }
-            }
-            if (!ok) break;
-            words.insert(words.end(), add.begin(), add.end());
-            slots_ok = i + 1;
-            if (slots_ok == 4 || slots_ok == 5) {          // instantiated kernel variants
-                P.n_brick_slots = slots_ok;
+        for (uint32_t i = 0; i < d->n_levels / 2 && i < 5; i++) {
+            std::vector<uint32_t> trial = words;
+            if (!add_level_brick(i, 0, trial, budget_words, 0) || !add_level_brick(i, 1, trial, budget_words, 0)) break;
+            words.swap(trial);
+            if (i + 1 == 4 || i + 1 == 5) {                // instantiated kernel variants
+                P.n_brick_slots = i + 1;
                 P.brick_words = (uint32_t)words.size();
             }
-            if (slots_ok == 5) break;
         }
         brick_tab.assign(words.begin(), words.begin() + P.brick_words);
+        // slots 5 and 6 as HBM-resident bricks (spatially coherent, no hash scatter) when small enough
+        if (P.n_brick_slots == 5) {
+            const size_t gbudget = ((size_t)512 << 20) >> 2;    // 512 MiB of words
+            for (uint32_t i = 5; i < 8 && i < d->n_levels / 2; i++) {
+                std::vector<uint32_t> trial = gbrick_tab;
+                if (!add_level_brick(i, 0, trial, gbudget, 0) || !add_level_brick(i, 1, trial, gbudget, 0)) break;
+                gbrick_tab.swap(trial);
+                P.n_gbrick_slots = i - 4;
+            }
+        }
     }
     // weight fragments
     std::vector<uint16_t> wf((size_t)D2R_N_WFRAG * 64 * 8);
@@ -389,11 +404,13 @@ int d2r_nerf_create(d2r_ctx *ctx, const d2r_nerf_desc *d, d2r_nerf **out)
     bool ok = hipMalloc(&m->d_grid, grid_bytes) == hipSuccess &&
               hipMalloc(&m->d_bricks, bricks.size() * 8) == hipSuccess &&
               hipMalloc(&m->d_wfrag, wf.size() * 2) == hipSuccess &&
-              hipMalloc(&m->d_brick_tab, std::max<size_t>(brick_tab.size(), 1) * 4) == hipSuccess;
+              hipMalloc(&m->d_brick_tab, std::max<size_t>(brick_tab.size(), 1) * 4) == hipSuccess &&
+              hipMalloc(&m->d_gbrick_tab, std::max<size_t>(gbrick_tab.size(), 1) * 4) == hipSuccess;
     ok = ok && hipMemcpy(m->d_grid, tab.data(), grid_bytes, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(m->d_bricks, bricks.data(), bricks.size() * 8, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(m->d_wfrag, wf.data(), wf.size() * 2, hipMemcpyHostToDevice) == hipSuccess &&
-         (brick_tab.empty() || hipMemcpy(m->d_brick_tab, brick_tab.data(), brick_tab.size() * 4, hipMemcpyHostToDevice) == hipSuccess);
+         (brick_tab.empty() || hipMemcpy(m->d_brick_tab, brick_tab.data(), brick_tab.size() * 4, hipMemcpyHostToDevice) == hipSuccess) &&
+         (gbrick_tab.empty() || hipMemcpy(m->d_gbrick_tab, gbrick_tab.data(), gbrick_tab.size() * 4, hipMemcpyHostToDevice) == hipSuccess);
     if (!ok) {
         d2r_nerf_destroy(m);
         return d2r_fail(ctx, D2R_ERR_MEMORY, "device allocation/upload failed for the NeRF model");
@@ -403,6 +420,8 @@ int d2r_nerf_create(d2r_ctx *ctx, const d2r_nerf_desc *d, d2r_nerf **out)
     P.bricks = (const uint64_t *)m->d_bricks;
     P.wfrag = (const uint4 *)m->d_wfrag;
     P.brick_tab = (const uint32_t *)m->d_brick_tab;
+    P.gbrick_tab = (const uint32_t *)m->d_gbrick_tab;
+    P.gbrick_bytes = (uint32_t)(std::max<size_t>(gbrick_tab.size(), 1) * 4);
     *out = m;
     return D2R_OK;
 }
@@ -414,6 +433,7 @@ void d2r_nerf_destroy(d2r_nerf *m)
     if (m->d_bricks) hipFree(m->d_bricks);
     if (m->d_wfrag) hipFree(m->d_wfrag);
     if (m->d_brick_tab) hipFree(m->d_brick_tab);
+    if (m->d_gbrick_tab) hipFree(m->d_gbrick_tab);
     delete m;
 }
 
@@ -428,15 +448,17 @@ static int check_view(d2r_ctx *ctx, const d2r_view *v)
 
 static int fetch_stats(d2r_ctx *ctx, uint64_t rays_total, bool accumulate)
 {
-    uint32_t c[4];
-    D2R_HIP(ctx, hipMemcpyAsync(c, ctx->counters.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+    uint32_t c[8];
+    D2R_HIP(ctx, hipMemcpyAsync(c, ctx->counters.p, 32, hipMemcpyDeviceToHost, ctx->stream));
     D2R_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    uint64_t samples;
+    uint64_t samples, iters;
     memcpy(&samples, &c[2], 8);
-    if (!accumulate) ctx->stats = d2r_render_stats{0, 0, 0};
+    memcpy(&iters, &c[4], 8);
+    if (!accumulate) ctx->stats = d2r_render_stats{0, 0, 0, 0};
     ctx->stats.rays_total += rays_total;
     ctx->stats.rays_alive += c[0];
     ctx->stats.samples += samples;
+    ctx->stats.wave_iters += iters;
     return D2R_OK;
 }
 
@@ -450,7 +472,7 @@ int d2r_render(d2r_ctx *ctx, const d2r_nerf *model, const d2r_view *view, const 
     hipSetDevice(ctx->device);
     const ViewParams V = d2r_view_params(view);
     const size_t px = (size_t)V.W * V.H;
-    ctx->stats = d2r_render_stats{0, 0, 0};
+    ctx->stats = d2r_render_stats{0, 0, 0, 0};
     // bound the pass size: 2^31 rays and ~1 GiB of fp32 frames
     uint32_t per = (uint32_t)std::max<size_t>(1, std::min<size_t>(n, (64u << 20) / px + 1));
     for (uint32_t c0 = 0; c0 < n; c0 += per) {
@@ -522,7 +544,7 @@ int d2r_render_composite(d2r_ctx *ctx, const d2r_nerf *fg, const d2r_view *view,
     hipSetDevice(ctx->device);
     const ViewParams V = d2r_view_params(view);
     const size_t px = (size_t)V.W * V.H;
-    ctx->stats = d2r_render_stats{0, 0, 0};
+    ctx->stats = d2r_render_stats{0, 0, 0, 0};
     const uint32_t per = (uint32_t)std::max<int64_t>(1, ctx->chunk);
     for (uint32_t c0 = 0; c0 < K; c0 += per) {
         uint32_t nc = std::min(per, K - c0);
@@ -648,8 +670,8 @@ int d2r_render_score(d2r_ctx *ctx, const d2r_nerf *fg, const d2r_clip *clip, con
     if ((rc = d2r_reserve(ctx, ctx->cams, (size_t)cap * 48))) return rc;
     if ((rc = d2r_reserve(ctx, ctx->frames, (size_t)cap * px * 3))) return rc;
     if ((rc = d2r_reserve(ctx, ctx->clipws[6], d2r_clip_patch_bytes(clip, cap)))) return rc;
-    if ((rc = d2r_reserve(ctx, ctx->counters, 64 + 16 * (size_t)((K + per - 1) / per)))) return rc;
-    ctx->stats = d2r_render_stats{0, 0, 0};
+    if ((rc = d2r_reserve(ctx, ctx->counters, 64 + 32 * (size_t)((K + per - 1) / per)))) return rc;
+    ctx->stats = d2r_render_stats{0, 0, 0, 0};
     for (uint32_t c0 = 0; c0 < K; c0 += per) {
         uint32_t nc = std::min(per, K - c0);
         if ((rc = d2r_launch_cameras_virtual(ctx, V, obj_pose_now, cam_pose, obj_poses_dev + (size_t)c0 * 16, nc, (float *)ctx->cams.p)))
@@ -657,7 +679,7 @@ int d2r_render_score(d2r_ctx *ctx, const d2r_nerf *fg, const d2r_clip *clip, con
         if ((rc = d2r_launch_render(ctx, fg, V, (const float *)ctx->cams.p, nc, true, nullptr, nullptr, (uint8_t *)ctx->frames.p)))
             return rc;
         // keep this chunk's counters for the stats read-back at the end
-        D2R_HIP(ctx, hipMemcpyAsync((uint8_t *)ctx->counters.p + 64 + 16 * (size_t)(c0 / per), ctx->counters.p, 16,
+        D2R_HIP(ctx, hipMemcpyAsync((uint8_t *)ctx->counters.p + 64 + 32 * (size_t)(c0 / per), ctx->counters.p, 32,
                                     hipMemcpyDeviceToDevice, ctx->stream));
         if (frames_out)
             D2R_HIP(ctx, hipMemcpyAsync(frames_out + (size_t)c0 * px * 3, ctx->frames.p, (size_t)nc * px * 3, hipMemcpyDeviceToHost, ctx->stream));
@@ -683,16 +705,19 @@ int d2r_collect_render_stats(d2r_ctx *ctx, uint32_t K)
     if (!ctx) return d2r_fail(nullptr, D2R_ERR_INVALID, "null ctx");
     const uint32_t per = (uint32_t)std::max<int64_t>(1, ctx->chunk);
     const uint32_t nchunks = (K + per - 1) / per;
-    std::vector<uint32_t> c((size_t)nchunks * 4);
+    std::vector<uint32_t> c((size_t)nchunks * 8);
     D2R_HIP(ctx, hipMemcpyAsync(c.data(), (uint8_t *)ctx->counters.p + 64, c.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
     D2R_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->stats.rays_alive = 0;
     ctx->stats.samples = 0;
+    ctx->stats.wave_iters = 0;
     for (uint32_t i = 0; i < nchunks; i++) {
-        uint64_t s;
-        memcpy(&s, &c[i * 4 + 2], 8);
-        ctx->stats.rays_alive += c[i * 4];
+        uint64_t s, it;
+        memcpy(&s, &c[i * 8 + 2], 8);
+        memcpy(&it, &c[i * 8 + 4], 8);
+        ctx->stats.rays_alive += c[i * 8];
         ctx->stats.samples += s;
+        ctx->stats.wave_iters += it;
     }
     return D2R_OK;
 }

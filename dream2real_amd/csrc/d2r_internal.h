@@ -45,9 +45,13 @@ struct NerfParams {
     uint32_t n_levels;
     int32_t n_dense;           // leading dense levels (slot kinds follow from it), -1 = irregular
     SlotMeta slot[D2R_MAX_LEVELS / 2];
+    uint32_t refill_min;       // free lanes in a wave before it pulls new rays from the queue
     uint32_t n_brick_slots;    // leading slots whose levels are de-hashed into LDS bricks (0, 4 or 5)
     uint32_t brick_words;      // total words of those bricks
     const uint32_t *brick_tab; // [brick_words] half2 entries, copied to LDS by every workgroup
+    uint32_t n_gbrick_slots;   // further slots de-hashed into dense bricks kept in HBM (spatially coherent)
+    uint32_t gbrick_bytes;
+    const uint32_t *gbrick_tab;
     const uint64_t *bricks;    // [32^3] 4x4x4-cell occupancy bricks
     const uint4 *wfrag;        // [24][64] MFMA A-operand fragments of the MLPs
     float bbox_lo[3], bbox_hi[3];  // bounding box of occupied cells (+margin), unit-cube units
@@ -78,7 +82,9 @@ struct d2r_ctx {
     d2r_render_stats stats{};
     int64_t chunk = 128;       // candidates per pass of the fused path
     int64_t march_blocks = 0;  // 0 = auto
-    int64_t use_bricks = 1;    // serve de-hashed coarse levels from LDS when the model has them
+    int64_t refill_min = 16;
+    int64_t use_bricks = 1;
+    int64_t gbrick_slots = 2;  // at most this many slots use HBM bricks (0..2)    // serve de-hashed coarse levels from LDS when the model has them
     // optional per-kernel timing (HIP events on the launch stream), see d2r_get_timing
     int64_t timing = 0;
     std::vector<hipEvent_t> ev_pool;
@@ -92,7 +98,7 @@ enum { D2R_T_MARCH = 0, D2R_T_RAYGEN = 1, D2R_T_CLIP = 2, D2R_T_PREP = 3, D2R_T_
 struct d2r_nerf {
     d2r_ctx *ctx;
     NerfParams P{};
-    void *d_grid = nullptr, *d_bricks = nullptr, *d_wfrag = nullptr, *d_brick_tab = nullptr;
+    void *d_grid = nullptr, *d_bricks = nullptr, *d_wfrag = nullptr, *d_brick_tab = nullptr, *d_gbrick_tab = nullptr;
 };
 
 int d2r_fail(d2r_ctx *ctx, int code, const std::string &msg);

@@ -22,6 +22,8 @@
 //                 in the same pass; finished rays write the final pixel (parity mode:
 //                 fp32 RGBA + depth; composite mode: depth test against the background,
 //                 un-premultiply, sRGB, uint8, alpha threshold).
+#include <algorithm>
+
 #include "d2r_internal.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -296,8 +298,8 @@ __device__ __forceinline__ f32x16 mfma(const uint4 &a, const uint4 &b, f32x16 c)
 
 enum { K_DENSE = 0, K_HASH = 1, K_MIXED = 2, K_BRICK = 3 };
 
-// kind of slot i: the first NB slots are LDS bricks; otherwise dense/hashed/mixed from the number
-// of leading dense levels ND (ND < 0: treat every slot as mixed)
+// kind of slot i: the first NB slots are bricks (LDS, then NGB of them in HBM); otherwise
+// dense/hashed/mixed from the number of leading dense levels ND (ND < 0: every slot mixed)
 template <int NB, int ND>
 __device__ __host__ constexpr int slot_kind(int i)
 {
@@ -377,31 +379,44 @@ __device__ __forceinline__ void slot_blend(const uint32_t *raw, const float *w, 
 // back-to-back (memory-level parallelism is what bounds this kernel), then the blends.
 // f[2*i], f[2*i+1] = features of slot i (this lane's level of the pair).  Matches oracle
 // hashgrid_encode().
-template <int NB, int ND>
+// NB slots from LDS bricks, the next NGB from HBM bricks, the rest from the hashed tables.
+template <int NB, int NGB, int ND>
 __device__ __forceinline__ void encode_sample(const NerfParams &P, const __amdgpu_buffer_rsrc_t &rs,
+                                              const __amdgpu_buffer_rsrc_t &rsb,
                                               const uint8_t *__restrict__ lds_bricks, bool hi, float x, float y,
                                               float z, float *f)
 {
-    // Global (table) slots: all addresses, then all gathers back-to-back (memory-level parallelism),
+    // Global slots: all addresses, then all gathers back-to-back (memory-level parallelism); the
     // LDS-brick slots are evaluated underneath while those are in flight, then the global blends.
-    constexpr int NG = 8 - NB;
+    // In a dense brick the two x-neighbour corners are adjacent words: ONE 8-byte gather per
+    // (y,z) pair halves the lane-gathers (the texture addresser's cost is per lane).
+    constexpr int NG = 8 - NB;          // slots fetched from HBM (bricks first, then tables)
     uint32_t off[NG > 0 ? NG : 1][8];
     float w[NG > 0 ? NG : 1][3];
     uint32_t raw[NG > 0 ? NG : 1][8];
-    if (NB <= 0) slot_addr<slot_kind<NB, ND>(0)>(P, 0, hi, x, y, z, off[0 - (NB <= 0 ? NB : 0)], w[0 - (NB <= 0 ? NB : 0)]);
-    if (NB <= 1) slot_addr<slot_kind<NB, ND>(1)>(P, 1, hi, x, y, z, off[NB <= 1 ? 1 - NB : 0], w[NB <= 1 ? 1 - NB : 0]);
-    if (NB <= 2) slot_addr<slot_kind<NB, ND>(2)>(P, 2, hi, x, y, z, off[NB <= 2 ? 2 - NB : 0], w[NB <= 2 ? 2 - NB : 0]);
-    if (NB <= 3) slot_addr<slot_kind<NB, ND>(3)>(P, 3, hi, x, y, z, off[NB <= 3 ? 3 - NB : 0], w[NB <= 3 ? 3 - NB : 0]);
-    if (NB <= 4) slot_addr<slot_kind<NB, ND>(4)>(P, 4, hi, x, y, z, off[NB <= 4 ? 4 - NB : 0], w[NB <= 4 ? 4 - NB : 0]);
-    if (NB <= 5) slot_addr<slot_kind<NB, ND>(5)>(P, 5, hi, x, y, z, off[NB <= 5 ? 5 - NB : 0], w[NB <= 5 ? 5 - NB : 0]);
-    if (NB <= 6) slot_addr<slot_kind<NB, ND>(6)>(P, 6, hi, x, y, z, off[NB <= 6 ? 6 - NB : 0], w[NB <= 6 ? 6 - NB : 0]);
-    if (NB <= 7) slot_addr<slot_kind<NB, ND>(7)>(P, 7, hi, x, y, z, off[NB <= 7 ? 7 - NB : 0], w[NB <= 7 ? 7 - NB : 0]);
+#define D2R_SLOT(I)                                                                                              \
+    if (NB <= I) {                                                                                               \
+        if (I < NB + NGB) slot_addr<K_BRICK>(P, I, hi, x, y, z, off[NB <= I ? I - NB : 0], w[NB <= I ? I - NB : 0]); \
+        else slot_addr<slot_kind<NB + NGB, ND>(I)>(P, I, hi, x, y, z, off[NB <= I ? I - NB : 0], w[NB <= I ? I - NB : 0]); \
+    }
+    D2R_SLOT(0) D2R_SLOT(1) D2R_SLOT(2) D2R_SLOT(3) D2R_SLOT(4) D2R_SLOT(5) D2R_SLOT(6) D2R_SLOT(7)
+#undef D2R_SLOT
     __builtin_amdgcn_sched_barrier(0);
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-    for (int i = 0; i < NG; i++)
+    for (int i = 0; i < NG; i++) {
+        if (i < NGB) {
 #pragma unroll
-        for (int c = 0; c < 8; c++)
-            raw[i][c] = __builtin_amdgcn_raw_buffer_load_b32(rs, off[i][c], P.slot[NB + i].off, 0);
+            for (int j = 0; j < 4; j++) {
+                u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsb, off[i][2 * j], 0, 0);
+                raw[i][2 * j] = v[0];
+                raw[i][2 * j + 1] = v[1];
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 8; c++) raw[i][c] = __builtin_amdgcn_raw_buffer_load_b32(rs, off[i][c], P.slot[NB + i].off, 0);
+        }
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < NB; i++) {
@@ -409,7 +424,11 @@ __device__ __forceinline__ void encode_sample(const NerfParams &P, const __amdgp
         float bw[3];
         slot_addr<K_BRICK>(P, i, hi, x, y, z, bo, bw);
 #pragma unroll
-        for (int c = 0; c < 8; c++) br[c] = *(const uint32_t *)(lds_bricks + bo[c]);
+        for (int j = 0; j < 4; j++) {
+            const uint32_t *p = (const uint32_t *)(lds_bricks + bo[2 * j]);
+            br[2 * j] = p[0];
+            br[2 * j + 1] = p[1];
+        }
         slot_blend(br, bw, f[2 * i], f[2 * i + 1]);
     }
 #pragma unroll
@@ -522,9 +541,9 @@ __device__ __forceinline__ void mlp_tiles(const uint4 *__restrict__ sw, uint32_t
 
 // Evaluate the wave's 64 samples (one per lane; `valid` marks lanes that have one).
 // On return every valid lane holds sigma and the network rgb of ITS OWN sample.
-template <int NB, int ND>
+template <int NB, int NGB, int ND>
 __device__ __forceinline__ void eval_wave(const NerfParams &P, const __amdgpu_buffer_rsrc_t &rs,
-                                          const uint4 *__restrict__ sw, const uint8_t *__restrict__ lds_bricks, uint32_t lane, bool valid, float x,
+                                          const __amdgpu_buffer_rsrc_t &rsb, const uint4 *__restrict__ sw, const uint8_t *__restrict__ lds_bricks, uint32_t lane, bool valid, float x,
                                           float y, float z, float dx, float dy, float dz, float &sigma,
                                           float &r, float &g, float &b)
 {
@@ -544,8 +563,8 @@ __device__ __forceinline__ void eval_wave(const NerfParams &P, const __amdgpu_bu
 #pragma unroll
     for (int i = 0; i < 16; i++) fa[i] = fb[i] = 0.f;
     // this lane's levels: 2i + hi for every slot i (slots 0..3 -> k-step 0, 4..7 -> k-step 1)
-    if (av) encode_sample<NB, ND>(P, rs, lds_bricks, hi, ax, ay, az, fa);
-    if (bv) encode_sample<NB, ND>(P, rs, lds_bricks, hi, bx, by, bz, fb);
+    if (av) encode_sample<NB, NGB, ND>(P, rs, rsb, lds_bricks, hi, ax, ay, az, fa);
+    if (bv) encode_sample<NB, NGB, ND>(P, rs, rsb, lds_bricks, hi, bx, by, bz, fb);
     sh16(adx, ady, adz, sa);
     sh16(bdx, bdy, bdz, sb);
     float sha[8], shb[8];
@@ -586,7 +605,7 @@ __global__ __launch_bounds__(256) void k_eval_points(NerfParams P, const float *
         dx = dirs[3 * i]; dy = dirs[3 * i + 1]; dz = dirs[3 * i + 2];
     }
     float s, r, g, b;
-    eval_wave<0, ND>(P, rs, sw, nullptr, lane, valid, x, y, z, dx, dy, dz, s, r, g, b);   // arbitrary points: no bricks
+    eval_wave<0, 0, ND>(P, rs, rs, sw, nullptr, lane, valid, x, y, z, dx, dy, dz, s, r, g, b);   // arbitrary points: no bricks
     if (valid) *(float4 *)(out + 4 * (size_t)i) = make_float4(s, r, g, b);
 }
 
@@ -595,7 +614,7 @@ __global__ __launch_bounds__(256) void k_eval_points(NerfParams P, const float *
 #ifndef D2R_MARCH_THREADS
 #define D2R_MARCH_THREADS 1024
 #endif
-template <bool COMPOSITE, int NB, int ND>
+template <bool COMPOSITE, int NB, int NGB, int ND>
 __global__ __launch_bounds__(D2R_MARCH_THREADS) void k_march(NerfParams P, ViewParams V, const float *__restrict__ cams,
                                                   const uint2 *__restrict__ queue,
                                                   const uint32_t *__restrict__ qcount,
@@ -617,6 +636,7 @@ __global__ __launch_bounds__(D2R_MARCH_THREADS) void k_march(NerfParams P, ViewP
     const uint32_t n_q = *qcount;
     const uint32_t WH = V.W * V.H;
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)P.grid, 0, P.grid_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void *)P.gbrick_tab, 0, P.gbrick_bytes, 0x00020000);
 
     bool alive = false, exhausted = false;
     Ray ray = {};
@@ -624,12 +644,12 @@ __global__ __launch_bounds__(D2R_MARCH_THREADS) void k_march(NerfParams P, ViewP
     float px = 0.f, py = 0.f, pz = 0.f;
     float C0 = 0.f, C1 = 0.f, C2 = 0.f, A = 0.f, Z = 0.f;
     float fwx = 0.f, fwy = 0.f, fwz = 0.f, cox = 0.f, coy = 0.f, coz = 0.f;
-    uint32_t nsamp = 0;
+    uint32_t nsamp = 0, niter = 0;
 
     for (;;) {
         // ---- refill free lanes from the ray queue (ballot + prefix popcount, one atomic per wave)
         unsigned long long freem = __ballot(!alive);
-        if (!exhausted && freem != 0ull && (__popcll(freem) >= 16 || freem == ~0ull)) {
+        if (!exhausted && freem != 0ull && (__popcll(freem) >= (int)P.refill_min || freem == ~0ull)) {
             uint32_t nfree = (uint32_t)__popcll(freem), base = 0;
             int leader = __ffsll((long long)freem) - 1;
             if ((int)lane == leader) base = atomicAdd(qhead, nfree);
@@ -659,10 +679,11 @@ __global__ __launch_bounds__(D2R_MARCH_THREADS) void k_march(NerfParams P, ViewP
             }
         }
         if (!__any(alive)) break;
+        niter++;
 
         // ---- evaluate this wave's samples
         float sigma, cr, cg, cb;
-        eval_wave<NB, ND>(P, rs, sw, lds_bricks, lane, alive, px, py, pz, ray.dx, ray.dy, ray.dz, sigma, cr, cg, cb);
+        eval_wave<NB, NGB, ND>(P, rs, rsb, sw, lds_bricks, lane, alive, px, py, pz, ray.dx, ray.dy, ray.dz, sigma, cr, cg, cb);
 
         // ---- composite + advance
         if (alive) {
@@ -723,7 +744,10 @@ __global__ __launch_bounds__(D2R_MARCH_THREADS) void k_march(NerfParams P, ViewP
     unsigned long long tot = nsamp;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
-    if (lane == 0 && tot) atomicAdd(sample_counter, tot);
+    if (lane == 0 && tot) {
+        atomicAdd(sample_counter, tot);
+        atomicAdd(sample_counter + 1, (unsigned long long)niter);     // wave-iterations (64 sample slots each)
+    }
 }
 
 // frames[c][pix] = bg_u8[pix] for every candidate (16-byte stores)
@@ -807,7 +831,7 @@ int d2r_launch_render(d2r_ctx *ctx, const d2r_nerf *m, const ViewParams &V, cons
     if ((rc = d2r_reserve(ctx, ctx->queue, rays * sizeof(uint2)))) return rc;
     if ((rc = d2r_reserve(ctx, ctx->counters, 64))) return rc;
     uint32_t *cnt = (uint32_t *)ctx->counters.p;
-    D2R_HIP(ctx, hipMemsetAsync(cnt, 0, 16, ctx->stream));
+    D2R_HIP(ctx, hipMemsetAsync(cnt, 0, 32, ctx->stream));
     if (composite) {
         if (ctx->bg_w != V.W || ctx->bg_h != V.H || !ctx->bg_u8.p)
             return d2r_fail(ctx, D2R_ERR_INVALID, "d2r_set_background must be called for this view first");
@@ -829,30 +853,39 @@ int d2r_launch_render(d2r_ctx *ctx, const d2r_nerf *m, const ViewParams &V, cons
     unsigned long long *sc = (unsigned long long *)(cnt + 2);
     const uint2 *q = (const uint2 *)ctx->queue.p;
     const uint32_t nb = (ctx->use_bricks && m->P.n_dense == 5) ? m->P.n_brick_slots : 0;
+    NerfParams PP = m->P;
+    PP.refill_min = (uint32_t)ctx->refill_min;
     const size_t lds = (size_t)D2R_N_WFRAG * 64 * 16 + (nb ? (size_t)m->P.brick_words * 4 : 0);
-#define D2R_MARCH(COMP, NB, ND)                                                                                   \
+    uint32_t ngb = nb == 5 ? std::min<uint32_t>((uint32_t)ctx->gbrick_slots, m->P.n_gbrick_slots) : 0;
+#define D2R_MARCH(COMP, NB, NGB, ND)                                                                              \
     do {                                                                                                          \
         static bool attr = false;                                                                                 \
         if (!attr) {                                                                                              \
-            (void)hipFuncSetAttribute((const void *)k_march<COMP, NB, ND>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            (void)hipFuncSetAttribute((const void *)k_march<COMP, NB, NGB, ND>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             attr = true;                                                                                          \
         }                                                                                                         \
-        hipLaunchKernelGGL((k_march<COMP, NB, ND>), dim3(blocks), dim3(D2R_MARCH_THREADS), lds, ctx->stream, m->P, V, cams_dev, q, \
+        hipLaunchKernelGGL((k_march<COMP, NB, NGB, ND>), dim3(blocks), dim3(D2R_MARCH_THREADS), lds, ctx->stream, PP, V, cams_dev, q, \
                            cnt, cnt + 1, COMP ? nullptr : rgba_dev, COMP ? nullptr : depth_dev,                   \
                            COMP ? bgd : nullptr, COMP ? frames_dev : nullptr, sc);                                \
     } while (0)
     // compile-time slot kinds: the usual tables have 5 leading dense levels; small objects get 4 or
-    // 5 LDS-bricked slots; anything else takes the generic (every slot mixed) instantiation
+    // 5 LDS-bricked slots (+ up to 2 HBM-bricked); anything else takes the generic instantiation
     if (composite) {
-        if (m->P.n_dense != 5) D2R_MARCH(true, 0, -1);
-        else if (nb == 5) D2R_MARCH(true, 5, 5);
-        else if (nb == 4) D2R_MARCH(true, 4, 5);
-        else D2R_MARCH(true, 0, 5);
+        if (m->P.n_dense != 5) D2R_MARCH(true, 0, 0, -1);
+        else if (nb == 5 && ngb == 3) D2R_MARCH(true, 5, 3, 5);
+        else if (nb == 5 && ngb == 2) D2R_MARCH(true, 5, 2, 5);
+        else if (nb == 5 && ngb == 1) D2R_MARCH(true, 5, 1, 5);
+        else if (nb == 5) D2R_MARCH(true, 5, 0, 5);
+        else if (nb == 4) D2R_MARCH(true, 4, 0, 5);
+        else D2R_MARCH(true, 0, 0, 5);
     } else {
-        if (m->P.n_dense != 5) D2R_MARCH(false, 0, -1);
-        else if (nb == 5) D2R_MARCH(false, 5, 5);
-        else if (nb == 4) D2R_MARCH(false, 4, 5);
-        else D2R_MARCH(false, 0, 5);
+        if (m->P.n_dense != 5) D2R_MARCH(false, 0, 0, -1);
+        else if (nb == 5 && ngb == 3) D2R_MARCH(false, 5, 3, 5);
+        else if (nb == 5 && ngb == 2) D2R_MARCH(false, 5, 2, 5);
+        else if (nb == 5 && ngb == 1) D2R_MARCH(false, 5, 1, 5);
+        else if (nb == 5) D2R_MARCH(false, 5, 0, 5);
+        else if (nb == 4) D2R_MARCH(false, 4, 0, 5);
+        else D2R_MARCH(false, 0, 0, 5);
     }
 #undef D2R_MARCH
     ctx->timing_end(tm);

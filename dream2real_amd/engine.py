@@ -59,7 +59,8 @@ class Context:
             self.check(self.lib.d2r_collect_render_stats(self.h, C.c_uint32(collect_K)))
         s = _lib.RenderStats()
         self.check(self.lib.d2r_get_render_stats(self.h, C.byref(s)))
-        return {"rays_total": s.rays_total, "rays_alive": s.rays_alive, "samples": s.samples}
+        return {"rays_total": s.rays_total, "rays_alive": s.rays_alive, "samples": s.samples,
+                "wave_iters": s.wave_iters}
 
     def timing(self) -> dict:
         """Device time per kernel family since set_option("timing", 1) (synchronises)."""

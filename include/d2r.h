@@ -215,6 +215,7 @@ typedef struct {
     uint64_t rays_total;
     uint64_t rays_alive;
     uint64_t samples;
+    uint64_t wave_iters;   /* marcher wave-iterations; lane utilisation = samples / (64 * wave_iters) */
 } d2r_render_stats;
 D2R_API int d2r_get_render_stats(d2r_ctx *ctx, d2r_render_stats *out);
 /* After an asynchronous d2r_render_score over K poses: synchronises the stream and gathers
@@ -234,8 +235,9 @@ typedef struct {
 } d2r_timing;
 D2R_API int d2r_get_timing(d2r_ctx *ctx, d2r_timing *out);
 
-/* Tunables ("chunk", "march_blocks", "timing", "bricks"); unknown keys return D2R_ERR_INVALID.
- * "bricks" (default 1): serve the de-hashed coarse levels of small models from LDS; 0 forces
+/* Tunables ("chunk", "march_blocks", "timing", "refill_min", "bricks"); unknown keys return D2R_ERR_INVALID.
+ * "refill_min" (default 16): free lanes a marcher wave accumulates before refilling from the ray
+ * queue.  "bricks" (default 1): serve the de-hashed coarse levels of small models from LDS; 0 forces
  * every level through the global tables (results are bit-identical either way). */
 D2R_API int d2r_ctx_set_option(d2r_ctx *ctx, const char *key, int64_t value);
 
