@@ -200,9 +200,13 @@ __global__ void k_patchify(const float *__restrict__ pv, uint32_t n, uint32_t S,
 
 enum { EPI_F32 = 0, EPI_BIAS_BF16 = 1, EPI_BIAS_GELU_BF16 = 2, EPI_BIAS_RESID_F32 = 3 };
 
-#define BM 128
+#define BM 256
 #define BN 128
 #define BK 64
+#define GEMM_STAGES 3
+#define GEMM_THREADS 512
+#define GEMM_STAGE_BYTES ((BM + BN) * BK * 2)          /* 48 KiB */
+#define GEMM_LDS_BYTES (GEMM_STAGES * GEMM_STAGE_BYTES) /* 144 KiB: one workgroup per CU */
 
 __device__ __forceinline__ uint32_t lds_off(uint32_t row, uint32_t chunk)
 {
@@ -227,15 +231,18 @@ __device__ __forceinline__ uint32_t lds_addr(const void *p)
     return (uint32_t)(size_t)(__attribute__((address_space(3))) const void *)p;
 }
 
-// A [M_pad][K] bf16, W [N][K] bf16, M_pad % 128 == 0, N % 128 == 0, K % 64 == 0
+// C = A[M,K] * W[N,K]^T.  A [M_pad][K] bf16, W [N][K] bf16, M_pad % 256 == 0, N % 128 == 0,
+// K % 64 == 0.  256x128x64 tiles, 8 waves (4 x 2, 64x64 each = 2x2 MFMA 32x32x16 tiles),
+// 3-stage LDS ring filled by LDS-DMA: tile kt+2 is issued before tile kt is computed and the
+// wait at the end of the iteration is COUNTED (vmcnt(6) = this wave's 6 copies of tile kt+2 stay
+// in flight across the barrier) — the loads are never drained inside the loop.
 template <int EPI>
-__global__ __launch_bounds__(256, 2) void k_gemm(const uint16_t *__restrict__ A, const uint16_t *__restrict__ W,
-                                                 const float *__restrict__ bias, void *__restrict__ Cout,
-                                                 uint32_t M_pad, uint32_t N, uint32_t K, uint32_t M_real)
+__global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm(const uint16_t *__restrict__ A,
+                                                          const uint16_t *__restrict__ W,
+                                                          const float *__restrict__ bias, void *__restrict__ Cout,
+                                                          uint32_t M_pad, uint32_t N, uint32_t K, uint32_t M_real)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint8_t *As = smem;                 // 2 x 16 KB
-    uint8_t *Bs = smem + 2 * BM * BK * 2;
     // XCD-aware tile order (bijective): blocks b, b+8, ... share an L2; give each XCD a
     // contiguous run of tiles, n fastest so neighbours reuse the same A row panel.
     const uint32_t nwg = gridDim.x, tiles_n = N / BN;
@@ -244,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm(const uint16_t *__restrict__ A,
     const uint32_t m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
 
     const uint32_t tid = threadIdx.x, lane = tid & 63;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // 0..7
     const uint32_t wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
     const uint32_t li = lane & 31, hi = lane >> 5;
 
@@ -256,38 +263,45 @@ __global__ __launch_bounds__(256, 2) void k_gemm(const uint16_t *__restrict__ A,
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-    // staging: wave w copies row blocks {4w..4w+3} (8 rows x 128 B each) of both operands.
-    // lane -> (row in block, physical chunk); the logical chunk it fetches is the swizzle inverse
+    // staging: an 8-row x 128-byte block per wave instruction.  A has 32 blocks (4 per wave), B 16
+    // (2 per wave).  lane -> (row in block, physical chunk); it fetches the swizzle-inverse chunk.
     const uint32_t r_in = lane >> 3, pc = lane & 7;
-    const uint16_t *ag[4], *wg[4];
+    const uint16_t *ag[4], *wg[2];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const uint32_t row = (wave * 4 + i) * 8 + r_in;
-        const uint32_t lc = pc ^ ((row >> 1) & 7u);
-        ag[i] = A + (size_t)(m0 + row) * K + lc * 8;
-        wg[i] = W + (size_t)(n0 + row) * K + lc * 8;
+        ag[i] = A + (size_t)(m0 + row) * K + (pc ^ ((row >> 1) & 7u)) * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const uint32_t row = (wave * 2 + i) * 8 + r_in;
+        wg[i] = W + (size_t)(n0 + row) * K + (pc ^ ((row >> 1) & 7u)) * 8;
     }
     const uint32_t nk = K / BK;
-    const uint32_t as_base = __builtin_amdgcn_readfirstlane(lds_addr(As));
-    const uint32_t bs_base = __builtin_amdgcn_readfirstlane(lds_addr(Bs));
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem));
     auto stage = [&](uint32_t buf, uint32_t kt) {
+        const uint32_t base = lds0 + buf * GEMM_STAGE_BYTES;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const uint32_t boff = buf * (BM * BK * 2) + (wave * 4 + i) * 1024;
-            glds16(ag[i] + (size_t)kt * BK, as_base + boff);
-            glds16(wg[i] + (size_t)kt * BK, bs_base + boff);
-        }
+        for (int i = 0; i < 4; i++) glds16(ag[i] + (size_t)kt * BK, base + (wave * 4 + i) * 1024);
+#pragma unroll
+        for (int i = 0; i < 2; i++) glds16(wg[i] + (size_t)kt * BK, base + BM * BK * 2 + (wave * 2 + i) * 1024);
     };
 
     stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();          // tile 0 landed and is visible to every wave
+    if (nk > 1) {
+        stage(1, 1);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // tile 0 landed, tile 1 in flight
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
 
+    uint32_t cur = 0;
     for (uint32_t kt = 0; kt < nk; kt++) {
-        const uint32_t cur = kt & 1;
-        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);       // next tile streams in under the MFMAs
-        const uint8_t *Ab = As + cur * (BM * BK * 2);
-        const uint8_t *Bb = Bs + cur * (BN * BK * 2);
+        // refill the buffer computed in the previous iteration (everyone left it at the last barrier)
+        if (kt + 2 < nk) stage(cur >= 1 ? cur - 1 : GEMM_STAGES - 1, kt + 2);
+        const uint8_t *Ab = smem + cur * GEMM_STAGE_BYTES;
+        const uint8_t *Bb = Ab + BM * BK * 2;
 #pragma unroll
         for (int s = 0; s < 4; s++) {
             uint4 fa[2], fb[2];
@@ -306,36 +320,59 @@ __global__ __launch_bounds__(256, 2) void k_gemm(const uint16_t *__restrict__ A,
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc[i][j], 0, 0, 0);
                 }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's share of the next tile landed
-        __syncthreads();                                     // ... everyone's did, and `cur` is free
+        // tile kt+1 must have landed; tile kt+2 (this wave's 6 most recent copies) may stay in flight
+        if (kt + 2 < nk)
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur = cur + 1 == GEMM_STAGES ? 0 : cur + 1;
     }
 
-    // epilogue: acc[i][j][r] -> row m0+wm+32i+(r&3)+8(r>>2)+4hi, col n0+wn+32j+li
-    const bool full = m0 + BM <= M_real;      // block-uniform: only the last row panel is ragged
+    // epilogue: each wave transposes its 64x64 fp32 tile through LDS (the ring is free now: the
+    // loop ended on a barrier) so that a lane owns 4 consecutive columns of a row: bias and
+    // activation on float4, 8-byte (bf16) / 16-byte (fp32) coalesced stores.
+    // acc[i][j][r] <-> row 32i+(r&3)+8(r>>2)+4hi, col 32j+li of the wave tile.
+    constexpr uint32_t EP_LD = 68;                                   // floats per LDS row (pad 4)
+    float *ep = (float *)smem + wave * (64 * EP_LD);                 // 17 KiB per wave, 136 KiB total
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const uint32_t col = n0 + wn + j * 32 + li;
-            const float bv = (EPI == EPI_F32) ? 0.f : bias[col];
+        for (int j = 0; j < 2; j++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const uint32_t row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if (!full && row >= M_real) continue;
-                float v = acc[i][j][r] + bv;
-                const size_t o = (size_t)row * N + col;
-                if (EPI == EPI_F32) {
-                    ((float *)Cout)[o] = v;
-                } else if (EPI == EPI_BIAS_BF16) {
-                    ((uint16_t *)Cout)[o] = f2bf(v);
-                } else if (EPI == EPI_BIAS_GELU_BF16) {
-                    v = v / (1.0f + __expf(-1.702f * v));
-                    ((uint16_t *)Cout)[o] = f2bf(v);
-                } else {
-                    ((float *)Cout)[o] += v;
-                }
+            for (int r = 0; r < 16; r++)
+                ep[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * EP_LD + j * 32 + li] = acc[i][j][r];
+    const uint32_t c4 = (lane & 15) * 4, rl0 = lane >> 4;
+    const uint32_t col = n0 + wn + c4;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (EPI != EPI_F32) bv = *(const float4 *)(bias + col);
+#pragma unroll 4
+    for (int k = 0; k < 16; k++) {
+        const uint32_t rl = rl0 + 4 * k, row = m0 + wm + rl;
+        float4 v = *(const float4 *)(ep + rl * EP_LD + c4);
+        if (row >= M_real) continue;
+        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+        const uint32_t o = row * N + col;                            // < 2^32 elements (checked on host)
+        if (EPI == EPI_F32) {
+            *(float4 *)((float *)Cout + o) = v;
+        } else if (EPI == EPI_BIAS_RESID_F32) {
+            float4 *dst = (float4 *)((float *)Cout + o);
+            float4 x = *dst;
+            *dst = make_float4(x.x + v.x, x.y + v.y, x.z + v.z, x.w + v.w);
+        } else {
+            if (EPI == EPI_BIAS_GELU_BF16) {
+                // quick_gelu: x * sigmoid(1.702 x) = x / (1 + exp2(-1.702 log2(e) x))
+                v.x *= __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930156f * v.x));
+                v.y *= __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930156f * v.y));
+                v.z *= __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930156f * v.z));
+                v.w *= __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930156f * v.w));
             }
+            uint2 pk;
+            pk.x = pack2(v.x, v.y);
+            pk.y = pack2(v.z, v.w);
+            *(uint2 *)((uint16_t *)Cout + o) = pk;
         }
+    }
 }
 
 // -------------------------------------------------------- embeddings + LN
@@ -740,13 +777,15 @@ static int launch_gemm(d2r_ctx *ctx, const uint16_t *A, const uint16_t *W, const
 {
     const uint32_t M_pad = round_up(M_real, BM);
     if (N % BN || K % BK) return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "GEMM N must be a multiple of 128 and K of 64");
+    if ((uint64_t)M_pad * N >= (1ull << 32)) return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "GEMM output too large for 32-bit indexing");
     const uint32_t nwg = (M_pad / BM) * (N / BN);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void *)k_gemm<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        (void)hipFuncSetAttribute((const void *)k_gemm<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_gemm<EPI>, dim3(nwg), dim3(256), 65536, ctx->stream, A, W, bias, C, M_pad, N, K, M_real);
+    hipLaunchKernelGGL(k_gemm<EPI>, dim3(nwg), dim3(GEMM_THREADS), GEMM_LDS_BYTES, ctx->stream, A, W, bias, C, M_pad, N, K,
+                       M_real);
     D2R_HIP(ctx, hipGetLastError());
     return D2R_OK;
 }
