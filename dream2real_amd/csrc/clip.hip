@@ -94,7 +94,10 @@ __device__ __forceinline__ uint32_t clip8(int v)
     return (uint32_t)min(max(v, 0), 255);
 }
 
-// grid (S/band_rows... bands, n); block 256.  dynamic LDS: max_rows * S * 3 bytes.
+// grid (bands of P output rows, n); block 256.  dynamic LDS: 3 planes of [S][max_rows] bytes
+// (column-major: the vertical pass then reads consecutive bytes).  Thread order in pass 1 follows
+// the SOURCE memory order — with rot90 consecutive source bytes are consecutive rotated rows —
+// so the uint8 frame is read coalesced in both orientations.
 __global__ __launch_bounds__(256) void k_preprocess(const uint8_t *__restrict__ frames, uint32_t w, uint32_t h,
                                                     int rot90, ResampleTables R, uint32_t S, uint32_t P,
                                                     uint32_t band, uint16_t *__restrict__ patches,
@@ -115,34 +118,39 @@ __global__ __launch_bounds__(256) void k_preprocess(const uint8_t *__restrict__ 
         y_first = R.top + row0;
         y_last = y_first + nrows;
     }
-    const int trows = y_last - y_first;
+    const uint32_t trows = (uint32_t)(y_last - y_first);
+    const uint32_t ld = (uint32_t)R.max_rows;                // bytes per LDS column
+    const uint32_t plane = S * ld;
     // pass 1: horizontal filter (or copy) into LDS, columns [left, left+S)
-    for (uint32_t i = threadIdx.x; i < (uint32_t)trows * S; i += blockDim.x) {
-        int ty = i / S, tx = i % S;
-        int sy = y_first + ty;                 // row in rotated source
-        int ox = R.left + tx;                  // column in resized image
-        uint32_t o[3];
+    for (uint32_t i = threadIdx.x; i < trows * S; i += blockDim.x) {
+        uint32_t ty, tx;
+        if (rot90) { tx = i / trows; ty = i - tx * trows; } else { ty = i / S; tx = i - ty * S; }
+        const int sy = y_first + (int)ty;      // row in rotated source
+        const int ox = R.left + (int)tx;       // column in resized image
+        uint32_t o0, o1, o2;
         if (R.need_h) {
-            int xmin = R.bounds_h[2 * ox], cnt = R.bounds_h[2 * ox + 1];
+            const int xmin = R.bounds_h[2 * ox], cnt = R.bounds_h[2 * ox + 1];
             const int *k = R.kk_h + (size_t)ox * R.ks_h;
             int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0;
             for (int x = 0; x < cnt; x++) {
-                int sx = xmin + x;
+                const int sx = xmin + x;
                 const uint8_t *p = rot90 ? src + ((size_t)sx * w + (w - 1 - sy)) * 3
                                          : src + ((size_t)sy * w + sx) * 3;
-                int kv = k[x];
+                const int kv = k[x];
                 s0 += p[0] * kv;
                 s1 += p[1] * kv;
                 s2 += p[2] * kv;
             }
-            o[0] = clip8(s0); o[1] = clip8(s1); o[2] = clip8(s2);
+            o0 = clip8(s0); o1 = clip8(s1); o2 = clip8(s2);
         } else {
             const uint8_t *p = rot90 ? src + ((size_t)ox * w + (w - 1 - sy)) * 3
                                      : src + ((size_t)sy * w + ox) * 3;
-            o[0] = p[0]; o[1] = p[1]; o[2] = p[2];
+            o0 = p[0]; o1 = p[1]; o2 = p[2];
         }
-        uint8_t *d = tmp + ((size_t)ty * S + tx) * 3;
-        d[0] = (uint8_t)o[0]; d[1] = (uint8_t)o[1]; d[2] = (uint8_t)o[2];
+        uint8_t *d = tmp + tx * ld + ty;
+        d[0] = (uint8_t)o0;
+        d[plane] = (uint8_t)o1;
+        d[2 * plane] = (uint8_t)o2;
     }
     __syncthreads();
     // pass 2: vertical filter, normalise, scatter patch-major
@@ -150,24 +158,24 @@ __global__ __launch_bounds__(256) void k_preprocess(const uint8_t *__restrict__ 
     const float stdv[3] = {0.26862954f, 0.26130258f, 0.27577711f};
     const uint32_t g = S / P;
     for (uint32_t i = threadIdx.x; i < nrows * S; i += blockDim.x) {
-        uint32_t ry = i / S, rx = i % S;
-        uint32_t oy = row0 + ry;
+        const uint32_t ry = i / S, rx = i % S;
+        const uint32_t oy = row0 + ry;
         uint32_t q[3];
+        const uint8_t *col = tmp + rx * ld;
         if (R.need_v) {
-            int ymin = R.bounds_v[2 * (R.top + oy)] - y_first, cnt = R.bounds_v[2 * (R.top + oy) + 1];
+            const int ymin = R.bounds_v[2 * (R.top + oy)] - y_first, cnt = R.bounds_v[2 * (R.top + oy) + 1];
             const int *k = R.kk_v + (size_t)(R.top + oy) * R.ks_v;
             int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0;
             for (int y = 0; y < cnt; y++) {
-                const uint8_t *p = tmp + ((size_t)(ymin + y) * S + rx) * 3;
-                int kv = k[y];
+                const uint8_t *p = col + ymin + y;
+                const int kv = k[y];
                 s0 += p[0] * kv;
-                s1 += p[1] * kv;
-                s2 += p[2] * kv;
+                s1 += p[plane] * kv;
+                s2 += p[2 * plane] * kv;
             }
             q[0] = clip8(s0); q[1] = clip8(s1); q[2] = clip8(s2);
         } else {
-            const uint8_t *p = tmp + ((size_t)ry * S + rx) * 3;
-            q[0] = p[0]; q[1] = p[1]; q[2] = p[2];
+            q[0] = col[ry]; q[1] = col[plane + ry]; q[2] = col[2 * plane + ry];
         }
 #pragma unroll
         for (int c = 0; c < 3; c++) {
@@ -585,56 +593,76 @@ __global__ __launch_bounds__(256, 2) void k_attention(const uint16_t *__restrict
 
 // ------------------------------------------------------------------ head
 
-// one block per image: post_layernorm(X[b*T]) -> proj -> L2 normalise -> logits
-__global__ __launch_bounds__(256) void k_head(const float *__restrict__ X, uint32_t T, uint32_t d,
-                                              const float *__restrict__ lw, const float *__restrict__ lb,
-                                              const float *__restrict__ proj, uint32_t D,
-                                              const float *__restrict__ text, uint32_t C, float logit_scale,
-                                              float *__restrict__ logits, float *__restrict__ embeds)
+// one 1024-thread block per image: post_layernorm(X[b*T]) -> proj -> L2 normalise -> logits.
+// 16 waves and 4 output rows per wave iteration keep ~48 loads per lane in flight: the
+// projection is a latency problem (1.5 MB of fp32 weights per image out of L2), not a flop one.
+#define HEAD_THREADS 1024
+__global__ __launch_bounds__(HEAD_THREADS) void k_head(const float *__restrict__ X, uint32_t T, uint32_t d,
+                                                       const float *__restrict__ lw, const float *__restrict__ lb,
+                                                       const float *__restrict__ proj, uint32_t D,
+                                                       const float *__restrict__ text, uint32_t C, float logit_scale,
+                                                       float *__restrict__ logits, float *__restrict__ embeds)
 {
     __shared__ float xs[1024];
     __shared__ float es[1024];
-    __shared__ float red[8];
+    __shared__ float red[16];
+    constexpr uint32_t NW = HEAD_THREADS / 64;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float *x = X + (size_t)blockIdx.x * T * d;
-    float s = 0.f;
-    for (uint32_t i = tid; i < d; i += 256) s += x[i];
-    s = wave_sum(s);
+    const float xv = tid < d ? x[tid] : 0.f;                         // d <= 1024
+    float s = wave_sum(xv);
     if (lane == 0) red[wave] = s;
     __syncthreads();
-    const float mu = (red[0] + red[1] + red[2] + red[3]) / (float)d;
+    float tot = 0.f;
+#pragma unroll
+    for (uint32_t i = 0; i < NW; i++) tot += red[i];
+    const float mu = tot / (float)d;
     __syncthreads();
-    float q = 0.f;
-    for (uint32_t i = tid; i < d; i += 256) {
-        float a = x[i] - mu;
-        q += a * a;
-    }
-    q = wave_sum(q);
+    const float dv = tid < d ? xv - mu : 0.f;
+    float q = wave_sum(dv * dv);
     if (lane == 0) red[wave] = q;
     __syncthreads();
-    const float rstd = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)d + 1e-5f);
-    for (uint32_t i = tid; i < d; i += 256) xs[i] = (x[i] - mu) * rstd * lw[i] + lb[i];
+    tot = 0.f;
+#pragma unroll
+    for (uint32_t i = 0; i < NW; i++) tot += red[i];
+    const float rstd = 1.0f / sqrtf(tot / (float)d + 1e-5f);
+    if (tid < d) xs[tid] = dv * rstd * lw[tid] + lb[tid];
     __syncthreads();
-    // projection: one wave per output row, lanes stride the dot product
+    // projection: wave handles rows o, o+NW, ... four at a time
     float nrm = 0.f;
-    for (uint32_t o = wave; o < D; o += 4) {
-        const float *pr = proj + (size_t)o * d;
-        float a = 0.f;
-        for (uint32_t i = lane; i < d; i += 64) a = fmaf(pr[i], xs[i], a);
-        a = wave_sum(a);
-        if (lane == 0) es[o] = a;
-        nrm += a * a;     // identical in every lane of the wave
+    for (uint32_t o = wave * 4; o < D; o += NW * 4) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        const float *p0 = proj + (size_t)o * d;
+        const bool v1 = o + 1 < D, v2 = o + 2 < D, v3 = o + 3 < D;
+        for (uint32_t i = lane; i < d; i += 64) {
+            const float xi = xs[i];
+            a0 = fmaf(p0[i], xi, a0);
+            if (v1) a1 = fmaf(p0[d + i], xi, a1);
+            if (v2) a2 = fmaf(p0[2 * d + i], xi, a2);
+            if (v3) a3 = fmaf(p0[3 * d + i], xi, a3);
+        }
+        a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
+        if (lane == 0) {
+            es[o] = a0;
+            if (v1) es[o + 1] = a1;
+            if (v2) es[o + 2] = a2;
+            if (v3) es[o + 3] = a3;
+        }
+        nrm += a0 * a0 + (v1 ? a1 * a1 : 0.f) + (v2 ? a2 * a2 : 0.f) + (v3 ? a3 * a3 : 0.f);
     }
     __syncthreads();
-    if (lane == 0) red[4 + wave] = nrm;
+    if (lane == 0) red[wave] = nrm;
     __syncthreads();
-    const float inv = 1.0f / sqrtf(red[4] + red[5] + red[6] + red[7]);
-    for (uint32_t i = tid; i < D; i += 256) {
-        es[i] *= inv;
-        if (embeds) embeds[(size_t)blockIdx.x * D + i] = es[i];
+    tot = 0.f;
+#pragma unroll
+    for (uint32_t i = 0; i < NW; i++) tot += red[i];
+    const float inv = 1.0f / sqrtf(tot);
+    if (tid < D) {
+        es[tid] *= inv;
+        if (embeds) embeds[(size_t)blockIdx.x * D + tid] = es[tid];
     }
     __syncthreads();
-    for (uint32_t c = wave; c < C; c += 4) {
+    for (uint32_t c = wave; c < C; c += NW) {
         float a = 0.f;
         for (uint32_t i = lane; i < D; i += 64) a = fmaf(es[i], text[(size_t)c * D + i], a);
         a = wave_sum(a);
@@ -834,7 +862,7 @@ int d2r_clip_forward(d2r_ctx *ctx, const d2r_clip *clip, const uint16_t *patches
         if ((rc = launch_gemm<EPI_BIAS_GELU_BF16>(ctx, Xn, L.w_fc1, L.b_fc1, H, rows, mlp, d))) return rc;
         if ((rc = launch_gemm<EPI_BIAS_RESID_F32>(ctx, H, L.w_fc2, L.b_fc2, X, rows, d, mlp))) return rc;
     }
-    hipLaunchKernelGGL(k_head, dim3(n), dim3(256), 0, ctx->stream, X, T, d, clip->w.post_w, clip->w.post_b,
+    hipLaunchKernelGGL(k_head, dim3(n), dim3(HEAD_THREADS), 0, ctx->stream, X, T, d, clip->w.post_w, clip->w.post_b,
                        clip->w.proj, D.proj_dim, text_dev, C, logit_scale, logits_dev, embeds_dev);
     D2R_HIP(ctx, hipGetLastError());
     return D2R_OK;
