@@ -12,7 +12,9 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 i=0
 for P in "${PASSES[@]}"; do
-  rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/p$i -o r -- python $ROOT/bench.py "$@" > $OUT/p$i.log 2>&1 || true
+  # hard limit per pass: a counter set that does not fit the PMC slots (SQ 8, TCC 4 with FETCH_SIZE
+  # costing 3, GRBM 2) makes rocprofv3 abort and then wait forever on the unfinished dispatch
+  timeout -k 10 ${PMC_PASS_TIMEOUT:-240} rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/p$i -o r -- python $ROOT/bench.py "$@" > $OUT/p$i.log 2>&1 || echo "pass $i ($P) failed or timed out"
   i=$((i+1))
 done
 python - <<PY

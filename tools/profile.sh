@@ -9,13 +9,13 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o r -- python $ROOT/bench.py "$@" > $OUT/bench.log 2>&1 || true
+timeout -k 10 ${PROF_TIMEOUT:-600} rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o r -- python $ROOT/bench.py "$@" > $OUT/bench.log 2>&1 || true
 rm -f $OUT/*.db $OUT/r_kernel_trace.csv
 python - <<PY
 import csv, sys
 rows = list(csv.DictReader(open("$OUT/r_kernel_stats.csv")))
 with open("$ROOT/gpurun_out/${TAG}_kernel_stats.md", "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats -- python bench.py $*\n\n")
+    f.write("# timeout -k 10 ${PROF_TIMEOUT:-600} rocprofv3 --kernel-trace --stats -- python bench.py $*\n\n")
     f.write("| kernel | calls | total ms | avg us | min us | max us | % |\n|---|---|---|---|---|---|---|\n")
     for r in rows[:24]:
         f.write(f"| {r['Name'][:60]} | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.2f} | {float(r['AverageNs'])/1e3:.1f} | {float(r['MinNs'])/1e3:.1f} | {float(r['MaxNs'])/1e3:.1f} | {float(r['Percentage']):.2f} |\n")
