@@ -27,6 +27,13 @@ CLIP_CONFIGS = {
     "vit_l14_336": dict(patch_size=14, hidden_size=1024, num_layers=24, num_heads=16, mlp=4096, image_size=336,
                         proj=768, text_hidden=768, text_layers=12, text_heads=12, text_mlp=3072,
                         vocab=49408, ctx=77),
+    # shallow ViT-L geometries (patch 14 -> padded patch GEMM, 257 / 577 tokens, d=1024) for parity tests
+    "vit_l14_x2": dict(patch_size=14, hidden_size=1024, num_layers=2, num_heads=16, mlp=4096, image_size=224,
+                       proj=768, text_hidden=768, text_layers=1, text_heads=12, text_mlp=3072,
+                       vocab=49408, ctx=77),
+    "vit_l14_336_x1": dict(patch_size=14, hidden_size=1024, num_layers=1, num_heads=16, mlp=4096, image_size=336,
+                           proj=768, text_hidden=768, text_layers=1, text_heads=12, text_mlp=3072,
+                           vocab=49408, ctx=77),
     # 2-layer model with the same code paths, for unit tests and committed goldens
     "vit_tiny": dict(patch_size=16, hidden_size=128, num_layers=2, num_heads=2, mlp=256, image_size=64,
                      proj=64, text_hidden=64, text_layers=2, text_heads=1, text_mlp=128,

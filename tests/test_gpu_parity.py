@@ -197,7 +197,7 @@ def test_preprocess_bit_exact(gpu, hw):
     sc.close()
 
 
-@pytest.mark.parametrize("name,n", [("vit_tiny", 9), ("vit_b16", 5)])
+@pytest.mark.parametrize("name,n", [("vit_tiny", 9), ("vit_b16", 5), ("vit_l14_x2", 3), ("vit_l14_336_x1", 2)])
 def test_vit_embeddings_match_oracle(gpu, name, n):
     engine, ctx = gpu["engine"], gpu["ctx"]
     cfg = CLIP_CONFIGS[name]
