@@ -208,13 +208,9 @@ __global__ void k_patchify(const float *__restrict__ pv, uint32_t n, uint32_t S,
 
 enum { EPI_F32 = 0, EPI_BIAS_BF16 = 1, EPI_BIAS_GELU_BF16 = 2, EPI_BIAS_RESID_F32 = 3 };
 
-#define BM 256
-#define BN 128
+#define BM 256                 /* row padding of every GEMM operand buffer (largest tile height) */
 #define BK 64
-#define GEMM_STAGES 3
 #define GEMM_THREADS 512
-#define GEMM_STAGE_BYTES ((BM + BN) * BK * 2)          /* 48 KiB */
-#define GEMM_LDS_BYTES (GEMM_STAGES * GEMM_STAGE_BYTES) /* 144 KiB: one workgroup per CU */
 
 __device__ __forceinline__ uint32_t lds_off(uint32_t row, uint32_t chunk)
 {
@@ -225,101 +221,113 @@ __device__ __forceinline__ uint32_t lds_off(uint32_t row, uint32_t chunk)
 // destination is wave-uniform base (M0) + lane*16, so the XOR swizzle is applied on the SOURCE
 // side.  Issued from inline asm so that hipcc does not see an in-flight LDS write and drain it
 // (vmcnt(0)) in front of every ds_read of the tile being computed; the waits are placed by hand
-// (cdna_hip_programming.md 5.7).  lds_byte_addr must be wave-uniform.
+// (cdna_hip_programming.md 5.7).  lds_byte_addr must be wave-uniform.  M0 is not preserved:
+// nothing else in these kernels uses it.
 __device__ __forceinline__ void glds16(const void *g, uint32_t lds_byte_addr)
 {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(g), "s"(lds_byte_addr)
-                 : "memory");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(lds_byte_addr) : "memory");
 }
 __device__ __forceinline__ uint32_t lds_addr(const void *p)
 {
     return (uint32_t)(size_t)(__attribute__((address_space(3))) const void *)p;
 }
+template <int N>
+__device__ __forceinline__ void wait_vmcnt()
+{
+    if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+}
 
-// C = A[M,K] * W[N,K]^T.  A [M_pad][K] bf16, W [N][K] bf16, M_pad % 256 == 0, N % 128 == 0,
-// K % 64 == 0.  256x128x64 tiles, 8 waves (4 x 2, 64x64 each = 2x2 MFMA 32x32x16 tiles),
-// 3-stage LDS ring filled by LDS-DMA: tile kt+2 is issued before tile kt is computed and the
-// wait at the end of the iteration is COUNTED (vmcnt(6) = this wave's 6 copies of tile kt+2 stay
-// in flight across the barrier) — the loads are never drained inside the loop.
-template <int EPI>
+// C = A[M,K] * W[N,K]^T.  A [M_pad][K] bf16, W [N][K] bf16, K % 64 == 0.
+// 8 waves as WGM x WGN, each wave MT x 2 MFMA 32x32x16 tiles:
+//   <WGM=4, WGN=2, MT=2, STAGES=3>  256x128 tile, 3-stage ring, counted vmcnt  (N = 768 products)
+//   <WGM=2, WGN=4, MT=4, STAGES=2>  256x256 tile, 2-stage                      (N >= 2304 products)
+// LDS-DMA staging: tile kt+STAGES-1 is issued before tile kt is computed; with 3 stages the wait at
+// the end of the iteration is COUNTED (this wave's copies of the newest tile stay in flight across
+// the barrier) — the loads are never drained inside the loop.
+template <int EPI, int WGM, int WGN, int MT, int STAGES>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm(const uint16_t *__restrict__ A,
                                                           const uint16_t *__restrict__ W,
                                                           const float *__restrict__ bias, void *__restrict__ Cout,
                                                           uint32_t M_pad, uint32_t N, uint32_t K, uint32_t M_real)
 {
+    constexpr uint32_t TBM = WGM * MT * 32, TBN = WGN * 64;
+    constexpr uint32_t STAGE_BYTES = (TBM + TBN) * BK * 2;
+    constexpr int A_PER_WAVE = TBM / 64, B_PER_WAVE = TBN / 64;     // 1 KiB copies per wave per stage
+    constexpr int PER_STAGE = A_PER_WAVE + B_PER_WAVE;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     // XCD-aware tile order (bijective): blocks b, b+8, ... share an L2; give each XCD a
     // contiguous run of tiles, n fastest so neighbours reuse the same A row panel.
-    const uint32_t nwg = gridDim.x, tiles_n = N / BN;
+    const uint32_t nwg = gridDim.x, tiles_n = N / TBN;
     const uint32_t xcd = blockIdx.x & 7u, loc = blockIdx.x >> 3, q = nwg >> 3, rr = nwg & 7u;
     const uint32_t tile = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
-    const uint32_t m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    const uint32_t m0 = (tile / tiles_n) * TBM, n0 = (tile % tiles_n) * TBN;
 
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // 0..7
-    const uint32_t wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const uint32_t wm = (wave / WGN) * (MT * 32), wn = (wave % WGN) * 64;
     const uint32_t li = lane & 31, hi = lane >> 5;
 
-    f32x16 acc[2][2];
+    f32x16 acc[MT][2];
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < MT; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-    // staging: an 8-row x 128-byte block per wave instruction.  A has 32 blocks (4 per wave), B 16
-    // (2 per wave).  lane -> (row in block, physical chunk); it fetches the swizzle-inverse chunk.
+    // staging: an 8-row x 128-byte block per wave instruction.  lane -> (row in block, physical
+    // chunk); it fetches the swizzle-inverse logical chunk.
     const uint32_t r_in = lane >> 3, pc = lane & 7;
-    const uint16_t *ag[4], *wg[2];
+    const uint16_t *ag[A_PER_WAVE], *wg[B_PER_WAVE];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const uint32_t row = (wave * 4 + i) * 8 + r_in;
+    for (int i = 0; i < A_PER_WAVE; i++) {
+        const uint32_t row = (wave * A_PER_WAVE + i) * 8 + r_in;
         ag[i] = A + (size_t)(m0 + row) * K + (pc ^ ((row >> 1) & 7u)) * 8;
     }
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const uint32_t row = (wave * 2 + i) * 8 + r_in;
+    for (int i = 0; i < B_PER_WAVE; i++) {
+        const uint32_t row = (wave * B_PER_WAVE + i) * 8 + r_in;
         wg[i] = W + (size_t)(n0 + row) * K + (pc ^ ((row >> 1) & 7u)) * 8;
     }
     const uint32_t nk = K / BK;
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem));
     auto stage = [&](uint32_t buf, uint32_t kt) {
-        const uint32_t base = lds0 + buf * GEMM_STAGE_BYTES;
+        const uint32_t base = lds0 + buf * STAGE_BYTES;
 #pragma unroll
-        for (int i = 0; i < 4; i++) glds16(ag[i] + (size_t)kt * BK, base + (wave * 4 + i) * 1024);
+        for (int i = 0; i < A_PER_WAVE; i++) glds16(ag[i] + (size_t)kt * BK, base + (wave * A_PER_WAVE + i) * 1024);
 #pragma unroll
-        for (int i = 0; i < 2; i++) glds16(wg[i] + (size_t)kt * BK, base + BM * BK * 2 + (wave * 2 + i) * 1024);
+        for (int i = 0; i < B_PER_WAVE; i++)
+            glds16(wg[i] + (size_t)kt * BK, base + TBM * BK * 2 + (wave * B_PER_WAVE + i) * 1024);
     };
 
+    // prologue: STAGES-1 tiles in flight, the first one landed
     stage(0, 0);
-    if (nk > 1) {
+    if (STAGES == 3 && nk > 1) {
         stage(1, 1);
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // tile 0 landed, tile 1 in flight
+        wait_vmcnt<PER_STAGE>();
     } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wait_vmcnt<0>();
     }
     __syncthreads();
 
     uint32_t cur = 0;
     for (uint32_t kt = 0; kt < nk; kt++) {
-        // refill the buffer computed in the previous iteration (everyone left it at the last barrier)
-        if (kt + 2 < nk) stage(cur >= 1 ? cur - 1 : GEMM_STAGES - 1, kt + 2);
-        const uint8_t *Ab = smem + cur * GEMM_STAGE_BYTES;
-        const uint8_t *Bb = Ab + BM * BK * 2;
+        // refill the buffer that was computed in the previous iteration (everyone left it at the barrier)
+        const uint32_t ahead = kt + STAGES - 1;
+        if (ahead < nk) stage(cur >= 1 ? cur - 1 : STAGES - 1, ahead);
+        const uint8_t *Ab = smem + cur * STAGE_BYTES;
+        const uint8_t *Bb = Ab + TBM * BK * 2;
 #pragma unroll
         for (int s = 0; s < 4; s++) {
-            uint4 fa[2], fb[2];
+            uint4 fa[MT], fb[2];
 #pragma unroll
-            for (int i = 0; i < 2; i++) {
-                fa[i] = *(const uint4 *)(Ab + lds_off(wm + i * 32 + li, 2 * s + hi));
-                fb[i] = *(const uint4 *)(Bb + lds_off(wn + i * 32 + li, 2 * s + hi));
-            }
+            for (int i = 0; i < MT; i++) fa[i] = *(const uint4 *)(Ab + lds_off(wm + i * 32 + li, 2 * s + hi));
 #pragma unroll
-            for (int i = 0; i < 2; i++)
+            for (int j = 0; j < 2; j++) fb[j] = *(const uint4 *)(Bb + lds_off(wn + j * 32 + li, 2 * s + hi));
+#pragma unroll
+            for (int i = 0; i < MT; i++)
 #pragma unroll
                 for (int j = 0; j < 2; j++) {
                     union { uint4 u; bf16x8 v; } a, b;
@@ -328,57 +336,57 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm(const uint16_t *__rest
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc[i][j], 0, 0, 0);
                 }
         }
-        // tile kt+1 must have landed; tile kt+2 (this wave's 6 most recent copies) may stay in flight
-        if (kt + 2 < nk)
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        // tile kt+1 must have landed; with 3 stages this wave's copies of tile kt+2 stay in flight
+        if (STAGES == 3 && ahead < nk)
+            wait_vmcnt<PER_STAGE>();
         else
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wait_vmcnt<0>();
         __syncthreads();
-        cur = cur + 1 == GEMM_STAGES ? 0 : cur + 1;
+        cur = cur + 1 == STAGES ? 0 : cur + 1;
     }
 
-    // epilogue: each wave transposes its 64x64 fp32 tile through LDS (the ring is free now: the
-    // loop ended on a barrier) so that a lane owns 4 consecutive columns of a row: bias and
+    // epilogue: 32 rows at a time each wave transposes its fp32 tile through LDS (the ring is free:
+    // the loop ended on a barrier) so that a lane owns 4 consecutive columns of a row: bias and
     // activation on float4, 8-byte (bf16) / 16-byte (fp32) coalesced stores.
     // acc[i][j][r] <-> row 32i+(r&3)+8(r>>2)+4hi, col 32j+li of the wave tile.
     constexpr uint32_t EP_LD = 68;                                   // floats per LDS row (pad 4)
-    float *ep = (float *)smem + wave * (64 * EP_LD);                 // 17 KiB per wave, 136 KiB total
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int r = 0; r < 16; r++)
-                ep[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * EP_LD + j * 32 + li] = acc[i][j][r];
+    float *ep = (float *)smem + wave * (32 * EP_LD);                 // 8.5 KiB per wave
     const uint32_t c4 = (lane & 15) * 4, rl0 = lane >> 4;
     const uint32_t col = n0 + wn + c4;
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (EPI != EPI_F32) bv = *(const float4 *)(bias + col);
+#pragma unroll
+    for (int i = 0; i < MT; i++) {
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) ep[((r & 3) + 8 * (r >> 2) + 4 * hi) * EP_LD + j * 32 + li] = acc[i][j][r];
 #pragma unroll 4
-    for (int k = 0; k < 16; k++) {
-        const uint32_t rl = rl0 + 4 * k, row = m0 + wm + rl;
-        float4 v = *(const float4 *)(ep + rl * EP_LD + c4);
-        if (row >= M_real) continue;
-        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-        const uint32_t o = row * N + col;                            // < 2^32 elements (checked on host)
-        if (EPI == EPI_F32) {
-            *(float4 *)((float *)Cout + o) = v;
-        } else if (EPI == EPI_BIAS_RESID_F32) {
-            float4 *dst = (float4 *)((float *)Cout + o);
-            float4 x = *dst;
-            *dst = make_float4(x.x + v.x, x.y + v.y, x.z + v.z, x.w + v.w);
-        } else {
-            if (EPI == EPI_BIAS_GELU_BF16) {
-                // quick_gelu: x * sigmoid(1.702 x) = x / (1 + exp2(-1.702 log2(e) x))
-                v.x *= __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930156f * v.x));
-                v.y *= __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930156f * v.y));
-                v.z *= __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930156f * v.z));
-                v.w *= __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930156f * v.w));
+        for (int k = 0; k < 8; k++) {
+            const uint32_t rl = rl0 + 4 * k, row = m0 + wm + i * 32 + rl;
+            float4 v = *(const float4 *)(ep + rl * EP_LD + c4);
+            if (row >= M_real) continue;
+            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+            const uint32_t o = row * N + col;                        // < 2^32 elements (checked on host)
+            if (EPI == EPI_F32) {
+                *(float4 *)((float *)Cout + o) = v;
+            } else if (EPI == EPI_BIAS_RESID_F32) {
+                float4 *dst = (float4 *)((float *)Cout + o);
+                float4 x = *dst;
+                *dst = make_float4(x.x + v.x, x.y + v.y, x.z + v.z, x.w + v.w);
+            } else {
+                if (EPI == EPI_BIAS_GELU_BF16) {
+                    // quick_gelu: x * sigmoid(1.702 x) = x / (1 + exp2(-1.702 log2(e) x))
+                    v.x *= __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930156f * v.x));
+                    v.y *= __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930156f * v.y));
+                    v.z *= __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930156f * v.z));
+                    v.w *= __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930156f * v.w));
+                }
+                uint2 pk;
+                pk.x = pack2(v.x, v.y);
+                pk.y = pack2(v.z, v.w);
+                *(uint2 *)((uint16_t *)Cout + o) = pk;
             }
-            uint2 pk;
-            pk.x = pack2(v.x, v.y);
-            pk.y = pack2(v.z, v.w);
-            *(uint2 *)((uint16_t *)Cout + o) = pk;
         }
     }
 }
@@ -799,23 +807,35 @@ int d2r_launch_preprocess(d2r_ctx *ctx, d2r_clip *clip, const uint8_t *frames_de
     return D2R_OK;
 }
 
+template <int EPI, int WGM, int WGN, int MT, int STAGES>
+static int launch_gemm_cfg(d2r_ctx *ctx, const uint16_t *A, const uint16_t *W, const float *bias, void *C,
+                           uint32_t M_real, uint32_t N, uint32_t K)
+{
+    constexpr uint32_t TBM = WGM * MT * 32, TBN = WGN * 64, LDS = STAGES * (TBM + TBN) * BK * 2;
+    const uint32_t M_pad = round_up(M_real, BM);
+    const uint32_t nwg = (M_pad / TBM) * (N / TBN);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)k_gemm<EPI, WGM, WGN, MT, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_gemm<EPI, WGM, WGN, MT, STAGES>), dim3(nwg), dim3(GEMM_THREADS), LDS, ctx->stream, A, W, bias, C,
+                       M_pad, N, K, M_real);
+    D2R_HIP(ctx, hipGetLastError());
+    return D2R_OK;
+}
+
 template <int EPI>
 static int launch_gemm(d2r_ctx *ctx, const uint16_t *A, const uint16_t *W, const float *bias, void *C,
                        uint32_t M_real, uint32_t N, uint32_t K)
 {
-    const uint32_t M_pad = round_up(M_real, BM);
-    if (N % BN || K % BK) return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "GEMM N must be a multiple of 128 and K of 64");
-    if ((uint64_t)M_pad * N >= (1ull << 32)) return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "GEMM output too large for 32-bit indexing");
-    const uint32_t nwg = (M_pad / BM) * (N / BN);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)k_gemm<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(k_gemm<EPI>, dim3(nwg), dim3(GEMM_THREADS), GEMM_LDS_BYTES, ctx->stream, A, W, bias, C, M_pad, N, K,
-                       M_real);
-    D2R_HIP(ctx, hipGetLastError());
-    return D2R_OK;
+    if (N % 128 || K % BK) return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "GEMM N must be a multiple of 128 and K of 64");
+    if ((uint64_t)round_up(M_real, BM) * N >= (1ull << 32))
+        return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "GEMM output too large for 32-bit indexing");
+    // wide outputs: 256x256 tiles (more flops per byte staged); narrow ones keep 256x128 so the tile
+    // count still covers the 256 CUs a few times
+    if (N % 256 == 0 && N >= 2048) return launch_gemm_cfg<EPI, 2, 4, 4, 2>(ctx, A, W, bias, C, M_real, N, K);
+    return launch_gemm_cfg<EPI, 4, 2, 2, 3>(ctx, A, W, bias, C, M_real, N, K);
 }
 
 // patches (bf16 [n*(T-1) padded to 128][Kp_pad]) -> logits/embeds.  Workspaces:
