@@ -64,7 +64,7 @@ def main():
     ap.add_argument("--poses-per-gpu", type=int, default=4096)
     ap.add_argument("--clip", default="vit_b16")
     ap.add_argument("--scene", default="shopping")
-    ap.add_argument("--chunk", type=int, default=128)
+    ap.add_argument("--chunk", type=int, default=512)
     ap.add_argument("--opt", action="append", default=[], help="library tunable key=value (repeatable)")
     ap.add_argument("--cpu-sample", type=int, default=6, help="candidates in the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
@@ -81,6 +81,7 @@ def main():
 
     rank, world, local = d2r_dist.init_from_env()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    local = local % torch.cuda.device_count()      # several ranks may share a GPU in smoke runs (gloo)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -153,7 +154,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device=dev if torch.distributed.get_backend() == "nccl" else "cpu")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     timing = ctx.timing()

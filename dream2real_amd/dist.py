@@ -32,9 +32,10 @@ def init_from_env(backend: str | None = None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"    # "nccl" is RCCL on ROCm
+            backend = os.environ.get("D2R_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+            # "nccl" is RCCL on ROCm; gloo is for CPU tests and for several ranks sharing one GPU
         if backend == "nccl":
-            torch.cuda.set_device(local)
+            torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
@@ -49,6 +50,8 @@ def allgather_logits(local_logits, n_total: int, rank: int, world: int):
         return local_logits
     C = local_logits.shape[1]
     n_max = -(-n_total // world)
+    if dist.get_backend() == "gloo" and local_logits.is_cuda:
+        local_logits = local_logits.cpu()          # gloo moves host memory
     pad = torch.zeros((n_max, C), dtype=local_logits.dtype, device=local_logits.device)
     pad[: local_logits.shape[0]] = local_logits
     out = torch.empty((world * n_max, C), dtype=local_logits.dtype, device=local_logits.device)

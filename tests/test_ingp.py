@@ -1,0 +1,43 @@
+"""Snapshot reader round trip on a synthetic .ingp written in the believed instant-ngp layout
+(no real snapshot is available offline — DESIGN.md section 1)."""
+import numpy as np
+import pytest
+
+from dream2real_amd import ingp
+from dream2real_amd.scene import make_scene
+
+
+def test_roundtrip(tmp_path):
+    scene = make_scene("pool_triangle")
+    views = [dict(fx=900.0, fy=910.0, cx=640.0, cy=350.0, w=1280, h=720), dict(fx=450.0, fy=455.0, cx=320.0, cy=175.0, w=640, h=360)]
+    path = str(tmp_path / "fg_base.ingp")
+    ingp.save_ingp(path, scene.fg, training_views=views, dataset_scale=1.0, dataset_offset=(0.0, 0.3, 0.5))
+    model, info = ingp.load_ingp(path)
+    for name in ("grid", "dw1", "dw2", "cw1", "cw2", "cw3", "occ_bits"):
+        np.testing.assert_array_equal(getattr(model, name), getattr(scene.fg, name))
+    np.testing.assert_array_equal(model.levels.offset, scene.fg.levels.offset)
+    assert info["dataset_offset"] == (0.0, 0.3, 0.5) and info["aabb_scale"] == 1
+    assert len(info["training_views"]) == 2
+    assert abs(info["training_views"][1]["cx"] - 320.0) < 1e-9 and info["training_views"][0]["w"] == 1280
+
+
+def test_morton_order_is_a_permutation():
+    m = ingp._morton_order()
+    assert m[0] == 0 and m[1] == 1 and m[2] == 128 and m[4] == 128 * 128 and m[7] == 1 + 128 + 128 * 128
+    assert np.array_equal(np.sort(m), np.arange(128 ** 3))
+
+
+def test_rejects_unknown_layouts(tmp_path):
+    import msgpack, zlib
+    scene = make_scene("pool_triangle")
+    path = str(tmp_path / "x.ingp")
+    ingp.save_ingp(path, scene.fg)
+    cfg = msgpack.unpackb(zlib.decompress(open(path, "rb").read()), raw=False)
+    cfg["snapshot"]["params_binary"] = cfg["snapshot"]["params_binary"][:-2]
+    open(path, "wb").write(zlib.compress(msgpack.packb(cfg, use_bin_type=True)))
+    with pytest.raises(ValueError):
+        ingp.load_ingp(path)
+    cfg["snapshot"]["nerf"]["aabb_scale"] = 2
+    open(path, "wb").write(zlib.compress(msgpack.packb(cfg, use_bin_type=True)))
+    with pytest.raises(NotImplementedError):
+        ingp.load_ingp(path)

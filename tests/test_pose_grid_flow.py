@@ -1,0 +1,159 @@
+"""Control flow of optimise_pose_grid (reference clip_scoring.py:71-234) with a fake renderer and
+scorer: validity scatter, score ratio, smoothing, argmax/best pose, best_render.png, cached
+renders, physics-only and template branches.  CPU only."""
+import os
+import types
+
+import numpy as np
+import pytest
+
+from dream2real_amd import clip_scoring
+from oracle import host_ref
+
+
+class FakeRenderer:
+    """renderer.render surface: K frames whose mean encodes the pose translation."""
+
+    def __init__(self, h=12, w=20):
+        self.h, self.w, self.calls = h, w, []
+
+    def render(self, valid_poses, render_poses, render_cam_pose_idx, depths_gt=None, movable_masks=None, save=True):
+        self.calls.append((np.array(valid_poses), np.array(render_poses), list(render_cam_pose_idx), save))
+        out = []
+        for T in np.asarray(valid_poses):
+            f = np.zeros((self.h, self.w, 3), np.uint8)
+            f[..., 0] = int(np.clip((T[0, 3] + 1) * 60, 0, 255))
+            f[..., 1] = int(np.clip((T[1, 3] + 1) * 60, 0, 255))
+            f[: self.h // 2, :, 2] = 200
+            out.append(f)
+        return out
+
+
+class FakeScorer:
+    def __init__(self):
+        self.seen = None
+
+    def score_frames(self, frames, text_embeds, rot90=True):
+        self.seen = (np.array(frames), np.array(text_embeds), rot90)
+        f = np.asarray(frames, np.float32)
+        g = 20 + f[..., 0].mean(axis=(1, 2)) / 10 + f[..., 1].mean(axis=(1, 2)) / 20
+        cols = [g] + [np.full_like(g, 18.0 + 0.1 * c) for c in range(text_embeds.shape[0] - 1)]
+        return np.stack(cols, 1).astype(np.float32)
+
+
+def _task(tmp, norm=("n",)):
+    import torch
+    sm = types.SimpleNamespace(scene_centre=torch.tensor([0.5, 0.0, 0.035]),
+                               opt_cam_poses=[torch.eye(4), torch.eye(4) * 2])
+    return types.SimpleNamespace(scene_model=sm, goal_caption="g", norm_captions=list(norm) if norm else None,
+                                 movable_masks=None, movable_obj=types.SimpleNamespace(pose=torch.eye(4)))
+
+
+def _valid(mask):
+    def check(pose_batch, task_model, valid_so_far):
+        import torch
+        v = valid_so_far.clone()
+        v[~torch.from_numpy(mask)] = False
+        return v
+    return check
+
+
+def test_scores_scatter_smoothing_argmax(tmp_path):
+    res = [6, 5, 2, 1, 1, 1]
+    N = 60
+    mask = np.ones(N, bool)
+    mask[[0, 7, 33]] = False
+    task = _task(tmp_path)
+    rend, sc = FakeRenderer(), FakeScorer()
+    text = np.eye(2, 8, dtype=np.float32)
+    best, poses, scores = clip_scoring.optimise_pose_grid(rend, None, [1], task, str(tmp_path), sample_res=res,
+                                                          phys_check=_valid(mask), scene_type=3, scorer=sc,
+                                                          text_embeds=text)
+    poses, scores = poses.numpy(), scores.numpy()
+    np.testing.assert_array_equal(poses, host_ref.sample_poses_grid([0.5, 0.0, 0.035], res, 3))
+    # the renderer saw exactly the valid poses, y/z-flipped (converter), and the chosen view
+    vp, rp, idx, save = rend.calls[0]
+    np.testing.assert_array_equal(vp, host_ref.converter(poses[mask].reshape(-1, 4, 4)))
+    np.testing.assert_array_equal(rp, host_ref.converter(np.eye(4)[None] * 2))
+    assert idx == [1] and sc.seen[2] is True
+    # expected scores through the oracle restatements
+    lg = sc.score_frames(rend.render(vp, rp, idx), text)
+    want = np.zeros(N, np.float32)
+    want[mask] = host_ref.score_logits(lg, True)
+    want = host_ref.spatially_smooth_heatmap(want, res)
+    np.testing.assert_allclose(scores, want, rtol=0, atol=1e-6)
+    assert (scores[~mask] == 0).all()
+    bi = int(np.argmax(want))
+    np.testing.assert_array_equal(best.numpy().reshape(16), poses[bi])
+    assert os.path.exists(tmp_path / "best_render.png")
+    from PIL import Image
+    im = np.asarray(Image.open(tmp_path / "best_render.png"))
+    assert im.shape == (20, 12, 3)                                   # rot90 of a 12x20 frame
+
+
+def test_no_norm_caption_and_no_smoothing(tmp_path):
+    task = _task(tmp_path, norm=None)
+    rend, sc = FakeRenderer(), FakeScorer()
+    best, poses, scores = clip_scoring.optimise_pose_grid(rend, None, [0], task, str(tmp_path), sample_res=[3, 3, 1, 1, 1, 1],
+                                                          phys_check=lambda p, t, v: v, scene_type=0, smoothing=False,
+                                                          scorer=sc, text_embeds=np.ones((1, 4), np.float32))
+    lg = sc.score_frames(rend.render(*rend.calls[0][:3]), np.ones((1, 4), np.float32))
+    np.testing.assert_allclose(scores.numpy(), lg[:, 0], rtol=0, atol=1e-6)
+
+
+def test_cached_renders_roundtrip(tmp_path):
+    """use_cache_renders (clip_scoring.py:89-104): validity from pose_scores.txt, frames from cb_render/."""
+    from PIL import Image
+    res = [4, 3, 1, 1, 1, 1]
+    mask = np.ones(12, bool)
+    mask[[2, 9]] = False
+    task = _task(tmp_path)
+    rend, sc = FakeRenderer(), FakeScorer()
+    text = np.eye(2, 8, dtype=np.float32)
+    _, poses, scores = clip_scoring.optimise_pose_grid(rend, None, [0], task, str(tmp_path), sample_res=res,
+                                                       phys_check=_valid(mask), scene_type=3, scorer=sc, text_embeds=text)
+    np.savetxt(tmp_path / "pose_scores.txt", scores.numpy())           # what dream2real.py:358 writes
+    os.makedirs(tmp_path / "cb_render")
+    for i, f in enumerate(rend.render(*rend.calls[0][:3])):
+        Image.fromarray(f).save(tmp_path / "cb_render" / f"cb_rgb_{i:04d}.png")
+    rend2 = FakeRenderer()
+    _, _, scores2 = clip_scoring.optimise_pose_grid(rend2, None, [0], task, str(tmp_path), sample_res=res,
+                                                    phys_check=None, scene_type=3, use_cache_renders=True, scorer=sc,
+                                                    text_embeds=text)
+    assert not rend2.calls
+    np.testing.assert_allclose(scores2.numpy(), scores.numpy(), rtol=0, atol=1e-6)
+    os.remove(tmp_path / "cb_render" / "cb_rgb_0000.png")
+    with pytest.raises(AssertionError):
+        clip_scoring.optimise_pose_grid(rend2, None, [0], task, str(tmp_path), sample_res=res, scene_type=3,
+                                        use_cache_renders=True, scorer=sc, text_embeds=text)
+
+
+def test_physics_only_templates_and_errors(tmp_path):
+    task = _task(tmp_path)
+    rend, sc = FakeRenderer(), FakeScorer()
+    res = [3, 2, 1, 1, 1, 1]
+    best, poses, scores = clip_scoring.optimise_pose_grid(rend, None, [0], task, str(tmp_path), sample_res=res,
+                                                          phys_check=lambda p, t, v: v, scene_type=3,
+                                                          physics_only=True, scorer=sc)
+    assert not rend.calls and (scores.numpy() == 1).all() and tuple(best.shape) == (4, 4)
+    # templates: 9 goal + 9 normalising captions -> 18 text embeddings
+    text = np.eye(18, 32, dtype=np.float32)
+    _, _, s2 = clip_scoring.optimise_pose_grid(rend, None, [0], task, str(tmp_path), sample_res=res,
+                                               phys_check=lambda p, t, v: v, scene_type=3, use_templates=True,
+                                               smoothing=False, scorer=sc, text_embeds=text)
+    lg = sc.score_frames(rend.render(*rend.calls[-1][:3]), text)
+    np.testing.assert_allclose(s2.numpy(), host_ref.score_logits_templates(lg, 9, True), rtol=1e-6)
+    with pytest.raises(AssertionError):          # wrong number of text embeddings
+        clip_scoring.optimise_pose_grid(rend, None, [0], task, str(tmp_path), sample_res=res,
+                                        phys_check=lambda p, t, v: v, scene_type=3, scorer=sc,
+                                        text_embeds=np.eye(3, 8, dtype=np.float32))
+    with pytest.raises(Exception):               # no pose survives the pre-render checks
+        clip_scoring.optimise_pose_grid(rend, None, [0], task, str(tmp_path), sample_res=res,
+                                        phys_check=lambda p, t, v: v & False, scene_type=3, scorer=sc, text_embeds=text)
+    with pytest.raises(ValueError):
+        clip_scoring.optimise_pose_grid(rend, None, [0], task, str(tmp_path), sample_res=res,
+                                        phys_check=lambda p, t, v: v, scene_type=3, text_embeds=text)
+    with pytest.raises(NotImplementedError):
+        clip_scoring.optimise_pose_grid(rend, None, [0], task, str(tmp_path), sample_res=res,
+                                        phys_check=lambda p, t, v: v, scene_type=3, use_vis_pcds=True, scorer=sc,
+                                        text_embeds=text)
