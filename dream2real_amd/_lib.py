@@ -15,7 +15,7 @@ EXPORTS = [
     "d2r_last_error", "d2r_nerf_create", "d2r_nerf_destroy", "d2r_render", "d2r_nerf_eval_points",
     "d2r_set_background", "d2r_render_composite", "d2r_clip_create", "d2r_clip_destroy",
     "d2r_clip_score_frames", "d2r_clip_preprocess", "d2r_clip_embed_pixels", "d2r_render_score",
-    "d2r_get_render_stats", "d2r_collect_render_stats", "d2r_ctx_set_option", "d2r_get_timing",
+    "d2r_get_render_stats", "d2r_collect_render_stats", "d2r_ctx_set_option", "d2r_get_timing", "d2r_text_create", "d2r_text_destroy", "d2r_text_encode",
 ]
 
 
@@ -40,6 +40,12 @@ class ViewC(C.Structure):
 
 class ClipDesc(C.Structure):
     _fields_ = [("image_size", C.c_uint32), ("patch_size", C.c_uint32), ("hidden_size", C.c_uint32),
+                ("num_layers", C.c_uint32), ("num_heads", C.c_uint32), ("mlp_size", C.c_uint32),
+                ("proj_dim", C.c_uint32)]
+
+
+class TextDesc(C.Structure):
+    _fields_ = [("vocab_size", C.c_uint32), ("context_length", C.c_uint32), ("hidden_size", C.c_uint32),
                 ("num_layers", C.c_uint32), ("num_heads", C.c_uint32), ("mlp_size", C.c_uint32),
                 ("proj_dim", C.c_uint32)]
 
@@ -80,6 +86,7 @@ def load() -> C.CDLL:
     lib.d2r_ctx_destroy.restype = None
     lib.d2r_nerf_destroy.restype = None
     lib.d2r_clip_destroy.restype = None
+    lib.d2r_text_destroy.restype = None
     for name in EXPORTS:
         getattr(lib, name)          # every declared symbol must be exported
     if lib.d2r_abi_version() != 1:

@@ -36,7 +36,7 @@ CLIP_CONFIGS = {
                            vocab=49408, ctx=77),
     # 2-layer model with the same code paths, for unit tests and committed goldens
     "vit_tiny": dict(patch_size=16, hidden_size=128, num_layers=2, num_heads=2, mlp=256, image_size=64,
-                     proj=64, text_hidden=64, text_layers=2, text_heads=1, text_mlp=128,
+                     proj=64, text_hidden=128, text_layers=2, text_heads=2, text_mlp=256,
                      vocab=512, ctx=16),
 }
 
@@ -119,3 +119,26 @@ def pack_vision_weights(sd: dict, cfg) -> np.ndarray:
         a = np.asarray(sd[name], np.float32).reshape(shape)
         parts.append(a.reshape(-1))
     return np.ascontiguousarray(np.concatenate(parts))
+
+
+def text_blob_order(cfg):
+    """(name, shape) of every tensor in the `d2r_text_create` weight blob, in order."""
+    d, mlp = cfg["text_hidden"], cfg["text_mlp"]
+    out = [("text_model.embeddings.token_embedding.weight", (cfg["vocab"], d)),
+           ("text_model.embeddings.position_embedding.weight", (cfg["ctx"], d))]
+    for l in range(cfg["text_layers"]):
+        p = f"text_model.encoder.layers.{l}"
+        out += [(p + ".layer_norm1.weight", (d,)), (p + ".layer_norm1.bias", (d,))]
+        for nm in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            out += [(f"{p}.self_attn.{nm}.weight", (d, d)), (f"{p}.self_attn.{nm}.bias", (d,))]
+        out += [(p + ".layer_norm2.weight", (d,)), (p + ".layer_norm2.bias", (d,)),
+                (p + ".mlp.fc1.weight", (mlp, d)), (p + ".mlp.fc1.bias", (mlp,)),
+                (p + ".mlp.fc2.weight", (d, mlp)), (p + ".mlp.fc2.bias", (d,))]
+    out += [("text_model.final_layer_norm.weight", (d,)), ("text_model.final_layer_norm.bias", (d,)),
+            ("text_projection.weight", (cfg["proj"], d))]
+    return out
+
+
+def pack_text_weights(sd: dict, cfg) -> np.ndarray:
+    return np.ascontiguousarray(np.concatenate(
+        [np.asarray(sd[n], np.float32).reshape(shape).reshape(-1) for n, shape in text_blob_order(cfg)]))

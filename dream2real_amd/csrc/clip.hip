@@ -480,6 +480,7 @@ __global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ X, 
 
 // QKV [rows][3d] bf16 (q | k | v, head h at columns h*64), out AO [rows][d] bf16.
 // grid (heads, images); block 256; dynamic LDS: K [T_pad][64] swizzled + Vt [64][T_pad+4].
+template <bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void k_attention(const uint16_t *__restrict__ QKV, uint16_t *__restrict__ AO,
                                                       uint32_t T, uint32_t T_pad, uint32_t d)
 {
@@ -523,7 +524,9 @@ __global__ __launch_bounds__(256, 2) void k_attention(const uint16_t *__restrict
 #pragma unroll
         for (int r = 0; r < 16; r++) o0[r] = o1[r] = 0.f;
         float m_run = -INFINITY, l_run = 0.f;
-        for (uint32_t kt = 0; kt < n_kt; kt++) {
+        // causal: key tiles beyond the last query row of this tile are fully masked
+        const uint32_t kt_end = CAUSAL ? min(n_kt, qt + 1) : n_kt;
+        for (uint32_t kt = 0; kt < kt_end; kt++) {
             f32x16 sacc;
 #pragma unroll
             for (int r = 0; r < 16; r++) sacc[r] = 0.f;
@@ -539,7 +542,8 @@ __global__ __launch_bounds__(256, 2) void k_attention(const uint16_t *__restrict
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 uint32_t key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                float sv = key < T ? sacc[r] * scale : -INFINITY;
+                // text tower: causal mask, key position <= query position
+                float sv = (key < T && (!CAUSAL || key <= qrow)) ? sacc[r] * scale : -INFINITY;
                 sacc[r] = sv;
                 tmax = fmaxf(tmax, sv);
             }
@@ -605,7 +609,8 @@ __global__ __launch_bounds__(256, 2) void k_attention(const uint16_t *__restrict
 // 16 waves and 4 output rows per wave iteration keep ~48 loads per lane in flight: the
 // projection is a latency problem (1.5 MB of fp32 weights per image out of L2), not a flop one.
 #define HEAD_THREADS 1024
-__global__ __launch_bounds__(HEAD_THREADS) void k_head(const float *__restrict__ X, uint32_t T, uint32_t d,
+__global__ __launch_bounds__(HEAD_THREADS) void k_head(const float *__restrict__ X, const uint32_t *__restrict__ pool_row,
+                                                       uint32_t T, uint32_t d,
                                                        const float *__restrict__ lw, const float *__restrict__ lb,
                                                        const float *__restrict__ proj, uint32_t D,
                                                        const float *__restrict__ text, uint32_t C, float logit_scale,
@@ -616,7 +621,8 @@ __global__ __launch_bounds__(HEAD_THREADS) void k_head(const float *__restrict__
     __shared__ float red[16];
     constexpr uint32_t NW = HEAD_THREADS / 64;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float *x = X + (size_t)blockIdx.x * T * d;
+    // vision: the class token (row 0 of the image); text: the EOS token's row
+    const float *x = X + ((size_t)blockIdx.x * T + (pool_row ? pool_row[blockIdx.x] : 0u)) * d;
     const float xv = tid < d ? x[tid] : 0.f;                         // d <= 1024
     float s = wave_sum(xv);
     if (lane == 0) red[wave] = s;
@@ -675,6 +681,28 @@ __global__ __launch_bounds__(HEAD_THREADS) void k_head(const float *__restrict__
         for (uint32_t i = lane; i < D; i += 64) a = fmaf(es[i], text[(size_t)c * D + i], a);
         a = wave_sum(a);
         if (lane == 0 && logits) logits[(size_t)blockIdx.x * C + c] = logit_scale * a;
+    }
+}
+
+// X[c*T + t] = token_embedding[ids[c][t]] + position_embedding[t]; pool_row[c] = argmax_t ids[c][t]
+// (EOS has the largest id: HF 4.27 pools at argmax, 5.x at the first EOS — identical here)
+__global__ void k_text_embed(const int32_t *__restrict__ ids, const float *__restrict__ tok, const float *__restrict__ pos,
+                             float *__restrict__ X, uint32_t *__restrict__ pool_row, uint32_t Cn, uint32_t T, uint32_t d,
+                             uint32_t vocab)
+{
+    const uint32_t row = blockIdx.x, c = row / T, t = row % T;
+    int32_t id = ids[row];
+    id = id < 0 ? 0 : (id >= (int32_t)vocab ? (int32_t)vocab - 1 : id);
+    for (uint32_t i = threadIdx.x; i < d; i += blockDim.x)
+        X[(size_t)row * d + i] = tok[(size_t)id * d + i] + pos[(size_t)t * d + i];
+    if (t == 0 && threadIdx.x == 0) {
+        int32_t best = ids[(size_t)c * T];
+        uint32_t bi = 0;
+        for (uint32_t k = 1; k < T; k++) {
+            int32_t v = ids[(size_t)c * T + k];
+            if (v > best) { best = v; bi = k; }
+        }
+        pool_row[c] = bi;
     }
 }
 
@@ -866,7 +894,8 @@ int d2r_clip_forward(d2r_ctx *ctx, const d2r_clip *clip, const uint16_t *patches
     const size_t attn_lds = (size_t)T_pad * 128 + (size_t)64 * (T_pad + 4) * 2;
     static bool attn_attr = false;
     if (!attn_attr) {
-        hipFuncSetAttribute((const void *)k_attention, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_attention<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_attention<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attn_attr = true;
     }
     if (attn_lds > 160 * 1024) return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "sequence too long for the attention LDS layout");
@@ -875,14 +904,14 @@ int d2r_clip_forward(d2r_ctx *ctx, const d2r_clip *clip, const uint16_t *patches
         hipLaunchKernelGGL(k_layernorm, dim3((rows + 3) / 4), dim3(256), 0, ctx->stream, X, L.ln1_w, L.ln1_b, Xn,
                            rows, d);
         if ((rc = launch_gemm<EPI_BIAS_BF16>(ctx, Xn, L.w_qkv, L.b_qkv, QKV, rows, 3 * d, d))) return rc;
-        hipLaunchKernelGGL(k_attention, dim3(D.num_heads, n), dim3(256), attn_lds, ctx->stream, QKV, AO, T, T_pad, d);
+        hipLaunchKernelGGL(k_attention<false>, dim3(D.num_heads, n), dim3(256), attn_lds, ctx->stream, QKV, AO, T, T_pad, d);
         if ((rc = launch_gemm<EPI_BIAS_RESID_F32>(ctx, AO, L.w_o, L.b_o, X, rows, d, d))) return rc;
         hipLaunchKernelGGL(k_layernorm, dim3((rows + 3) / 4), dim3(256), 0, ctx->stream, X, L.ln2_w, L.ln2_b, Xn,
                            rows, d);
         if ((rc = launch_gemm<EPI_BIAS_GELU_BF16>(ctx, Xn, L.w_fc1, L.b_fc1, H, rows, mlp, d))) return rc;
         if ((rc = launch_gemm<EPI_BIAS_RESID_F32>(ctx, H, L.w_fc2, L.b_fc2, X, rows, d, mlp))) return rc;
     }
-    hipLaunchKernelGGL(k_head, dim3(n), dim3(HEAD_THREADS), 0, ctx->stream, X, T, d, clip->w.post_w, clip->w.post_b,
+    hipLaunchKernelGGL(k_head, dim3(n), dim3(HEAD_THREADS), 0, ctx->stream, X, (const uint32_t *)nullptr, T, d, clip->w.post_w, clip->w.post_b,
                        clip->w.proj, D.proj_dim, text_dev, C, logit_scale, logits_dev, embeds_dev);
     D2R_HIP(ctx, hipGetLastError());
     return D2R_OK;
@@ -998,6 +1027,142 @@ extern "C" void d2r_clip_destroy(d2r_clip *c)
     if (!c) return;
     for (void *p : c->allocs) hipFree(p);
     delete c;
+}
+
+// ---------------------------------------------------------------- text tower
+
+struct d2r_text {
+    d2r_ctx *ctx;
+    d2r_text_desc desc;
+    std::vector<void *> allocs;
+    const float *tok, *pos, *fin_w, *fin_b, *proj;
+    std::vector<ClipWeights::Layer> layers;
+};
+
+extern "C" int d2r_text_create(d2r_ctx *ctx, const d2r_text_desc *desc, const float *weights, size_t n_floats,
+                               d2r_text **out)
+{
+    if (!ctx || !desc || !weights || !out) return d2r_fail(ctx, D2R_ERR_INVALID, "null argument");
+    const uint32_t d = desc->hidden_size, mlp = desc->mlp_size, V = desc->vocab_size, Tc = desc->context_length;
+    if (d % 128 || mlp % 128 || d > 1024 || desc->proj_dim > 1024 || d / desc->num_heads != 64 || Tc == 0 || Tc > 512)
+        return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "unsupported text tower geometry (need head_dim 64, d,mlp % 128 == 0)");
+    (void)hipSetDevice(ctx->device);
+    size_t expect = (size_t)V * d + (size_t)Tc * d +
+                    (size_t)desc->num_layers * (4 * (size_t)d + 4 * ((size_t)d * d + d) + (size_t)mlp * d + mlp + (size_t)d * mlp + d) +
+                    2 * d + (size_t)desc->proj_dim * d;
+    if (n_floats != expect) return d2r_fail(ctx, D2R_ERR_INVALID, "text weight blob size does not match the descriptor");
+    d2r_text *t = new d2r_text();
+    t->ctx = ctx;
+    t->desc = *desc;
+    float *blob = nullptr;
+    if (hipMalloc(&blob, n_floats * 4) != hipSuccess) { delete t; return d2r_fail(ctx, D2R_ERR_MEMORY, "hipMalloc failed for text weights"); }
+    t->allocs.push_back(blob);
+    if (hipMemcpy(blob, weights, n_floats * 4, hipMemcpyHostToDevice) != hipSuccess) { d2r_text_destroy(t); return d2r_fail(ctx, D2R_ERR_DEVICE, "weight upload failed"); }
+    size_t off = 0;
+    auto f32 = [&](size_t n) { const float *p = blob + off; off += n; return p; };
+    bool ok = true;
+    auto bf16 = [&](const float *src, uint32_t rows, uint32_t K) -> uint16_t * {
+        uint16_t *p = nullptr;
+        if (hipMalloc(&p, (size_t)rows * K * 2) != hipSuccess) { ok = false; return nullptr; }
+        t->allocs.push_back(p);
+        size_t tot = (size_t)rows * K;
+        hipLaunchKernelGGL(k_convert_bf16, dim3((uint32_t)((tot + 255) / 256)), dim3(256), 0, ctx->stream, src, p, rows, K, K);
+        return p;
+    };
+    t->tok = f32((size_t)V * d);
+    t->pos = f32((size_t)Tc * d);
+    t->layers.resize(desc->num_layers);
+    for (uint32_t l = 0; l < desc->num_layers && ok; l++) {
+        ClipWeights::Layer &L = t->layers[l];
+        L.ln1_w = f32(d);
+        L.ln1_b = f32(d);
+        uint16_t *wqkv = nullptr;
+        float *bqkv = nullptr;
+        if (hipMalloc(&wqkv, (size_t)3 * d * d * 2) != hipSuccess || hipMalloc(&bqkv, (size_t)3 * d * 4) != hipSuccess) { ok = false; break; }
+        t->allocs.push_back(wqkv);
+        t->allocs.push_back(bqkv);
+        for (int j = 0; j < 3; j++) {
+            const float *wj = f32((size_t)d * d), *bj = f32(d);
+            size_t tot = (size_t)d * d;
+            hipLaunchKernelGGL(k_convert_bf16, dim3((uint32_t)((tot + 255) / 256)), dim3(256), 0, ctx->stream, wj,
+                               wqkv + (size_t)j * d * d, d, d, d);
+            (void)hipMemcpyAsync(bqkv + (size_t)j * d, bj, (size_t)d * 4, hipMemcpyDeviceToDevice, ctx->stream);
+        }
+        L.w_qkv = wqkv;
+        L.b_qkv = bqkv;
+        L.w_o = bf16(f32((size_t)d * d), d, d);
+        L.b_o = f32(d);
+        L.ln2_w = f32(d);
+        L.ln2_b = f32(d);
+        L.w_fc1 = bf16(f32((size_t)mlp * d), mlp, d);
+        L.b_fc1 = f32(mlp);
+        L.w_fc2 = bf16(f32((size_t)d * mlp), d, mlp);
+        L.b_fc2 = f32(d);
+    }
+    t->fin_w = f32(d);
+    t->fin_b = f32(d);
+    t->proj = f32((size_t)desc->proj_dim * d);
+    if (!ok || hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess) {
+        d2r_text_destroy(t);
+        return d2r_fail(ctx, D2R_ERR_DEVICE, "text weight conversion failed");
+    }
+    *out = t;
+    return D2R_OK;
+}
+
+extern "C" void d2r_text_destroy(d2r_text *t)
+{
+    if (!t) return;
+    for (void *p : t->allocs) (void)hipFree(p);
+    delete t;
+}
+
+// CLIPModel text forward (causal pre-LN transformer, EOS pooling, text_projection, L2 norm):
+// replaces the text half of reference clip_scoring.py:177-180, run ONCE per task instead of per batch.
+extern "C" int d2r_text_encode(d2r_ctx *ctx, const d2r_text *tt, const int32_t *input_ids, uint32_t Cn, uint32_t T,
+                               float *embeds_out)
+{
+    if (!ctx || !tt || !input_ids || !embeds_out) return d2r_fail(ctx, D2R_ERR_INVALID, "null argument");
+    const d2r_text_desc &D = tt->desc;
+    if (Cn == 0 || T == 0 || T > D.context_length) return d2r_fail(ctx, D2R_ERR_INVALID, "bad caption batch shape");
+    (void)hipSetDevice(ctx->device);
+    const uint32_t d = D.hidden_size, mlp = D.mlp_size, rows = Cn * T, rows_pad = round_up(rows, BM);
+    int rc;
+    if ((rc = d2r_reserve(ctx, ctx->clipws[1], (size_t)rows_pad * d * 4))) return rc;
+    if ((rc = d2r_reserve(ctx, ctx->clipws[2], (size_t)rows_pad * d * 2))) return rc;
+    if ((rc = d2r_reserve(ctx, ctx->clipws[3], (size_t)rows_pad * 3 * d * 2))) return rc;
+    if ((rc = d2r_reserve(ctx, ctx->clipws[4], (size_t)rows_pad * d * 2))) return rc;
+    if ((rc = d2r_reserve(ctx, ctx->clipws[5], (size_t)rows_pad * mlp * 2))) return rc;
+    if ((rc = d2r_reserve(ctx, ctx->pix, (size_t)rows * 4 + (size_t)Cn * 4))) return rc;
+    if ((rc = d2r_reserve(ctx, ctx->logits, (size_t)Cn * D.proj_dim * 4))) return rc;
+    if ((rc = d2r_reserve(ctx, ctx->text, 16))) return rc;
+    float *X = (float *)ctx->clipws[1].p;
+    uint16_t *Xn = (uint16_t *)ctx->clipws[2].p, *QKV = (uint16_t *)ctx->clipws[3].p;
+    uint16_t *AO = (uint16_t *)ctx->clipws[4].p, *H = (uint16_t *)ctx->clipws[5].p;
+    int32_t *ids_dev = (int32_t *)ctx->pix.p;
+    uint32_t *pool = (uint32_t *)(ids_dev + rows);
+    D2R_HIP(ctx, hipMemcpyAsync(ids_dev, input_ids, (size_t)rows * 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_text_embed, dim3(rows), dim3(128), 0, ctx->stream, ids_dev, tt->tok, tt->pos, X, pool, Cn, T, d,
+                       D.vocab_size);
+    const uint32_t T_pad = round_up(T, 32);
+    const size_t attn_lds = (size_t)T_pad * 128 + (size_t)64 * (T_pad + 4) * 2;
+    for (uint32_t l = 0; l < D.num_layers; l++) {
+        const ClipWeights::Layer &L = tt->layers[l];
+        hipLaunchKernelGGL(k_layernorm, dim3((rows + 3) / 4), dim3(256), 0, ctx->stream, X, L.ln1_w, L.ln1_b, Xn, rows, d);
+        if ((rc = launch_gemm<EPI_BIAS_BF16>(ctx, Xn, L.w_qkv, L.b_qkv, QKV, rows, 3 * d, d))) return rc;
+        hipLaunchKernelGGL(k_attention<true>, dim3(D.num_heads, Cn), dim3(256), attn_lds, ctx->stream, QKV, AO, T, T_pad, d);
+        if ((rc = launch_gemm<EPI_BIAS_RESID_F32>(ctx, AO, L.w_o, L.b_o, X, rows, d, d))) return rc;
+        hipLaunchKernelGGL(k_layernorm, dim3((rows + 3) / 4), dim3(256), 0, ctx->stream, X, L.ln2_w, L.ln2_b, Xn, rows, d);
+        if ((rc = launch_gemm<EPI_BIAS_GELU_BF16>(ctx, Xn, L.w_fc1, L.b_fc1, H, rows, mlp, d))) return rc;
+        if ((rc = launch_gemm<EPI_BIAS_RESID_F32>(ctx, H, L.w_fc2, L.b_fc2, X, rows, d, mlp))) return rc;
+    }
+    hipLaunchKernelGGL(k_head, dim3(Cn), dim3(HEAD_THREADS), 0, ctx->stream, X, (const uint32_t *)pool, T, d, tt->fin_w,
+                       tt->fin_b, tt->proj, D.proj_dim, (const float *)ctx->text.p, 0u, 1.0f, (float *)nullptr,
+                       (float *)ctx->logits.p);
+    D2R_HIP(ctx, hipGetLastError());
+    D2R_HIP(ctx, hipMemcpyAsync(embeds_out, ctx->logits.p, (size_t)Cn * D.proj_dim * 4, hipMemcpyDeviceToHost, ctx->stream));
+    D2R_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return D2R_OK;
 }
 
 uint32_t d2r_clip_image_size(const d2r_clip *c) { return c->desc.image_size; }

@@ -14,7 +14,7 @@ import dataclasses
 import numpy as np
 
 from . import _lib
-from .clip_model import pack_vision_weights
+from .clip_model import pack_text_weights, pack_vision_weights
 from .scene import NerfModel, View
 
 Shade = "Shade"     # pyngp.Shade
@@ -249,6 +249,39 @@ class ClipScorer:
         emb = np.empty((n, self.cfg["proj"]), np.float32)
         self.ctx.check(self.ctx.lib.d2r_clip_embed_pixels(self.ctx.h, self.h, _lib.ptr(pv), C.c_uint32(n), _lib.ptr(emb)))
         return emb
+
+
+class TextEncoder:
+    """CLIP text tower on the GPU: tokenised captions -> L2-normalised text embeddings, computed
+    once per task and cached by the caller (reference clip_scoring.py:177-180 redoes it per batch)."""
+
+    def __init__(self, ctx: Context, cfg: dict, state_dict: dict):
+        self.ctx, self.cfg = ctx, cfg
+        blob = pack_text_weights(state_dict, cfg)
+        desc = _lib.TextDesc(cfg["vocab"], cfg["ctx"], cfg["text_hidden"], cfg["text_layers"], cfg["text_heads"],
+                             cfg["text_mlp"], cfg["proj"])
+        h = C.c_void_p()
+        ctx.check(ctx.lib.d2r_text_create(ctx.h, C.byref(desc), _lib.ptr(blob), C.c_size_t(blob.size), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.d2r_text_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def encode(self, input_ids) -> np.ndarray:
+        ids = np.ascontiguousarray(input_ids, np.int32)
+        Cn, T = ids.shape
+        out = np.empty((Cn, self.cfg["proj"]), np.float32)
+        self.ctx.check(self.ctx.lib.d2r_text_encode(self.ctx.h, self.h, _lib.ptr(ids), C.c_uint32(Cn), C.c_uint32(T),
+                                                    _lib.ptr(out)))
+        return out
 
 
 def render_score_device(ctx: Context, fg: Testbed, scorer: ClipScorer, view: View, obj_pose_now, cam_pose,

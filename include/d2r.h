@@ -190,6 +190,37 @@ D2R_API int d2r_clip_preprocess(d2r_ctx *ctx, const d2r_clip *clip, const uint8_
 D2R_API int d2r_clip_embed_pixels(d2r_ctx *ctx, const d2r_clip *clip, const float *pixel_values,
                                   uint32_t n, float *embeds_out);
 
+/* ------------------------------------------------------------- text tower */
+
+typedef struct {
+    uint32_t vocab_size;      /* 49408 */
+    uint32_t context_length;  /* 77 */
+    uint32_t hidden_size;     /* 512 / 768 (head dim must be 64) */
+    uint32_t num_layers;      /* 12 */
+    uint32_t num_heads;       /* 8 / 12 */
+    uint32_t mlp_size;        /* 2048 / 3072 */
+    uint32_t proj_dim;        /* D */
+} d2r_text_desc;
+typedef struct d2r_text d2r_text;
+
+/*
+ * replaces the text tower of CLIPModel (reference clip_scoring.py:150,180).  weights: host fp32
+ * blob in this order (Hugging Face names): token_embedding.weight [V][d],
+ * position_embedding.weight [ctx][d], per layer the same 16 tensors as d2r_clip_create,
+ * final_layer_norm.{weight,bias}, text_projection.weight [D][d].
+ */
+D2R_API int d2r_text_create(d2r_ctx *ctx, const d2r_text_desc *desc, const float *weights,
+                            size_t n_floats, d2r_text **out);
+D2R_API void d2r_text_destroy(d2r_text *text);
+/*
+ * input_ids host [C][T] int32 (tokenised captions, EOS = largest id) -> embeds_out host [C][D],
+ * L2-normalised: the cached text embeddings d2r_clip_score_frames / d2r_render_score take.
+ * The reference re-encodes the captions for every image batch (clip_scoring.py:176-180); here the
+ * caller does it once per task.
+ */
+D2R_API int d2r_text_encode(d2r_ctx *ctx, const d2r_text *text, const int32_t *input_ids, uint32_t C,
+                            uint32_t T, float *embeds_out);
+
 /* --------------------------------------------------- the fused hot path */
 
 /*

@@ -231,6 +231,28 @@ def test_vit_golden_image_embeds(gpu, goldens):
     sc.close()
 
 
+@pytest.mark.parametrize("name", ["vit_tiny", "vit_b16"])
+def test_text_tower_matches_oracle_and_hf_golden(gpu, goldens, name):
+    """Causal text transformer + EOS pooling + projection on the GPU vs the numpy oracle and the
+    committed Hugging Face golden (ids include an EOS in mid-sequence followed by padding)."""
+    engine, ctx = gpu["engine"], gpu["ctx"]
+    cfg = CLIP_CONFIGS[name]
+    sd = random_clip_state_dict(cfg, seed=6)
+    enc = engine.TextEncoder(ctx, cfg, sd)
+    ids = goldens[f"g5_{name}_ids"]
+    got = enc.encode(ids)
+    want = clip_ref.text_embeds(ids, sd, cfg)
+    assert (1.0 - cosine(got, want)).max() < 2e-4
+    assert (1.0 - cosine(got, goldens[f"g5_{name}_text_embeds"])).max() < 2e-4
+    np.testing.assert_allclose(np.linalg.norm(got, axis=1), 1.0, atol=1e-5)
+    # a different caption batch shape (ragged vs the context length) on the same encoder
+    r = np.random.Generator(np.random.PCG64(9))
+    ids2 = r.integers(2, cfg["vocab"] - 2, size=(5, 7))
+    ids2[:, -1] = cfg["vocab"] - 1
+    assert (1.0 - cosine(enc.encode(ids2), clip_ref.text_embeds(ids2, sd, cfg))).max() < 2e-4
+    enc.close()
+
+
 def test_optimise_pose_grid_end_to_end(gpu, tmp_path):
     """Pose batch in, scores out through the reference-shaped Python API (config 0 shapes:
     32 poses, 160x90), against the oracle pipeline; argmax pose identical."""
