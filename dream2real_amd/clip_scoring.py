@@ -3,8 +3,10 @@
 Mirrors reference clip_scoring.py:71-234 (`optimise_pose_grid`): same positional arguments,
 same return triple (best_pose 4x4, pose_batch [N,16], pose_scores [N]) as torch tensors, same
 failure on zero valid poses.  Differences forced by the environment are keyword-only extras:
-`scorer` (a dream2real_amd.engine.ClipScorer holding the CLIP weights on the GPU) and
-`text_embeds` (cached, L2-normalised [C,D]; the reference re-encodes the captions every batch).
+`scorer` (a dream2real_amd.engine.ClipScorer holding the CLIP weights on the GPU) and either
+`text_embeds` (cached, L2-normalised [C,D]) or `text_encoder` + `tokenizer` (an
+engine.TextEncoder and a callable captions -> int32 ids [C,T]; the embeddings are then computed
+once on the GPU — the reference re-tokenises and re-encodes the captions every batch).
 """
 from __future__ import annotations
 
@@ -53,7 +55,7 @@ def build_captions(goal_caption, norm_captions, use_templates):
 def optimise_pose_grid(renderer, depths_gt, render_cam_pose_idx, task_model, data_dir, sample_res=None,
                        phys_check=None, use_templates=False, scene_type=0, use_vis_pcds=False,
                        use_cache_renders=False, smoothing=True, physics_only=False, *, scorer=None,
-                       text_embeds=None, show=False):
+                       text_embeds=None, text_encoder=None, tokenizer=None, show=False):
     import torch
 
     if sample_res is None:
@@ -98,8 +100,10 @@ def optimise_pose_grid(renderer, depths_gt, render_cam_pose_idx, task_model, dat
     captions, n_goal = build_captions(task_model.goal_caption, task_model.norm_captions, use_templates)
     if text_embeds is None:
         text_embeds = getattr(task_model, "text_embeds", None)
+    if text_embeds is None and text_encoder is not None and tokenizer is not None:
+        text_embeds = text_encoder.encode(np.asarray(tokenizer(captions), np.int32))   # once per task
     if text_embeds is None:
-        raise ValueError("cached text embeddings are required (no tokenizer/text tower offline)")
+        raise ValueError("text embeddings are required: pass text_embeds=, or text_encoder= and tokenizer=")
     text_embeds = np.asarray(text_embeds, np.float32)
     assert text_embeds.shape[0] == len(captions), "one text embedding per caption"
 

@@ -157,3 +157,21 @@ def test_physics_only_templates_and_errors(tmp_path):
         clip_scoring.optimise_pose_grid(rend, None, [0], task, str(tmp_path), sample_res=res,
                                         phys_check=lambda p, t, v: v, scene_type=3, use_vis_pcds=True, scorer=sc,
                                         text_embeds=text)
+
+
+def test_text_encoder_hook(tmp_path):
+    """captions -> tokenizer -> text encoder happens once and feeds the scorer."""
+    task = _task(tmp_path)
+    rend, sc = FakeRenderer(), FakeScorer()
+    calls = []
+
+    class Enc:
+        def encode(self, ids):
+            calls.append(np.array(ids))
+            return np.eye(ids.shape[0], 8, dtype=np.float32)
+
+    tok = lambda caps: [[len(c), 7, 9] for c in caps]
+    clip_scoring.optimise_pose_grid(rend, None, [0], task, str(tmp_path), sample_res=[2, 2, 1, 1, 1, 1],
+                                    phys_check=lambda p, t, v: v, scene_type=3, scorer=sc, text_encoder=Enc(), tokenizer=tok)
+    assert len(calls) == 1 and calls[0].shape == (2, 3) and calls[0][0, 0] == 1       # "g", "n"
+    np.testing.assert_array_equal(sc.seen[1], np.eye(2, 8, dtype=np.float32))
