@@ -310,6 +310,36 @@ def test_optimise_pose_grid_end_to_end(gpu, tmp_path):
     sc.close()
 
 
+def test_renderer_with_sensor_depth_background(gpu, tmp_path):
+    """depths_gt branch of renderer.render (reference combined_rendering.py:107-110): background
+    depth from the rectified sensor depth, pushed far where the rectified movable mask is 0."""
+    from dream2real_amd import combined_rendering
+    scene, fg, bg = gpu["scene"], gpu["fg"], gpu["bg"]
+    W = H = 96
+    task = make_task(scene, fg, bg)
+    rend = combined_rendering.renderer(str(tmp_path), task, resolution=(W, H))
+    depth = np.full((1, 720, 1280), 2.0, np.float16)
+    depth[:, :, :640] = 0.2                          # left half of the view: something nearer than the object
+    masks = np.ones((1, 720, 1280), bool)
+    masks[:, 300:420, 580:700] = False               # where the object sits today: treated as "far"
+    poses = host_ref.sample_poses_grid(scene.scene_centre, [3, 3, 1, 1, 1, 1], scene.scene_type).reshape(-1, 4, 4)
+    frames = rend.render(host_ref.converter(poses), host_ref.converter(np.asarray(scene.cam_poses, np.float32))[:1], [0],
+                         depths_gt=depth, movable_masks=masks, save=True)
+    assert len(frames) == 9 and (tmp_path / "cb_render" / "cb_rgb_0008.png").exists()
+    # oracle with the same rectified background depth
+    pipe = OraclePipeline(scene, W, H)
+    bg_rgba, _ = pipe.background()
+    d = combined_rendering.rectify_depth(depth[0], (W, H))
+    d[combined_rendering.rectify_mask(masks[0], (W, H)) == 0] = 100.0
+    want = pipe.frames(poses, bg=(bg_rgba, d))
+    diff = np.abs(np.stack(frames).astype(int) - want.astype(int)).max(-1)
+    assert diff.max() <= 1 and (diff > 0).mean() < 0.02
+    # the near half hides the object, the far half shows it
+    base = render_ref.composite(np.zeros((H, W, 4), np.float32), np.zeros((H, W), np.float32), bg_rgba, d)
+    changed = (np.stack(frames) != base[None]).any(-1)
+    assert changed[:, :, : W // 2 - 2].sum() == 0 and changed[:, :, W // 2:].sum() > 50
+
+
 def test_fused_render_score_device_path(gpu):
     """d2r_render_score on device pointers == render_composite + score_frames."""
     import torch
