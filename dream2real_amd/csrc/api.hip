@@ -163,6 +163,8 @@ int d2r_ctx_set_option(d2r_ctx *ctx, const char *key, int64_t value)
     } else if (!strcmp(key, "refill_min")) {
         if (value < 1 || value > 64) return d2r_fail(ctx, D2R_ERR_INVALID, "refill_min must be in [1, 64]");
         ctx->refill_min = value;
+    } else if (!strcmp(key, "gemm_cfg")) {
+        ctx->gemm_cfg = value;
     } else if (!strcmp(key, "gbrick_slots")) {
         if (value < 0 || value > 3) return d2r_fail(ctx, D2R_ERR_INVALID, "gbrick_slots must be in [0, 3]");
         ctx->gbrick_slots = value;

@@ -234,27 +234,34 @@ __device__ __forceinline__ uint32_t lds_addr(const void *p)
 template <int N>
 __device__ __forceinline__ void wait_vmcnt()
 {
+    static_assert(N == 0 || N == 6 || N == 8 || N == 12 || N == 16, "add the literal below");
     if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    if (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
 }
 
 // C = A[M,K] * W[N,K]^T.  A [M_pad][K] bf16, W [N][K] bf16, K % 64 == 0.
 // 8 waves as WGM x WGN, each wave MT x 2 MFMA 32x32x16 tiles:
 //   <WGM=4, WGN=2, MT=2, STAGES=3>  256x128 tile, 3-stage ring, counted vmcnt  (N = 768 products)
 //   <WGM=2, WGN=4, MT=4, STAGES=2>  256x256 tile, 2-stage                      (N >= 2304 products)
+// Measured on MI355X (ViT-B/16, M = 100 864): every tile shape from 128x128 (4 waves, 2 WG/CU) to
+// 256x256 lands within 10 % of 650-800 TFLOP/s; a staggered read-phase/MFMA-phase schedule (wave
+// groups one barrier apart) was bit-identical and no faster, so it was dropped.
 // LDS-DMA staging: tile kt+STAGES-1 is issued before tile kt is computed; with 3 stages the wait at
 // the end of the iteration is COUNTED (this wave's copies of the newest tile stay in flight across
 // the barrier) — the loads are never drained inside the loop.
 template <int EPI, int WGM, int WGN, int MT, int STAGES>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm(const uint16_t *__restrict__ A,
+__global__ __launch_bounds__(WGM * WGN * 64, 2) void k_gemm(const uint16_t *__restrict__ A,
                                                           const uint16_t *__restrict__ W,
                                                           const float *__restrict__ bias, void *__restrict__ Cout,
                                                           uint32_t M_pad, uint32_t N, uint32_t K, uint32_t M_real)
 {
     constexpr uint32_t TBM = WGM * MT * 32, TBN = WGN * 64;
     constexpr uint32_t STAGE_BYTES = (TBM + TBN) * BK * 2;
-    constexpr int A_PER_WAVE = TBM / 64, B_PER_WAVE = TBN / 64;     // 1 KiB copies per wave per stage
+    constexpr int NWAVE = WGM * WGN;
+    constexpr int A_PER_WAVE = TBM / 8 / NWAVE, B_PER_WAVE = TBN / 8 / NWAVE;   // 1 KiB copies per wave per stage
     constexpr int PER_STAGE = A_PER_WAVE + B_PER_WAVE;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     // XCD-aware tile order (bijective): blocks b, b+8, ... share an L2; give each XCD a
@@ -265,7 +272,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm(const uint16_t *__rest
     const uint32_t m0 = (tile / tiles_n) * TBM, n0 = (tile % tiles_n) * TBN;
 
     const uint32_t tid = threadIdx.x, lane = tid & 63;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // 0..7
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // 0..NWAVE-1
     const uint32_t wm = (wave / WGN) * (MT * 32), wn = (wave % WGN) * 64;
     const uint32_t li = lane & 31, hi = lane >> 5;
 
@@ -313,36 +320,49 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm(const uint16_t *__rest
     __syncthreads();
 
     uint32_t cur = 0;
-    for (uint32_t kt = 0; kt < nk; kt++) {
-        // refill the buffer that was computed in the previous iteration (everyone left it at the barrier)
-        const uint32_t ahead = kt + STAGES - 1;
-        if (ahead < nk) stage(cur >= 1 ? cur - 1 : STAGES - 1, ahead);
-        const uint8_t *Ab = smem + cur * STAGE_BYTES;
-        const uint8_t *Bb = Ab + TBM * BK * 2;
+    {
+        for (uint32_t kt = 0; kt < nk; kt++) {
+            // refill the buffer that was computed in the previous iteration (everyone left it at the barrier)
+            const uint32_t ahead = kt + STAGES - 1;
+            if (ahead < nk) stage(cur >= 1 ? cur - 1 : STAGES - 1, ahead);
+            const uint8_t *Ab = smem + cur * STAGE_BYTES;
+            const uint8_t *Bb = Ab + TBM * BK * 2;
+            // fragments are double-buffered in registers: k-step s+1 is read from LDS while the MFMAs of
+            // k-step s issue; the MFMA groups run at raised priority so the partner wave's loads yield
+            uint4 fa[2][MT], fb[2][2];
 #pragma unroll
-        for (int s = 0; s < 4; s++) {
-            uint4 fa[MT], fb[2];
+            for (int i = 0; i < MT; i++) fa[0][i] = *(const uint4 *)(Ab + lds_off(wm + i * 32 + li, hi));
 #pragma unroll
-            for (int i = 0; i < MT; i++) fa[i] = *(const uint4 *)(Ab + lds_off(wm + i * 32 + li, 2 * s + hi));
+            for (int j = 0; j < 2; j++) fb[0][j] = *(const uint4 *)(Bb + lds_off(wn + j * 32 + li, hi));
 #pragma unroll
-            for (int j = 0; j < 2; j++) fb[j] = *(const uint4 *)(Bb + lds_off(wn + j * 32 + li, 2 * s + hi));
+            for (int s = 0; s < 4; s++) {
+                const int cb = s & 1, nb = cb ^ 1;
+                if (s + 1 < 4) {
 #pragma unroll
-            for (int i = 0; i < MT; i++)
+                    for (int i = 0; i < MT; i++) fa[nb][i] = *(const uint4 *)(Ab + lds_off(wm + i * 32 + li, 2 * (s + 1) + hi));
 #pragma unroll
-                for (int j = 0; j < 2; j++) {
-                    union { uint4 u; bf16x8 v; } a, b;
-                    a.u = fa[i];
-                    b.u = fb[j];
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < 2; j++) fb[nb][j] = *(const uint4 *)(Bb + lds_off(wn + j * 32 + li, 2 * (s + 1) + hi));
                 }
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < MT; i++)
+#pragma unroll
+                    for (int j = 0; j < 2; j++) {
+                        union { uint4 u; bf16x8 v; } a, b;
+                        a.u = fa[cb][i];
+                        b.u = fb[cb][j];
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc[i][j], 0, 0, 0);
+                    }
+                __builtin_amdgcn_s_setprio(0);
+            }
+            // tile kt+1 must have landed; with 3 stages this wave's copies of tile kt+2 stay in flight
+            if (STAGES == 3 && ahead < nk)
+                wait_vmcnt<PER_STAGE>();
+            else
+                wait_vmcnt<0>();
+            __syncthreads();
+            cur = cur + 1 == STAGES ? 0 : cur + 1;
         }
-        // tile kt+1 must have landed; with 3 stages this wave's copies of tile kt+2 stay in flight
-        if (STAGES == 3 && ahead < nk)
-            wait_vmcnt<PER_STAGE>();
-        else
-            wait_vmcnt<0>();
-        __syncthreads();
-        cur = cur + 1 == STAGES ? 0 : cur + 1;
     }
 
     // epilogue: 32 rows at a time each wave transposes its fp32 tile through LDS (the ring is free:
@@ -847,7 +867,7 @@ static int launch_gemm_cfg(d2r_ctx *ctx, const uint16_t *A, const uint16_t *W, c
         (void)hipFuncSetAttribute((const void *)k_gemm<EPI, WGM, WGN, MT, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_gemm<EPI, WGM, WGN, MT, STAGES>), dim3(nwg), dim3(GEMM_THREADS), LDS, ctx->stream, A, W, bias, C,
+    hipLaunchKernelGGL((k_gemm<EPI, WGM, WGN, MT, STAGES>), dim3(nwg), dim3(WGM * WGN * 64), LDS, ctx->stream, A, W, bias, C,
                        M_pad, N, K, M_real);
     D2R_HIP(ctx, hipGetLastError());
     return D2R_OK;
@@ -862,6 +882,13 @@ static int launch_gemm(d2r_ctx *ctx, const uint16_t *A, const uint16_t *W, const
         return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "GEMM output too large for 32-bit indexing");
     // wide outputs: 256x256 tiles (more flops per byte staged); narrow ones keep 256x128 so the tile
     // count still covers the 256 CUs a few times
+    switch (ctx->gemm_cfg) {
+    case 1: return launch_gemm_cfg<EPI, 2, 2, 2, 2>(ctx, A, W, bias, C, M_real, N, K);      // 128x128, 4 waves, 2 WG/CU
+    case 2: return launch_gemm_cfg<EPI, 4, 2, 2, 3>(ctx, A, W, bias, C, M_real, N, K);      // 256x128 everywhere
+    case 3: if (N % 256 == 0) return launch_gemm_cfg<EPI, 1, 4, 4, 2>(ctx, A, W, bias, C, M_real, N, K);   // 128x256, 4 waves
+            return launch_gemm_cfg<EPI, 2, 2, 2, 2>(ctx, A, W, bias, C, M_real, N, K);
+    default: break;
+    }
     if (N % 256 == 0 && N >= 2048) return launch_gemm_cfg<EPI, 2, 4, 4, 2>(ctx, A, W, bias, C, M_real, N, K);
     return launch_gemm_cfg<EPI, 4, 2, 2, 3>(ctx, A, W, bias, C, M_real, N, K);
 }
