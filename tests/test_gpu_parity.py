@@ -156,6 +156,49 @@ def test_lds_bricks_are_bit_identical_to_global_tables(gpu):
     assert out[0][2] == out[1][2] > 10000
 
 
+@pytest.mark.parametrize("variant", ["small_tables", "bigger_object", "huge_object"])
+def test_other_kernel_instantiations(gpu, variant):
+    """The march kernel is instantiated per table/occupancy shape: generic slot kinds for a level
+    table with 3 dense levels (2^15-entry tables), 4 LDS-bricked slots for a bigger object, no
+    bricks for an object filling a quarter of the cube.  Each against the oracle."""
+    import dataclasses
+    from dream2real_amd.scene import NerfModel, ellipsoid_occupancy, grid_levels, make_synthetic_nerf, world_to_ngp
+    engine, ctx, scene = gpu["engine"], gpu["ctx"], gpu["scene"]
+    centre = world_to_ngp(scene.obj_pose[:3, 3])
+    if variant == "small_tables":
+        levels = grid_levels(log2_hashmap_size=15)
+        assert list(levels.hashed).index(True) == 3
+        occ = ellipsoid_occupancy(centre, (0.04, 0.05, 0.04))
+    elif variant == "bigger_object":
+        levels = grid_levels()
+        occ = ellipsoid_occupancy(centre, (0.09, 0.11, 0.09))
+    else:
+        levels = grid_levels()
+        occ = ellipsoid_occupancy((0.5, 0.5, 0.5), (0.3, 0.3, 0.3))
+    model = make_synthetic_nerf(occ, seed_grid=21, seed_mlp=22, levels=levels)
+    tb = engine.Testbed(ctx, model)
+    tb.background_color = [0.0, 0.0, 0.0, 1.0]
+    W, H = 96, 54
+    pipe = OraclePipeline(scene, W, H)
+    pipe.fg = render_ref.OracleNerf(model)
+    poses = host_ref.sample_poses_grid(scene.scene_centre, [2, 2, 1, 1, 1, 1], scene.scene_type).reshape(-1, 4, 4)
+    cams = np.stack([pipe.fg_camera(p) for p in poses])
+    rgba, depth = tb.render_batch(cams, W, H)
+    for i, p in enumerate(poses):
+        orgba, odepth = pipe.fg_render(p)
+        assert ((depth[i] > 0) == (odepth > 0)).all()
+        np.testing.assert_allclose(rgba[i], orgba, rtol=0, atol=5e-3)
+        np.testing.assert_allclose(depth[i], odepth, rtol=0, atol=2e-3)
+    assert abs(tb.last_samples - pipe.n_samples) <= 0.01 * pipe.n_samples and pipe.n_samples > 2000
+    # bricks on/off bit-identical for this shape too
+    ctx.set_option("bricks", 0)
+    rgba0, depth0 = tb.render_batch(cams, W, H)
+    ctx.set_option("bricks", 1)
+    np.testing.assert_array_equal(rgba0, rgba)
+    np.testing.assert_array_equal(depth0, depth)
+    tb.close()
+
+
 def test_alpha_threshold_and_transparent_fg(gpu):
     """fg background alpha 0 (in-process trained models): semi-transparent
     silhouette pixels fall under the 130/255 alpha threshold and turn black."""
