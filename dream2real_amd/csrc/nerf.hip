@@ -384,8 +384,9 @@ template <int NB, int NGB, int ND>
 __device__ __forceinline__ void encode_sample(const NerfParams &P, const __amdgpu_buffer_rsrc_t &rs,
                                               const __amdgpu_buffer_rsrc_t &rsb,
                                               const uint8_t *__restrict__ lds_bricks, bool hi, float x, float y,
-                                              float z, float *f)
+                                              float z, uint4 &p0, uint4 &p1)
 {
+    float f[16];
     // Global slots: all addresses, then all gathers back-to-back (memory-level parallelism); the
     // LDS-brick slots are evaluated underneath while those are in flight, then the global blends.
     // In a dense brick the two x-neighbour corners are adjacent words: ONE 8-byte gather per
@@ -433,6 +434,9 @@ __device__ __forceinline__ void encode_sample(const NerfParams &P, const __amdgp
     }
 #pragma unroll
     for (int i = 0; i < NG; i++) slot_blend(raw[i], w[i], f[2 * (NB + i)], f[2 * (NB + i) + 1]);
+    // straight into the two bf16 B fragments of density layer 1 (k-step 0: slots 0..3, 1: slots 4..7)
+    p0.x = pack2(f[0], f[1]); p0.y = pack2(f[2], f[3]); p0.z = pack2(f[4], f[5]); p0.w = pack2(f[6], f[7]);
+    p1.x = pack2(f[8], f[9]); p1.y = pack2(f[10], f[11]); p1.z = pack2(f[12], f[13]); p1.w = pack2(f[14], f[15]);
 }
 
 __device__ __forceinline__ void sh16(float x, float y, float z, float *o)
@@ -479,20 +483,11 @@ __device__ __forceinline__ uint4 relu_pack(const f32x16 &a, int r0)
 // in lanes n and n+32, which hold half of its features each.  The two tiles' accumulator chains
 // are independent, so their MFMAs are interleaved to fill each other's dependent-accumulate
 // latency.  Returns raw density-net output 0 and colour-net outputs 0..2 in lanes 0..31.
-__device__ __forceinline__ void mlp_tiles(const uint4 *__restrict__ sw, uint32_t lane, const float *featA,
-                                          const float *featB, const float *shA, const float *shB, float *outA,
-                                          float *outB)
+__device__ __forceinline__ void mlp_tiles(const uint4 *__restrict__ sw, uint32_t lane, const uint4 &a0,
+                                          const uint4 &a1, const uint4 &b0, const uint4 &b1, const uint4 &sA,
+                                          const uint4 &sB, float *outA, float *outB)
 {
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    uint4 a0, a1, b0, b1;
-    a0.x = pack2(featA[0], featA[1]); a0.y = pack2(featA[2], featA[3]);
-    a0.z = pack2(featA[4], featA[5]); a0.w = pack2(featA[6], featA[7]);
-    a1.x = pack2(featA[8], featA[9]); a1.y = pack2(featA[10], featA[11]);
-    a1.z = pack2(featA[12], featA[13]); a1.w = pack2(featA[14], featA[15]);
-    b0.x = pack2(featB[0], featB[1]); b0.y = pack2(featB[2], featB[3]);
-    b0.z = pack2(featB[4], featB[5]); b0.w = pack2(featB[6], featB[7]);
-    b1.x = pack2(featB[8], featB[9]); b1.y = pack2(featB[10], featB[11]);
-    b1.z = pack2(featB[12], featB[13]); b1.w = pack2(featB[14], featB[15]);
     // density layer 1: 64 x 32  (4 independent accumulators)
     uint4 w0 = sw[0 * 64 + lane], w1 = sw[1 * 64 + lane], w2 = sw[2 * 64 + lane], w3 = sw[3 * 64 + lane];
     f32x16 hA0 = mfma(w0, a0, zero), hB0 = mfma(w0, b0, zero), hA1 = mfma(w2, a0, zero), hB1 = mfma(w2, b0, zero);
@@ -508,11 +503,9 @@ __device__ __forceinline__ void mlp_tiles(const uint4 *__restrict__ sw, uint32_t
     outA[0] = dA[0];
     outB[0] = dB[0];
     // colour layer 1: 64 x 32, input = [density out (no activation) | SH]
-    uint4 cA, sA, cB, sB;
+    uint4 cA, cB;
     cA.x = pack2(dA[0], dA[1]); cA.y = pack2(dA[2], dA[3]); cA.z = pack2(dA[4], dA[5]); cA.w = pack2(dA[6], dA[7]);
     cB.x = pack2(dB[0], dB[1]); cB.y = pack2(dB[2], dB[3]); cB.z = pack2(dB[4], dB[5]); cB.w = pack2(dB[6], dB[7]);
-    sA.x = pack2(shA[0], shA[1]); sA.y = pack2(shA[2], shA[3]); sA.z = pack2(shA[4], shA[5]); sA.w = pack2(shA[6], shA[7]);
-    sB.x = pack2(shB[0], shB[1]); sB.y = pack2(shB[2], shB[3]); sB.z = pack2(shB[4], shB[5]); sB.w = pack2(shB[6], shB[7]);
     w0 = sw[8 * 64 + lane]; w1 = sw[9 * 64 + lane]; w2 = sw[10 * 64 + lane]; w3 = sw[11 * 64 + lane];
     f32x16 gA0 = mfma(w0, cA, zero), gB0 = mfma(w0, cB, zero), gA1 = mfma(w2, cA, zero), gB1 = mfma(w2, cB, zero);
     gA0 = mfma(w1, sA, gA0); gB0 = mfma(w1, sB, gB0); gA1 = mfma(w3, sA, gA1); gB1 = mfma(w3, sB, gB1);
@@ -559,22 +552,29 @@ __device__ __forceinline__ void eval_wave(const NerfParams &P, const __amdgpu_bu
     float bdx = hi ? dx : qdx, bdy = hi ? dy : qdy, bdz = hi ? dz : qdz;
     bool av = hi ? qvalid : valid, bv = hi ? valid : qvalid;
 
-    float fa[16], fb[16], sa[16], sb[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) fa[i] = fb[i] = 0.f;
-    // this lane's levels: 2i + hi for every slot i (slots 0..3 -> k-step 0, 4..7 -> k-step 1)
-    if (av) encode_sample<NB, NGB, ND>(P, rs, rsb, lds_bricks, hi, ax, ay, az, fa);
-    if (bv) encode_sample<NB, NGB, ND>(P, rs, rsb, lds_bricks, hi, bx, by, bz, fb);
-    sh16(adx, ady, adz, sa);
-    sh16(bdx, bdy, bdz, sb);
-    float sha[8], shb[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        sha[j] = hi ? sa[8 + j] : sa[j];
-        shb[j] = hi ? sb[8 + j] : sb[j];
+    // SH of both directions first (cheap, frees the direction registers), packed at once into the
+    // colour net's second B fragment: this lane holds coefficients 8hi..8hi+7
+    uint4 shfA, shfB;
+    {
+        float sa[16];
+        sh16(adx, ady, adz, sa);
+        shfA.x = pack2(hi ? sa[8] : sa[0], hi ? sa[9] : sa[1]);
+        shfA.y = pack2(hi ? sa[10] : sa[2], hi ? sa[11] : sa[3]);
+        shfA.z = pack2(hi ? sa[12] : sa[4], hi ? sa[13] : sa[5]);
+        shfA.w = pack2(hi ? sa[14] : sa[6], hi ? sa[15] : sa[7]);
+        sh16(bdx, bdy, bdz, sa);
+        shfB.x = pack2(hi ? sa[8] : sa[0], hi ? sa[9] : sa[1]);
+        shfB.y = pack2(hi ? sa[10] : sa[2], hi ? sa[11] : sa[3]);
+        shfB.z = pack2(hi ? sa[12] : sa[4], hi ? sa[13] : sa[5]);
+        shfB.w = pack2(hi ? sa[14] : sa[6], hi ? sa[15] : sa[7]);
     }
+    // this lane's levels: 2i + hi for every slot i (slots 0..3 -> k-step 0, 4..7 -> k-step 1);
+    // the features go straight into bf16 fragments (8 registers per sample instead of 16 floats)
+    uint4 fa0 = make_uint4(0, 0, 0, 0), fa1 = fa0, fb0 = fa0, fb1 = fa0;
+    if (av) encode_sample<NB, NGB, ND>(P, rs, rsb, lds_bricks, hi, ax, ay, az, fa0, fa1);
+    if (bv) encode_sample<NB, NGB, ND>(P, rs, rsb, lds_bricks, hi, bx, by, bz, fb0, fb1);
     float oa[4], ob[4];
-    mlp_tiles(sw, lane, fa, fb, sha, shb, oa, ob);
+    mlp_tiles(sw, lane, fa0, fa1, fb0, fb1, shfA, shfB, oa, ob);
     const float s0 = oa[0], r0 = oa[1], g0 = oa[2], b0 = oa[3];
     const float s1 = ob[0], r1 = ob[1], g1 = ob[2], b1 = ob[3];
     // tile-1 results live in lanes 0..31; their owners are lanes 32..63
