@@ -357,7 +357,9 @@ __device__ __forceinline__ void slot_addr(const NerfParams &P, int slot, bool hi
     }
 }
 
-// trilinear blend of the 8 corner entries, corner weights in the oracle's order ((wx*wy)*wz)
+// trilinear blend of the 8 corner entries, corner weights in the oracle's order ((wx*wy)*wz).
+// v_fma_mix_f32 multiplies the fp32 weight with one half of the packed fp16 pair and accumulates
+// in fp32 directly — no fp16->fp32 converts (hipcc does not form it with fp32 denormals on).
 __device__ __forceinline__ void slot_blend(const uint32_t *raw, const float *w, float &o0, float &o1)
 {
     const float ux = 1.0f - w[0], uy = 1.0f - w[1], uz = 1.0f - w[2];
@@ -366,10 +368,8 @@ __device__ __forceinline__ void slot_blend(const uint32_t *raw, const float *w, 
 #pragma unroll
     for (int c = 0; c < 8; c++) {
         const float wc = xy[c & 3] * ((c & 4) ? w[2] : uz);
-        union { uint32_t u; _Float16 h[2]; } cv;
-        cv.u = raw[c];
-        a0 = fmaf(wc, (float)cv.h[0], a0);
-        a1 = fmaf(wc, (float)cv.h[1], a1);
+        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[0,1,0]" : "+v"(a0) : "v"(wc), "v"(raw[c]));
+        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "+v"(a1) : "v"(wc), "v"(raw[c]));
     }
     o0 = a0;
     o1 = a1;
@@ -532,42 +532,43 @@ __device__ __forceinline__ void mlp_tiles(const uint4 *__restrict__ sw, uint32_t
     outB[1] = oB[0]; outB[2] = oB[1]; outB[3] = oB[2];
 }
 
+// SH fragments of the wave's ray directions: the colour net's second B fragment for tile 0
+// (directions of lanes 0..31) and tile 1 (lanes 32..63); this lane holds coefficients
+// 8hi..8hi+7.  Directions are per RAY, so k_march recomputes these only when it refills.
+__device__ __forceinline__ void sh_fragments(uint32_t lane, float dx, float dy, float dz, uint4 &shfA, uint4 &shfB)
+{
+    const bool hi = lane >= 32;
+    float qdx = __shfl_xor(dx, 32), qdy = __shfl_xor(dy, 32), qdz = __shfl_xor(dz, 32);
+    float sa[16];
+    sh16(hi ? qdx : dx, hi ? qdy : dy, hi ? qdz : dz, sa);
+    shfA.x = pack2(hi ? sa[8] : sa[0], hi ? sa[9] : sa[1]);
+    shfA.y = pack2(hi ? sa[10] : sa[2], hi ? sa[11] : sa[3]);
+    shfA.z = pack2(hi ? sa[12] : sa[4], hi ? sa[13] : sa[5]);
+    shfA.w = pack2(hi ? sa[14] : sa[6], hi ? sa[15] : sa[7]);
+    sh16(hi ? dx : qdx, hi ? dy : qdy, hi ? dz : qdz, sa);
+    shfB.x = pack2(hi ? sa[8] : sa[0], hi ? sa[9] : sa[1]);
+    shfB.y = pack2(hi ? sa[10] : sa[2], hi ? sa[11] : sa[3]);
+    shfB.z = pack2(hi ? sa[12] : sa[4], hi ? sa[13] : sa[5]);
+    shfB.w = pack2(hi ? sa[14] : sa[6], hi ? sa[15] : sa[7]);
+}
+
 // Evaluate the wave's 64 samples (one per lane; `valid` marks lanes that have one).
 // On return every valid lane holds sigma and the network rgb of ITS OWN sample.
 template <int NB, int NGB, int ND>
 __device__ __forceinline__ void eval_wave(const NerfParams &P, const __amdgpu_buffer_rsrc_t &rs,
-                                          const __amdgpu_buffer_rsrc_t &rsb, const uint4 *__restrict__ sw, const uint8_t *__restrict__ lds_bricks, uint32_t lane, bool valid, float x,
-                                          float y, float z, float dx, float dy, float dz, float &sigma,
+                                          const __amdgpu_buffer_rsrc_t &rsb, const uint4 *__restrict__ sw,
+                                          const uint8_t *__restrict__ lds_bricks, uint32_t lane, bool valid, float x,
+                                          float y, float z, const uint4 &shfA, const uint4 &shfB, float &sigma,
                                           float &r, float &g, float &b)
 {
     const bool hi = lane >= 32;
     // partner lane (l ^ 32) owns the other sample of this lane's column
     float qx = __shfl_xor(x, 32), qy = __shfl_xor(y, 32), qz = __shfl_xor(z, 32);
-    float qdx = __shfl_xor(dx, 32), qdy = __shfl_xor(dy, 32), qdz = __shfl_xor(dz, 32);
     bool qvalid = __shfl_xor((int)valid, 32) != 0;
     // tile 0 = samples of lanes 0..31, tile 1 = samples of lanes 32..63
     float ax = hi ? qx : x, ay = hi ? qy : y, az = hi ? qz : z;      // tile-0 sample seen by this lane
     float bx = hi ? x : qx, by = hi ? y : qy, bz = hi ? z : qz;      // tile-1 sample
-    float adx = hi ? qdx : dx, ady = hi ? qdy : dy, adz = hi ? qdz : dz;
-    float bdx = hi ? dx : qdx, bdy = hi ? dy : qdy, bdz = hi ? dz : qdz;
     bool av = hi ? qvalid : valid, bv = hi ? valid : qvalid;
-
-    // SH of both directions first (cheap, frees the direction registers), packed at once into the
-    // colour net's second B fragment: this lane holds coefficients 8hi..8hi+7
-    uint4 shfA, shfB;
-    {
-        float sa[16];
-        sh16(adx, ady, adz, sa);
-        shfA.x = pack2(hi ? sa[8] : sa[0], hi ? sa[9] : sa[1]);
-        shfA.y = pack2(hi ? sa[10] : sa[2], hi ? sa[11] : sa[3]);
-        shfA.z = pack2(hi ? sa[12] : sa[4], hi ? sa[13] : sa[5]);
-        shfA.w = pack2(hi ? sa[14] : sa[6], hi ? sa[15] : sa[7]);
-        sh16(bdx, bdy, bdz, sa);
-        shfB.x = pack2(hi ? sa[8] : sa[0], hi ? sa[9] : sa[1]);
-        shfB.y = pack2(hi ? sa[10] : sa[2], hi ? sa[11] : sa[3]);
-        shfB.z = pack2(hi ? sa[12] : sa[4], hi ? sa[13] : sa[5]);
-        shfB.w = pack2(hi ? sa[14] : sa[6], hi ? sa[15] : sa[7]);
-    }
     // this lane's levels: 2i + hi for every slot i (slots 0..3 -> k-step 0, 4..7 -> k-step 1);
     // the features go straight into bf16 fragments (8 registers per sample instead of 16 floats)
     uint4 fa0 = make_uint4(0, 0, 0, 0), fa1 = fa0, fb0 = fa0, fb1 = fa0;
@@ -575,15 +576,14 @@ __device__ __forceinline__ void eval_wave(const NerfParams &P, const __amdgpu_bu
     if (bv) encode_sample<NB, NGB, ND>(P, rs, rsb, lds_bricks, hi, bx, by, bz, fb0, fb1);
     float oa[4], ob[4];
     mlp_tiles(sw, lane, fa0, fa1, fb0, fb1, shfA, shfB, oa, ob);
-    const float s0 = oa[0], r0 = oa[1], g0 = oa[2], b0 = oa[3];
-    const float s1 = ob[0], r1 = ob[1], g1 = ob[2], b1 = ob[3];
     // tile-1 results live in lanes 0..31; their owners are lanes 32..63
-    float ts = __shfl_xor(s1, 32), tr = __shfl_xor(r1, 32), tg = __shfl_xor(g1, 32), tb = __shfl_xor(b1, 32);
-    float sr = hi ? ts : s0;
-    sigma = expf(sr);
-    r = 1.0f / (1.0f + expf(-(hi ? tr : r0)));
-    g = 1.0f / (1.0f + expf(-(hi ? tg : g0)));
-    b = 1.0f / (1.0f + expf(-(hi ? tb : b0)));
+    float ts = __shfl_xor(ob[0], 32), tr = __shfl_xor(ob[1], 32), tg = __shfl_xor(ob[2], 32), tb = __shfl_xor(ob[3], 32);
+    // sigma = exp(x), rgb = sigmoid(x) through the hardware exp2 / rcp (1-2 ulp)
+    const float L2E = 1.4426950408889634f;
+    sigma = __builtin_amdgcn_exp2f(L2E * (hi ? ts : oa[0]));
+    r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-L2E * (hi ? tr : oa[1])));
+    g = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-L2E * (hi ? tg : oa[2])));
+    b = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-L2E * (hi ? tb : oa[3])));
 }
 
 // field evaluation at arbitrary points (parity hook used by tests through d2r_eval_points)
@@ -605,7 +605,9 @@ __global__ __launch_bounds__(256) void k_eval_points(NerfParams P, const float *
         dx = dirs[3 * i]; dy = dirs[3 * i + 1]; dz = dirs[3 * i + 2];
     }
     float s, r, g, b;
-    eval_wave<0, 0, ND>(P, rs, rs, sw, nullptr, lane, valid, x, y, z, dx, dy, dz, s, r, g, b);   // arbitrary points: no bricks
+    uint4 shfA, shfB;
+    sh_fragments(lane, dx, dy, dz, shfA, shfB);
+    eval_wave<0, 0, ND>(P, rs, rs, sw, nullptr, lane, valid, x, y, z, shfA, shfB, s, r, g, b);   // arbitrary points: no bricks
     if (valid) *(float4 *)(out + 4 * (size_t)i) = make_float4(s, r, g, b);
 }
 
@@ -645,6 +647,7 @@ __global__ __launch_bounds__(D2R_MARCH_THREADS) void k_march(NerfParams P, ViewP
     float C0 = 0.f, C1 = 0.f, C2 = 0.f, A = 0.f, Z = 0.f;
     float fwx = 0.f, fwy = 0.f, fwz = 0.f, cox = 0.f, coy = 0.f, coz = 0.f;
     uint32_t nsamp = 0, niter = 0;
+    uint4 shfA = make_uint4(0, 0, 0, 0), shfB = shfA;
 
     for (;;) {
         // ---- refill free lanes from the ray queue (ballot + prefix popcount, one atomic per wave)
@@ -655,6 +658,7 @@ __global__ __launch_bounds__(D2R_MARCH_THREADS) void k_march(NerfParams P, ViewP
             if ((int)lane == leader) base = atomicAdd(qhead, nfree);
             base = __shfl(base, leader);
             if (base + nfree >= n_q) exhausted = true;
+            const bool was_alive = alive;
             if (!alive) {
                 uint32_t idx = base + (uint32_t)__popcll(freem & ((1ull << lane) - 1ull));
                 if (idx < n_q) {
@@ -677,13 +681,17 @@ __global__ __launch_bounds__(D2R_MARCH_THREADS) void k_march(NerfParams P, ViewP
                     alive = true;
                 }
             }
+            (void)was_alive;
+            // ray directions changed in some lanes: refresh the wave's SH fragments (all lanes
+            // take part: a lane's fragment also carries its partner's direction)
+            sh_fragments(lane, ray.dx, ray.dy, ray.dz, shfA, shfB);
         }
         if (!__any(alive)) break;
         niter++;
 
         // ---- evaluate this wave's samples
         float sigma, cr, cg, cb;
-        eval_wave<NB, NGB, ND>(P, rs, rsb, sw, lds_bricks, lane, alive, px, py, pz, ray.dx, ray.dy, ray.dz, sigma, cr, cg, cb);
+        eval_wave<NB, NGB, ND>(P, rs, rsb, sw, lds_bricks, lane, alive, px, py, pz, shfA, shfB, sigma, cr, cg, cb);
 
         // ---- composite + advance
         if (alive) {
