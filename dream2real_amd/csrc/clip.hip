@@ -889,7 +889,9 @@ static int launch_gemm(d2r_ctx *ctx, const uint16_t *A, const uint16_t *W, const
             return launch_gemm_cfg<EPI, 2, 2, 2, 2>(ctx, A, W, bias, C, M_real, N, K);
     default: break;
     }
-    if (N % 256 == 0 && N >= 2048) return launch_gemm_cfg<EPI, 2, 4, 4, 2>(ctx, A, W, bias, C, M_real, N, K);
+    // 256x256 tiles whenever they still cover the 256 CUs at least ~4 times, else 256x128
+    const uint64_t tiles256 = (uint64_t)(round_up(M_real, BM) / 256) * (N / 256);
+    if (N % 256 == 0 && (N >= 2048 || tiles256 >= 1024)) return launch_gemm_cfg<EPI, 2, 4, 4, 2>(ctx, A, W, bias, C, M_real, N, K);
     return launch_gemm_cfg<EPI, 4, 2, 2, 3>(ctx, A, W, bias, C, M_real, N, K);
 }
 
