@@ -162,8 +162,21 @@ def main():
     ctx.set_option("timing", 0)
     stats = ctx.render_stats(collect_K=K_local)          # counters of the last step
 
+    def recorded_traffic():
+        """HBM-side bytes per k_march launch from the committed PMC passes (bench.py cannot run
+        under --pmc itself); only reported when it was measured on this exact workload."""
+        try:
+            t = json.load(open(os.path.join(REPO, "profiles", "r01_march_traffic.json")))
+        except OSError:
+            return None, None
+        wl = t["workload"]
+        if (wl["scene"], wl["width"], wl["height"], wl["chunk"], wl["clip"]) != (args.scene, W, H, args.chunk, args.clip):
+            return None, None
+        return t["traffic_bytes_per_launch"], "profiles/r01_march_traffic.json (FETCH_SIZE+WRITE_SIZE, uncorrected: narrow gathers)"
+
     if rank == 0:
         total = N * args.steps
+        traffic, traffic_src = recorded_traffic()
         value = total / elapsed
         samples_per_launch = stats["samples"] / max(1, -(-K_local // args.chunk))
         march_avg_s = timing["march_ms"] / max(1, timing["march_launches"]) * 1e-3
@@ -180,7 +193,9 @@ def main():
                        "parallelism": f"pose-shard x{world}" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "k_march (hash-grid fetch + fused MLP + compositing)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
+                         "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": int(samples_per_launch * ALGO_BYTES_PER_SAMPLE),
                          "samples_per_launch": int(samples_per_launch),
                          "lane_utilisation": round(stats["samples"] / max(1, 64 * stats["wave_iters"]), 4),
                          "avg_launch_ms": round(march_avg_s * 1e3, 4),
