@@ -28,8 +28,16 @@ sys.path.insert(0, REPO)
 ALGO_BYTES_PER_SAMPLE = 512          # L*8*F*2 B = 16*8*2*2
 HBM_PEAK_GBPS = 8000.0               # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_BF16_PEAK_TFLOPS = 2500.0       # dense bf16
-VIT_B16_GFLOP = 35.1                 # per image
 MLP_FLOP_PER_SAMPLE = 20480
+
+
+def vit_gflop(cfg) -> float:
+    """Forward FLOPs per image of the vision tower (35.1 GFLOP for ViT-B/16)."""
+    P, d, mlp, L = cfg["patch_size"], cfg["hidden_size"], cfg["mlp"], cfg["num_layers"]
+    npatch = (cfg["image_size"] // P) ** 2
+    T = npatch + 1
+    per_layer = 2 * T * (4 * d * d + 2 * d * mlp) + 4 * T * T * d
+    return (2 * npatch * d * 3 * P * P + L * per_layer + 2 * d * cfg["proj"]) / 1e9
 
 
 def cpu_baseline(scene, W, H, cfg, sd, text, poses_world, n_sample):
@@ -50,7 +58,7 @@ def cpu_baseline(scene, W, H, cfg, sd, text, poses_world, n_sample):
     return {"value": round(n_sample / dt, 4), "unit": "candidates/s", "cores": os.cpu_count(),
             "kind": "port",
             "sample": f"{n_sample} of the {len(poses_world)} candidates at {W}x{H}: oracle C render+composite "
-                      f"(OpenMP, {render_ref.num_threads()} threads, {t_render:.1f}s) + numpy fp32 ViT-B/16 "
+                      f"(OpenMP, {render_ref.num_threads()} threads, {t_render:.1f}s) + numpy fp32 ViT "
                       f"(BLAS threads, {t_clip:.1f}s)"}, frames, lg, idx
 
 
@@ -182,7 +190,7 @@ def main():
         march_avg_s = timing["march_ms"] / max(1, timing["march_launches"]) * 1e-3
         achieved = samples_per_launch * ALGO_BYTES_PER_SAMPLE / march_avg_s / 1e9 if march_avg_s > 0 else 0.0
         n_img = K_local * args.steps
-        clip_tflops = VIT_B16_GFLOP * 1e9 * n_img / (timing["clip_ms"] * 1e-3) / 1e12 if args.clip == "vit_b16" and timing["clip_ms"] > 0 else None
+        clip_tflops = vit_gflop(cfg) * 1e9 * n_img / (timing["clip_ms"] * 1e-3) / 1e12 if timing["clip_ms"] > 0 else None
         out = {
             "metric": "candidate renders scored/sec (640x360)", "value": round(value, 2), "unit": "candidates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -200,7 +208,8 @@ def main():
                          "lane_utilisation": round(stats["samples"] / max(1, 64 * stats["wave_iters"]), 4),
                          "avg_launch_ms": round(march_avg_s * 1e3, 4),
                          "mlp_tflops": round(samples_per_launch * MLP_FLOP_PER_SAMPLE / march_avg_s / 1e12, 3) if march_avg_s > 0 else None},
-            "roofline_vit": {"bound": "mfma", "achieved": round(clip_tflops, 2) if clip_tflops else None,
+            "roofline_vit": {"bound": "mfma", "gflop_per_image": round(vit_gflop(cfg), 2),
+                             "achieved": round(clip_tflops, 2) if clip_tflops else None,
                              "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": round(clip_tflops / MFMA_BF16_PEAK_TFLOPS, 5) if clip_tflops else None},
             "device_ms_per_step": {k.replace("_ms", ""): round(v / args.steps, 3) for k, v in timing.items() if k.endswith("_ms")},
