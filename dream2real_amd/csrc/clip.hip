@@ -300,13 +300,20 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void k_gemm(const uint16_t *__re
     }
     const uint32_t nk = K / BK;
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem));
-    auto stage = [&](uint32_t buf, uint32_t kt) {
+    // copy `idx` (0 .. PER_STAGE-1) of this wave's share of tile kt into ring buffer buf
+    auto stage_one = [&](uint32_t buf, uint32_t kt, int idx) {
         const uint32_t base = lds0 + buf * STAGE_BYTES;
 #pragma unroll
-        for (int i = 0; i < A_PER_WAVE; i++) glds16(ag[i] + (size_t)kt * BK, base + (wave * A_PER_WAVE + i) * 1024);
+        for (int i = 0; i < A_PER_WAVE; i++)
+            if (idx == i) glds16(ag[i] + (size_t)kt * BK, base + (wave * A_PER_WAVE + i) * 1024);
 #pragma unroll
         for (int i = 0; i < B_PER_WAVE; i++)
-            glds16(wg[i] + (size_t)kt * BK, base + TBM * BK * 2 + (wave * B_PER_WAVE + i) * 1024);
+            if (idx == A_PER_WAVE + i)
+                glds16(wg[i] + (size_t)kt * BK, base + TBM * BK * 2 + (wave * B_PER_WAVE + i) * 1024);
+    };
+    auto stage = [&](uint32_t buf, uint32_t kt) {
+#pragma unroll
+        for (int c = 0; c < PER_STAGE; c++) stage_one(buf, kt, c);
     };
 
     // prologue: STAGES-1 tiles in flight, the first one landed
@@ -324,7 +331,8 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void k_gemm(const uint16_t *__re
         for (uint32_t kt = 0; kt < nk; kt++) {
             // refill the buffer that was computed in the previous iteration (everyone left it at the barrier)
             const uint32_t ahead = kt + STAGES - 1;
-            if (ahead < nk) stage(cur >= 1 ? cur - 1 : STAGES - 1, ahead);
+            const uint32_t nbuf = cur >= 1 ? cur - 1 : STAGES - 1;
+            const bool fill = ahead < nk;                  // block-uniform
             const uint8_t *Ab = smem + cur * STAGE_BYTES;
             const uint8_t *Bb = Ab + TBM * BK * 2;
             // fragments are double-buffered in registers: k-step s+1 is read from LDS while the MFMAs of
@@ -342,6 +350,13 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void k_gemm(const uint16_t *__re
                     for (int i = 0; i < MT; i++) fa[nb][i] = *(const uint4 *)(Ab + lds_off(wm + i * 32 + li, 2 * (s + 1) + hi));
 #pragma unroll
                     for (int j = 0; j < 2; j++) fb[nb][j] = *(const uint4 *)(Bb + lds_off(wn + j * 32 + li, 2 * (s + 1) + hi));
+                }
+                // this k-step's share of the next tile's LDS-DMA: issued between the fragment reads and
+                // the MFMA group instead of in one burst ahead of the first MFMA of the iteration
+                if (fill) {
+#pragma unroll
+                    for (int c = s * ((PER_STAGE + 3) / 4); c < (s + 1) * ((PER_STAGE + 3) / 4) && c < PER_STAGE; c++)
+                        stage_one(nbuf, ahead, c);
                 }
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
