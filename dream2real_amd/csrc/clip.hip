@@ -208,6 +208,12 @@ __global__ void k_patchify(const float *__restrict__ pv, uint32_t n, uint32_t S,
 
 enum { EPI_F32 = 0, EPI_BIAS_BF16 = 1, EPI_BIAS_GELU_BF16 = 2, EPI_BIAS_RESID_F32 = 3 };
 
+// Development-only ablation switches for k_gemm (bitmask, default 0 = the real kernel):
+//   1 no LDS-DMA, 2 no fragment ds_reads, 4 no epilogue, 8 no MFMA.  Results are garbage when set;
+//   used by tools/gemm_ablate.sh to see where the time of the loop goes.
+#ifndef D2R_GEMM_ABLATE
+#define D2R_GEMM_ABLATE 0
+#endif
 #define BM 256                 /* row padding of every GEMM operand buffer (largest tile height) */
 #define BK 64
 #define GEMM_THREADS 512
@@ -302,6 +308,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void k_gemm(const uint16_t *__re
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem));
     // copy `idx` (0 .. PER_STAGE-1) of this wave's share of tile kt into ring buffer buf
     auto stage_one = [&](uint32_t buf, uint32_t kt, int idx) {
+        if (D2R_GEMM_ABLATE & 1) return;
         const uint32_t base = lds0 + buf * STAGE_BYTES;
 #pragma unroll
         for (int i = 0; i < A_PER_WAVE; i++)
@@ -339,17 +346,17 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void k_gemm(const uint16_t *__re
             // k-step s issue; the MFMA groups run at raised priority so the partner wave's loads yield
             uint4 fa[2][MT], fb[2][2];
 #pragma unroll
-            for (int i = 0; i < MT; i++) fa[0][i] = *(const uint4 *)(Ab + lds_off(wm + i * 32 + li, hi));
+            for (int i = 0; i < MT; i++) fa[0][i] = (D2R_GEMM_ABLATE & 2) ? make_uint4(lane, kt, i, 1) : *(const uint4 *)(Ab + lds_off(wm + i * 32 + li, hi));
 #pragma unroll
-            for (int j = 0; j < 2; j++) fb[0][j] = *(const uint4 *)(Bb + lds_off(wn + j * 32 + li, hi));
+            for (int j = 0; j < 2; j++) fb[0][j] = (D2R_GEMM_ABLATE & 2) ? make_uint4(lane, kt, j, 2) : *(const uint4 *)(Bb + lds_off(wn + j * 32 + li, hi));
 #pragma unroll
             for (int s = 0; s < 4; s++) {
                 const int cb = s & 1, nb = cb ^ 1;
                 if (s + 1 < 4) {
 #pragma unroll
-                    for (int i = 0; i < MT; i++) fa[nb][i] = *(const uint4 *)(Ab + lds_off(wm + i * 32 + li, 2 * (s + 1) + hi));
+                    for (int i = 0; i < MT; i++) fa[nb][i] = (D2R_GEMM_ABLATE & 2) ? make_uint4(lane, kt, i, s) : *(const uint4 *)(Ab + lds_off(wm + i * 32 + li, 2 * (s + 1) + hi));
 #pragma unroll
-                    for (int j = 0; j < 2; j++) fb[nb][j] = *(const uint4 *)(Bb + lds_off(wn + j * 32 + li, 2 * (s + 1) + hi));
+                    for (int j = 0; j < 2; j++) fb[nb][j] = (D2R_GEMM_ABLATE & 2) ? make_uint4(lane, kt, j, s) : *(const uint4 *)(Bb + lds_off(wn + j * 32 + li, 2 * (s + 1) + hi));
                 }
                 // this k-step's share of the next tile's LDS-DMA: issued between the fragment reads and
                 // the MFMA group instead of in one burst ahead of the first MFMA of the iteration
@@ -366,7 +373,11 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void k_gemm(const uint16_t *__re
                         union { uint4 u; bf16x8 v; } a, b;
                         a.u = fa[cb][i];
                         b.u = fb[cb][j];
+#if (D2R_GEMM_ABLATE & 8) && defined(__HIP_DEVICE_COMPILE__)
+                        asm volatile("" ::"v"(a.u.x), "v"(b.u.x));      // keep the fragments live
+#else
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc[i][j], 0, 0, 0);
+#endif
                     }
                 __builtin_amdgcn_s_setprio(0);
             }
@@ -384,6 +395,15 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void k_gemm(const uint16_t *__re
     // the loop ended on a barrier) so that a lane owns 4 consecutive columns of a row: bias and
     // activation on float4, 8-byte (bf16) / 16-byte (fp32) coalesced stores.
     // acc[i][j][r] <-> row 32i+(r&3)+8(r>>2)+4hi, col 32j+li of the wave tile.
+#if (D2R_GEMM_ABLATE & 4) && defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int i = 0; i < MT; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) asm volatile("" ::"v"(acc[i][j][r]));
+    return;
+#endif
     constexpr uint32_t EP_LD = 68;                                   // floats per LDS row (pad 4)
     float *ep = (float *)smem + wave * (32 * EP_LD);                 // 8.5 KiB per wave
     const uint32_t c4 = (lane & 15) * 4, rl0 = lane >> 4;
@@ -897,13 +917,7 @@ static int launch_gemm(d2r_ctx *ctx, const uint16_t *A, const uint16_t *W, const
         return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "GEMM output too large for 32-bit indexing");
     // wide outputs: 256x256 tiles (more flops per byte staged); narrow ones keep 256x128 so the tile
     // count still covers the 256 CUs a few times
-    switch (ctx->gemm_cfg) {
-    case 1: return launch_gemm_cfg<EPI, 2, 2, 2, 2>(ctx, A, W, bias, C, M_real, N, K);      // 128x128, 4 waves, 2 WG/CU
-    case 2: return launch_gemm_cfg<EPI, 4, 2, 2, 3>(ctx, A, W, bias, C, M_real, N, K);      // 256x128 everywhere
-    case 3: if (N % 256 == 0) return launch_gemm_cfg<EPI, 1, 4, 4, 2>(ctx, A, W, bias, C, M_real, N, K);   // 128x256, 4 waves
-            return launch_gemm_cfg<EPI, 2, 2, 2, 2>(ctx, A, W, bias, C, M_real, N, K);
-    default: break;
-    }
+    if (ctx->gemm_cfg == 2) return launch_gemm_cfg<EPI, 4, 2, 2, 3>(ctx, A, W, bias, C, M_real, N, K);   // force 256x128
     // 256x256 tiles whenever they still cover the 256 CUs at least ~4 times, else 256x128
     const uint64_t tiles256 = (uint64_t)(round_up(M_real, BM) / 256) * (N / 256);
     if (N % 256 == 0 && (N >= 2048 || tiles256 >= 1024)) return launch_gemm_cfg<EPI, 2, 4, 4, 2>(ctx, A, W, bias, C, M_real, N, K);
