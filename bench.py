@@ -72,7 +72,7 @@ def main():
     ap.add_argument("--poses-per-gpu", type=int, default=4096)
     ap.add_argument("--clip", default="vit_b16")
     ap.add_argument("--scene", default="shopping")
-    ap.add_argument("--chunk", type=int, default=512)
+    ap.add_argument("--chunk", type=int, default=1024)
     ap.add_argument("--opt", action="append", default=[], help="library tunable key=value (repeatable)")
     ap.add_argument("--cpu-sample", type=int, default=6, help="candidates in the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()

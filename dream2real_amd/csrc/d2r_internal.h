@@ -80,7 +80,7 @@ struct d2r_ctx {
     Buf bg_rgba, bg_depth, bg_u8;
     uint32_t bg_w = 0, bg_h = 0;
     d2r_render_stats stats{};
-    int64_t chunk = 512;       // candidates per pass of the fused path
+    int64_t chunk = 1024;       // candidates per pass of the fused path
     int64_t march_blocks = 0;  // 0 = auto
     int64_t refill_min = 16;
     int64_t gemm_cfg = 0;      // experiment switch for the GEMM tile configuration (0 = default)

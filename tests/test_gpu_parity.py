@@ -128,7 +128,7 @@ def test_composited_frames_match_oracle(gpu):
     TC = host_ref.converter(np.asarray(scene.cam_poses, np.float32))[0]
     ctx.set_option("chunk", 5)          # ragged chunking: 24 poses in passes of 5
     frames = fg.render_composite(view, T1, TC, host_ref.converter(poses.astype(np.float32)))
-    ctx.set_option("chunk", 512)
+    ctx.set_option("chunk", 1024)
     want = pipe.frames(poses, bg=obg)
     diff = np.abs(frames.astype(int) - want.astype(int)).max(-1)
     assert diff.max() <= 1
@@ -417,7 +417,7 @@ def test_fused_render_score_device_path(gpu):
     engine.render_score_device(ctx, fg, sc, view, T1, TC, p_dev.data_ptr(), len(poses), text, lg_dev.data_ptr(), frames)
     ctx.synchronize()
     st = ctx.render_stats(collect_K=len(poses))
-    ctx.set_option("chunk", 512)
+    ctx.set_option("chunk", 1024)
     got = lg_dev.cpu().numpy()
     frames2 = fg.render_composite(view, T1, TC, poses_ngp.reshape(-1, 4, 4))
     np.testing.assert_array_equal(frames, frames2)
