@@ -768,6 +768,16 @@ __global__ void k_frames_init(const uint4 *__restrict__ bg_u8, uint4 *__restrict
     for (uint32_t c = blockIdx.y; c < n_cams; c += gridDim.y) frames[(size_t)c * n_vec + i] = v;
 }
 
+// same, for frame sizes whose byte count is not a multiple of 16 (unaligned frame starts)
+__global__ void k_frames_init_bytes(const uint8_t *__restrict__ bg_u8, uint8_t *__restrict__ frames, uint32_t n_bytes,
+                                    uint32_t n_cams)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_bytes) return;
+    uint8_t v = bg_u8[i];
+    for (uint32_t c = blockIdx.y; c < n_cams; c += gridDim.y) frames[(size_t)c * n_bytes + i] = v;
+}
+
 // background pixel as it appears in the composited frame when the fg does not win the depth
 // test (reference combined_rendering.py:147-153 applied to bg_image)
 __global__ void k_bg_quantize(const float *__restrict__ bg_rgba, uint8_t *__restrict__ out, uint32_t n)
@@ -843,11 +853,15 @@ int d2r_launch_render(d2r_ctx *ctx, const d2r_nerf *m, const ViewParams &V, cons
     if (composite) {
         if (ctx->bg_w != V.W || ctx->bg_h != V.H || !ctx->bg_u8.p)
             return d2r_fail(ctx, D2R_ERR_INVALID, "d2r_set_background must be called for this view first");
-        uint32_t n_vec = (uint32_t)((size_t)V.W * V.H * 3 / 16);
-        if ((size_t)n_vec * 16 != (size_t)V.W * V.H * 3)
-            return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "width*height*3 must be a multiple of 16");
-        hipLaunchKernelGGL(k_frames_init, dim3((n_vec + 255) / 256, n < 64 ? n : 64), dim3(256), 0, ctx->stream,
-                           (const uint4 *)ctx->bg_u8.p, (uint4 *)frames_dev, n_vec, n);
+        const uint32_t n_bytes = V.W * V.H * 3;
+        if (n_bytes % 16 == 0) {
+            const uint32_t n_vec = n_bytes / 16;
+            hipLaunchKernelGGL(k_frames_init, dim3((n_vec + 255) / 256, n < 64 ? n : 64), dim3(256), 0, ctx->stream,
+                               (const uint4 *)ctx->bg_u8.p, (uint4 *)frames_dev, n_vec, n);
+        } else {
+            hipLaunchKernelGGL(k_frames_init_bytes, dim3((n_bytes + 255) / 256, n < 64 ? n : 64), dim3(256), 0,
+                               ctx->stream, (const uint8_t *)ctx->bg_u8.p, frames_dev, n_bytes, n);
+        }
     }
     const uint32_t tiles = ((V.W + 15) / 16) * ((V.H + 15) / 16);
     size_t tr = ctx->timing_begin(D2R_T_RAYGEN);

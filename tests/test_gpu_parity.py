@@ -114,11 +114,12 @@ def test_testbed_surface_shade_and_depth(gpu):
         fg.render(W, H, 4, True)
 
 
-def test_composited_frames_match_oracle(gpu):
+@pytest.mark.parametrize("W,H", [(160, 90), (70, 50)])
+def test_composited_frames_match_oracle(gpu, W, H):
     """renderer.render: K candidates -> uint8 frames (depth test, un-premultiply, sRGB,
-    quantise, alpha threshold), same background on both sides."""
+    quantise, alpha threshold), same background on both sides.  70x50: frame byte count not a
+    multiple of 16 (byte-granular background broadcast)."""
     scene, fg, ctx = gpu["scene"], gpu["fg"], gpu["ctx"]
-    W, H = 160, 90
     pipe = OraclePipeline(scene, W, H)
     poses = host_ref.sample_poses_grid(scene.scene_centre, [4, 3, 2, 1, 1, 1], scene.scene_type).reshape(-1, 4, 4)
     obg = pipe.background()
