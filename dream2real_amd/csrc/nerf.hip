@@ -479,57 +479,56 @@ __device__ __forceinline__ uint4 relu_pack(const f32x16 &a, int r0)
     return o;
 }
 
-// Both tiles of the wave through both MLPs, layer by layer.  Tile t = 32 samples: sample n lives
-// in lanes n and n+32, which hold half of its features each.  The two tiles' accumulator chains
-// are independent, so their MFMAs are interleaved to fill each other's dependent-accumulate
-// latency.  Returns raw density-net output 0 and colour-net outputs 0..2 in lanes 0..31.
-__device__ __forceinline__ void mlp_tiles(const uint4 *__restrict__ sw, uint32_t lane, const uint4 &a0,
-                                          const uint4 &a1, const uint4 &b0, const uint4 &b1, const uint4 &sA,
-                                          const uint4 &sB, float *outA, float *outB)
+// One tile (32 samples: sample n lives in lanes n and n+32, which hold half of its features each)
+// through both MLPs.  Returns raw density-net output 0 and colour-net outputs 0..2 in lanes 0..31.
+// Scheduling fences between the layers keep hipcc from hoisting later layers' LDS weight reads
+// above the current MFMA chain (that inflated the live register set past 3 waves/SIMD).
+__device__ __forceinline__ void mlp_tile(const uint4 *__restrict__ sw, uint32_t lane, const uint4 &a0,
+                                         const uint4 &a1, const uint4 &sh, float *out)
 {
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    // density layer 1: 64 x 32  (4 independent accumulators)
-    uint4 w0 = sw[0 * 64 + lane], w1 = sw[1 * 64 + lane], w2 = sw[2 * 64 + lane], w3 = sw[3 * 64 + lane];
-    f32x16 hA0 = mfma(w0, a0, zero), hB0 = mfma(w0, b0, zero), hA1 = mfma(w2, a0, zero), hB1 = mfma(w2, b0, zero);
-    hA0 = mfma(w1, a1, hA0); hB0 = mfma(w1, b1, hB0); hA1 = mfma(w3, a1, hA1); hB1 = mfma(w3, b1, hB1);
-    uint4 pA0 = relu_pack(hA0, 0), pA1 = relu_pack(hA0, 8), pA2 = relu_pack(hA1, 0), pA3 = relu_pack(hA1, 8);
-    uint4 pB0 = relu_pack(hB0, 0), pB1 = relu_pack(hB0, 8), pB2 = relu_pack(hB1, 0), pB3 = relu_pack(hB1, 8);
+    // density layer 1: 64 x 32
+    f32x16 h0 = mfma(sw[0 * 64 + lane], a0, zero), h1 = mfma(sw[2 * 64 + lane], a0, zero);
+    h0 = mfma(sw[1 * 64 + lane], a1, h0);
+    h1 = mfma(sw[3 * 64 + lane], a1, h1);
+    uint4 p0 = relu_pack(h0, 0), p1 = relu_pack(h0, 8), p2 = relu_pack(h1, 0), p3 = relu_pack(h1, 8);
+    __builtin_amdgcn_sched_barrier(0);
     // density layer 2: 16 (padded 32) x 64
-    w0 = sw[4 * 64 + lane]; w1 = sw[5 * 64 + lane]; w2 = sw[6 * 64 + lane]; w3 = sw[7 * 64 + lane];
-    f32x16 dA = mfma(w0, pA0, zero), dB = mfma(w0, pB0, zero);
-    dA = mfma(w1, pA1, dA); dB = mfma(w1, pB1, dB);
-    dA = mfma(w2, pA2, dA); dB = mfma(w2, pB2, dB);
-    dA = mfma(w3, pA3, dA); dB = mfma(w3, pB3, dB);
-    outA[0] = dA[0];
-    outB[0] = dB[0];
+    f32x16 dd = mfma(sw[4 * 64 + lane], p0, zero);
+    dd = mfma(sw[5 * 64 + lane], p1, dd);
+    dd = mfma(sw[6 * 64 + lane], p2, dd);
+    dd = mfma(sw[7 * 64 + lane], p3, dd);
+    out[0] = dd[0];
     // colour layer 1: 64 x 32, input = [density out (no activation) | SH]
-    uint4 cA, cB;
-    cA.x = pack2(dA[0], dA[1]); cA.y = pack2(dA[2], dA[3]); cA.z = pack2(dA[4], dA[5]); cA.w = pack2(dA[6], dA[7]);
-    cB.x = pack2(dB[0], dB[1]); cB.y = pack2(dB[2], dB[3]); cB.z = pack2(dB[4], dB[5]); cB.w = pack2(dB[6], dB[7]);
-    w0 = sw[8 * 64 + lane]; w1 = sw[9 * 64 + lane]; w2 = sw[10 * 64 + lane]; w3 = sw[11 * 64 + lane];
-    f32x16 gA0 = mfma(w0, cA, zero), gB0 = mfma(w0, cB, zero), gA1 = mfma(w2, cA, zero), gB1 = mfma(w2, cB, zero);
-    gA0 = mfma(w1, sA, gA0); gB0 = mfma(w1, sB, gB0); gA1 = mfma(w3, sA, gA1); gB1 = mfma(w3, sB, gB1);
-    pA0 = relu_pack(gA0, 0); pA1 = relu_pack(gA0, 8); pA2 = relu_pack(gA1, 0); pA3 = relu_pack(gA1, 8);
-    pB0 = relu_pack(gB0, 0); pB1 = relu_pack(gB0, 8); pB2 = relu_pack(gB1, 0); pB3 = relu_pack(gB1, 8);
+    uint4 cd;
+    cd.x = pack2(dd[0], dd[1]); cd.y = pack2(dd[2], dd[3]); cd.z = pack2(dd[4], dd[5]); cd.w = pack2(dd[6], dd[7]);
+    __builtin_amdgcn_sched_barrier(0);
+    h0 = mfma(sw[8 * 64 + lane], cd, zero);
+    h1 = mfma(sw[10 * 64 + lane], cd, zero);
+    h0 = mfma(sw[9 * 64 + lane], sh, h0);
+    h1 = mfma(sw[11 * 64 + lane], sh, h1);
+    p0 = relu_pack(h0, 0); p1 = relu_pack(h0, 8); p2 = relu_pack(h1, 0); p3 = relu_pack(h1, 8);
+    __builtin_amdgcn_sched_barrier(0);
     // colour layer 2: 64 x 64
-    f32x16 eA0 = zero, eB0 = zero, eA1 = zero, eB1 = zero;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const uint4 u0 = sw[(12 + q) * 64 + lane], u1 = sw[(16 + q) * 64 + lane];
-        const uint4 xa = q == 0 ? pA0 : q == 1 ? pA1 : q == 2 ? pA2 : pA3;
-        const uint4 xb = q == 0 ? pB0 : q == 1 ? pB1 : q == 2 ? pB2 : pB3;
-        eA0 = mfma(u0, xa, eA0); eB0 = mfma(u0, xb, eB0); eA1 = mfma(u1, xa, eA1); eB1 = mfma(u1, xb, eB1);
-    }
-    pA0 = relu_pack(eA0, 0); pA1 = relu_pack(eA0, 8); pA2 = relu_pack(eA1, 0); pA3 = relu_pack(eA1, 8);
-    pB0 = relu_pack(eB0, 0); pB1 = relu_pack(eB0, 8); pB2 = relu_pack(eB1, 0); pB3 = relu_pack(eB1, 8);
+    h0 = mfma(sw[12 * 64 + lane], p0, zero);
+    h1 = mfma(sw[16 * 64 + lane], p0, zero);
+    h0 = mfma(sw[13 * 64 + lane], p1, h0);
+    h1 = mfma(sw[17 * 64 + lane], p1, h1);
+    h0 = mfma(sw[14 * 64 + lane], p2, h0);
+    h1 = mfma(sw[18 * 64 + lane], p2, h1);
+    h0 = mfma(sw[15 * 64 + lane], p3, h0);
+    h1 = mfma(sw[19 * 64 + lane], p3, h1);
+    p0 = relu_pack(h0, 0); p1 = relu_pack(h0, 8); p2 = relu_pack(h1, 0); p3 = relu_pack(h1, 8);
+    __builtin_amdgcn_sched_barrier(0);
     // colour layer 3: 16 (padded 32) x 64
-    w0 = sw[20 * 64 + lane]; w1 = sw[21 * 64 + lane]; w2 = sw[22 * 64 + lane]; w3 = sw[23 * 64 + lane];
-    f32x16 oA = mfma(w0, pA0, zero), oB = mfma(w0, pB0, zero);
-    oA = mfma(w1, pA1, oA); oB = mfma(w1, pB1, oB);
-    oA = mfma(w2, pA2, oA); oB = mfma(w2, pB2, oB);
-    oA = mfma(w3, pA3, oA); oB = mfma(w3, pB3, oB);
-    outA[1] = oA[0]; outA[2] = oA[1]; outA[3] = oA[2];
-    outB[1] = oB[0]; outB[2] = oB[1]; outB[3] = oB[2];
+    dd = mfma(sw[20 * 64 + lane], p0, zero);
+    dd = mfma(sw[21 * 64 + lane], p1, dd);
+    dd = mfma(sw[22 * 64 + lane], p2, dd);
+    dd = mfma(sw[23 * 64 + lane], p3, dd);
+    out[1] = dd[0];
+    out[2] = dd[1];
+    out[3] = dd[2];
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // SH fragments of the wave's ray directions: the colour net's second B fragment for tile 0
@@ -575,7 +574,9 @@ __device__ __forceinline__ void eval_wave(const NerfParams &P, const __amdgpu_bu
     if (av) encode_sample<NB, NGB, ND>(P, rs, rsb, lds_bricks, hi, ax, ay, az, fa0, fa1);
     if (bv) encode_sample<NB, NGB, ND>(P, rs, rsb, lds_bricks, hi, bx, by, bz, fb0, fb1);
     float oa[4], ob[4];
-    mlp_tiles(sw, lane, fa0, fa1, fb0, fb1, shfA, shfB, oa, ob);
+    __builtin_amdgcn_sched_barrier(0);
+    mlp_tile(sw, lane, fa0, fa1, shfA, oa);
+    mlp_tile(sw, lane, fb0, fb1, shfB, ob);
     // tile-1 results live in lanes 0..31; their owners are lanes 32..63
     float ts = __shfl_xor(ob[0], 32), tr = __shfl_xor(ob[1], 32), tg = __shfl_xor(ob[2], 32), tb = __shfl_xor(ob[3], 32);
     // sigma = exp(x), rgb = sigmoid(x) through the hardware exp2 / rcp (1-2 ulp)
@@ -613,8 +614,10 @@ __global__ __launch_bounds__(256) void k_eval_points(NerfParams P, const float *
 
 // ------------------------------------------------------------------ marcher
 
+// 768 threads = 12 waves = 3 per SIMD (168 VGPRs): the sweet spot measured on MI355X; 512 leaves
+// latency exposed, 1024 spills heavily.
 #ifndef D2R_MARCH_THREADS
-#define D2R_MARCH_THREADS 1024
+#define D2R_MARCH_THREADS 768
 #endif
 template <bool COMPOSITE, int NB, int NGB, int ND>
 __global__ __launch_bounds__(D2R_MARCH_THREADS) void k_march(NerfParams P, ViewParams V, const float *__restrict__ cams,
@@ -645,7 +648,8 @@ __global__ __launch_bounds__(D2R_MARCH_THREADS) void k_march(NerfParams P, ViewP
     uint32_t k = 0, ray_id = 0;
     float px = 0.f, py = 0.f, pz = 0.f;
     float C0 = 0.f, C1 = 0.f, C2 = 0.f, A = 0.f, Z = 0.f;
-    float fwx = 0.f, fwy = 0.f, fwz = 0.f, cox = 0.f, coy = 0.f, coz = 0.f;
+    // depth of a sample along the camera axis: z = fwd.(p - c) = t * (d.fwd) + (o - c).fwd
+    float zslope = 0.f, zbase = 0.f;
     uint32_t nsamp = 0, niter = 0;
     uint4 shfA = make_uint4(0, 0, 0, 0), shfB = shfA;
 
@@ -675,8 +679,8 @@ __global__ __launch_bounds__(D2R_MARCH_THREADS) void k_march(NerfParams P, ViewP
                     px = fmaf(t, ray.dx, ray.ox);
                     py = fmaf(t, ray.dy, ray.oy);
                     pz = fmaf(t, ray.dz, ray.oz);
-                    fwx = cam[2]; fwy = cam[6]; fwz = cam[10];
-                    cox = cam[3]; coy = cam[7]; coz = cam[11];
+                    zslope = (ray.dx * cam[2] + ray.dy * cam[6] + ray.dz * cam[10]) * V.inv_scale;
+                    zbase = ((ray.ox - cam[3]) * cam[2] + (ray.oy - cam[7]) * cam[6] + (ray.oz - cam[11]) * cam[10]) * V.inv_scale;
                     C0 = C1 = C2 = A = Z = 0.f;
                     alive = true;
                 }
@@ -699,7 +703,7 @@ __global__ __launch_bounds__(D2R_MARCH_THREADS) void k_march(NerfParams P, ViewP
             float T = 1.0f - A;
             float alpha = 1.0f - expf(-sigma * D2R_DT);
             float wgt = alpha * T;
-            float zz = ((px - cox) * fwx + (py - coy) * fwy + (pz - coz) * fwz) * V.inv_scale;
+            float zz = fmaf(fmaf((float)k, D2R_DT, ray.t0), zslope, zbase);
             C0 = fmaf(wgt, cr, C0);
             C1 = fmaf(wgt, cg, C1);
             C2 = fmaf(wgt, cb, C2);
