@@ -84,8 +84,7 @@ def main():
     from dream2real_amd.clip_model import CLIP_CONFIGS, random_clip_state_dict
     from dream2real_amd.clip_scoring import reduce_logits
     from dream2real_amd.geometry_utils import spatially_smooth_heatmap
-    from dream2real_amd.scene import make_scene
-    from tests.parity_utils import make_task, scene_text_embeds
+    from dream2real_amd.scene import make_scene, make_task, scene_text_embeds
 
     rank, world, local = d2r_dist.init_from_env()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"

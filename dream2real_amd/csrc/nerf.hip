@@ -662,7 +662,6 @@ __global__ __launch_bounds__(D2R_MARCH_THREADS) void k_march(NerfParams P, ViewP
             if ((int)lane == leader) base = atomicAdd(qhead, nfree);
             base = __shfl(base, leader);
             if (base + nfree >= n_q) exhausted = true;
-            const bool was_alive = alive;
             if (!alive) {
                 uint32_t idx = base + (uint32_t)__popcll(freem & ((1ull << lane) - 1ull));
                 if (idx < n_q) {
@@ -685,7 +684,6 @@ __global__ __launch_bounds__(D2R_MARCH_THREADS) void k_march(NerfParams P, ViewP
                     alive = true;
                 }
             }
-            (void)was_alive;
             // ray directions changed in some lanes: refresh the wave's SH fragments (all lanes
             // take part: a lane's fragment also carries its partner's direction)
             sh_fragments(lane, ray.dx, ray.dy, ray.dz, shfA, shfB);

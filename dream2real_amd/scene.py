@@ -229,3 +229,31 @@ def make_scene(kind: str = "shopping") -> SyntheticScene:
                      look_at_opencv(eye + np.array([0.1, 0.0, 0.02]), scene_centre)])
     return SyntheticScene(kind, scene_type, scene_centre, fg, bg, obj_pose, cams,
                           fg_background=(0.0, 0.0, 0.0, 1.0))
+
+
+def scene_text_embeds(image_embed, n_caps: int = 2, seed: int = 5, noise: float = 0.8) -> np.ndarray:
+    """Cached "caption" embeddings for a synthetic task: seeded unit vectors positively correlated
+    with an image embedding of the scene (as a real goal/normalising caption pair would be), so the
+    logits are positive and the goal/norm ratio is well conditioned.  Input data only."""
+    e = np.asarray(image_embed, np.float64).reshape(-1)
+    r = np.random.Generator(np.random.PCG64(seed))
+    t = e[None] + noise * r.standard_normal((n_caps, e.size)) / np.sqrt(e.size) * np.linalg.norm(e)
+    return (t / np.linalg.norm(t, axis=-1, keepdims=True)).astype(np.float32)
+
+
+def make_task(scene: SyntheticScene, fg_tb=None, bg_tb=None):
+    """Duck-typed TaskModel (reference scene_model.py:45-130) for a synthetic scene: the fields
+    optimise_pose_grid / renderer read."""
+    import types
+
+    import torch
+    sm = types.SimpleNamespace(scene_centre=torch.tensor(scene.scene_centre, dtype=torch.float32),
+                               opt_cam_poses=[torch.tensor(p, dtype=torch.float32) for p in scene.cam_poses],
+                               device="cpu")
+    return types.SimpleNamespace(
+        scene_model=sm,
+        movable_obj=types.SimpleNamespace(vis_model=fg_tb, pose=torch.tensor(scene.obj_pose, dtype=torch.float32)),
+        task_bground_obj=types.SimpleNamespace(vis_model=bg_tb),
+        goal_caption="an apple inside a blue and white bowl",
+        norm_captions=["an apple and a blue and white bowl"],
+        movable_masks=None)
