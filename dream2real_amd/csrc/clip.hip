@@ -535,9 +535,11 @@ __global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ X, 
 
 // QKV [rows][3d] bf16 (q | k | v, head h at columns h*64), out AO [rows][d] bf16.
 // grid (heads, images); block 256; dynamic LDS: K [T_pad][64] swizzled + Vt [64][T_pad+4].
+#define ATTN_THREADS 512
 template <bool CAUSAL>
-__global__ __launch_bounds__(256, 2) void k_attention(const uint16_t *__restrict__ QKV, uint16_t *__restrict__ AO,
-                                                      uint32_t T, uint32_t T_pad, uint32_t d)
+__global__ __launch_bounds__(ATTN_THREADS, 2) void k_attention(const uint16_t *__restrict__ QKV,
+                                                               uint16_t *__restrict__ AO, uint32_t T, uint32_t T_pad,
+                                                               uint32_t d)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *Ks = smem;                                  // T_pad * 128 B
@@ -551,24 +553,39 @@ __global__ __launch_bounds__(256, 2) void k_attention(const uint16_t *__restrict
     const uint16_t *Kg = Qg + d;
     const uint16_t *Vg = Qg + 2 * d;
 
-    // stage K (row-major, swizzled 16-B chunks) and V^T; rows >= T are zero
-    for (uint32_t i = tid; i < T_pad * 8; i += 256) {
+    // stage K (row-major, swizzled 16-B chunks); rows >= T are zero
+    for (uint32_t i = tid; i < T_pad * 8; i += ATTN_THREADS) {
         uint32_t key = i >> 3, c = i & 7;
-        uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
-        if (key < T) {
-            kv = *(const uint4 *)(Kg + (size_t)key * ld + c * 8);
-            vv = *(const uint4 *)(Vg + (size_t)key * ld + c * 8);
-        }
+        uint4 kv = make_uint4(0, 0, 0, 0);
+        if (key < T) kv = *(const uint4 *)(Kg + (size_t)key * ld + c * 8);
         *(uint4 *)(Ks + lds_off(key, c)) = kv;
-        const uint16_t *ve = (const uint16_t *)&vv;
+    }
+    // stage V^T: a task takes 4 keys x 8 dims (four 16-byte loads), transposes the 4x8 block in
+    // registers (v_perm_b32) and writes one 8-byte word of 4 consecutive keys per dim
+    for (uint32_t i = tid; i < (T_pad / 4) * 8; i += ATTN_THREADS) {
+        const uint32_t kb = (i >> 3) * 4, c = i & 7;
+        uint4 v[4];
 #pragma unroll
-        for (int e = 0; e < 8; e++) Vt[(c * 8 + e) * vstride + key] = ve[e];
+        for (int k = 0; k < 4; k++)
+            v[k] = kb + k < T ? *(const uint4 *)(Vg + (size_t)(kb + k) * ld + c * 8) : make_uint4(0, 0, 0, 0);
+        const uint32_t *w0 = (const uint32_t *)&v[0], *w1 = (const uint32_t *)&v[1];
+        const uint32_t *w2 = (const uint32_t *)&v[2], *w3 = (const uint32_t *)&v[3];
+#pragma unroll
+        for (int p = 0; p < 4; p++) {      // dims 2p, 2p+1 live in word p of every key's chunk
+            uint2 lo, hi2;
+            lo.x = __builtin_amdgcn_perm(w1[p], w0[p], 0x05040100);   // (key0.lo16, key1.lo16)
+            lo.y = __builtin_amdgcn_perm(w3[p], w2[p], 0x05040100);
+            hi2.x = __builtin_amdgcn_perm(w1[p], w0[p], 0x07060302);  // (key0.hi16, key1.hi16)
+            hi2.y = __builtin_amdgcn_perm(w3[p], w2[p], 0x07060302);
+            *(uint2 *)(Vt + (size_t)(c * 8 + 2 * p) * vstride + kb) = lo;
+            *(uint2 *)(Vt + (size_t)(c * 8 + 2 * p + 1) * vstride + kb) = hi2;
+        }
     }
     __syncthreads();
 
     const float scale = 0.125f;   // head_dim^-0.5, head_dim = 64
     const uint32_t n_qt = (T + 31) / 32, n_kt = T_pad / 32;
-    for (uint32_t qt = wave; qt < n_qt; qt += 4) {
+    for (uint32_t qt = wave; qt < n_qt; qt += ATTN_THREADS / 64) {
         const uint32_t qrow = qt * 32 + li;
         // B operand of S^T = K Q^T: lane (q, hi) holds Q[q][16s + 8hi .. +8)
         uint4 qf[4];
@@ -962,7 +979,7 @@ int d2r_clip_forward(d2r_ctx *ctx, const d2r_clip *clip, const uint16_t *patches
         hipLaunchKernelGGL(k_layernorm, dim3((rows + 3) / 4), dim3(256), 0, ctx->stream, X, L.ln1_w, L.ln1_b, Xn,
                            rows, d);
         if ((rc = launch_gemm<EPI_BIAS_BF16>(ctx, Xn, L.w_qkv, L.b_qkv, QKV, rows, 3 * d, d))) return rc;
-        hipLaunchKernelGGL(k_attention<false>, dim3(D.num_heads, n), dim3(256), attn_lds, ctx->stream, QKV, AO, T, T_pad, d);
+        hipLaunchKernelGGL(k_attention<false>, dim3(D.num_heads, n), dim3(ATTN_THREADS), attn_lds, ctx->stream, QKV, AO, T, T_pad, d);
         if ((rc = launch_gemm<EPI_BIAS_RESID_F32>(ctx, AO, L.w_o, L.b_o, X, rows, d, d))) return rc;
         hipLaunchKernelGGL(k_layernorm, dim3((rows + 3) / 4), dim3(256), 0, ctx->stream, X, L.ln2_w, L.ln2_b, Xn,
                            rows, d);
@@ -1208,7 +1225,7 @@ extern "C" int d2r_text_encode(d2r_ctx *ctx, const d2r_text *tt, const int32_t *
         const ClipWeights::Layer &L = tt->layers[l];
         hipLaunchKernelGGL(k_layernorm, dim3((rows + 3) / 4), dim3(256), 0, ctx->stream, X, L.ln1_w, L.ln1_b, Xn, rows, d);
         if ((rc = launch_gemm<EPI_BIAS_BF16>(ctx, Xn, L.w_qkv, L.b_qkv, QKV, rows, 3 * d, d))) return rc;
-        hipLaunchKernelGGL(k_attention<true>, dim3(D.num_heads, Cn), dim3(256), attn_lds, ctx->stream, QKV, AO, T, T_pad, d);
+        hipLaunchKernelGGL(k_attention<true>, dim3(D.num_heads, Cn), dim3(ATTN_THREADS), attn_lds, ctx->stream, QKV, AO, T, T_pad, d);
         if ((rc = launch_gemm<EPI_BIAS_RESID_F32>(ctx, AO, L.w_o, L.b_o, X, rows, d, d))) return rc;
         hipLaunchKernelGGL(k_layernorm, dim3((rows + 3) / 4), dim3(256), 0, ctx->stream, X, L.ln2_w, L.ln2_b, Xn, rows, d);
         if ((rc = launch_gemm<EPI_BIAS_GELU_BF16>(ctx, Xn, L.w_fc1, L.b_fc1, H, rows, mlp, d))) return rc;
