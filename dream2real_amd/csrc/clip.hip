@@ -214,6 +214,14 @@ enum { EPI_F32 = 0, EPI_BIAS_BF16 = 1, EPI_BIAS_GELU_BF16 = 2, EPI_BIAS_RESID_F3
 #ifndef D2R_GEMM_ABLATE
 #define D2R_GEMM_ABLATE 0
 #endif
+// L2 prefetch distance of k_gemm in k-steps beyond the LDS-DMA (0 = off); bit 8: also touch the
+// fp32 residual tile during the first k-steps of the residual epilogue variant
+#ifndef D2R_GEMM_PF
+#define D2R_GEMM_PF 0
+#endif
+#ifndef D2R_GEMM_ST            /* cache policy of the bf16 output stores (experiment): 0 plain, 1 nt, 2 sc1, 3 sc0 sc1 */
+#define D2R_GEMM_ST 0
+#endif
 #define BM 256                 /* row padding of every GEMM operand buffer (largest tile height) */
 #define BK 64
 #define GEMM_THREADS 512
@@ -240,12 +248,8 @@ __device__ __forceinline__ uint32_t lds_addr(const void *p)
 template <int N>
 __device__ __forceinline__ void wait_vmcnt()
 {
-    static_assert(N == 0 || N == 6 || N == 8 || N == 12 || N == 16, "add the literal below");
-    if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    if (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    if (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 // C = A[M,K] * W[N,K]^T.  A [M_pad][K] bf16, W [N][K] bf16, K % 64 == 0.
@@ -297,19 +301,49 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void k_gemm(const uint16_t *__re
 #pragma unroll
     for (int i = 0; i < A_PER_WAVE; i++) {
         const uint32_t row = (wave * A_PER_WAVE + i) * 8 + r_in;
-        ag[i] = A + (size_t)(m0 + row) * K + (pc ^ ((row >> 1) & 7u)) * 8;
+#ifdef D2R_GEMM_LDPAD   /* measurement only: garbage operands read with a padded row stride */
+        ag[i] = A + (size_t)((m0 + row) % (uint32_t)((size_t)M_pad * K / (K + D2R_GEMM_LDPAD))) * (K + D2R_GEMM_LDPAD) + (pc ^ ((D2R_GEMM_ABLATE & 32) ? 0u : ((row >> 1) & 7u))) * 8;
+#else
+        ag[i] = A + (size_t)(m0 + row) * K + (pc ^ ((D2R_GEMM_ABLATE & 32) ? 0u : ((row >> 1) & 7u))) * 8;
+#endif
     }
 #pragma unroll
     for (int i = 0; i < B_PER_WAVE; i++) {
         const uint32_t row = (wave * B_PER_WAVE + i) * 8 + r_in;
-        wg[i] = W + (size_t)(n0 + row) * K + (pc ^ ((row >> 1) & 7u)) * 8;
+#ifdef D2R_GEMM_LDPAD
+        wg[i] = W + (size_t)((n0 + row) % (uint32_t)((size_t)N * K / (K + D2R_GEMM_LDPAD))) * (K + D2R_GEMM_LDPAD) + (pc ^ ((D2R_GEMM_ABLATE & 32) ? 0u : ((row >> 1) & 7u))) * 8;
+#else
+        wg[i] = W + (size_t)(n0 + row) * K + (pc ^ ((D2R_GEMM_ABLATE & 32) ? 0u : ((row >> 1) & 7u))) * 8;
+#endif
     }
     const uint32_t nk = K / BK;
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    u32x4_t sink = {0, 0, 0, 0};      // ablation 16 only
+    // L2 prefetch (experiment): lanes 0-31 touch this wave's share of the A rows, lanes 32-63 of the
+    // W rows, one 128-byte line each, PF_D k-steps ahead of the LDS-DMA.  The load's result is never
+    // read; pf stays live to the end of the kernel so its register is not reused under the load.
+    constexpr int PF_D = D2R_GEMM_PF & 0xff;
+    constexpr bool PF_R = (D2R_GEMM_PF & 0x100) && EPI == EPI_BIAS_RESID_F32;
+    uint32_t pf = 0;
+    const uint16_t *pfp = li + wave * (TBM / NWAVE) < TBM && hi == 0
+                              ? A + (size_t)(m0 + wave * (TBM / NWAVE) + (li % (TBM / NWAVE))) * K
+                              : W + (size_t)(n0 + wave * (TBN / NWAVE) + (li % (TBN / NWAVE))) * K;
     // copy `idx` (0 .. PER_STAGE-1) of this wave's share of tile kt into ring buffer buf
     auto stage_one = [&](uint32_t buf, uint32_t kt, int idx) {
         if (D2R_GEMM_ABLATE & 1) return;
+        if ((D2R_GEMM_ABLATE & 64) && idx >= A_PER_WAVE) return;      // measurement only: A operand only
         const uint32_t base = lds0 + buf * STAGE_BYTES;
+#if (D2R_GEMM_ABLATE & 16) && defined(__HIP_DEVICE_COMPILE__)
+        // measurement only: same global reads into a dead register quad instead of the LDS
+#pragma unroll
+        for (int i = 0; i < A_PER_WAVE; i++)
+            if (idx == i) asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(sink) : "v"(ag[i] + (size_t)kt * BK) : "memory");
+#pragma unroll
+        for (int i = 0; i < B_PER_WAVE; i++)
+            if (idx == A_PER_WAVE + i) asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(sink) : "v"(wg[i] + (size_t)kt * BK) : "memory");
+        return;
+#endif
 #pragma unroll
         for (int i = 0; i < A_PER_WAVE; i++)
             if (idx == i) glds16(ag[i] + (size_t)kt * BK, base + (wave * A_PER_WAVE + i) * 1024);
@@ -323,6 +357,17 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void k_gemm(const uint16_t *__re
         for (int c = 0; c < PER_STAGE; c++) stage_one(buf, kt, c);
     };
 
+#ifdef D2R_GEMM_STAGGER
+    // The first round of workgroups (one per CU) starts spread over one tile time so that later
+    // rounds do not run their epilogues (HBM writes) all at once and their main loops (no HBM
+    // traffic) all at once.  100 MHz wall clock ticks; a tile takes about 1.4 us per k-step.
+    if (blockIdx.x < 256 && gridDim.x >= 1024) {
+        const uint32_t slot = (blockIdx.x >> 3) % D2R_GEMM_STAGGER;
+        // s_sleep 16 = about 1024 shader cycles; a k-step takes about 3300
+        const uint32_t n_sleep = (nk * 33u + 80u) * slot / (D2R_GEMM_STAGGER * 10u);
+        for (uint32_t i = 0; i < n_sleep; i++) __builtin_amdgcn_s_sleep(16);
+    }
+#endif
     // prologue: STAGES-1 tiles in flight, the first one landed
     stage(0, 0);
     if (STAGES == 3 && nk > 1) {
@@ -382,10 +427,27 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void k_gemm(const uint16_t *__re
                 __builtin_amdgcn_s_setprio(0);
             }
             // tile kt+1 must have landed; with 3 stages this wave's copies of tile kt+2 stay in flight
-            if (STAGES == 3 && ahead < nk)
-                wait_vmcnt<PER_STAGE>();
-            else
-                wait_vmcnt<0>();
+            bool pf_on = false;
+            if (PF_D > 0) {
+                pf_on = ahead + PF_D < nk;
+                if (pf_on) asm volatile("global_load_dword %0, %1, off" : "+v"(pf) : "v"(pfp + (size_t)(ahead + PF_D) * BK) : "memory");
+            }
+            if (PF_R) {
+                // 4 loads per wave cover the wave's 32 rows x (TBN*4/128) lines of the residual tile
+                if (kt < TBN / 64) {
+                    const uint32_t idx = kt * 64 + lane, lpr = TBN / 32;     // lines per row
+                    uint32_t row = m0 + wave * (TBM / NWAVE) + idx / lpr;
+                    row = row < M_real ? row : M_real - 1;
+                    const float *rp = (const float *)Cout + (size_t)row * N + n0 + (idx % lpr) * 32;
+                    asm volatile("global_load_dword %0, %1, off" : "+v"(pf) : "v"(rp) : "memory");
+                    pf_on = true;      // counted below as one more op in flight (a landed A-prefetch is harmless to wait for)
+                }
+            }
+            if (STAGES == 3 && ahead < nk) {
+                if (pf_on) wait_vmcnt<PER_STAGE + 1>(); else wait_vmcnt<PER_STAGE>();
+            } else {
+                if (pf_on) wait_vmcnt<1>(); else wait_vmcnt<0>();
+            }
             __syncthreads();
             cur = cur + 1 == STAGES ? 0 : cur + 1;
         }
@@ -404,43 +466,89 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void k_gemm(const uint16_t *__re
             for (int r = 0; r < 16; r++) asm volatile("" ::"v"(acc[i][j][r]));
     return;
 #endif
+    if (PF_D > 0 || PF_R || (D2R_GEMM_ABLATE & 16)) {
+        wait_vmcnt<0>();
+        asm volatile("" ::"v"(pf), "v"(sink));
+    }
     constexpr uint32_t EP_LD = 68;                                   // floats per LDS row (pad 4)
     float *ep = (float *)smem + wave * (32 * EP_LD);                 // 8.5 KiB per wave
-    const uint32_t c4 = (lane & 15) * 4, rl0 = lane >> 4;
-    const uint32_t col = n0 + wn + c4;
-    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (EPI != EPI_F32) bv = *(const float4 *)(bias + col);
-#pragma unroll
-    for (int i = 0; i < MT; i++) {
+    auto transpose_in = [&](int i) {
+        if (D2R_GEMM_ABLATE & 256) return;
 #pragma unroll
         for (int j = 0; j < 2; j++)
 #pragma unroll
             for (int r = 0; r < 16; r++) ep[((r & 3) + 8 * (r >> 2) + 4 * hi) * EP_LD + j * 32 + li] = acc[i][j][r];
-#pragma unroll 4
-        for (int k = 0; k < 8; k++) {
-            const uint32_t rl = rl0 + 4 * k, row = m0 + wm + i * 32 + rl;
-            float4 v = *(const float4 *)(ep + rl * EP_LD + c4);
-            if (row >= M_real) continue;
-            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-            const uint32_t o = row * N + col;                        // < 2^32 elements (checked on host)
-            if (EPI == EPI_F32) {
-                *(float4 *)((float *)Cout + o) = v;
-            } else if (EPI == EPI_BIAS_RESID_F32) {
-                float4 *dst = (float4 *)((float *)Cout + o);
-                float4 x = *dst;
-                *dst = make_float4(x.x + v.x, x.y + v.y, x.z + v.z, x.w + v.w);
-            } else {
+    };
+    if (EPI == EPI_F32 || EPI == EPI_BIAS_RESID_F32) {
+        // fp32 outputs: a lane owns 4 columns of a row, 16 lanes a 256-byte row segment.  The residual
+        // rows of TWO 32-row groups (16 float4 per lane) are requested before the first transpose, so
+        // a tile pays two HBM round trips instead of eight.
+        const uint32_t c4 = (lane & 15) * 4, rl0 = lane >> 4;
+        const uint32_t col = n0 + wn + c4;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (EPI != EPI_F32) bv = *(const float4 *)(bias + col);
+        static_assert(MT % 2 == 0, "epilogue handles m-tiles in pairs");
+#pragma unroll
+        for (int ih = 0; ih < MT; ih += 2) {
+            float4 xr[2][8];
+            if (EPI == EPI_BIAS_RESID_F32) {
+#pragma unroll
+                for (int ii = 0; ii < 2; ii++)
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const uint32_t row = m0 + wm + (ih + ii) * 32 + rl0 + 4 * k;
+                        xr[ii][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (row < M_real && !(D2R_GEMM_ABLATE & 128)) xr[ii][k] = *(const float4 *)((const float *)Cout + row * N + col);
+                    }
+            }
+#pragma unroll
+            for (int ii = 0; ii < 2; ii++) {
+                transpose_in(ih + ii);
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const uint32_t rl = rl0 + 4 * k, row = m0 + wm + (ih + ii) * 32 + rl;
+                    float4 v = (D2R_GEMM_ABLATE & 256) ? make_float4(acc[ih + ii][0][k], acc[ih + ii][0][k + 8], acc[ih + ii][1][k], acc[ih + ii][1][k + 8])
+                                                       : *(const float4 *)(ep + rl * EP_LD + c4);
+                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                    if (EPI == EPI_BIAS_RESID_F32) {
+                        v.x += xr[ii][k].x; v.y += xr[ii][k].y; v.z += xr[ii][k].z; v.w += xr[ii][k].w;
+                    }
+#if (D2R_GEMM_ABLATE & 128) && defined(__HIP_DEVICE_COMPILE__)
+                    asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+                    continue;
+#endif
+                    if (row < M_real) *(float4 *)((float *)Cout + row * N + col) = v;       // < 2^32 elements (checked on host)
+                }
+            }
+        }
+    } else {
+        // bf16 outputs: a lane owns 8 columns (one 16-byte store), 8 lanes a 128-byte row segment
+        const uint32_t c8 = (lane & 7) * 8, rl0 = lane >> 3;
+        const uint32_t col = n0 + wn + c8;
+        const float4 b0 = *(const float4 *)(bias + col), b1 = *(const float4 *)(bias + col + 4);
+#pragma unroll
+        for (int i = 0; i < MT; i++) {
+            transpose_in(i);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t rl = rl0 + 8 * k, row = m0 + wm + i * 32 + rl;
+                float4 u = (D2R_GEMM_ABLATE & 256) ? make_float4(acc[i][0][k], acc[i][0][k + 8], acc[i][1][k], acc[i][1][k + 8])
+                                                   : *(const float4 *)(ep + rl * EP_LD + c8);
+                float4 w = (D2R_GEMM_ABLATE & 256) ? make_float4(acc[i][0][k + 4], acc[i][0][k + 12], acc[i][1][k + 4], acc[i][1][k + 12])
+                                                   : *(const float4 *)(ep + rl * EP_LD + c8 + 4);
+                float f[8] = {u.x + b0.x, u.y + b0.y, u.z + b0.z, u.w + b0.w, w.x + b1.x, w.y + b1.y, w.z + b1.z, w.w + b1.w};
                 if (EPI == EPI_BIAS_GELU_BF16) {
                     // quick_gelu: x * sigmoid(1.702 x) = x / (1 + exp2(-1.702 log2(e) x))
-                    v.x *= __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930156f * v.x));
-                    v.y *= __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930156f * v.y));
-                    v.z *= __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930156f * v.z));
-                    v.w *= __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930156f * v.w));
+#pragma unroll
+                    for (int e = 0; e < 8; e++)
+                        f[e] *= __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930156f * f[e]));
                 }
-                uint2 pk;
-                pk.x = pack2(v.x, v.y);
-                pk.y = pack2(v.z, v.w);
-                *(uint2 *)((uint16_t *)Cout + o) = pk;
+                const uint4 pk = make_uint4(pack2(f[0], f[1]), pack2(f[2], f[3]), pack2(f[4], f[5]), pack2(f[6], f[7]));
+#if (D2R_GEMM_ABLATE & 128) && defined(__HIP_DEVICE_COMPILE__)
+                asm volatile("" ::"v"(pk.x), "v"(pk.y), "v"(pk.z), "v"(pk.w));
+                continue;
+#endif
+                if (row < M_real) *(uint4 *)((uint16_t *)Cout + row * N + col) = pk;
             }
         }
     }

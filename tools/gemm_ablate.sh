@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run on the GPU box: rebuild libd2r with each k_gemm ablation mask and report CLIP ms/step.
-for A in 0 1 2 3 4 7 8 12; do
+for A in ${MASKS:-0 1 2 3 4 7 8 12}; do
   touch dream2real_amd/csrc/clip.hip
   make -C dream2real_amd/csrc -j3 GEMM_ABLATE=$A 2>&1 | grep -E " error" 
   echo -n "ablate=$A  "
