@@ -252,6 +252,101 @@ __device__ __forceinline__ void wait_vmcnt()
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// Epilogue shared by the GEMM kernels: each wave transposes its fp32 tile through LDS 32 rows at a
+// time (the staging ring is free: the main loop ended on a barrier with no DMA in flight) so that a
+// lane owns consecutive columns of a row: bias / quick_gelu / fp32 residual on float4, 16-byte stores.
+// acc[i][j][r] <-> row 32i+(r&3)+8(r>>2)+4hi, col 32j+li of the wave tile whose origin is (row0, col0).
+template <int EPI, int MT>
+__device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], uint8_t *smem, uint32_t wave, uint32_t lane,
+                                              uint32_t row0, uint32_t col0, const float *__restrict__ bias,
+                                              void *__restrict__ Cout, uint32_t N, uint32_t M_real)
+{
+    const uint32_t li = lane & 31, hi = lane >> 5;
+    const uint32_t m0 = row0, wm = 0, n0 = col0, wn = 0;
+    constexpr uint32_t EP_LD = 68;                                   // floats per LDS row (pad 4)
+    float *ep = (float *)smem + wave * (32 * EP_LD);                 // 8.5 KiB per wave
+    auto transpose_in = [&](int i) {
+        if (D2R_GEMM_ABLATE & 256) return;
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) ep[((r & 3) + 8 * (r >> 2) + 4 * hi) * EP_LD + j * 32 + li] = acc[i][j][r];
+    };
+    if (EPI == EPI_F32 || EPI == EPI_BIAS_RESID_F32) {
+        // fp32 outputs: a lane owns 4 columns of a row, 16 lanes a 256-byte row segment.  The residual
+        // rows of TWO 32-row groups (16 float4 per lane) are requested before the first transpose, so
+        // a tile pays two HBM round trips instead of eight.
+        const uint32_t c4 = (lane & 15) * 4, rl0 = lane >> 4;
+        const uint32_t col = n0 + wn + c4;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (EPI != EPI_F32) bv = *(const float4 *)(bias + col);
+        static_assert(MT % 2 == 0, "epilogue handles m-tiles in pairs");
+#pragma unroll
+        for (int ih = 0; ih < MT; ih += 2) {
+            float4 xr[2][8];
+            if (EPI == EPI_BIAS_RESID_F32) {
+#pragma unroll
+                for (int ii = 0; ii < 2; ii++)
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const uint32_t row = m0 + wm + (ih + ii) * 32 + rl0 + 4 * k;
+                        xr[ii][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (row < M_real && !(D2R_GEMM_ABLATE & 128)) xr[ii][k] = *(const float4 *)((const float *)Cout + row * N + col);
+                    }
+            }
+#pragma unroll
+            for (int ii = 0; ii < 2; ii++) {
+                transpose_in(ih + ii);
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const uint32_t rl = rl0 + 4 * k, row = m0 + wm + (ih + ii) * 32 + rl;
+                    float4 v = (D2R_GEMM_ABLATE & 256) ? make_float4(acc[ih + ii][0][k], acc[ih + ii][0][k + 8], acc[ih + ii][1][k], acc[ih + ii][1][k + 8])
+                                                       : *(const float4 *)(ep + rl * EP_LD + c4);
+                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                    if (EPI == EPI_BIAS_RESID_F32) {
+                        v.x += xr[ii][k].x; v.y += xr[ii][k].y; v.z += xr[ii][k].z; v.w += xr[ii][k].w;
+                    }
+#if (D2R_GEMM_ABLATE & 128) && defined(__HIP_DEVICE_COMPILE__)
+                    asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+                    continue;
+#endif
+                    if (row < M_real) *(float4 *)((float *)Cout + row * N + col) = v;       // < 2^32 elements (checked on host)
+                }
+            }
+        }
+    } else {
+        // bf16 outputs: a lane owns 8 columns (one 16-byte store), 8 lanes a 128-byte row segment
+        const uint32_t c8 = (lane & 7) * 8, rl0 = lane >> 3;
+        const uint32_t col = n0 + wn + c8;
+        const float4 b0 = *(const float4 *)(bias + col), b1 = *(const float4 *)(bias + col + 4);
+#pragma unroll
+        for (int i = 0; i < MT; i++) {
+            transpose_in(i);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t rl = rl0 + 8 * k, row = m0 + wm + i * 32 + rl;
+                float4 u = (D2R_GEMM_ABLATE & 256) ? make_float4(acc[i][0][k], acc[i][0][k + 8], acc[i][1][k], acc[i][1][k + 8])
+                                                   : *(const float4 *)(ep + rl * EP_LD + c8);
+                float4 w = (D2R_GEMM_ABLATE & 256) ? make_float4(acc[i][0][k + 4], acc[i][0][k + 12], acc[i][1][k + 4], acc[i][1][k + 12])
+                                                   : *(const float4 *)(ep + rl * EP_LD + c8 + 4);
+                float f[8] = {u.x + b0.x, u.y + b0.y, u.z + b0.z, u.w + b0.w, w.x + b1.x, w.y + b1.y, w.z + b1.z, w.w + b1.w};
+                if (EPI == EPI_BIAS_GELU_BF16) {
+                    // quick_gelu: x * sigmoid(1.702 x) = x / (1 + exp2(-1.702 log2(e) x))
+#pragma unroll
+                    for (int e = 0; e < 8; e++)
+                        f[e] *= __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930156f * f[e]));
+                }
+                const uint4 pk = make_uint4(pack2(f[0], f[1]), pack2(f[2], f[3]), pack2(f[4], f[5]), pack2(f[6], f[7]));
+#if (D2R_GEMM_ABLATE & 128) && defined(__HIP_DEVICE_COMPILE__)
+                asm volatile("" ::"v"(pk.x), "v"(pk.y), "v"(pk.z), "v"(pk.w));
+                continue;
+#endif
+                if (row < M_real) *(uint4 *)((uint16_t *)Cout + row * N + col) = pk;
+            }
+        }
+    }
+}
+
 // C = A[M,K] * W[N,K]^T.  A [M_pad][K] bf16, W [N][K] bf16, K % 64 == 0.
 // 8 waves as WGM x WGN, each wave MT x 2 MFMA 32x32x16 tiles:
 //   <WGM=4, WGN=2, MT=2, STAGES=3>  256x128 tile, 3-stage ring, counted vmcnt  (N = 768 products)
@@ -470,88 +565,180 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void k_gemm(const uint16_t *__re
         wait_vmcnt<0>();
         asm volatile("" ::"v"(pf), "v"(sink));
     }
-    constexpr uint32_t EP_LD = 68;                                   // floats per LDS row (pad 4)
-    float *ep = (float *)smem + wave * (32 * EP_LD);                 // 8.5 KiB per wave
-    auto transpose_in = [&](int i) {
-        if (D2R_GEMM_ABLATE & 256) return;
+    gemm_epilogue<EPI, MT>(acc, smem, wave, lane, m0 + wm, n0 + wn, bias, Cout, N, M_real);
+}
+
+// ---- 256x256x64 GEMM with a half-tile staging ring that never drains ("8-phase" K loop) ----
+//
+// Same operands, tile order and epilogue as k_gemm<EPI, 2, 4, 4, 2>, different K loop.  The 128 KiB of
+// LDS are 8 slots of 16 KiB, one per half-tile kind and K-tile parity:
+//     A half h = rows {128 wm + 64 h + 0..63 : wm = 0,1},  B half h = W rows {64 wn + 32 h + 0..31 : wn = 0..3}
+// so a wave's 128x64 output splits into four 64x32 quadrants (mh, nh), each needing ONE A half and ONE B
+// half.  A K-tile pair is 8 phases; every phase
+//     1. reads one half-tile from LDS into fragment registers that the current MFMAs do not use,
+//     2. issues the LDS-DMA of one half-tile 6 phases ahead (2 x 1 KiB per wave) into the slot that was
+//        read two phases ago,
+//     3. runs the 8 MFMAs of one quadrant from fragments read in earlier phases,
+//     4. waits until all but its 10 newest DMAs have landed, lgkmcnt(0), workgroup barrier.
+// Position s of the half-tile sequence (kind s mod 8: A0 B0 B1 A1 | A0 B1 B0 A1, the second group for
+// the odd K-tile) lives in slot s mod 8, is staged in phase s-6, has landed by the barrier that ends
+// phase s-1 and is read in phase s; its slot is restaged in phase s+2.  Five half-tiles (80 KiB per CU)
+// are in flight at every barrier and no wait ever drains the queue until the last K-tile pair.
+// Quadrant order (0,0)(0,1)(1,1)(1,0) | (0,1)(0,0)(1,0)(1,1) makes the register set that a phase
+// overwrites the one its MFMAs do not read.  Requires K % 128 == 0, N % 256 == 0.
+__device__ __forceinline__ void glds16s(uint32_t voff, const void *sbase, uint32_t lds_byte_addr)
+{
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A, const uint16_t *__restrict__ W,
+                                                 const float *__restrict__ bias, void *__restrict__ Cout,
+                                                 uint32_t M_pad, uint32_t N, uint32_t K, uint32_t M_real)
+{
+    constexpr uint32_t SLOT = 128 * BK * 2;          // 16 KiB
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t nwg = gridDim.x, tiles_n = N / 256;
+    const uint32_t xcd = blockIdx.x & 7u, loc = blockIdx.x >> 3, q = nwg >> 3, rr8 = nwg & 7u;
+    const uint32_t tile = (xcd < rr8 ? xcd * (q + 1) : rr8 * (q + 1) + (xcd - rr8) * q) + loc;
+    const uint32_t m0 = (tile / tiles_n) * 256, n0 = (tile % tiles_n) * 256;
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t wm = wave >> 2, wn = wave & 3;
+    const uint32_t li = lane & 31, hi = lane >> 5;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) ep[((r & 3) + 8 * (r >> 2) + 4 * hi) * EP_LD + j * 32 + li] = acc[i][j][r];
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+    // staging: piece qq of a half-tile = 8 slot rows x 128 B per wave instruction
+    const uint32_t r_in = lane >> 3, pc = lane & 7;
+    uint32_t voffA[2], voffB[2];
+#pragma unroll
+    for (int qq = 0; qq < 2; qq++) {
+        const uint32_t sr = (wave * 2 + qq) * 8 + r_in;                       // slot row 0..127
+        const uint32_t chunk = pc ^ ((sr >> 1) & 7u);
+        voffA[qq] = (((sr >> 6) * 128 + (sr & 63)) * K + chunk * 8) * 2;       // bytes from the half's first row
+        voffB[qq] = (((sr >> 5) * 64 + (sr & 31)) * K + chunk * 8) * 2;
+    }
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+    const uint32_t nk = K / BK;
+    // kind -> operand / half
+    auto stage_pos = [&](int kind, uint32_t kt) {
+        const bool isA = kind == 0 || kind == 3 || kind == 4 || kind == 7;
+        const uint32_t h = (kind == 2 || kind == 3 || kind == 5 || kind == 7) ? 1u : 0u;
+        const uint16_t *base = isA ? A + (size_t)(m0 + h * 64) * K + (size_t)kt * BK
+                                   : W + (size_t)(n0 + h * 32) * K + (size_t)kt * BK;
+#pragma unroll
+        for (int qq = 0; qq < 2; qq++)
+            glds16s(isA ? voffA[qq] : voffB[qq], base, lds0 + kind * SLOT + (wave * 2 + qq) * 1024);
     };
-    if (EPI == EPI_F32 || EPI == EPI_BIAS_RESID_F32) {
-        // fp32 outputs: a lane owns 4 columns of a row, 16 lanes a 256-byte row segment.  The residual
-        // rows of TWO 32-row groups (16 float4 per lane) are requested before the first transpose, so
-        // a tile pays two HBM round trips instead of eight.
-        const uint32_t c4 = (lane & 15) * 4, rl0 = lane >> 4;
-        const uint32_t col = n0 + wn + c4;
-        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (EPI != EPI_F32) bv = *(const float4 *)(bias + col);
-        static_assert(MT % 2 == 0, "epilogue handles m-tiles in pairs");
+    // fragment read addresses: the swizzle term is the same for every row this lane reads
+    // ((row >> 1) & 7 == (li >> 1) & 7), so four byte offsets per operand serve all kinds; the slot and
+    // m-tile go into the instruction's immediate offset (kinds 4-7 lie beyond its 64 KiB reach and
+    // add 65536 on the VALU instead of keeping eight more address registers alive)
+    uint32_t aoff[4], boff[4];
 #pragma unroll
-        for (int ih = 0; ih < MT; ih += 2) {
-            float4 xr[2][8];
-            if (EPI == EPI_BIAS_RESID_F32) {
-#pragma unroll
-                for (int ii = 0; ii < 2; ii++)
-#pragma unroll
-                    for (int k = 0; k < 8; k++) {
-                        const uint32_t row = m0 + wm + (ih + ii) * 32 + rl0 + 4 * k;
-                        xr[ii][k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (row < M_real && !(D2R_GEMM_ABLATE & 128)) xr[ii][k] = *(const float4 *)((const float *)Cout + row * N + col);
-                    }
-            }
-#pragma unroll
-            for (int ii = 0; ii < 2; ii++) {
-                transpose_in(ih + ii);
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    const uint32_t rl = rl0 + 4 * k, row = m0 + wm + (ih + ii) * 32 + rl;
-                    float4 v = (D2R_GEMM_ABLATE & 256) ? make_float4(acc[ih + ii][0][k], acc[ih + ii][0][k + 8], acc[ih + ii][1][k], acc[ih + ii][1][k + 8])
-                                                       : *(const float4 *)(ep + rl * EP_LD + c4);
-                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-                    if (EPI == EPI_BIAS_RESID_F32) {
-                        v.x += xr[ii][k].x; v.y += xr[ii][k].y; v.z += xr[ii][k].z; v.w += xr[ii][k].w;
-                    }
-#if (D2R_GEMM_ABLATE & 128) && defined(__HIP_DEVICE_COMPILE__)
-                    asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
-                    continue;
-#endif
-                    if (row < M_real) *(float4 *)((float *)Cout + row * N + col) = v;       // < 2^32 elements (checked on host)
-                }
-            }
+    for (int s4 = 0; s4 < 4; s4++) {
+        const uint32_t sw = ((2 * s4 + hi) ^ ((li >> 1) & 7u)) << 4;
+        aoff[s4] = (wm * 64 + li) * 128 + sw;
+        boff[s4] = (wn * 32 + li) * 128 + sw;
+    }
+    uint4 fa[2][2][4], fb[2][4];
+    auto read_pos = [&](int kind) {
+        const bool isA = kind == 0 || kind == 3 || kind == 4 || kind == 7;
+        const int h = (kind == 2 || kind == 3 || kind == 5 || kind == 7) ? 1 : 0;
+        uint32_t far = 0;
+        if (kind >= 4) {
+            far = 65536;
+            asm volatile("" : "+v"(far));            // not loop-invariant for the optimiser
         }
-    } else {
-        // bf16 outputs: a lane owns 8 columns (one 16-byte store), 8 lanes a 128-byte row segment
-        const uint32_t c8 = (lane & 7) * 8, rl0 = lane >> 3;
-        const uint32_t col = n0 + wn + c8;
-        const float4 b0 = *(const float4 *)(bias + col), b1 = *(const float4 *)(bias + col + 4);
+        const uint8_t *sb = smem + (kind & 3) * SLOT;
+        if (isA) {
 #pragma unroll
-        for (int i = 0; i < MT; i++) {
-            transpose_in(i);
+            for (int mt = 0; mt < 2; mt++)
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint32_t rl = rl0 + 8 * k, row = m0 + wm + i * 32 + rl;
-                float4 u = (D2R_GEMM_ABLATE & 256) ? make_float4(acc[i][0][k], acc[i][0][k + 8], acc[i][1][k], acc[i][1][k + 8])
-                                                   : *(const float4 *)(ep + rl * EP_LD + c8);
-                float4 w = (D2R_GEMM_ABLATE & 256) ? make_float4(acc[i][0][k + 4], acc[i][0][k + 12], acc[i][1][k + 4], acc[i][1][k + 12])
-                                                   : *(const float4 *)(ep + rl * EP_LD + c8 + 4);
-                float f[8] = {u.x + b0.x, u.y + b0.y, u.z + b0.z, u.w + b0.w, w.x + b1.x, w.y + b1.y, w.z + b1.z, w.w + b1.w};
-                if (EPI == EPI_BIAS_GELU_BF16) {
-                    // quick_gelu: x * sigmoid(1.702 x) = x / (1 + exp2(-1.702 log2(e) x))
+                for (int s4 = 0; s4 < 4; s4++) fa[h][mt][s4] = *(const uint4 *)(sb + (aoff[s4] + far) + mt * 4096);
+        } else {
 #pragma unroll
-                    for (int e = 0; e < 8; e++)
-                        f[e] *= __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930156f * f[e]));
-                }
-                const uint4 pk = make_uint4(pack2(f[0], f[1]), pack2(f[2], f[3]), pack2(f[4], f[5]), pack2(f[6], f[7]));
-#if (D2R_GEMM_ABLATE & 128) && defined(__HIP_DEVICE_COMPILE__)
-                asm volatile("" ::"v"(pk.x), "v"(pk.y), "v"(pk.z), "v"(pk.w));
-                continue;
-#endif
-                if (row < M_real) *(uint4 *)((uint16_t *)Cout + row * N + col) = pk;
+            for (int s4 = 0; s4 < 4; s4++) fb[h][s4] = *(const uint4 *)(sb + (boff[s4] + far));
+        }
+    };
+    auto mfma_quadrant = [&](int mh, int nh) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++)
+#pragma unroll
+            for (int mt = 0; mt < 2; mt++) {
+                union { uint4 u; bf16x8 v; } a, b;
+                a.u = fa[mh][mt][s4];
+                b.u = fb[nh][s4];
+                acc[mh * 2 + mt][nh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc[mh * 2 + mt][nh], 0, 0, 0);
             }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto bar = [&]() {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+
+    // prologue: positions 0..7 (both K-tiles of the first pair) are requested at once
+#pragma unroll
+    for (int kind = 0; kind < 8; kind++) stage_pos(kind, kind >= 4 ? 1u : 0u);
+    wait_vmcnt<10>();                                 // positions 0, 1, 2 have landed
+    bar();
+    read_pos(0);
+    read_pos(1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    bar();                                            // slots 0, 1 may be restaged from phase 2 on
+    // The two wave rows run half a phase apart: wm = 1 starts one barrier late, so that on every SIMD
+    // one wave is in its MFMA section while the other reads LDS and issues DMA.  A wave waits for the
+    // DMA that the NEXT phase reads at the end of its section that precedes the barrier in front of
+    // group 0's next read section: after the MFMAs for wm = 0, after the DMA issue for wm = 1.
+    if (wm == 1) bar();
+
+    const uint32_t n_iter = nk / 2;
+    for (uint32_t u = 0; u < n_iter; u++) {
+        const bool last = u + 1 == n_iter;            // block-uniform
+#pragma unroll
+        for (int P = 0; P < 8; P++) {
+            auto wait_next = [&]() {                  // position 8u+P+3 must have landed; younger ones stay in flight
+                if (!last) {
+                    wait_vmcnt<10>();
+                } else {
+                    if (P == 0) wait_vmcnt<8>();
+                    if (P == 1) wait_vmcnt<6>();
+                    if (P == 2) wait_vmcnt<4>();
+                    if (P == 3) wait_vmcnt<2>();
+                    if (P == 4) wait_vmcnt<0>();
+                }
+            };
+            // read section: position 8u+P+2 (kind (P+2) mod 8) for the next phase's MFMAs; stage position
+            // 8u+P+8 (kind P) of K-tile 2(u+1) + (P >= 4) -- nothing is left to stage in the last pair
+            if (!(last && P >= 6)) read_pos((P + 2) & 7);
+            if (!last) stage_pos(P, 2 * (u + 1) + (P >= 4 ? 1u : 0u));
+            if (wm == 1) wait_next();
+            __builtin_amdgcn_sched_barrier(0);
+            bar();
+            // MFMA section
+            const int mh = (P == 2 || P == 3 || P == 6 || P == 7) ? 1 : 0;
+            const int nh = (P == 1 || P == 2 || P == 4 || P == 7) ? 1 : 0;
+            mfma_quadrant(mh, nh);
+            __builtin_amdgcn_sched_barrier(0);
+            if (wm == 0) wait_next();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            bar();
         }
     }
+    if (wm == 0) bar();
+    __syncthreads();
+    gemm_epilogue<EPI, 4>(acc, smem, wave, lane, m0 + wm * 128, n0 + wn * 64, bias, Cout, N, M_real);
 }
 
 // -------------------------------------------------------- embeddings + LN
@@ -1045,7 +1232,21 @@ static int launch_gemm(d2r_ctx *ctx, const uint16_t *A, const uint16_t *W, const
     if (ctx->gemm_cfg == 2) return launch_gemm_cfg<EPI, 4, 2, 2, 3>(ctx, A, W, bias, C, M_real, N, K);   // force 256x128
     // 256x256 tiles whenever they still cover the 256 CUs at least ~4 times, else 256x128
     const uint64_t tiles256 = (uint64_t)(round_up(M_real, BM) / 256) * (N / 256);
-    if (N % 256 == 0 && (N >= 2048 || tiles256 >= 1024)) return launch_gemm_cfg<EPI, 2, 4, 4, 2>(ctx, A, W, bias, C, M_real, N, K);
+    if (N % 256 == 0 && (N >= 2048 || tiles256 >= 1024)) {
+        if (K % 128 == 0 && ctx->gemm_cfg != 1) {         // gemm_cfg 1 = the two-stage K loop (kept for comparison)
+            const uint32_t M_pad = round_up(M_real, BM);
+            static bool attr8 = false;
+            if (!attr8) {
+                (void)hipFuncSetAttribute((const void *)k_gemm8<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+                attr8 = true;
+            }
+            hipLaunchKernelGGL((k_gemm8<EPI>), dim3((M_pad / 256) * (N / 256)), dim3(512), 128 * 1024, ctx->stream, A, W, bias,
+                               C, M_pad, N, K, M_real);
+            D2R_HIP(ctx, hipGetLastError());
+            return D2R_OK;
+        }
+        return launch_gemm_cfg<EPI, 2, 4, 4, 2>(ctx, A, W, bias, C, M_real, N, K);
+    }
     return launch_gemm_cfg<EPI, 4, 2, 2, 3>(ctx, A, W, bias, C, M_real, N, K);
 }
 
