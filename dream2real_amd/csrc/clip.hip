@@ -219,6 +219,9 @@ enum { EPI_F32 = 0, EPI_BIAS_BF16 = 1, EPI_BIAS_GELU_BF16 = 2, EPI_BIAS_RESID_F3
 #ifndef D2R_GEMM_PF
 #define D2R_GEMM_PF 0
 #endif
+#ifndef D2R_GEMM_LD            /* cache policy of the k_gemm8 LDS-DMA loads (experiment): 0 plain, 1 nt, 2 sc1, 3 sc0 */
+#define D2R_GEMM_LD 0
+#endif
 #ifndef D2R_GEMM_ST            /* cache policy of the bf16 output stores (experiment): 0 plain, 1 nt, 2 sc1, 3 sc0 sc1 */
 #define D2R_GEMM_ST 0
 #endif
@@ -256,28 +259,33 @@ __device__ __forceinline__ void wait_vmcnt()
 // time (the staging ring is free: the main loop ended on a barrier with no DMA in flight) so that a
 // lane owns consecutive columns of a row: bias / quick_gelu / fp32 residual on float4, 16-byte stores.
 // acc[i][j][r] <-> row 32i+(r&3)+8(r>>2)+4hi, col 32j+li of the wave tile whose origin is (row0, col0).
-template <int EPI, int MT>
-__device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], uint8_t *smem, uint32_t wave, uint32_t lane,
+#define EP_LD 68u                          /* floats per row of the epilogue's LDS transpose buffer (pad 4) */
+#define EP_WAVE_FLOATS (8u * EP_LD)        /* 8 rows per wave: 2176 bytes */
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+// `hook` runs once, after the first batch of residual loads has been issued (at the top for the other
+// variants): the persistent kernel requests the next tile's operands there, behind the loads whose
+// compiler-placed vmcnt waits would otherwise also wait for those requests.
+template <int EPI, int MT, typename Hook = NoHook>
+__device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], float *ep, uint32_t lane,
                                               uint32_t row0, uint32_t col0, const float *__restrict__ bias,
-                                              void *__restrict__ Cout, uint32_t N, uint32_t M_real)
+                                              void *__restrict__ Cout, uint32_t N, uint32_t M_real, Hook hook = Hook())
 {
+    // ep: this wave's private 8 x EP_LD float buffer.  Eight rows of the wave tile at a time:
+    // acc[i][j][4p..4p+3] of both lane halves are rows 8p..8p+7 of m-tile i.
     const uint32_t li = lane & 31, hi = lane >> 5;
-    const uint32_t m0 = row0, wm = 0, n0 = col0, wn = 0;
-    constexpr uint32_t EP_LD = 68;                                   // floats per LDS row (pad 4)
-    float *ep = (float *)smem + wave * (32 * EP_LD);                 // 8.5 KiB per wave
-    auto transpose_in = [&](int i) {
+    auto transpose_in = [&](int i, int p8) {
         if (D2R_GEMM_ABLATE & 256) return;
 #pragma unroll
         for (int j = 0; j < 2; j++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) ep[((r & 3) + 8 * (r >> 2) + 4 * hi) * EP_LD + j * 32 + li] = acc[i][j][r];
+            for (int r = 0; r < 4; r++) ep[(r + 4 * hi) * EP_LD + j * 32 + li] = acc[i][j][4 * p8 + r];
     };
     if (EPI == EPI_F32 || EPI == EPI_BIAS_RESID_F32) {
         // fp32 outputs: a lane owns 4 columns of a row, 16 lanes a 256-byte row segment.  The residual
         // rows of TWO 32-row groups (16 float4 per lane) are requested before the first transpose, so
         // a tile pays two HBM round trips instead of eight.
         const uint32_t c4 = (lane & 15) * 4, rl0 = lane >> 4;
-        const uint32_t col = n0 + wn + c4;
+        const uint32_t col = col0 + c4;
         float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
         if (EPI != EPI_F32) bv = *(const float4 *)(bias + col);
         static_assert(MT % 2 == 0, "epilogue handles m-tiles in pairs");
@@ -289,46 +297,51 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], uint8_t *sme
                 for (int ii = 0; ii < 2; ii++)
 #pragma unroll
                     for (int k = 0; k < 8; k++) {
-                        const uint32_t row = m0 + wm + (ih + ii) * 32 + rl0 + 4 * k;
+                        const uint32_t row = row0 + (ih + ii) * 32 + rl0 + 4 * k;
                         xr[ii][k] = make_float4(0.f, 0.f, 0.f, 0.f);
                         if (row < M_real && !(D2R_GEMM_ABLATE & 128)) xr[ii][k] = *(const float4 *)((const float *)Cout + row * N + col);
                     }
             }
+            if (ih == 0) hook();
 #pragma unroll
-            for (int ii = 0; ii < 2; ii++) {
-                transpose_in(ih + ii);
+            for (int ii = 0; ii < 2; ii++)
 #pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    const uint32_t rl = rl0 + 4 * k, row = m0 + wm + (ih + ii) * 32 + rl;
-                    float4 v = (D2R_GEMM_ABLATE & 256) ? make_float4(acc[ih + ii][0][k], acc[ih + ii][0][k + 8], acc[ih + ii][1][k], acc[ih + ii][1][k + 8])
-                                                       : *(const float4 *)(ep + rl * EP_LD + c4);
-                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-                    if (EPI == EPI_BIAS_RESID_F32) {
-                        v.x += xr[ii][k].x; v.y += xr[ii][k].y; v.z += xr[ii][k].z; v.w += xr[ii][k].w;
-                    }
+                for (int p8 = 0; p8 < 4; p8++) {
+                    transpose_in(ih + ii, p8);
+#pragma unroll
+                    for (int qq = 0; qq < 2; qq++) {
+                        const int k = 2 * p8 + qq;
+                        const uint32_t row = row0 + (ih + ii) * 32 + rl0 + 4 * k;
+                        float4 v = (D2R_GEMM_ABLATE & 256) ? make_float4(acc[ih + ii][0][k], acc[ih + ii][0][k + 8], acc[ih + ii][1][k], acc[ih + ii][1][k + 8])
+                                                           : *(const float4 *)(ep + (rl0 + 4 * qq) * EP_LD + c4);
+                        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                        if (EPI == EPI_BIAS_RESID_F32) {
+                            v.x += xr[ii][k].x; v.y += xr[ii][k].y; v.z += xr[ii][k].z; v.w += xr[ii][k].w;
+                        }
 #if (D2R_GEMM_ABLATE & 128) && defined(__HIP_DEVICE_COMPILE__)
-                    asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
-                    continue;
+                        asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+                        continue;
 #endif
-                    if (row < M_real) *(float4 *)((float *)Cout + row * N + col) = v;       // < 2^32 elements (checked on host)
+                        if (row < M_real) *(float4 *)((float *)Cout + row * N + col) = v;       // < 2^32 elements (checked on host)
+                    }
                 }
-            }
         }
     } else {
         // bf16 outputs: a lane owns 8 columns (one 16-byte store), 8 lanes a 128-byte row segment
         const uint32_t c8 = (lane & 7) * 8, rl0 = lane >> 3;
-        const uint32_t col = n0 + wn + c8;
+        const uint32_t col = col0 + c8;
         const float4 b0 = *(const float4 *)(bias + col), b1 = *(const float4 *)(bias + col + 4);
+        hook();
 #pragma unroll
         for (int i = 0; i < MT; i++) {
-            transpose_in(i);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const uint32_t rl = rl0 + 8 * k, row = m0 + wm + i * 32 + rl;
+                transpose_in(i, k);
+                const uint32_t row = row0 + i * 32 + rl0 + 8 * k;
                 float4 u = (D2R_GEMM_ABLATE & 256) ? make_float4(acc[i][0][k], acc[i][0][k + 8], acc[i][1][k], acc[i][1][k + 8])
-                                                   : *(const float4 *)(ep + rl * EP_LD + c8);
+                                                   : *(const float4 *)(ep + rl0 * EP_LD + c8);
                 float4 w = (D2R_GEMM_ABLATE & 256) ? make_float4(acc[i][0][k + 4], acc[i][0][k + 12], acc[i][1][k + 4], acc[i][1][k + 12])
-                                                   : *(const float4 *)(ep + rl * EP_LD + c8 + 4);
+                                                   : *(const float4 *)(ep + rl0 * EP_LD + c8 + 4);
                 float f[8] = {u.x + b0.x, u.y + b0.y, u.z + b0.z, u.w + b0.w, w.x + b1.x, w.y + b1.y, w.z + b1.z, w.w + b1.w};
                 if (EPI == EPI_BIAS_GELU_BF16) {
                     // quick_gelu: x * sigmoid(1.702 x) = x / (1 + exp2(-1.702 log2(e) x))
@@ -565,7 +578,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void k_gemm(const uint16_t *__re
         wait_vmcnt<0>();
         asm volatile("" ::"v"(pf), "v"(sink));
     }
-    gemm_epilogue<EPI, MT>(acc, smem, wave, lane, m0 + wm, n0 + wn, bias, Cout, N, M_real);
+    gemm_epilogue<EPI, MT>(acc, (float *)smem + wave * EP_WAVE_FLOATS, lane, m0 + wm, n0 + wn, bias, Cout, N, M_real);
 }
 
 // ---- 256x256x64 GEMM with a half-tile staging ring that never drains ("8-phase" K loop) ----
@@ -588,7 +601,15 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void k_gemm(const uint16_t *__re
 // overwrites the one its MFMAs do not read.  Requires K % 128 == 0, N % 256 == 0.
 __device__ __forceinline__ void glds16s(uint32_t voff, const void *sbase, uint32_t lds_byte_addr)
 {
+#if D2R_GEMM_LD == 1
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" : : "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
+#elif D2R_GEMM_LD == 2
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 sc1" : : "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
+#elif D2R_GEMM_LD == 3
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 sc0" : : "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
+#else
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
+#endif
 }
 
 template <int EPI>
@@ -598,23 +619,18 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
 {
     constexpr uint32_t SLOT = 128 * BK * 2;          // 16 KiB
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint32_t nwg = gridDim.x, tiles_n = N / 256;
-    const uint32_t xcd = blockIdx.x & 7u, loc = blockIdx.x >> 3, q = nwg >> 3, rr8 = nwg & 7u;
-    const uint32_t tile = (xcd < rr8 ? xcd * (q + 1) : rr8 * (q + 1) + (xcd - rr8) * q) + loc;
-    const uint32_t m0 = (tile / tiles_n) * 256, n0 = (tile % tiles_n) * 256;
-
+    // persistent: gridDim.x workgroups (one per CU) walk the tiles.  Tiles are numbered n-fastest; XCD x
+    // (blockIdx & 7) owns the contiguous range [x T/8, (x+1) T/8) and its 32 workgroups take
+    // consecutive tiles of it in every round, so the CUs behind one L2 share A row panels.
+    const uint32_t tiles_n = N / 256, n_tiles = (M_pad / 256) * tiles_n;
+    const uint32_t xcd = blockIdx.x & 7u, loc = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    const uint32_t t_begin = (uint32_t)((uint64_t)n_tiles * xcd / 8), t_end = (uint32_t)((uint64_t)n_tiles * (xcd + 1) / 8);
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t wm = wave >> 2, wn = wave & 3;
     const uint32_t li = lane & 31, hi = lane >> 5;
 
     f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
     // staging: piece qq of a half-tile = 8 slot rows x 128 B per wave instruction
     const uint32_t r_in = lane >> 3, pc = lane & 7;
@@ -629,14 +645,21 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem));
     const uint32_t nk = K / BK;
     // kind -> operand / half
-    auto stage_pos = [&](int kind, uint32_t kt) {
+    uint32_t m0 = 0, n0 = 0;                           // tile whose K loop runs
+    auto stage_pos_at = [&](int kind, uint32_t kt, uint32_t m0, uint32_t n0) {
         const bool isA = kind == 0 || kind == 3 || kind == 4 || kind == 7;
         const uint32_t h = (kind == 2 || kind == 3 || kind == 5 || kind == 7) ? 1u : 0u;
         const uint16_t *base = isA ? A + (size_t)(m0 + h * 64) * K + (size_t)kt * BK
                                    : W + (size_t)(n0 + h * 32) * K + (size_t)kt * BK;
+        if (D2R_GEMM_ABLATE & 1) return;
 #pragma unroll
         for (int qq = 0; qq < 2; qq++)
             glds16s(isA ? voffA[qq] : voffB[qq], base, lds0 + kind * SLOT + (wave * 2 + qq) * 1024);
+    };
+    auto stage_pos = [&](int kind, uint32_t kt) { stage_pos_at(kind, kt, m0, n0); };
+    auto tile_origin = [&](uint32_t t, uint32_t &tm, uint32_t &tn) {
+        tm = (t / tiles_n) * 256;
+        tn = (t % tiles_n) * 256;
     };
     // fragment read addresses: the swizzle term is the same for every row this lane reads
     // ((row >> 1) & 7 == (li >> 1) & 7), so four byte offsets per operand serve all kinds; the slot and
@@ -659,6 +682,14 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
             asm volatile("" : "+v"(far));            // not loop-invariant for the optimiser
         }
         const uint8_t *sb = smem + (kind & 3) * SLOT;
+        if (D2R_GEMM_ABLATE & 2) {
+#pragma unroll
+            for (int s4 = 0; s4 < 4; s4++) {
+                if (isA) fa[h][0][s4] = fa[h][1][s4] = make_uint4(lane, kind, s4, far);
+                else fb[h][s4] = make_uint4(lane, kind, s4, far);
+            }
+            return;
+        }
         if (isA) {
 #pragma unroll
             for (int mt = 0; mt < 2; mt++)
@@ -678,7 +709,11 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
                 union { uint4 u; bf16x8 v; } a, b;
                 a.u = fa[mh][mt][s4];
                 b.u = fb[nh][s4];
+#if (D2R_GEMM_ABLATE & 8) && defined(__HIP_DEVICE_COMPILE__)
+                asm volatile("" ::"v"(a.u.x), "v"(b.u.x));
+#else
                 acc[mh * 2 + mt][nh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc[mh * 2 + mt][nh], 0, 0, 0);
+#endif
             }
         __builtin_amdgcn_s_setprio(0);
     };
@@ -688,10 +723,26 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
         asm volatile("" ::: "memory");
     };
 
-    // prologue: positions 0..7 (both K-tiles of the first pair) are requested at once
+    // positions 0..7 (both K-tiles of the first pair) of the first tile are requested at once; for later
+    // tiles the same requests are issued in front of the previous tile's epilogue
+    uint32_t t = t_begin + loc;
+    if (t >= t_end) return;
+    tile_origin(t, m0, n0);
 #pragma unroll
     for (int kind = 0; kind < 8; kind++) stage_pos(kind, kind >= 4 ? 1u : 0u);
-    wait_vmcnt<10>();                                 // positions 0, 1, 2 have landed
+    float *ep = (float *)(smem + 8 * SLOT) + wave * EP_WAVE_FLOATS;      // transpose buffer behind the ring
+
+    for (;;) {
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    // everything in flight is drained ONCE per tile: the eight half-tiles requested a whole epilogue ago
+    // and that epilogue's stores (stores share the vmcnt counter and may retire out of order with loads,
+    // so the counted waits below are only sound with no store outstanding)
+    wait_vmcnt<0>();
     bar();
     read_pos(0);
     read_pos(1);
@@ -737,8 +788,31 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
         }
     }
     if (wm == 0) bar();
-    __syncthreads();
-    gemm_epilogue<EPI, 4>(acc, smem, wave, lane, m0 + wm * 128, n0 + wn * 64, bias, Cout, N, M_real);
+    // every wave is past its last fragment read and every DMA of this tile has landed: the ring is free.
+    // Request the next tile's first eight half-tiles now; they land while this tile's epilogue runs.
+    const uint32_t t_next = t + per_xcd;
+    const uint32_t em = m0 + wm * 128, en = n0 + wn * 64;
+    auto request_next = [&]() {
+        if (t_next < t_end) {
+            tile_origin(t_next, m0, n0);
+#pragma unroll
+            for (int kind = 0; kind < 8; kind++) stage_pos(kind, kind >= 4 ? 1u : 0u);
+        }
+    };
+#if (D2R_GEMM_ABLATE & 4) && defined(__HIP_DEVICE_COMPILE__)
+    request_next();
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) asm volatile("" ::"v"(acc[i][j][r]));
+#else
+    gemm_epilogue<EPI, 4>(acc, ep, lane, em, en, bias, Cout, N, M_real, request_next);
+#endif
+    if (t_next >= t_end) break;
+    t = t_next;
+    }
 }
 
 // -------------------------------------------------------- embeddings + LN
@@ -1237,11 +1311,11 @@ static int launch_gemm(d2r_ctx *ctx, const uint16_t *A, const uint16_t *W, const
             const uint32_t M_pad = round_up(M_real, BM);
             static bool attr8 = false;
             if (!attr8) {
-                (void)hipFuncSetAttribute((const void *)k_gemm8<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+                (void)hipFuncSetAttribute((const void *)k_gemm8<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024 + 8 * EP_WAVE_FLOATS * 4);
                 attr8 = true;
             }
-            hipLaunchKernelGGL((k_gemm8<EPI>), dim3((M_pad / 256) * (N / 256)), dim3(512), 128 * 1024, ctx->stream, A, W, bias,
-                               C, M_pad, N, K, M_real);
+            constexpr uint32_t LDS8 = 128 * 1024 + 8 * EP_WAVE_FLOATS * 4;
+            hipLaunchKernelGGL((k_gemm8<EPI>), dim3(256), dim3(512), LDS8, ctx->stream, A, W, bias, C, M_pad, N, K, M_real);
             D2R_HIP(ctx, hipGetLastError());
             return D2R_OK;
         }
