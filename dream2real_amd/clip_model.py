@@ -142,3 +142,43 @@ def text_blob_order(cfg):
 def pack_text_weights(sd: dict, cfg) -> np.ndarray:
     return np.ascontiguousarray(np.concatenate(
         [np.asarray(sd[n], np.float32).reshape(shape).reshape(-1) for n, shape in text_blob_order(cfg)]))
+
+
+def infer_clip_config(sd: dict) -> dict:
+    """CLIP geometry from the tensor shapes of a Hugging Face `CLIPModel` state dict (head_dim 64, as
+    in every OpenAI CLIP ViT)."""
+    pe = sd["vision_model.embeddings.patch_embedding.weight"]
+    d, P = int(pe.shape[0]), int(pe.shape[-1])
+    n_tok = int(sd["vision_model.embeddings.position_embedding.weight"].shape[0])
+    g = int(round((n_tok - 1) ** 0.5))
+    if g * g + 1 != n_tok:
+        raise ValueError(f"{n_tok} vision positions is not a square grid plus the class token")
+
+    def n_layers(prefix):
+        n = 0
+        while f"{prefix}.layers.{n}.layer_norm1.weight" in sd:
+            n += 1
+        return n
+
+    cfg = dict(patch_size=P, hidden_size=d, num_layers=n_layers("vision_model.encoder"), num_heads=d // 64,
+               mlp=int(sd["vision_model.encoder.layers.0.mlp.fc1.weight"].shape[0]), image_size=g * P,
+               proj=int(sd["visual_projection.weight"].shape[0]))
+    if "text_model.embeddings.token_embedding.weight" in sd:
+        te = sd["text_model.embeddings.token_embedding.weight"]
+        td = int(te.shape[1])
+        cfg.update(text_hidden=td, text_layers=n_layers("text_model.encoder"), text_heads=td // 64,
+                   text_mlp=int(sd["text_model.encoder.layers.0.mlp.fc1.weight"].shape[0]),
+                   vocab=int(te.shape[0]), ctx=int(sd["text_model.embeddings.position_embedding.weight"].shape[0]))
+    return cfg
+
+
+def load_clip_safetensors(path: str):
+    """-> (cfg, state_dict of fp32 numpy arrays) from a Hugging Face CLIP `model.safetensors`
+    (the reference's `CLIPModel.from_pretrained(...)`, clip_scoring.py:150; fp32, fp16 or bf16 on
+    disk).  Buffers that are not weights (`position_ids`) are dropped."""
+    from safetensors.torch import load_file
+    raw = load_file(path)
+    sd = {k: v.float().numpy() for k, v in raw.items() if not k.endswith("position_ids")}
+    if "logit_scale" in sd:
+        sd["logit_scale"] = np.float32(sd["logit_scale"].reshape(-1)[0])
+    return infer_clip_config(sd), sd

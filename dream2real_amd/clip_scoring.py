@@ -5,7 +5,8 @@ same return triple (best_pose 4x4, pose_batch [N,16], pose_scores [N]) as torch 
 failure on zero valid poses.  Differences forced by the environment are keyword-only extras:
 `scorer` (a dream2real_amd.engine.ClipScorer holding the CLIP weights on the GPU) and either
 `text_embeds` (cached, L2-normalised [C,D]) or `text_encoder` + `tokenizer` (an
-engine.TextEncoder and a callable captions -> int32 ids [C,T]; the embeddings are then computed
+engine.TextEncoder and a callable captions -> int32 ids [C,T], e.g. tokenizer.ClipBpeTokenizer
+built from the checkpoint's vocab.json / merges.txt; the embeddings are then computed
 once on the GPU — the reference re-tokenises and re-encodes the captions every batch).
 """
 from __future__ import annotations
@@ -101,7 +102,10 @@ def optimise_pose_grid(renderer, depths_gt, render_cam_pose_idx, task_model, dat
     if text_embeds is None:
         text_embeds = getattr(task_model, "text_embeds", None)
     if text_embeds is None and text_encoder is not None and tokenizer is not None:
-        text_embeds = text_encoder.encode(np.asarray(tokenizer(captions), np.int32))   # once per task
+        ids = tokenizer(captions)                      # ids, or (ids, attention_mask) like tokenizer.ClipBpeTokenizer
+        if isinstance(ids, tuple):
+            ids = ids[0]
+        text_embeds = text_encoder.encode(np.asarray(ids, np.int32))   # once per task
     if text_embeds is None:
         raise ValueError("text embeddings are required: pass text_embeds=, or text_encoder= and tokenizer=")
     text_embeds = np.asarray(text_embeds, np.float32)

@@ -262,13 +262,16 @@ __device__ __forceinline__ void wait_vmcnt()
 #define EP_LD 68u                          /* floats per row of the epilogue's LDS transpose buffer (pad 4) */
 #define EP_WAVE_FLOATS (8u * EP_LD)        /* 8 rows per wave: 2176 bytes */
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
-// `hook` runs once, after the first batch of residual loads has been issued (at the top for the other
-// variants): the persistent kernel requests the next tile's operands there, behind the loads whose
-// compiler-placed vmcnt waits would otherwise also wait for those requests.
+// Every output buffer has M_pad rows, so rows >= M_real are computed and stored like the others
+// (they only ever feed rows >= M_real downstream): the epilogue is straight-line code, which lets
+// hipcc place exact counted vmcnt waits instead of a vmcnt(0) in every predicated block.
+// `hook` runs once: the persistent kernel requests the next tile's operands there.  It sits where no
+// later compiler-placed wait can also wait for those requests: after the bias values have been
+// consumed (bf16 variants), after the LAST batch of residual loads has been issued (fp32 residual).
 template <int EPI, int MT, typename Hook = NoHook>
 __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], float *ep, uint32_t lane,
                                               uint32_t row0, uint32_t col0, const float *__restrict__ bias,
-                                              void *__restrict__ Cout, uint32_t N, uint32_t M_real, Hook hook = Hook())
+                                              void *__restrict__ Cout, uint32_t N, Hook hook = Hook())
 {
     // ep: this wave's private 8 x EP_LD float buffer.  Eight rows of the wave tile at a time:
     // acc[i][j][4p..4p+3] of both lane halves are rows 8p..8p+7 of m-tile i.
@@ -287,8 +290,12 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], float *ep, u
         const uint32_t c4 = (lane & 15) * 4, rl0 = lane >> 4;
         const uint32_t col = col0 + c4;
         float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (EPI != EPI_F32) bv = *(const float4 *)(bias + col);
+        if (EPI != EPI_F32) {
+            bv = *(const float4 *)(bias + col);
+            asm volatile("" : "+v"(bv.x), "+v"(bv.y), "+v"(bv.z), "+v"(bv.w));      // loaded before anything else is issued
+        }
         static_assert(MT % 2 == 0, "epilogue handles m-tiles in pairs");
+        if (EPI == EPI_F32) hook();
 #pragma unroll
         for (int ih = 0; ih < MT; ih += 2) {
             float4 xr[2][8];
@@ -298,11 +305,11 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], float *ep, u
 #pragma unroll
                     for (int k = 0; k < 8; k++) {
                         const uint32_t row = row0 + (ih + ii) * 32 + rl0 + 4 * k;
-                        xr[ii][k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (row < M_real && !(D2R_GEMM_ABLATE & 128)) xr[ii][k] = *(const float4 *)((const float *)Cout + row * N + col);
+                        xr[ii][k] = (D2R_GEMM_ABLATE & 128) ? make_float4(0.f, 0.f, 0.f, 0.f)
+                                                            : *(const float4 *)((const float *)Cout + row * N + col);
                     }
+                if (ih == MT - 2) hook();
             }
-            if (ih == 0) hook();
 #pragma unroll
             for (int ii = 0; ii < 2; ii++)
 #pragma unroll
@@ -322,7 +329,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], float *ep, u
                         asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
                         continue;
 #endif
-                        if (row < M_real) *(float4 *)((float *)Cout + row * N + col) = v;       // < 2^32 elements (checked on host)
+                        *(float4 *)((float *)Cout + row * N + col) = v;       // < 2^32 elements (checked on host)
                     }
                 }
         }
@@ -330,7 +337,8 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], float *ep, u
         // bf16 outputs: a lane owns 8 columns (one 16-byte store), 8 lanes a 128-byte row segment
         const uint32_t c8 = (lane & 7) * 8, rl0 = lane >> 3;
         const uint32_t col = col0 + c8;
-        const float4 b0 = *(const float4 *)(bias + col), b1 = *(const float4 *)(bias + col + 4);
+        float4 b0 = *(const float4 *)(bias + col), b1 = *(const float4 *)(bias + col + 4);
+        asm volatile("" : "+v"(b0.x), "+v"(b0.y), "+v"(b0.z), "+v"(b0.w), "+v"(b1.x), "+v"(b1.y), "+v"(b1.z), "+v"(b1.w));
         hook();
 #pragma unroll
         for (int i = 0; i < MT; i++) {
@@ -354,7 +362,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], float *ep, u
                 asm volatile("" ::"v"(pk.x), "v"(pk.y), "v"(pk.z), "v"(pk.w));
                 continue;
 #endif
-                if (row < M_real) *(uint4 *)((uint16_t *)Cout + row * N + col) = pk;
+                *(uint4 *)((uint16_t *)Cout + row * N + col) = pk;
             }
         }
     }
@@ -578,7 +586,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void k_gemm(const uint16_t *__re
         wait_vmcnt<0>();
         asm volatile("" ::"v"(pf), "v"(sink));
     }
-    gemm_epilogue<EPI, MT>(acc, (float *)smem + wave * EP_WAVE_FLOATS, lane, m0 + wm, n0 + wn, bias, Cout, N, M_real);
+    gemm_epilogue<EPI, MT>(acc, (float *)smem + wave * EP_WAVE_FLOATS, lane, m0 + wm, n0 + wn, bias, Cout, N);
 }
 
 // ---- 256x256x64 GEMM with a half-tile staging ring that never drains ("8-phase" K loop) ----
@@ -808,7 +816,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
 #pragma unroll
             for (int r = 0; r < 16; r++) asm volatile("" ::"v"(acc[i][j][r]));
 #else
-    gemm_epilogue<EPI, 4>(acc, ep, lane, em, en, bias, Cout, N, M_real, request_next);
+    gemm_epilogue<EPI, 4>(acc, ep, lane, em, en, bias, Cout, N, request_next);
 #endif
     if (t_next >= t_end) break;
     t = t_next;

@@ -297,6 +297,29 @@ def test_text_tower_matches_oracle_and_hf_golden(gpu, goldens, name):
     enc.close()
 
 
+def test_captions_to_text_embeds_through_the_bpe_tokenizer(gpu):
+    """captions -> ClipBpeTokenizer (pinned against HF on the committed vocabulary) -> GPU text
+    tower; padding after the end token must not change the embedding (causal mask), and the
+    result equals the numpy oracle on the same ids."""
+    import os
+    from dream2real_amd.tokenizer import ClipBpeTokenizer
+    engine, ctx = gpu["engine"], gpu["ctx"]
+    g = os.path.join(os.path.dirname(__file__), "golden")
+    tok = ClipBpeTokenizer.from_files(os.path.join(g, "bpe_vocab.json"), os.path.join(g, "bpe_merges.txt"), context_length=32)
+    cfg = dict(CLIP_CONFIGS["vit_tiny"], vocab=len(tok.vocab), ctx=32)
+    sd = random_clip_state_dict(cfg, seed=6)
+    enc = engine.TextEncoder(ctx, cfg, sd)
+    caps = ["an apple inside a blue and white bowl", "an apple and a blue and white bowl", "a photo of an apple"]
+    ids, mask = tok(caps)
+    got = enc.encode(ids)
+    assert (1.0 - cosine(got, clip_ref.text_embeds(ids, sd, cfg))).max() < 2e-4
+    full, _ = tok(caps, pad_to_context=True)
+    np.testing.assert_allclose(enc.encode(full), got, atol=2e-6)
+    one, _ = tok(caps[2:])                               # alone (no padding at all)
+    np.testing.assert_allclose(enc.encode(one)[0], got[2], atol=2e-6)
+    enc.close()
+
+
 def test_optimise_pose_grid_end_to_end(gpu, tmp_path):
     """Pose batch in, scores out through the reference-shaped Python API (config 0 shapes:
     32 poses, 160x90), against the oracle pipeline; argmax pose identical."""
