@@ -762,7 +762,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
     // group 0's next read section: after the MFMAs for wm = 0, after the DMA issue for wm = 1.
     if (wm == 1) bar();
 
-    const uint32_t n_iter = nk / 2;
+    // measurement only (bit 512): even workgroups skip the K loop, odd ones the epilogue
+    const uint32_t n_iter = ((D2R_GEMM_ABLATE & 512) && !(blockIdx.x & 8)) ? 0 : nk / 2;
     for (uint32_t u = 0; u < n_iter; u++) {
         const bool last = u + 1 == n_iter;            // block-uniform
 #pragma unroll
@@ -816,7 +817,17 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
 #pragma unroll
             for (int r = 0; r < 16; r++) asm volatile("" ::"v"(acc[i][j][r]));
 #else
-    gemm_epilogue<EPI, 4>(acc, ep, lane, em, en, bias, Cout, N, request_next);
+    if ((D2R_GEMM_ABLATE & 512) && (blockIdx.x & 8)) {
+        request_next();
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) asm volatile("" ::"v"(acc[i][j][r]));
+    } else {
+        gemm_epilogue<EPI, 4>(acc, ep, lane, em, en, bias, Cout, N, request_next);
+    }
 #endif
     if (t_next >= t_end) break;
     t = t_next;
