@@ -941,12 +941,15 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void k_attention(const uint16_t *_
     const uint16_t *Kg = Qg + d;
     const uint16_t *Vg = Qg + 2 * d;
 
-    // stage K (row-major, swizzled 16-B chunks); rows >= T are zero
-    for (uint32_t i = tid; i < T_pad * 8; i += ATTN_THREADS) {
-        uint32_t key = i >> 3, c = i & 7;
-        uint4 kv = make_uint4(0, 0, 0, 0);
-        if (key < T) kv = *(const uint4 *)(Kg + (size_t)key * ld + c * 8);
-        *(uint4 *)(Ks + lds_off(key, c)) = kv;
+    // K (row-major, swizzled 16-byte chunks) goes straight to LDS by LDS-DMA, 8 key rows per wave
+    // instruction, issued before anything else so it overlaps the V transposes.  Rows >= T repeat row
+    // T-1: their scores are masked by a select below, so any finite value does.
+    {
+        const uint32_t ks0 = __builtin_amdgcn_readfirstlane(lds_addr(Ks));
+        for (uint32_t b = __builtin_amdgcn_readfirstlane(wave); b < T_pad / 8; b += ATTN_THREADS / 64) {
+            const uint32_t row = b * 8 + (lane >> 3), src_row = row < T ? row : T - 1;
+            glds16(Kg + (size_t)src_row * ld + ((lane & 7) ^ ((row >> 1) & 7u)) * 8, ks0 + b * 1024);
+        }
     }
     // stage V^T: a task takes 4 keys x 8 dims (four 16-byte loads), transposes the 4x8 block in
     // registers (v_perm_b32) and writes one 8-byte word of 4 consecutive keys per dim
@@ -955,7 +958,7 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void k_attention(const uint16_t *_
         uint4 v[4];
 #pragma unroll
         for (int k = 0; k < 4; k++)
-            v[k] = kb + k < T ? *(const uint4 *)(Vg + (size_t)(kb + k) * ld + c * 8) : make_uint4(0, 0, 0, 0);
+            v[k] = *(const uint4 *)(Vg + (size_t)(kb + k < T ? kb + k : T - 1) * ld + c * 8);   // keys >= T: finite filler, their P is 0
         const uint32_t *w0 = (const uint32_t *)&v[0], *w1 = (const uint32_t *)&v[1];
         const uint32_t *w2 = (const uint32_t *)&v[2], *w3 = (const uint32_t *)&v[3];
 #pragma unroll
@@ -969,9 +972,10 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void k_attention(const uint16_t *_
             *(uint2 *)(Vt + (size_t)(c * 8 + 2 * p + 1) * vstride + kb) = hi2;
         }
     }
+    wait_vmcnt<0>();              // this wave's K copies have landed
     __syncthreads();
 
-    const float scale = 0.125f;   // head_dim^-0.5, head_dim = 64
+    const float sm_c = 0.125f * 1.4426950408889634f;   // head_dim^-0.5 * log2(e), head_dim = 64
     const uint32_t n_qt = (T + 31) / 32, n_kt = T_pad / 32;
     for (uint32_t qt = wave; qt < n_qt; qt += ATTN_THREADS / 64) {
         const uint32_t qrow = qt * 32 + li;
@@ -997,33 +1001,42 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void k_attention(const uint16_t *_
                 b.u = qf[s];
                 sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, sacc, 0, 0, 0);
             }
-            // lane (q, hi), reg r  <->  key kt*32 + (r&3) + 8*(r>>2) + 4*hi
-            float tmax = -INFINITY;
+            // lane (q, hi), reg r  <->  key kt*32 + (r&3) + 8*(r>>2) + 4*hi.  Softmax in the exp2 domain:
+            // p = exp2(s*c - m) with c = head_dim^-0.5 * log2(e) and m the running maximum of s*c.  Only
+            // the tile that holds keys >= T (and, for the causal text tower, the diagonal tile) needs
+            // the mask; the select keeps garbage in K rows >= T out of the arithmetic.
+            const bool need_mask = (kt + 1) * 32 > T || (CAUSAL && kt == qt);      // wave-uniform
+            if (need_mask) {
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                uint32_t key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                // text tower: causal mask, key position <= query position
-                float sv = (key < T && (!CAUSAL || key <= qrow)) ? sacc[r] * scale : -INFINITY;
-                sacc[r] = sv;
-                tmax = fmaxf(tmax, sv);
+                for (int r = 0; r < 16; r++) {
+                    const uint32_t key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    sacc[r] = (key < T && (!CAUSAL || key <= qrow)) ? sacc[r] : -INFINITY;
+                }
             }
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+            float tmax = sacc[0];
+#pragma unroll
+            for (int r = 1; r < 16; r++) tmax = fmaxf(tmax, sacc[r]);
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32)) * sm_c;
             const float m_new = fmaxf(m_run, tmax);
-            const float alpha = __expf(m_run - m_new);      // m_run = -inf on the first tile -> 0
+            // rescale the running sums only when some query's maximum moved (exact: alpha would be 1)
+            if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);      // m_run = -inf on the first tile -> 0
+                l_run *= alpha;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    o0[r] *= alpha;
+                    o1[r] *= alpha;
+                }
+                m_run = m_new;
+            }
             float psum = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                float p = __expf(sacc[r] - m_new);
-                sacc[r] = p;
-                psum += p;
+                const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[r], sm_c, -m_new));
+                sacc[r] = pr;
+                psum += pr;
             }
-            l_run = l_run * alpha + psum;
-            m_run = m_new;
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                o0[r] *= alpha;
-                o1[r] *= alpha;
-            }
+            l_run += psum;
             // O^T[d][q] += V^T[d][key] P^T[key][q]; P regs 8s..8s+7 are the B fragment of k-step s
 #pragma unroll
             for (int s = 0; s < 2; s++) {
