@@ -42,7 +42,7 @@ int d2r_reserve(d2r_ctx *ctx, d2r_ctx::Buf &b, size_t bytes)
         b.p = nullptr;
         return d2r_fail(ctx, D2R_ERR_MEMORY, "hipMalloc(" + std::to_string(want) + ") failed");
     }
-    b.cap = want;
+    b.cap = want - 64;     // kernels may read a few bytes past the last element (k_preprocess: 4-byte pixel loads)
     hipMemsetAsync(b.p, 0, want, ctx->stream);   // padded rows/columns of GEMM operands must be finite
     return D2R_OK;
 }

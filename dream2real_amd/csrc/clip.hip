@@ -137,9 +137,11 @@ __global__ __launch_bounds__(256) void k_preprocess(const uint8_t *__restrict__ 
                 const uint8_t *p = rot90 ? src + ((size_t)sx * w + (w - 1 - sy)) * 3
                                          : src + ((size_t)sy * w + sx) * 3;
                 const int kv = k[x];
-                s0 += p[0] * kv;
-                s1 += p[1] * kv;
-                s2 += p[2] * kv;
+                uint32_t px;                     // one unaligned 4-byte load per RGB pixel (the 4th byte is unused;
+                __builtin_memcpy(&px, p, 4);     //  every device buffer has slack behind its last element)
+                s0 += (int)(px & 0xffu) * kv;
+                s1 += (int)((px >> 8) & 0xffu) * kv;
+                s2 += (int)((px >> 16) & 0xffu) * kv;
             }
             o0 = clip8(s0); o1 = clip8(s1); o2 = clip8(s2);
         } else {
