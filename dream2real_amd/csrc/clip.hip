@@ -8,10 +8,11 @@
 //                  point with the uint8 intermediate staged in LDS) + centre crop +
 //                  rescale/normalise, written patch-major in bf16 so patch embedding is a
 //                  plain GEMM; optional fp32 pixel_values for parity
-//   k_gemm         C = A[M,K] * W[N,K]^T on v_mfma_f32_32x32x16_bf16, 128x128x64 tiles,
-//                  XOR-swizzled LDS (conflict-free ds_read_b128), register-staged double
-//                  buffering, XCD-aware tile order, fused epilogues (bias, quick_gelu,
-//                  fp32 residual accumulate)
+//   k_gemm8        C = A[M,K] * W[N,K]^T on v_mfma_f32_32x32x16_bf16: persistent 256x256x64 tiles,
+//                  operands staged by LDS-DMA into a ring of eight 16 KiB half-tile slots that
+//                  never drains (counted vmcnt, 8 phases per K-tile pair), XOR-swizzled LDS
+//                  (conflict-free ds_read_b128), XCD-aware tile order, fused epilogues (bias,
+//                  quick_gelu, fp32 residual); k_gemm is the plain-K-loop variant for small outputs
 //   k_embed_ln     [class | patches] + position embedding + pre_layrnorm -> fp32 residual
 //   k_layernorm    fp32 residual -> bf16 GEMM operand, one wave per token
 //   k_attention    flash-style attention per (image, head): S^T = K Q^T so each query's
@@ -210,22 +211,12 @@ __global__ void k_patchify(const float *__restrict__ pv, uint32_t n, uint32_t S,
 
 enum { EPI_F32 = 0, EPI_BIAS_BF16 = 1, EPI_BIAS_GELU_BF16 = 2, EPI_BIAS_RESID_F32 = 3 };
 
-// Development-only ablation switches for k_gemm (bitmask, default 0 = the real kernel):
-//   1 no LDS-DMA, 2 no fragment ds_reads, 4 no epilogue, 8 no MFMA.  Results are garbage when set;
-//   used by tools/gemm_ablate.sh to see where the time of the loop goes.
+// Development-only ablation switches of k_gemm8 and the shared epilogue (bitmask, default 0 = the real
+// kernel): 1 no LDS-DMA, 2 no fragment ds_reads, 4 no epilogue, 8 no MFMA, 128 no global loads/stores in
+// the epilogue, 256 no LDS transposes in the epilogue.  Results are garbage when set; tools/gemm_ablate.sh
+// rebuilds with each mask to see where the time of a tile goes.
 #ifndef D2R_GEMM_ABLATE
 #define D2R_GEMM_ABLATE 0
-#endif
-// L2 prefetch distance of k_gemm in k-steps beyond the LDS-DMA (0 = off); bit 8: also touch the
-// fp32 residual tile during the first k-steps of the residual epilogue variant
-#ifndef D2R_GEMM_PF
-#define D2R_GEMM_PF 0
-#endif
-#ifndef D2R_GEMM_LD            /* cache policy of the k_gemm8 LDS-DMA loads (experiment): 0 plain, 1 nt, 2 sc1, 3 sc0 */
-#define D2R_GEMM_LD 0
-#endif
-#ifndef D2R_GEMM_ST            /* cache policy of the bf16 output stores (experiment): 0 plain, 1 nt, 2 sc1, 3 sc0 sc1 */
-#define D2R_GEMM_ST 0
 #endif
 #define BM 256                 /* row padding of every GEMM operand buffer (largest tile height) */
 #define BK 64
@@ -370,21 +361,19 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], float *ep, u
     }
 }
 
-// C = A[M,K] * W[N,K]^T.  A [M_pad][K] bf16, W [N][K] bf16, K % 64 == 0.
+// C = A[M,K] * W[N,K]^T.  A [M_pad][K] bf16, W [N][K] bf16, K % 64 == 0.  The plain-K-loop GEMM that
+// serves what k_gemm8 below does not (outputs with few 256x256 tiles, K not a multiple of 128).
 // 8 waves as WGM x WGN, each wave MT x 2 MFMA 32x32x16 tiles:
-//   <WGM=4, WGN=2, MT=2, STAGES=3>  256x128 tile, 3-stage ring, counted vmcnt  (N = 768 products)
-//   <WGM=2, WGN=4, MT=4, STAGES=2>  256x256 tile, 2-stage                      (N >= 2304 products)
-// Measured on MI355X (ViT-B/16, M = 100 864): every tile shape from 128x128 (4 waves, 2 WG/CU) to
-// 256x256 lands within 10 % of 650-800 TFLOP/s; a staggered read-phase/MFMA-phase schedule (wave
-// groups one barrier apart) was bit-identical and no faster, so it was dropped.
+//   <WGM=4, WGN=2, MT=2, STAGES=3>  256x128 tile, 3-stage ring, counted vmcnt
+//   <WGM=2, WGN=4, MT=4, STAGES=2>  256x256 tile, 2-stage
 // LDS-DMA staging: tile kt+STAGES-1 is issued before tile kt is computed; with 3 stages the wait at
 // the end of the iteration is COUNTED (this wave's copies of the newest tile stay in flight across
-// the barrier) — the loads are never drained inside the loop.
+// the barrier) -- the loads are never drained inside the loop.
 template <int EPI, int WGM, int WGN, int MT, int STAGES>
 __global__ __launch_bounds__(WGM * WGN * 64, 2) void k_gemm(const uint16_t *__restrict__ A,
                                                           const uint16_t *__restrict__ W,
                                                           const float *__restrict__ bias, void *__restrict__ Cout,
-                                                          uint32_t M_pad, uint32_t N, uint32_t K, uint32_t M_real)
+                                                          uint32_t M_pad, uint32_t N, uint32_t K)
 {
     constexpr uint32_t TBM = WGM * MT * 32, TBN = WGN * 64;
     constexpr uint32_t STAGE_BYTES = (TBM + TBN) * BK * 2;
@@ -419,49 +408,18 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void k_gemm(const uint16_t *__re
 #pragma unroll
     for (int i = 0; i < A_PER_WAVE; i++) {
         const uint32_t row = (wave * A_PER_WAVE + i) * 8 + r_in;
-#ifdef D2R_GEMM_LDPAD   /* measurement only: garbage operands read with a padded row stride */
-        ag[i] = A + (size_t)((m0 + row) % (uint32_t)((size_t)M_pad * K / (K + D2R_GEMM_LDPAD))) * (K + D2R_GEMM_LDPAD) + (pc ^ ((D2R_GEMM_ABLATE & 32) ? 0u : ((row >> 1) & 7u))) * 8;
-#else
-        ag[i] = A + (size_t)(m0 + row) * K + (pc ^ ((D2R_GEMM_ABLATE & 32) ? 0u : ((row >> 1) & 7u))) * 8;
-#endif
+        ag[i] = A + (size_t)(m0 + row) * K + (pc ^ ((row >> 1) & 7u)) * 8;
     }
 #pragma unroll
     for (int i = 0; i < B_PER_WAVE; i++) {
         const uint32_t row = (wave * B_PER_WAVE + i) * 8 + r_in;
-#ifdef D2R_GEMM_LDPAD
-        wg[i] = W + (size_t)((n0 + row) % (uint32_t)((size_t)N * K / (K + D2R_GEMM_LDPAD))) * (K + D2R_GEMM_LDPAD) + (pc ^ ((D2R_GEMM_ABLATE & 32) ? 0u : ((row >> 1) & 7u))) * 8;
-#else
-        wg[i] = W + (size_t)(n0 + row) * K + (pc ^ ((D2R_GEMM_ABLATE & 32) ? 0u : ((row >> 1) & 7u))) * 8;
-#endif
+        wg[i] = W + (size_t)(n0 + row) * K + (pc ^ ((row >> 1) & 7u)) * 8;
     }
     const uint32_t nk = K / BK;
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem));
-    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-    u32x4_t sink = {0, 0, 0, 0};      // ablation 16 only
-    // L2 prefetch (experiment): lanes 0-31 touch this wave's share of the A rows, lanes 32-63 of the
-    // W rows, one 128-byte line each, PF_D k-steps ahead of the LDS-DMA.  The load's result is never
-    // read; pf stays live to the end of the kernel so its register is not reused under the load.
-    constexpr int PF_D = D2R_GEMM_PF & 0xff;
-    constexpr bool PF_R = (D2R_GEMM_PF & 0x100) && EPI == EPI_BIAS_RESID_F32;
-    uint32_t pf = 0;
-    const uint16_t *pfp = li + wave * (TBM / NWAVE) < TBM && hi == 0
-                              ? A + (size_t)(m0 + wave * (TBM / NWAVE) + (li % (TBM / NWAVE))) * K
-                              : W + (size_t)(n0 + wave * (TBN / NWAVE) + (li % (TBN / NWAVE))) * K;
     // copy `idx` (0 .. PER_STAGE-1) of this wave's share of tile kt into ring buffer buf
     auto stage_one = [&](uint32_t buf, uint32_t kt, int idx) {
-        if (D2R_GEMM_ABLATE & 1) return;
-        if ((D2R_GEMM_ABLATE & 64) && idx >= A_PER_WAVE) return;      // measurement only: A operand only
         const uint32_t base = lds0 + buf * STAGE_BYTES;
-#if (D2R_GEMM_ABLATE & 16) && defined(__HIP_DEVICE_COMPILE__)
-        // measurement only: same global reads into a dead register quad instead of the LDS
-#pragma unroll
-        for (int i = 0; i < A_PER_WAVE; i++)
-            if (idx == i) asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(sink) : "v"(ag[i] + (size_t)kt * BK) : "memory");
-#pragma unroll
-        for (int i = 0; i < B_PER_WAVE; i++)
-            if (idx == A_PER_WAVE + i) asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(sink) : "v"(wg[i] + (size_t)kt * BK) : "memory");
-        return;
-#endif
 #pragma unroll
         for (int i = 0; i < A_PER_WAVE; i++)
             if (idx == i) glds16(ag[i] + (size_t)kt * BK, base + (wave * A_PER_WAVE + i) * 1024);
@@ -475,17 +433,6 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void k_gemm(const uint16_t *__re
         for (int c = 0; c < PER_STAGE; c++) stage_one(buf, kt, c);
     };
 
-#ifdef D2R_GEMM_STAGGER
-    // The first round of workgroups (one per CU) starts spread over one tile time so that later
-    // rounds do not run their epilogues (HBM writes) all at once and their main loops (no HBM
-    // traffic) all at once.  100 MHz wall clock ticks; a tile takes about 1.4 us per k-step.
-    if (blockIdx.x < 256 && gridDim.x >= 1024) {
-        const uint32_t slot = (blockIdx.x >> 3) % D2R_GEMM_STAGGER;
-        // s_sleep 16 = about 1024 shader cycles; a k-step takes about 3300
-        const uint32_t n_sleep = (nk * 33u + 80u) * slot / (D2R_GEMM_STAGGER * 10u);
-        for (uint32_t i = 0; i < n_sleep; i++) __builtin_amdgcn_s_sleep(16);
-    }
-#endif
     // prologue: STAGES-1 tiles in flight, the first one landed
     stage(0, 0);
     if (STAGES == 3 && nk > 1) {
@@ -497,97 +444,58 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void k_gemm(const uint16_t *__re
     __syncthreads();
 
     uint32_t cur = 0;
-    {
-        for (uint32_t kt = 0; kt < nk; kt++) {
-            // refill the buffer that was computed in the previous iteration (everyone left it at the barrier)
-            const uint32_t ahead = kt + STAGES - 1;
-            const uint32_t nbuf = cur >= 1 ? cur - 1 : STAGES - 1;
-            const bool fill = ahead < nk;                  // block-uniform
-            const uint8_t *Ab = smem + cur * STAGE_BYTES;
-            const uint8_t *Bb = Ab + TBM * BK * 2;
-            // fragments are double-buffered in registers: k-step s+1 is read from LDS while the MFMAs of
-            // k-step s issue; the MFMA groups run at raised priority so the partner wave's loads yield
-            uint4 fa[2][MT], fb[2][2];
+    for (uint32_t kt = 0; kt < nk; kt++) {
+        // refill the buffer that was computed in the previous iteration (everyone left it at the barrier)
+        const uint32_t ahead = kt + STAGES - 1;
+        const uint32_t nbuf = cur >= 1 ? cur - 1 : STAGES - 1;
+        const bool fill = ahead < nk;                  // block-uniform
+        const uint8_t *Ab = smem + cur * STAGE_BYTES;
+        const uint8_t *Bb = Ab + TBM * BK * 2;
+        // fragments are double-buffered in registers: k-step s+1 is read from LDS while the MFMAs of
+        // k-step s issue; the MFMA groups run at raised priority so the partner wave's loads yield
+        uint4 fa[2][MT], fb[2][2];
 #pragma unroll
-            for (int i = 0; i < MT; i++) fa[0][i] = (D2R_GEMM_ABLATE & 2) ? make_uint4(lane, kt, i, 1) : *(const uint4 *)(Ab + lds_off(wm + i * 32 + li, hi));
+        for (int i = 0; i < MT; i++) fa[0][i] = *(const uint4 *)(Ab + lds_off(wm + i * 32 + li, hi));
 #pragma unroll
-            for (int j = 0; j < 2; j++) fb[0][j] = (D2R_GEMM_ABLATE & 2) ? make_uint4(lane, kt, j, 2) : *(const uint4 *)(Bb + lds_off(wn + j * 32 + li, hi));
+        for (int j = 0; j < 2; j++) fb[0][j] = *(const uint4 *)(Bb + lds_off(wn + j * 32 + li, hi));
 #pragma unroll
-            for (int s = 0; s < 4; s++) {
-                const int cb = s & 1, nb = cb ^ 1;
-                if (s + 1 < 4) {
+        for (int s = 0; s < 4; s++) {
+            const int cb = s & 1, nb = cb ^ 1;
+            if (s + 1 < 4) {
 #pragma unroll
-                    for (int i = 0; i < MT; i++) fa[nb][i] = (D2R_GEMM_ABLATE & 2) ? make_uint4(lane, kt, i, s) : *(const uint4 *)(Ab + lds_off(wm + i * 32 + li, 2 * (s + 1) + hi));
+                for (int i = 0; i < MT; i++) fa[nb][i] = *(const uint4 *)(Ab + lds_off(wm + i * 32 + li, 2 * (s + 1) + hi));
 #pragma unroll
-                    for (int j = 0; j < 2; j++) fb[nb][j] = (D2R_GEMM_ABLATE & 2) ? make_uint4(lane, kt, j, s) : *(const uint4 *)(Bb + lds_off(wn + j * 32 + li, 2 * (s + 1) + hi));
+                for (int j = 0; j < 2; j++) fb[nb][j] = *(const uint4 *)(Bb + lds_off(wn + j * 32 + li, 2 * (s + 1) + hi));
+            }
+            // this k-step's share of the next tile's LDS-DMA: issued between the fragment reads and
+            // the MFMA group instead of in one burst ahead of the first MFMA of the iteration
+            if (fill) {
+#pragma unroll
+                for (int c = s * ((PER_STAGE + 3) / 4); c < (s + 1) * ((PER_STAGE + 3) / 4) && c < PER_STAGE; c++)
+                    stage_one(nbuf, ahead, c);
+            }
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < MT; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    union { uint4 u; bf16x8 v; } a, b;
+                    a.u = fa[cb][i];
+                    b.u = fb[cb][j];
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc[i][j], 0, 0, 0);
                 }
-                // this k-step's share of the next tile's LDS-DMA: issued between the fragment reads and
-                // the MFMA group instead of in one burst ahead of the first MFMA of the iteration
-                if (fill) {
-#pragma unroll
-                    for (int c = s * ((PER_STAGE + 3) / 4); c < (s + 1) * ((PER_STAGE + 3) / 4) && c < PER_STAGE; c++)
-                        stage_one(nbuf, ahead, c);
-                }
-                __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int i = 0; i < MT; i++)
-#pragma unroll
-                    for (int j = 0; j < 2; j++) {
-                        union { uint4 u; bf16x8 v; } a, b;
-                        a.u = fa[cb][i];
-                        b.u = fb[cb][j];
-#if (D2R_GEMM_ABLATE & 8) && defined(__HIP_DEVICE_COMPILE__)
-                        asm volatile("" ::"v"(a.u.x), "v"(b.u.x));      // keep the fragments live
-#else
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc[i][j], 0, 0, 0);
-#endif
-                    }
-                __builtin_amdgcn_s_setprio(0);
-            }
-            // tile kt+1 must have landed; with 3 stages this wave's copies of tile kt+2 stay in flight
-            bool pf_on = false;
-            if (PF_D > 0) {
-                pf_on = ahead + PF_D < nk;
-                if (pf_on) asm volatile("global_load_dword %0, %1, off" : "+v"(pf) : "v"(pfp + (size_t)(ahead + PF_D) * BK) : "memory");
-            }
-            if (PF_R) {
-                // 4 loads per wave cover the wave's 32 rows x (TBN*4/128) lines of the residual tile
-                if (kt < TBN / 64) {
-                    const uint32_t idx = kt * 64 + lane, lpr = TBN / 32;     // lines per row
-                    uint32_t row = m0 + wave * (TBM / NWAVE) + idx / lpr;
-                    row = row < M_real ? row : M_real - 1;
-                    const float *rp = (const float *)Cout + (size_t)row * N + n0 + (idx % lpr) * 32;
-                    asm volatile("global_load_dword %0, %1, off" : "+v"(pf) : "v"(rp) : "memory");
-                    pf_on = true;      // counted below as one more op in flight (a landed A-prefetch is harmless to wait for)
-                }
-            }
-            if (STAGES == 3 && ahead < nk) {
-                if (pf_on) wait_vmcnt<PER_STAGE + 1>(); else wait_vmcnt<PER_STAGE>();
-            } else {
-                if (pf_on) wait_vmcnt<1>(); else wait_vmcnt<0>();
-            }
-            __syncthreads();
-            cur = cur + 1 == STAGES ? 0 : cur + 1;
+            __builtin_amdgcn_s_setprio(0);
         }
+        // tile kt+1 must have landed; with 3 stages this wave's copies of tile kt+2 stay in flight
+        if (STAGES == 3 && ahead < nk)
+            wait_vmcnt<PER_STAGE>();
+        else
+            wait_vmcnt<0>();
+        __syncthreads();
+        cur = cur + 1 == STAGES ? 0 : cur + 1;
     }
-
-    // epilogue: 32 rows at a time each wave transposes its fp32 tile through LDS (the ring is free:
-    // the loop ended on a barrier) so that a lane owns 4 consecutive columns of a row: bias and
-    // activation on float4, 8-byte (bf16) / 16-byte (fp32) coalesced stores.
-    // acc[i][j][r] <-> row 32i+(r&3)+8(r>>2)+4hi, col 32j+li of the wave tile.
-#if (D2R_GEMM_ABLATE & 4) && defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-    for (int i = 0; i < MT; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) asm volatile("" ::"v"(acc[i][j][r]));
-    return;
-#endif
-    if (PF_D > 0 || PF_R || (D2R_GEMM_ABLATE & 16)) {
-        wait_vmcnt<0>();
-        asm volatile("" ::"v"(pf), "v"(sink));
-    }
+    // the ring is free (the loop ended on a barrier with nothing in flight): its first bytes serve as
+    // the epilogue's transpose buffers
     gemm_epilogue<EPI, MT>(acc, (float *)smem + wave * EP_WAVE_FLOATS, lane, m0 + wm, n0 + wn, bias, Cout, N);
 }
 
@@ -611,21 +519,13 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void k_gemm(const uint16_t *__re
 // overwrites the one its MFMAs do not read.  Requires K % 128 == 0, N % 256 == 0.
 __device__ __forceinline__ void glds16s(uint32_t voff, const void *sbase, uint32_t lds_byte_addr)
 {
-#if D2R_GEMM_LD == 1
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" : : "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
-#elif D2R_GEMM_LD == 2
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 sc1" : : "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
-#elif D2R_GEMM_LD == 3
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 sc0" : : "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
-#else
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
-#endif
 }
 
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A, const uint16_t *__restrict__ W,
                                                  const float *__restrict__ bias, void *__restrict__ Cout,
-                                                 uint32_t M_pad, uint32_t N, uint32_t K, uint32_t M_real)
+                                                 uint32_t M_pad, uint32_t N, uint32_t K)
 {
     constexpr uint32_t SLOT = 128 * BK * 2;          // 16 KiB
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -764,8 +664,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
     // group 0's next read section: after the MFMAs for wm = 0, after the DMA issue for wm = 1.
     if (wm == 1) bar();
 
-    // measurement only (bit 512): even workgroups skip the K loop, odd ones the epilogue
-    const uint32_t n_iter = ((D2R_GEMM_ABLATE & 512) && !(blockIdx.x & 8)) ? 0 : nk / 2;
+    const uint32_t n_iter = nk / 2;
     for (uint32_t u = 0; u < n_iter; u++) {
         const bool last = u + 1 == n_iter;            // block-uniform
 #pragma unroll
@@ -819,17 +718,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
 #pragma unroll
             for (int r = 0; r < 16; r++) asm volatile("" ::"v"(acc[i][j][r]));
 #else
-    if ((D2R_GEMM_ABLATE & 512) && (blockIdx.x & 8)) {
-        request_next();
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-#pragma unroll
-            for (int j = 0; j < 2; j++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) asm volatile("" ::"v"(acc[i][j][r]));
-    } else {
-        gemm_epilogue<EPI, 4>(acc, ep, lane, em, en, bias, Cout, N, request_next);
-    }
+    gemm_epilogue<EPI, 4>(acc, ep, lane, em, en, bias, Cout, N, request_next);
 #endif
     if (t_next >= t_end) break;
     t = t_next;
@@ -1323,7 +1212,7 @@ static int launch_gemm_cfg(d2r_ctx *ctx, const uint16_t *A, const uint16_t *W, c
         attr_set = true;
     }
     hipLaunchKernelGGL((k_gemm<EPI, WGM, WGN, MT, STAGES>), dim3(nwg), dim3(WGM * WGN * 64), LDS, ctx->stream, A, W, bias, C,
-                       M_pad, N, K, M_real);
+                       M_pad, N, K);
     D2R_HIP(ctx, hipGetLastError());
     return D2R_OK;
 }
@@ -1349,7 +1238,7 @@ static int launch_gemm(d2r_ctx *ctx, const uint16_t *A, const uint16_t *W, const
                 attr8 = true;
             }
             constexpr uint32_t LDS8 = 128 * 1024 + 8 * EP_WAVE_FLOATS * 4;
-            hipLaunchKernelGGL((k_gemm8<EPI>), dim3(256), dim3(512), LDS8, ctx->stream, A, W, bias, C, M_pad, N, K, M_real);
+            hipLaunchKernelGGL((k_gemm8<EPI>), dim3(256), dim3(512), LDS8, ctx->stream, A, W, bias, C, M_pad, N, K);
             D2R_HIP(ctx, hipGetLastError());
             return D2R_OK;
         }
