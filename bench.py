@@ -72,7 +72,7 @@ def main():
     ap.add_argument("--poses-per-gpu", type=int, default=4096)
     ap.add_argument("--clip", default="vit_b16")
     ap.add_argument("--scene", default="shopping")
-    ap.add_argument("--chunk", type=int, default=1024)
+    ap.add_argument("--chunk", type=int, default=4096, help="candidates per pass (the library caps it per model/view)")
     ap.add_argument("--opt", action="append", default=[], help="library tunable key=value (repeatable)")
     ap.add_argument("--cpu-sample", type=int, default=6, help="candidates in the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
@@ -169,6 +169,9 @@ def main():
     ctx.set_option("timing", 0)
     stats = ctx.render_stats(collect_K=K_local)          # counters of the last step
 
+    launches_per_step = max(1, round(timing["march_launches"] / max(1, args.steps)))
+    per_launch = -(-K_local // launches_per_step)          # candidates per k_march launch actually used
+
     def recorded_traffic():
         """HBM-side bytes per k_march launch from the committed PMC passes (bench.py cannot run
         under --pmc itself); only reported when it was measured on this exact workload."""
@@ -177,7 +180,7 @@ def main():
         except OSError:
             return None, None
         wl = t["workload"]
-        if (wl["scene"], wl["width"], wl["height"], wl["chunk"], wl["clip"]) != (args.scene, W, H, args.chunk, args.clip):
+        if (wl["scene"], wl["width"], wl["height"], wl["chunk"], wl["clip"]) != (args.scene, W, H, per_launch, args.clip):
             return None, None
         return t["traffic_bytes_per_launch"], "profiles/r01_march_traffic.json (FETCH_SIZE+WRITE_SIZE, uncorrected: narrow gathers)"
 
@@ -185,7 +188,7 @@ def main():
         total = N * args.steps
         traffic, traffic_src = recorded_traffic()
         value = total / elapsed
-        samples_per_launch = stats["samples"] / max(1, -(-K_local // args.chunk))
+        samples_per_launch = stats["samples"] / launches_per_step
         march_avg_s = timing["march_ms"] / max(1, timing["march_launches"]) * 1e-3
         achieved = samples_per_launch * ALGO_BYTES_PER_SAMPLE / march_avg_s / 1e9 if march_avg_s > 0 else 0.0
         n_img = K_local * args.steps
@@ -196,7 +199,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"BASELINE.json configs[1]: {args.scene} scene, {args.poses_per_gpu} candidate poses per GPU, "
-                                   f"{W}x{H}, bf16 MLP + {args.clip}", "poses_total": N, "chunk": args.chunk,
+                                   f"{W}x{H}, bf16 MLP + {args.clip}", "poses_total": N, "chunk": per_launch,
                        "parallelism": f"pose-shard x{world}" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "k_march (hash-grid fetch + fused MLP + compositing)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",

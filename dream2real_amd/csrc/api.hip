@@ -18,6 +18,17 @@ size_t d2r_clip_patch_bytes(const d2r_clip *, uint32_t n);
 int d2r_launch_eval_points(d2r_ctx *, const d2r_nerf *, const float *xyz, const float *dirs, uint32_t n, float *out);
 uint32_t d2r_clip_image_size(const d2r_clip *);
 uint32_t d2r_clip_proj_dim(const d2r_clip *);
+uint32_t d2r_clip_max_images(const d2r_clip *);
+
+// Candidates (images) per pass: the "chunk" option, capped so that one pass stays inside the 32-bit
+// indexing of the ray queue (rays) and of the GEMM outputs (rows x widest layer).
+static uint32_t pass_size(const d2r_ctx *ctx, const d2r_clip *clip, size_t px)
+{
+    uint64_t per = (uint64_t)std::max<int64_t>(1, ctx->chunk);
+    if (clip) per = std::min<uint64_t>(per, d2r_clip_max_images(clip));
+    if (px) per = std::min<uint64_t>(per, std::max<uint64_t>(1, 0xffffffffull / px));
+    return (uint32_t)per;
+}
 
 static thread_local std::string g_err;
 
@@ -155,7 +166,7 @@ int d2r_ctx_set_option(d2r_ctx *ctx, const char *key, int64_t value)
 {
     if (!ctx || !key) return d2r_fail(ctx, D2R_ERR_INVALID, "null argument");
     if (!strcmp(key, "chunk")) {
-        if (value < 1 || value > 4096) return d2r_fail(ctx, D2R_ERR_INVALID, "chunk must be in [1, 4096]");
+        if (value < 1 || value > 16384) return d2r_fail(ctx, D2R_ERR_INVALID, "chunk must be in [1, 16384]");
         ctx->chunk = value;
     } else if (!strcmp(key, "march_blocks")) {
         if (value < 0 || value > 65535) return d2r_fail(ctx, D2R_ERR_INVALID, "march_blocks out of range");
@@ -547,7 +558,7 @@ int d2r_render_composite(d2r_ctx *ctx, const d2r_nerf *fg, const d2r_view *view,
     const ViewParams V = d2r_view_params(view);
     const size_t px = (size_t)V.W * V.H;
     ctx->stats = d2r_render_stats{0, 0, 0, 0};
-    const uint32_t per = (uint32_t)std::max<int64_t>(1, ctx->chunk);
+    const uint32_t per = pass_size(ctx, nullptr, px);
     for (uint32_t c0 = 0; c0 < K; c0 += per) {
         uint32_t nc = std::min(per, K - c0);
         if ((rc = d2r_reserve(ctx, ctx->poses, (size_t)nc * 64))) return rc;
@@ -586,7 +597,7 @@ int d2r_clip_score_frames(d2r_ctx *ctx, const d2r_clip *clip, const uint8_t *fra
     if (rc) return rc;
     const size_t px = (size_t)w * h;
     const uint32_t D = d2r_clip_proj_dim(clip);
-    const uint32_t per = (uint32_t)std::max<int64_t>(1, ctx->chunk);
+    const uint32_t per = pass_size(ctx, clip, 0);
     for (uint32_t c0 = 0; c0 < n; c0 += per) {
         uint32_t nc = std::min(per, n - c0);
         if ((rc = d2r_reserve(ctx, ctx->frames, (size_t)nc * px * 3))) return rc;
@@ -634,7 +645,7 @@ int d2r_clip_embed_pixels(d2r_ctx *ctx, const d2r_clip *clip, const float *pixel
     const size_t S = d2r_clip_image_size(clip);
     const uint32_t D = d2r_clip_proj_dim(clip);
     int rc;
-    const uint32_t per = (uint32_t)std::max<int64_t>(1, ctx->chunk);
+    const uint32_t per = pass_size(ctx, clip, 0);
     for (uint32_t c0 = 0; c0 < n; c0 += per) {
         uint32_t nc = std::min(per, n - c0);
         if ((rc = d2r_reserve(ctx, ctx->pix, (size_t)nc * 3 * S * S * 4))) return rc;
@@ -666,7 +677,8 @@ int d2r_render_score(d2r_ctx *ctx, const d2r_nerf *fg, const d2r_clip *clip, con
     if ((rc = upload_text(ctx, clip, text_embeds, C))) return rc;
     const ViewParams V = d2r_view_params(view);
     const size_t px = (size_t)V.W * V.H;
-    const uint32_t per = (uint32_t)std::max<int64_t>(1, ctx->chunk);
+    const uint32_t per = pass_size(ctx, clip, px);
+    ctx->last_pass = per;
     // workspaces are sized once for a full chunk so that no allocation happens inside the loop
     const uint32_t cap = std::min(per, K);
     if ((rc = d2r_reserve(ctx, ctx->cams, (size_t)cap * 48))) return rc;
@@ -705,7 +717,7 @@ int d2r_render_score(d2r_ctx *ctx, const d2r_nerf *fg, const d2r_clip *clip, con
 int d2r_collect_render_stats(d2r_ctx *ctx, uint32_t K)
 {
     if (!ctx) return d2r_fail(nullptr, D2R_ERR_INVALID, "null ctx");
-    const uint32_t per = (uint32_t)std::max<int64_t>(1, ctx->chunk);
+    const uint32_t per = std::max<uint32_t>(1, ctx->last_pass);
     const uint32_t nchunks = (K + per - 1) / per;
     std::vector<uint32_t> c((size_t)nchunks * 8);
     D2R_HIP(ctx, hipMemcpyAsync(c.data(), (uint8_t *)ctx->counters.p + 64, c.size() * 4, hipMemcpyDeviceToHost, ctx->stream));

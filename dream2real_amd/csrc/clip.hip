@@ -23,6 +23,8 @@
 
 #include <math.h>
 
+#include <algorithm>
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -1305,6 +1307,14 @@ int d2r_launch_patchify(d2r_ctx *ctx, const d2r_clip *clip, const float *pv_dev,
                        clip->desc.image_size, clip->desc.patch_size, patches_dev, clip->Kp_pad);
     D2R_HIP(ctx, hipGetLastError());
     return D2R_OK;
+}
+
+// largest image count whose GEMM outputs (rows padded to BM x the widest layer) keep 32-bit indices
+uint32_t d2r_clip_max_images(const d2r_clip *clip)
+{
+    const uint64_t widest = std::max<uint64_t>(3ull * clip->desc.hidden_size, clip->desc.mlp_size);
+    const uint64_t rows = (0xffffffffull / widest) / BM * BM;
+    return (uint32_t)std::max<uint64_t>(1, rows / clip->T);
 }
 
 size_t d2r_clip_patch_bytes(const d2r_clip *clip, uint32_t n)

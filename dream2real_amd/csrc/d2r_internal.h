@@ -80,7 +80,8 @@ struct d2r_ctx {
     Buf bg_rgba, bg_depth, bg_u8;
     uint32_t bg_w = 0, bg_h = 0;
     d2r_render_stats stats{};
-    int64_t chunk = 1024;       // candidates per pass of the fused path
+    int64_t chunk = 4096;       // candidates per pass (capped per model/view by pass_size() in api.hip)
+    uint32_t last_pass = 0;     // pass size the last d2r_render_score used (for its stats read-back)
     int64_t march_blocks = 0;  // 0 = auto
     int64_t refill_min = 16;
     int64_t gemm_cfg = 0;      // experiment switch for the GEMM tile configuration (0 = default)
