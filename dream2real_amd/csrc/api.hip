@@ -181,6 +181,8 @@ int d2r_ctx_set_option(d2r_ctx *ctx, const char *key, int64_t value)
         ctx->gbrick_slots = value;
     } else if (!strcmp(key, "bricks")) {
         ctx->use_bricks = value != 0;
+    } else if (!strcmp(key, "raygen_rect")) {
+        ctx->raygen_rect = value != 0;
     } else if (!strcmp(key, "timing")) {
         ctx->timing = value != 0;
         ctx->ev_used = 0;

@@ -86,6 +86,7 @@ struct d2r_ctx {
     int64_t refill_min = 16;
     int64_t gemm_cfg = 0;      // experiment switch for the GEMM tile configuration (0 = default)
     int64_t use_bricks = 1;
+    int64_t raygen_rect = 1;   // composite mode: generate rays only inside the projected occupied bbox
     int64_t gbrick_slots = 2;  // at most this many slots use HBM bricks (0..2)    // serve de-hashed coarse levels from LDS when the model has them
     // optional per-kernel timing (HIP events on the launch stream), see d2r_get_timing
     int64_t timing = 0;

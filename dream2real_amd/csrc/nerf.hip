@@ -286,6 +286,106 @@ __global__ __launch_bounds__(256) void k_raygen(NerfParams P, ViewParams V, cons
     }
 }
 
+// Composite mode (frames already hold the background): only pixels whose ray can reach the occupied
+// bounding box need a ray.  All rays leave the camera centre, so with the eight box corners in front
+// of the camera the box projects into the bounding rectangle of the projected corners; the block
+// walks the 16x16 tiles of that rectangle (+2 px) instead of the whole frame.  A camera that is not a
+// rigid transform, or a corner at or behind the camera plane, falls back to the full frame.
+// grid: (n_cams, parts); block 256 = 4 waves, each wave an 8x8 pixel tile.
+__global__ __launch_bounds__(256) void k_raygen_rect(NerfParams P, ViewParams V, const float *__restrict__ cams,
+                                                     uint2 *__restrict__ queue, uint32_t *__restrict__ qcount)
+{
+    const uint32_t cam_i = blockIdx.x;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float cam[12];
+#pragma unroll
+    for (int j = 0; j < 12; j++) cam[j] = cams[(size_t)cam_i * 12 + j];
+    int x0 = 0, y0 = 0, x1 = (int)V.W - 1, y1 = (int)V.H - 1;
+    {
+        bool ok = true;
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int b = a; b < 3; b++) {
+                const float dot = cam[a] * cam[b] + cam[4 + a] * cam[4 + b] + cam[8 + a] * cam[8 + b];
+                ok = ok && fabsf(dot - (a == b ? 1.0f : 0.0f)) < 1e-3f;
+            }
+        float pxmin = INFINITY, pxmax = -INFINITY, pymin = INFINITY, pymax = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const float qx = ((c & 1) ? P.bbox_hi[0] : P.bbox_lo[0]) - cam[3];
+            const float qy = ((c & 2) ? P.bbox_hi[1] : P.bbox_lo[1]) - cam[7];
+            const float qz = ((c & 4) ? P.bbox_hi[2] : P.bbox_lo[2]) - cam[11];
+            const float cx = cam[0] * qx + cam[4] * qy + cam[8] * qz;      // R^T (p - t)
+            const float cy = cam[1] * qx + cam[5] * qy + cam[9] * qz;
+            const float cz = cam[2] * qx + cam[6] * qy + cam[10] * qz;
+            ok = ok && cz > 1e-3f;                                          // false for NaN too
+            const float fx = V.center[0] * (float)V.W + cx / cz * V.focal[0] - 0.5f;   // pixel whose centre sees the corner
+            const float fy = V.center[1] * (float)V.H + cy / cz * V.focal[1] - 0.5f;
+            pxmin = fminf(pxmin, fx); pxmax = fmaxf(pxmax, fx);
+            pymin = fminf(pymin, fy); pymax = fmaxf(pymax, fy);
+        }
+        ok = ok && pxmax - pxmin < 1e6f && pymax - pymin < 1e6f;           // finite
+        if (ok) {
+            x0 = max(x0, (int)floorf(fmaxf(pxmin, -4.f)) - 2);
+            y0 = max(y0, (int)floorf(fmaxf(pymin, -4.f)) - 2);
+            x1 = min(x1, (int)ceilf(fminf(pxmax, (float)V.W + 4.f)) + 2);
+            y1 = min(y1, (int)ceilf(fminf(pymax, (float)V.H + 4.f)) + 2);
+        }
+    }
+    if (x0 > x1 || y0 > y1) return;                                         // the box is off screen
+    const int tx0 = x0 >> 4, ty0 = y0 >> 4, ntx = (x1 >> 4) - tx0 + 1, nty = (y1 >> 4) - ty0 + 1;
+    // live rays are collected in LDS and appended to the global queue with ONE atomic per flush: the
+    // queue counter is a single address, and one atomic per wave (~10^6 per pass) was what bounded
+    // the full-frame generator
+    constexpr uint32_t CAP = 2048;
+    __shared__ uint2 pending[CAP];
+    __shared__ uint32_t n_pending, flush_base;
+    if (threadIdx.x == 0) n_pending = 0;
+    __syncthreads();
+    auto flush = [&]() {                       // block-uniform call sites only
+        __syncthreads();
+        const uint32_t np_ = n_pending;
+        if (threadIdx.x == 0 && np_) flush_base = atomicAdd(qcount, np_);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < np_; i += 256) queue[flush_base + i] = pending[i];
+        __syncthreads();
+        if (threadIdx.x == 0) n_pending = 0;
+        __syncthreads();
+    };
+    uint32_t since_flush = 0;
+    for (int t = (int)blockIdx.y; t < ntx * nty; t += (int)gridDim.y) {
+        if (since_flush + 256 > CAP) {         // worst case every pixel of every tile so far is live
+            flush();
+            since_flush = 0;
+        }
+        since_flush += 256;
+        const uint32_t px = (uint32_t)(tx0 + t % ntx) * 16 + (wave & 1) * 8 + (lane & 7);
+        const uint32_t py = (uint32_t)(ty0 + t / ntx) * 16 + (wave >> 1) * 8 + (lane >> 3);
+        bool alive = false;
+        uint32_t k = 0;
+        if (px < V.W && py < V.H) {
+            Ray r;
+            if (make_ray(P, V, cam, px, py, r, k)) {
+                float x, y, z;
+                alive = next_sample(P, r, k, x, y, z);
+            }
+        }
+        const uint32_t ray_id = cam_i * (V.W * V.H) + py * V.W + px;
+        unsigned long long m = __ballot(alive);
+        if (m) {
+            uint32_t cnt = (uint32_t)__popcll(m), base = 0;
+            if (lane == (uint32_t)__ffsll((long long)m) - 1) base = atomicAdd(&n_pending, cnt);
+            base = __shfl(base, __ffsll((long long)m) - 1);
+            if (alive) {
+                uint32_t off = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                pending[base + off] = make_uint2(ray_id, k);
+            }
+        }
+    }
+    flush();
+}
+
 // ------------------------------------------------------- field evaluation
 
 __device__ __forceinline__ f32x16 mfma(const uint4 &a, const uint4 &b, f32x16 c)
@@ -867,9 +967,12 @@ int d2r_launch_render(d2r_ctx *ctx, const d2r_nerf *m, const ViewParams &V, cons
     }
     const uint32_t tiles = ((V.W + 15) / 16) * ((V.H + 15) / 16);
     size_t tr = ctx->timing_begin(D2R_T_RAYGEN);
-    hipLaunchKernelGGL(k_raygen, dim3(tiles, n), dim3(256), 0, ctx->stream, m->P, V, cams_dev,
-                       (uint2 *)ctx->queue.p, cnt, composite ? nullptr : rgba_dev,
-                       composite ? nullptr : depth_dev);
+    if (composite && ctx->raygen_rect)
+        hipLaunchKernelGGL(k_raygen_rect, dim3(n, 4), dim3(256), 0, ctx->stream, m->P, V, cams_dev, (uint2 *)ctx->queue.p, cnt);
+    else
+        hipLaunchKernelGGL(k_raygen, dim3(tiles, n), dim3(256), 0, ctx->stream, m->P, V, cams_dev,
+                           (uint2 *)ctx->queue.p, cnt, composite ? nullptr : rgba_dev,
+                           composite ? nullptr : depth_dev);
     ctx->timing_end(tr);
     size_t tm = ctx->timing_begin(D2R_T_MARCH);
     int blocks = ctx->march_blocks > 0 ? (int)ctx->march_blocks : 256;     // persistent: one per CU

@@ -138,6 +138,41 @@ def test_composited_frames_match_oracle(gpu, W, H):
     assert st["rays_total"] == len(poses) * W * H and st["samples"] > 0
 
 
+def test_rect_culled_raygen_is_bit_identical_to_full_frame_raygen(gpu):
+    """Composite mode only generates rays inside the projected occupied bounding box; frames and
+    ray/sample counts must equal the full-frame ray generator's, including for objects that are
+    partly or wholly off screen and ones at / behind the camera plane (full-frame fallback)."""
+    scene, fg, ctx = gpu["scene"], gpu["fg"], gpu["ctx"]
+    W, H = 320, 180
+    pipe = OraclePipeline(scene, W, H)
+    base = host_ref.sample_poses_grid(scene.scene_centre, [3, 3, 1, 1, 1, 1], scene.scene_type).reshape(-1, 4, 4)
+    extra = []
+    for dx, dy, dz in [(0.18, 0.0, 0.0), (-0.22, 0.1, 0.0), (0.0, 0.16, 0.0), (0.6, 0.6, 0.0),
+                       (0.0, 0.0, 0.3), (0.0, 0.0, 0.52), (0.0, 0.0, 0.58), (0.0, 0.0, 0.75)]:
+        p = np.array(scene.obj_pose, np.float64).reshape(4, 4).copy()
+        p[:3, 3] += (dx, dy, dz)
+        extra.append(p)
+    poses = np.concatenate([base, np.stack(extra)]).astype(np.float32)
+    obg = pipe.background()
+    view = fg.view(W, H)
+    ctx.set_background(view, obg[0], obg[1])
+    T1 = host_ref.converter(np.asarray(scene.obj_pose, np.float32)[None])[0]
+    TC = host_ref.converter(np.asarray(scene.cam_poses, np.float32))[0]
+    out = {}
+    for flag in (1, 0):
+        ctx.set_option("raygen_rect", flag)
+        frames = fg.render_composite(view, T1, TC, host_ref.converter(poses))
+        st = ctx.render_stats()
+        out[flag] = (frames, st["rays_alive"], st["samples"])
+    ctx.set_option("raygen_rect", 1)
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    assert out[0][1] == out[1][1] > 1000 and out[0][2] == out[1][2]
+    # the candidate set really covers both cases: objects in view and objects entirely out of view
+    # (their frame is the plain background, which the first far-off-screen candidate shows)
+    per_frame_rays = [(f != out[1][0][len(base) + 3]).any() for f in out[1][0]]
+    assert any(per_frame_rays[:len(base)]) and not all(per_frame_rays)
+
+
 def test_lds_bricks_are_bit_identical_to_global_tables(gpu):
     """The de-hashed bounding-box bricks served from LDS hold exactly the table values: frames and
     sample counts with and without them are bit-identical."""
