@@ -148,6 +148,10 @@ __global__ void k_cameras_virtual(ViewParams V, Mat16 obj_now, Mat16 cam, const 
     for (int j = 0; j < 12; j++) cams_out[(size_t)i * 12 + j] = o[j];
 }
 
+#ifndef D2R_MARCH_RESERVE
+#define D2R_MARCH_RESERVE 128          /* queue entries a wave reserves per atomic */
+#endif
+
 // --------------------------------------------------------------------- rays
 
 struct Ray {
@@ -744,6 +748,7 @@ __global__ __launch_bounds__(D2R_MARCH_THREADS) void k_march(NerfParams P, ViewP
     __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void *)P.gbrick_tab, 0, P.gbrick_bytes, 0x00020000);
 
     bool alive = false, exhausted = false;
+    uint32_t res_lo = 0, res_hi = 0;           // wave-uniform: this wave's reserved range of queue entries
     Ray ray = {};
     uint32_t k = 0, ray_id = 0;
     float px = 0.f, py = 0.f, pz = 0.f;
@@ -756,15 +761,25 @@ __global__ __launch_bounds__(D2R_MARCH_THREADS) void k_march(NerfParams P, ViewP
     for (;;) {
         // ---- refill free lanes from the ray queue (ballot + prefix popcount, one atomic per wave)
         unsigned long long freem = __ballot(!alive);
-        if (!exhausted && freem != 0ull && (__popcll(freem) >= (int)P.refill_min || freem == ~0ull)) {
-            uint32_t nfree = (uint32_t)__popcll(freem), base = 0;
-            int leader = __ffsll((long long)freem) - 1;
-            if ((int)lane == leader) base = atomicAdd(qhead, nfree);
-            base = __shfl(base, leader);
-            if (base + nfree >= n_q) exhausted = true;
+        if ((!exhausted || res_lo < res_hi) && freem != 0ull && (__popcll(freem) >= (int)P.refill_min || freem == ~0ull)) {
+            const uint32_t nfree = (uint32_t)__popcll(freem);
+            if (res_lo == res_hi) {
+                // this wave's reservation is used up: take the next D2R_MARCH_RESERVE queue entries with
+                // one atomic (the queue head is a single address; one atomic per refill was ~10^6 per pass)
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(qhead, (uint32_t)D2R_MARCH_RESERVE);
+                base = __builtin_amdgcn_readfirstlane(base);
+                res_lo = min(base, n_q);
+                res_hi = min(base + (uint32_t)D2R_MARCH_RESERVE, n_q);
+                if (base + D2R_MARCH_RESERVE >= n_q) exhausted = true;
+            }
+            const uint32_t take = min(nfree, res_hi - res_lo);
+            const uint32_t first = res_lo;
+            res_lo += take;
             if (!alive) {
-                uint32_t idx = base + (uint32_t)__popcll(freem & ((1ull << lane) - 1ull));
-                if (idx < n_q) {
+                const uint32_t rank = (uint32_t)__popcll(freem & ((1ull << lane) - 1ull));
+                const uint32_t idx = first + rank;
+                if (rank < take) {
                     uint2 q = queue[idx];
                     ray_id = q.x;
                     k = q.y;
