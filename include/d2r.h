@@ -266,10 +266,18 @@ typedef struct {
 } d2r_timing;
 D2R_API int d2r_get_timing(d2r_ctx *ctx, d2r_timing *out);
 
-/* Tunables ("chunk", "march_blocks", "timing", "refill_min", "bricks"); unknown keys return D2R_ERR_INVALID.
- * "refill_min" (default 16): free lanes a marcher wave accumulates before refilling from the ray
- * queue.  "bricks" (default 1): serve the de-hashed coarse levels of small models from LDS; 0 forces
- * every level through the global tables (results are bit-identical either way). */
+/* Tunables; unknown keys return D2R_ERR_INVALID.
+ * "chunk" (default 4096, 1..16384): candidates / images per pass; the library lowers it per model and
+ *     view so that one pass stays inside the 32-bit indexing of the ray queue and the GEMM outputs.
+ * "refill_min" (default 64, 1..64): free lanes a marcher wave accumulates before it takes new rays
+ *     from the queue (64 = a wave runs its 64 rays to the end).
+ * "bricks" (default 1): serve the de-hashed coarse levels of small models from LDS; 0 forces every
+ *     level through the global tables.  "gbrick_slots" (default 2, 0..3): slots served from de-hashed
+ *     bricks in HBM.  "raygen_rect" (default 1): composite mode generates rays only inside the projected
+ *     occupied bounding box.  Results are bit-identical whatever these three are set to.
+ * "timing" (0/1): record HIP events per kernel group for d2r_get_timing.  "march_blocks" (default 0 =
+ *     one persistent workgroup per CU), "gemm_cfg" (0 default, 1 plain-K-loop 256x256 kernel, 2 force
+ *     256x128): development switches. */
 D2R_API int d2r_ctx_set_option(d2r_ctx *ctx, const char *key, int64_t value);
 
 #ifdef __cplusplus
