@@ -524,6 +524,24 @@ __device__ __forceinline__ void glds16s(uint32_t voff, const void *sbase, uint32
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
 }
 
+#ifdef D2R_GEMM_STAMPS
+// development only: shader-clock cycles wave 0 of every workgroup spends per tile section,
+// [EPI][0 drain wait, 1 K loop, 2 epilogue, 3 tiles]
+__device__ unsigned long long d2r_gemm_stamps[4][4];
+extern "C" __attribute__((visibility("default"))) int d2r_debug_gemm_stamps(unsigned long long *out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(d2r_gemm_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(d2r_gemm_stamps), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#define STAMP(var) const unsigned long long var = __builtin_readcyclecounter()
+#else
+#define STAMP(var)
+#endif
+
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A, const uint16_t *__restrict__ W,
                                                  const float *__restrict__ bias, void *__restrict__ Cout,
@@ -651,6 +669,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
         for (int j = 0; j < 2; j++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    STAMP(ts0);
     // everything in flight is drained ONCE per tile: the eight half-tiles requested a whole epilogue ago
     // and that epilogue's stores (stores share the vmcnt counter and may retire out of order with loads,
     // so the counted waits below are only sound with no store outstanding)
@@ -660,6 +679,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
     read_pos(1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     bar();                                            // slots 0, 1 may be restaged from phase 2 on
+    STAMP(ts1);
     // The two wave rows run half a phase apart: wm = 1 starts one barrier late, so that on every SIMD
     // one wave is in its MFMA section while the other reads LDS and issues DMA.  A wave waits for the
     // DMA that the NEXT phase reads at the end of its section that precedes the barrier in front of
@@ -700,6 +720,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
         }
     }
     if (wm == 0) bar();
+    STAMP(ts2);
     // every wave is past its last fragment read and every DMA of this tile has landed: the ring is free.
     // Request the next tile's first eight half-tiles now; they land while this tile's epilogue runs.
     const uint32_t t_next = t + per_xcd;
@@ -721,6 +742,17 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
             for (int r = 0; r < 16; r++) asm volatile("" ::"v"(acc[i][j][r]));
 #else
     gemm_epilogue<EPI, 4>(acc, ep, lane, em, en, bias, Cout, N, request_next);
+#endif
+#ifdef D2R_GEMM_STAMPS
+    {
+        const unsigned long long ts3 = __builtin_readcyclecounter();
+        if (tid == 0) {
+            atomicAdd(&d2r_gemm_stamps[EPI][0], ts1 - ts0);
+            atomicAdd(&d2r_gemm_stamps[EPI][1], ts2 - ts1);
+            atomicAdd(&d2r_gemm_stamps[EPI][2], ts3 - ts2);
+            atomicAdd(&d2r_gemm_stamps[EPI][3], 1ull);
+        }
+    }
 #endif
     if (t_next >= t_end) break;
     t = t_next;

@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Run on the GPU box with libd2r built with EXTRA=-DD2R_GEMM_STAMPS: average shader-clock cycles
+per tile that wave 0 of a k_gemm8 workgroup spends waiting for the drained queue, in the K loop and
+in the epilogue, per epilogue kind, over one bench-sized ViT forward."""
+import ctypes as C
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from dream2real_amd import engine, _lib
+from dream2real_amd.clip_model import CLIP_CONFIGS, random_clip_state_dict
+
+ctx = engine.Context(0)
+cfg = CLIP_CONFIGS["vit_b16"]
+sc = engine.ClipScorer(ctx, cfg, random_clip_state_dict(cfg, seed=6, text=False))
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+pv = np.random.default_rng(0).standard_normal((n, 3, 224, 224), dtype=np.float32)
+lib = _lib.load()
+out = (C.c_ulonglong * 16)()
+sc.embed_pixels(pv)
+lib.d2r_debug_gemm_stamps(out, 1)
+sc.embed_pixels(pv)
+lib.d2r_debug_gemm_stamps(out, 0)
+names = ["patch (fp32)", "QKV (bias bf16)", "fc1 (gelu bf16)", "out-proj + fc2 (fp32 residual)"]
+for e in range(4):
+    w, k, ep, t = out[4 * e:4 * e + 4]
+    if t:
+        print(f"{names[e]:34s} tiles/WG-wave0 {t:7d}  drain {w / t:9.0f}  K loop {k / t:9.0f}  epilogue {ep / t:9.0f} cycles/tile")
