@@ -1,0 +1,58 @@
+"""Static checks on the generated gfx950 code (no GPU needed: hipcc cross-compiles).
+
+k_gemm8 orders its LDS-DMA ring with COUNTED `s_waitcnt vmcnt(N)`.  That is only sound while
+every outstanding vector-memory operation of the wave is one of its own loads (loads retire in
+order; stores share the counter and may retire out of order with them).  A register spill STORE
+between the first and the last MFMA of the K loop would break that silently, so the build is
+checked for it.  Spill reloads (loads) are tolerated but reported."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dream2real_amd", "csrc")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+@pytest.fixture(scope="module")
+def clip_isa(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("isa") / "clip.s"
+    flags = re.search(r"CXXFLAGS\s*=\s*(.*?)\n\s*-Wall", open(os.path.join(CSRC, "Makefile")).read(), re.S)
+    assert flags, "Makefile CXXFLAGS not found"
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-DD2R_MARCH_THREADS=768",
+           "-DD2R_GEMM_ABLATE=0", "-I" + os.path.join(CSRC, "..", "..", "include"), "-S", "--cuda-device-only",
+           "-o", str(out), os.path.join(CSRC, "clip.hip")]
+    subprocess.run(cmd, check=True, capture_output=True, timeout=900)
+    return open(out).read()
+
+
+def kernels(isa, prefix):
+    for m in re.finditer(r"^(_Z\d+%s\w*):[^\n]*\n(.*?)s_endpgm" % prefix, isa, re.S | re.M):
+        yield m.group(1), m.group(2).split("\n")
+
+
+def test_no_spill_stores_inside_the_counted_vmcnt_k_loop(clip_isa):
+    seen = 0
+    for name, lines in kernels(clip_isa, "k_gemm8"):
+        mf = [i for i, l in enumerate(lines) if "v_mfma" in l]
+        assert len(mf) >= 64, name
+        body = lines[mf[0]:mf[-1] + 1]
+        stores = [l for l in body if "scratch_store" in l]
+        assert not stores, f"{name}: spill stores inside the K loop: {stores[:3]}"
+        seen += 1
+    assert seen >= 4          # one instantiation per epilogue kind
+
+
+def test_k_loop_waits_are_counted_not_drained(clip_isa):
+    """between the MFMAs of the steady-state loop the only vmcnt waits are the hand-placed counted ones
+    (10 outstanding) plus the tail's 8/6/4/2/0; a compiler-inserted vmcnt(0) in the steady state would
+    show up as more than a handful of vmcnt(0)."""
+    for name, lines in kernels(clip_isa, "k_gemm8"):
+        mf = [i for i, l in enumerate(lines) if "v_mfma" in l]
+        body = "\n".join(lines[mf[0]:mf[-1] + 1])
+        assert body.count("vmcnt(10)") >= 8, name
+        assert len(re.findall(r"vmcnt\(0\)", body)) <= 4, name
