@@ -866,6 +866,16 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void k_attention(const uint16_t *_
     const uint16_t *Kg = Qg + d;
     const uint16_t *Vg = Qg + 2 * d;
 
+    // this wave's first query tile is requested before the staging so that its latency hides under it
+    // (B operand of S^T = K Q^T: lane (q, hi) holds Q[q][16s + 8hi .. +8))
+    const uint32_t n_qt = (T + 31) / 32, n_kt = T_pad / 32;
+    uint4 qf[4];
+    {
+        const uint32_t qrow0 = wave * 32 + li;
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+            qf[s] = (wave < n_qt && qrow0 < T) ? *(const uint4 *)(Qg + (size_t)qrow0 * ld + 16 * s + 8 * hi) : make_uint4(0, 0, 0, 0);
+    }
     // K (row-major, swizzled 16-byte chunks) goes straight to LDS by LDS-DMA, 8 key rows per wave
     // instruction, issued before anything else so it overlaps the V transposes.  Rows >= T repeat row
     // T-1: their scores are masked by a select below, so any finite value does.
@@ -901,14 +911,13 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void k_attention(const uint16_t *_
     __syncthreads();
 
     const float sm_c = 0.125f * 1.4426950408889634f;   // head_dim^-0.5 * log2(e), head_dim = 64
-    const uint32_t n_qt = (T + 31) / 32, n_kt = T_pad / 32;
     for (uint32_t qt = wave; qt < n_qt; qt += ATTN_THREADS / 64) {
         const uint32_t qrow = qt * 32 + li;
-        // B operand of S^T = K Q^T: lane (q, hi) holds Q[q][16s + 8hi .. +8)
-        uint4 qf[4];
+        if (qt != wave) {
 #pragma unroll
-        for (int s = 0; s < 4; s++)
-            qf[s] = qrow < T ? *(const uint4 *)(Qg + (size_t)qrow * ld + 16 * s + 8 * hi) : make_uint4(0, 0, 0, 0);
+            for (int s = 0; s < 4; s++)
+                qf[s] = qrow < T ? *(const uint4 *)(Qg + (size_t)qrow * ld + 16 * s + 8 * hi) : make_uint4(0, 0, 0, 0);
+        }
         f32x16 o0, o1;
 #pragma unroll
         for (int r = 0; r < 16; r++) o0[r] = o1[r] = 0.f;
