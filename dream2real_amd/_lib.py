@@ -9,6 +9,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libd2r.so")
+ABI_VERSION = 2          # D2R_ABI_VERSION of include/d2r.h this binding was written against
 
 EXPORTS = [
     "d2r_abi_version", "d2r_ctx_create", "d2r_ctx_destroy", "d2r_ctx_set_stream", "d2r_ctx_synchronize",
@@ -28,7 +29,7 @@ class NerfDesc(C.Structure):
                 ("level_res", C.c_void_p), ("level_size", C.c_void_p), ("level_offset", C.c_void_p),
                 ("n_entries", C.c_uint32), ("grid_fp16", C.c_void_p), ("dw1_fp16", C.c_void_p),
                 ("dw2_fp16", C.c_void_p), ("cw1_fp16", C.c_void_p), ("cw2_fp16", C.c_void_p),
-                ("cw3_fp16", C.c_void_p), ("occupancy_bits", C.c_void_p)]
+                ("cw3_fp16", C.c_void_p), ("occupancy_bits", C.c_void_p), ("aabb_scale", C.c_uint32)]
 
 
 class ViewC(C.Structure):
@@ -89,7 +90,7 @@ def load() -> C.CDLL:
     lib.d2r_text_destroy.restype = None
     for name in EXPORTS:
         getattr(lib, name)          # every declared symbol must be exported
-    if lib.d2r_abi_version() != 1:
+    if lib.d2r_abi_version() != ABI_VERSION:
         raise D2RError("libd2r.so ABI version mismatch")
     _lib = lib
     return lib

@@ -310,29 +310,44 @@ int d2r_nerf_create(d2r_ctx *ctx, const d2r_nerf_desc *d, d2r_nerf **out)
         for (uint32_t e = 0; e < a.size; e++) tab[base + 2 * (size_t)e] = src[a.offset + e];
         for (uint32_t e = 0; e < b.size; e++) tab[base + 2 * (size_t)e + 1] = src[b.offset + e];
     }
-    // occupancy -> 4x4x4 bricks + bounding box of occupied cells
-    std::vector<uint64_t> bricks(32 * 32 * 32, 0);
-    int lo[3] = {D2R_GRID, D2R_GRID, D2R_GRID}, hi[3] = {-1, -1, -1};
-    for (int z = 0; z < D2R_GRID; z++)
-        for (int y = 0; y < D2R_GRID; y++)
-            for (int x = 0; x < D2R_GRID; x++) {
-                uint32_t idx = x + D2R_GRID * (y + D2R_GRID * z);
-                if ((d->occupancy_bits[idx >> 3] >> (idx & 7)) & 1) {
-                    bricks[(x >> 2) + 32 * ((y >> 2) + 32 * (z >> 2))] |= 1ull << ((x & 3) + 4 * (y & 3) + 16 * (z & 3));
-                    int c[3] = {x, y, z};
-                    for (int a = 0; a < 3; a++) {
-                        lo[a] = std::min(lo[a], c[a]);
-                        hi[a] = std::max(hi[a], c[a]);
+    // occupancy -> 4x4x4 bricks per cascade + bounding box of occupied cells, in the unit cube of
+    // the model's box (cascade c spans side 2^c / aabb_scale of it, centred)
+    const uint32_t aabb = d->aabb_scale ? d->aabb_scale : 1u;
+    if (aabb != 1u && aabb != 2u)
+        return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "aabb_scale must be 1 or 2");
+    const uint32_t n_casc = aabb == 2u ? 2u : 1u;
+    P.aabb_scale = aabb;
+    std::vector<uint64_t> bricks((size_t)n_casc * 32 * 32 * 32, 0);
+    float blo[3] = {2.f, 2.f, 2.f}, bhi[3] = {-2.f, -2.f, -2.f};
+    int lo[3] = {D2R_GRID, D2R_GRID, D2R_GRID}, hi[3] = {-1, -1, -1};     // cascade-0 cell range (aabb_scale 1 bricks)
+    for (uint32_t cs = 0; cs < n_casc; cs++) {
+        const uint8_t *bits = d->occupancy_bits + (size_t)cs * (D2R_GRID * D2R_GRID * D2R_GRID / 8);
+        const float side = (float)(1u << cs) / (float)aabb, org = 0.5f - 0.5f * side;   // of the cascade, normalised
+        for (int z = 0; z < D2R_GRID; z++)
+            for (int y = 0; y < D2R_GRID; y++)
+                for (int x = 0; x < D2R_GRID; x++) {
+                    uint32_t idx = x + D2R_GRID * (y + D2R_GRID * z);
+                    if ((bits[idx >> 3] >> (idx & 7)) & 1) {
+                        bricks[(size_t)cs * 32768 + (x >> 2) + 32 * ((y >> 2) + 32 * (z >> 2))] |= 1ull << ((x & 3) + 4 * (y & 3) + 16 * (z & 3));
+                        int c[3] = {x, y, z};
+                        for (int a = 0; a < 3; a++) {
+                            if (cs == 0) {
+                                lo[a] = std::min(lo[a], c[a]);
+                                hi[a] = std::max(hi[a], c[a]);
+                            }
+                            blo[a] = std::min(blo[a], org + side * (float)c[a] / D2R_GRID);
+                            bhi[a] = std::max(bhi[a], org + side * (float)(c[a] + 1) / D2R_GRID);
+                        }
                     }
                 }
-            }
+    }
     for (int a = 0; a < 3; a++) {
-        if (hi[a] < 0) {          // nothing occupied: empty box
+        if (bhi[a] < blo[a]) {          // nothing occupied: empty box
             P.bbox_lo[a] = 2.f;
             P.bbox_hi[a] = -2.f;
         } else {
-            P.bbox_lo[a] = (float)lo[a] / D2R_GRID - 1e-4f;
-            P.bbox_hi[a] = (float)(hi[a] + 1) / D2R_GRID + 1e-4f;
+            P.bbox_lo[a] = blo[a] - 1e-4f;
+            P.bbox_hi[a] = bhi[a] + 1e-4f;
         }
     }
     // De-hashed, bounding-box-local dense bricks of the leading levels (small objects): the
@@ -373,7 +388,7 @@ int d2r_nerf_create(d2r_ctx *ctx, const d2r_nerf_desc *d, d2r_nerf **out)
                 }
         return true;
     };
-    if (hi[0] >= 0 && P.n_dense >= 0) {
+    if (aabb == 1u && hi[0] >= 0 && P.n_dense >= 0) {
         const size_t budget_words = (160 * 1024 - (size_t)D2R_N_WFRAG * 64 * 16) / 4;
         std::vector<uint32_t> words;
         for (uint32_t i = 0; i < d->n_levels / 2 && i < 5; i++) {

@@ -13,6 +13,9 @@
 #define D2R_GRID 128
 #define D2R_DT 0.0016914558f           // sqrt(3)/1024
 #define D2R_INV_DT (1.0f / D2R_DT)
+// aabb_scale 2 (oracle/d2r_oracle.c "cone stepping"): t_{k+1} = t_k + max(dt, t_k/256) in closed form
+#define D2R_CONE 0.00390625f
+#define D2R_T_LINEAR (D2R_DT * 256.0f)
 #define D2R_N_WFRAG 24                 // MLP weight fragments (see nerf.hip)
 
 struct LevelMeta {
@@ -52,7 +55,8 @@ struct NerfParams {
     uint32_t n_gbrick_slots;   // further slots de-hashed into dense bricks kept in HBM (spatially coherent)
     uint32_t gbrick_bytes;
     const uint32_t *gbrick_tab;
-    const uint64_t *bricks;    // [32^3] 4x4x4-cell occupancy bricks
+    const uint64_t *bricks;    // [n_cascades][32^3] 4x4x4-cell occupancy bricks
+    uint32_t aabb_scale;       // 1, or 2: two cascades, cone stepping, positions normalised to the box (k_*<.., CONE>)
     const uint4 *wfrag;        // [24][64] MFMA A-operand fragments of the MLPs
     float bbox_lo[3], bbox_hi[3];  // bounding box of occupied cells (+margin), unit-cube units
 };

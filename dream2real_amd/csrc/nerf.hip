@@ -155,13 +155,48 @@ __global__ void k_cameras_virtual(ViewParams V, Mat16 obj_now, Mat16 cam, const 
 // --------------------------------------------------------------------- rays
 
 struct Ray {
-    float ox, oy, oz, dx, dy, dz;
-    float t0;
+    float ox, oy, oz, dx, dy, dz;      // in the unit cube of the model's box (d is the unit direction / aabb_scale)
+    float t0;                          // distance (world units) of lattice point 0
     uint32_t k_hi;
+    uint32_t k1;                       // CONE only: last lattice point of the constant-step stretch, and its distance
+    float t1;
 };
+
+// aabb_scale 2 (template parameter CONE): the lattice of a ray is the cone-stepping sequence
+// t_{k+1} = t_k + max(dt, t_k / 256) in closed form -- t0 + k dt up to k1, t1 (1 + 1/256)^(k - k1) after it,
+// the power as the fixed-order product of fp32 constants that oracle/d2r_oracle.c uses (same bits).
+__device__ __forceinline__ float cone_pow(uint32_t n)
+{
+    const float P2[12] = {1.00390625f,         1.0078277587890625f, 1.015716791152954f,  1.0316805839538574f,
+                          1.0643649101257324f, 1.1328725814819336f, 1.2834001779556274f, 1.6471161842346191f,
+                          2.712991714477539f,  7.360323429107666f,  54.17436218261719f,  2934.861572265625f};
+    float r = 1.0f;
+#pragma unroll
+    for (int i = 0; i < 12; i++)
+        if ((n >> i) & 1u) r = r * P2[i];
+    return r;
+}
+template <bool CONE>
+__device__ __forceinline__ float lattice_t(const Ray &r, uint32_t k)
+{
+    if (!CONE) return fmaf((float)k, D2R_DT, r.t0);
+    return k <= r.k1 ? fmaf((float)k, D2R_DT, r.t0) : r.t1 * cone_pow(k - r.k1);
+}
+template <bool CONE>
+__device__ __forceinline__ float lattice_dt(float t)
+{
+    return CONE ? fmaxf(D2R_DT, t * D2R_CONE) : D2R_DT;
+}
+// a lattice index at or below the one whose distance is t (conservative by `slack` points either way)
+__device__ __forceinline__ float cone_index_of(const Ray &r, float t)
+{
+    if (t <= r.t1) return (t - r.t0) * D2R_INV_DT;
+    return (float)r.k1 + __log2f(t / r.t1) * 177.79119873046875f;       // 1 / log2(1 + 1/256)
+}
 
 // pixel -> ray, lattice origin and the [k_lo, k_hi] window in which occupied cells can lie.
 // Same fma sequence as the oracle (d2r_oracle_render).
+template <bool CONE>
 __device__ __forceinline__ bool make_ray(const NerfParams &P, const ViewParams &V, const float *cam,
                                          uint32_t px, uint32_t py, Ray &r, uint32_t &k_lo)
 {
@@ -178,24 +213,49 @@ __device__ __forceinline__ bool make_ray(const NerfParams &P, const ViewParams &
     float inv_len = 1.0f / sqrtf(fmaf(d[2], d[2], fmaf(d[1], d[1], d[0] * d[0])));
 #pragma unroll
     for (int i = 0; i < 3; i++) d[i] *= inv_len;
-    float tmin = -INFINITY, tmax = INFINITY, bmin = -INFINITY, bmax = INFINITY;
+    // the model's box: the unit cube, or (CONE) the cube of side 2 centred at 0.5
+    const float box_lo = CONE ? -0.5f : 0.0f, box_hi = CONE ? 1.5f : 1.0f;
+    float tmin = -INFINITY, tmax = INFINITY;
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         float inv = 1.0f / d[i];
-        float t0 = (0.0f - o[i]) * inv, t1 = (1.0f - o[i]) * inv;
+        float t0 = (box_lo - o[i]) * inv, t1 = (box_hi - o[i]) * inv;
         tmin = fmaxf(tmin, fminf(t0, t1));
         tmax = fminf(tmax, fmaxf(t0, t1));
+    }
+    if (CONE) {
+        // from here on in the unit cube of the box; distances stay world distances
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            o[i] = fmaf(o[i] - 0.5f, 0.5f, 0.5f);
+            d[i] *= 0.5f;
+        }
+    }
+    float bmin = -INFINITY, bmax = INFINITY;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        float inv = 1.0f / d[i];
         float b0 = (P.bbox_lo[i] - o[i]) * inv, b1 = (P.bbox_hi[i] - o[i]) * inv;
         bmin = fmaxf(bmin, fminf(b0, b1));
         bmax = fminf(bmax, fmaxf(b0, b1));
     }
     r.ox = o[0]; r.oy = o[1]; r.oz = o[2];
     r.dx = d[0]; r.dy = d[1]; r.dz = d[2];
+    r.k1 = 0;
+    r.t1 = 0.f;
     if (!(tmax >= tmin && tmax > 0.f)) return false;
     r.t0 = fmaxf(tmin, 0.0f) + 1e-6f;
     float hi = fminf(bmax, tmax);
     if (!(hi >= bmin) || hi < r.t0) return false;
     float lo = fmaxf(bmin, r.t0);
+    if (CONE) {
+        r.k1 = r.t0 >= D2R_T_LINEAR ? 0u : (uint32_t)ceilf((D2R_T_LINEAR - r.t0) * D2R_INV_DT);
+        r.t1 = fmaf((float)r.k1, D2R_DT, r.t0);
+        float kl = floorf(cone_index_of(r, lo)) - 2.0f;
+        k_lo = kl > 0.f ? (uint32_t)kl : 0u;
+        r.k_hi = (uint32_t)ceilf(cone_index_of(r, hi)) + 2u;
+        return true;
+    }
     float kl = floorf((lo - r.t0) * D2R_INV_DT) - 1.0f;
     k_lo = kl > 0.f ? (uint32_t)kl : 0u;
     r.k_hi = (uint32_t)ceilf((hi - r.t0) * D2R_INV_DT) + 1u;
@@ -205,34 +265,59 @@ __device__ __forceinline__ bool make_ray(const NerfParams &P, const ViewParams &
 // Advance k to the next lattice sample t0+k*dt that lies in an occupied cell.
 // Empty 4^3 bricks / empty cells are skipped conservatively (never past an untested
 // lattice point that could be in another cell).  Returns false when the ray is finished.
+template <bool CONE>
 __device__ __forceinline__ bool next_sample(const NerfParams &P, const Ray &r, uint32_t &k, float &px,
                                             float &py, float &pz)
 {
     // approximate reciprocals are enough: they only size the conservative skip below
     float ix = __builtin_amdgcn_rcpf(r.dx), iy = __builtin_amdgcn_rcpf(r.dy), iz = __builtin_amdgcn_rcpf(r.dz);
     while (k <= r.k_hi) {
-        float t = fmaf((float)k, D2R_DT, r.t0);
+        float t = lattice_t<CONE>(r, k);
         px = fmaf(t, r.dx, r.ox);
         py = fmaf(t, r.dy, r.oy);
         pz = fmaf(t, r.dz, r.oz);
         if (px < 0.f || px > 1.f || py < 0.f || py > 1.f || pz < 0.f || pz > 1.f) return false;
-        int cx = min(max((int)(px * (float)D2R_GRID), 0), D2R_GRID - 1);
-        int cy = min(max((int)(py * (float)D2R_GRID), 0), D2R_GRID - 1);
-        int cz = min(max((int)(pz * (float)D2R_GRID), 0), D2R_GRID - 1);
-        uint64_t w = P.bricks[(cx >> 2) + 32 * ((cy >> 2) + 32 * (cz >> 2))];
+        // occupancy cascade (CONE): 1 outside the unit cube or once the step spans a cell of cascade 0;
+        // cascade 1 spans the whole box (cells 1/128 of it), cascade 0 its central half (cells 1/256)
+        int mip = 0;
+        float qx = px, qy = py, qz = pz, cell = 1.0f / (float)D2R_GRID, corg = 0.f;
+        if (CONE) {
+            const float mx = fmaxf(fmaxf(fabsf(px - 0.5f), fabsf(py - 0.5f)), fabsf(pz - 0.5f));
+            mip = (mx >= 0.25f || lattice_dt<CONE>(t) * 256.0f >= 1.0f) ? 1 : 0;
+            if (mip == 0) {
+                qx = fmaf(px - 0.5f, 2.0f, 0.5f);
+                qy = fmaf(py - 0.5f, 2.0f, 0.5f);
+                qz = fmaf(pz - 0.5f, 2.0f, 0.5f);
+                cell = 0.5f / (float)D2R_GRID;
+                corg = 0.25f;
+            }
+        }
+        int cx = min(max((int)(qx * (float)D2R_GRID), 0), D2R_GRID - 1);
+        int cy = min(max((int)(qy * (float)D2R_GRID), 0), D2R_GRID - 1);
+        int cz = min(max((int)(qz * (float)D2R_GRID), 0), D2R_GRID - 1);
+        uint64_t w = P.bricks[(size_t)mip * 32768 + (cx >> 2) + 32 * ((cy >> 2) + 32 * (cz >> 2))];
         uint32_t bit = (cx & 3) + 4 * (cy & 3) + 16 * (cz & 3);
         if ((w >> bit) & 1ull) return true;
-        // skip: to the far face of the empty brick, or of the empty cell
+        // skip: to the far face of the empty brick, or of the empty cell (box units: cell size `cell`, origin `corg`)
         int sh = (w == 0ull) ? 2 : 0;
-        float cs = (float)(1 << sh) * (1.0f / (float)D2R_GRID);
-        float lx = (float)((cx >> sh) << sh) * (1.0f / (float)D2R_GRID);
-        float ly = (float)((cy >> sh) << sh) * (1.0f / (float)D2R_GRID);
-        float lz = (float)((cz >> sh) << sh) * (1.0f / (float)D2R_GRID);
+        float cs = (float)(1 << sh) * cell;
+        float lx = fmaf((float)((cx >> sh) << sh), cell, corg);
+        float ly = fmaf((float)((cy >> sh) << sh), cell, corg);
+        float lz = fmaf((float)((cz >> sh) << sh), cell, corg);
         float tx = ((r.dx > 0.f ? lx + cs : lx) - px) * ix;
         float ty = ((r.dy > 0.f ? ly + cs : ly) - py) * iy;
         float tz = ((r.dz > 0.f ? lz + cs : lz) - pz) * iz;
         float dist = fminf(fminf(tx, ty), tz);
-        int n = (int)floorf(dist * D2R_INV_DT);
+        // whole steps that surely stay inside the skipped region: the steps only grow along the ray, so
+        // sizing them by the step at the far end is conservative; and never across the distance at which
+        // the cascade choice changes with the step size (t = 1)
+        int n;
+        if (CONE) {
+            if (mip == 0) dist = fminf(dist, 1.0f - t);
+            n = (int)floorf(dist / lattice_dt<CONE>(t + fmaxf(dist, 0.f)));
+        } else {
+            n = (int)floorf(dist * D2R_INV_DT);
+        }
         k += (uint32_t)max(n, 1);
     }
     return false;
@@ -248,6 +333,7 @@ __device__ __forceinline__ void empty_pixel(const ViewParams &V, float *rgba)
 }
 
 // grid: (tiles of 16x16 pixels, n_cams); block 256 = 4 waves, each wave an 8x8 pixel tile
+template <bool CONE>
 __global__ __launch_bounds__(256) void k_raygen(NerfParams P, ViewParams V, const float *__restrict__ cams,
                                                 uint2 *__restrict__ queue, uint32_t *__restrict__ qcount,
                                                 float *__restrict__ rgba_out, float *__restrict__ depth_out)
@@ -265,9 +351,9 @@ __global__ __launch_bounds__(256) void k_raygen(NerfParams P, ViewParams V, cons
 #pragma unroll
         for (int j = 0; j < 12; j++) cam[j] = cams[(size_t)cam_i * 12 + j];
         Ray r;
-        if (make_ray(P, V, cam, px, py, r, k)) {
+        if (make_ray<CONE>(P, V, cam, px, py, r, k)) {
             float x, y, z;
-            alive = next_sample(P, r, k, x, y, z);
+            alive = next_sample<CONE>(P, r, k, x, y, z);
         }
     }
     const uint32_t ray_id = cam_i * (V.W * V.H) + py * V.W + px;
@@ -296,6 +382,7 @@ __global__ __launch_bounds__(256) void k_raygen(NerfParams P, ViewParams V, cons
 // walks the 16x16 tiles of that rectangle (+2 px) instead of the whole frame.  A camera that is not a
 // rigid transform, or a corner at or behind the camera plane, falls back to the full frame.
 // grid: (n_cams, parts); block 256 = 4 waves, each wave an 8x8 pixel tile.
+template <bool CONE>
 __global__ __launch_bounds__(256) void k_raygen_rect(NerfParams P, ViewParams V, const float *__restrict__ cams,
                                                      uint2 *__restrict__ queue, uint32_t *__restrict__ qcount)
 {
@@ -317,9 +404,12 @@ __global__ __launch_bounds__(256) void k_raygen_rect(NerfParams P, ViewParams V,
         float pxmin = INFINITY, pxmax = -INFINITY, pymin = INFINITY, pymax = -INFINITY;
 #pragma unroll
         for (int c = 0; c < 8; c++) {
-            const float qx = ((c & 1) ? P.bbox_hi[0] : P.bbox_lo[0]) - cam[3];
-            const float qy = ((c & 2) ? P.bbox_hi[1] : P.bbox_lo[1]) - cam[7];
-            const float qz = ((c & 4) ? P.bbox_hi[2] : P.bbox_lo[2]) - cam[11];
+            // box-unit corner -> world (CONE: the box is the cube of side 2 about 0.5)
+            const float wx = (c & 1) ? P.bbox_hi[0] : P.bbox_lo[0], wy = (c & 2) ? P.bbox_hi[1] : P.bbox_lo[1];
+            const float wz = (c & 4) ? P.bbox_hi[2] : P.bbox_lo[2];
+            const float qx = (CONE ? fmaf(wx - 0.5f, 2.0f, 0.5f) : wx) - cam[3];
+            const float qy = (CONE ? fmaf(wy - 0.5f, 2.0f, 0.5f) : wy) - cam[7];
+            const float qz = (CONE ? fmaf(wz - 0.5f, 2.0f, 0.5f) : wz) - cam[11];
             const float cx = cam[0] * qx + cam[4] * qy + cam[8] * qz;      // R^T (p - t)
             const float cy = cam[1] * qx + cam[5] * qy + cam[9] * qz;
             const float cz = cam[2] * qx + cam[6] * qy + cam[10] * qz;
@@ -370,9 +460,9 @@ __global__ __launch_bounds__(256) void k_raygen_rect(NerfParams P, ViewParams V,
         uint32_t k = 0;
         if (px < V.W && py < V.H) {
             Ray r;
-            if (make_ray(P, V, cam, px, py, r, k)) {
+            if (make_ray<CONE>(P, V, cam, px, py, r, k)) {
                 float x, y, z;
-                alive = next_sample(P, r, k, x, y, z);
+                alive = next_sample<CONE>(P, r, k, x, y, z);
             }
         }
         const uint32_t ray_id = cam_i * (V.W * V.H) + py * V.W + px;
@@ -723,7 +813,7 @@ __global__ __launch_bounds__(256) void k_eval_points(NerfParams P, const float *
 #ifndef D2R_MARCH_THREADS
 #define D2R_MARCH_THREADS 768
 #endif
-template <bool COMPOSITE, int NB, int NGB, int ND>
+template <bool COMPOSITE, int NB, int NGB, int ND, bool CONE = false>
 __global__ __launch_bounds__(D2R_MARCH_THREADS) void k_march(NerfParams P, ViewParams V, const float *__restrict__ cams,
                                                   const uint2 *__restrict__ queue,
                                                   const uint32_t *__restrict__ qcount,
@@ -788,20 +878,25 @@ __global__ __launch_bounds__(D2R_MARCH_THREADS) void k_march(NerfParams P, ViewP
 #pragma unroll
                     for (int j = 0; j < 12; j++) cam[j] = cams[(size_t)cam_i * 12 + j];
                     uint32_t klo;
-                    make_ray(P, V, cam, pix % V.W, pix / V.W, ray, klo);
-                    float t = fmaf((float)k, D2R_DT, ray.t0);
+                    make_ray<CONE>(P, V, cam, pix % V.W, pix / V.W, ray, klo);
+                    float t = lattice_t<CONE>(ray, k);
                     px = fmaf(t, ray.dx, ray.ox);
                     py = fmaf(t, ray.dy, ray.oy);
                     pz = fmaf(t, ray.dz, ray.oz);
-                    zslope = (ray.dx * cam[2] + ray.dy * cam[6] + ray.dz * cam[10]) * V.inv_scale;
-                    zbase = ((ray.ox - cam[3]) * cam[2] + (ray.oy - cam[7]) * cam[6] + (ray.oz - cam[11]) * cam[10]) * V.inv_scale;
+                    // world-space ray for the depth (CONE: the stored ray lives in the unit cube of the box)
+                    const float wdx = CONE ? ray.dx * 2.0f : ray.dx, wdy = CONE ? ray.dy * 2.0f : ray.dy, wdz = CONE ? ray.dz * 2.0f : ray.dz;
+                    const float wox = CONE ? fmaf(ray.ox - 0.5f, 2.0f, 0.5f) : ray.ox, woy = CONE ? fmaf(ray.oy - 0.5f, 2.0f, 0.5f) : ray.oy;
+                    const float woz = CONE ? fmaf(ray.oz - 0.5f, 2.0f, 0.5f) : ray.oz;
+                    zslope = (wdx * cam[2] + wdy * cam[6] + wdz * cam[10]) * V.inv_scale;
+                    zbase = ((wox - cam[3]) * cam[2] + (woy - cam[7]) * cam[6] + (woz - cam[11]) * cam[10]) * V.inv_scale;
                     C0 = C1 = C2 = A = Z = 0.f;
                     alive = true;
                 }
             }
             // ray directions changed in some lanes: refresh the wave's SH fragments (all lanes
             // take part: a lane's fragment also carries its partner's direction)
-            sh_fragments(lane, ray.dx, ray.dy, ray.dz, shfA, shfB);
+            if (CONE) sh_fragments(lane, ray.dx * 2.0f, ray.dy * 2.0f, ray.dz * 2.0f, shfA, shfB);     // unit direction
+            else sh_fragments(lane, ray.dx, ray.dy, ray.dz, shfA, shfB);
         }
         if (!__any(alive)) break;
         niter++;
@@ -814,9 +909,10 @@ __global__ __launch_bounds__(D2R_MARCH_THREADS) void k_march(NerfParams P, ViewP
         if (alive) {
             nsamp++;
             float T = 1.0f - A;
-            float alpha = 1.0f - expf(-sigma * D2R_DT);
+            const float tk = lattice_t<CONE>(ray, k);
+            float alpha = 1.0f - expf(-sigma * lattice_dt<CONE>(tk));
             float wgt = alpha * T;
-            float zz = fmaf(fmaf((float)k, D2R_DT, ray.t0), zslope, zbase);
+            float zz = fmaf(tk, zslope, zbase);
             C0 = fmaf(wgt, cr, C0);
             C1 = fmaf(wgt, cg, C1);
             C2 = fmaf(wgt, cb, C2);
@@ -830,7 +926,7 @@ __global__ __launch_bounds__(D2R_MARCH_THREADS) void k_march(NerfParams P, ViewP
                 done = true;
             } else {
                 k++;
-                done = !next_sample(P, ray, k, px, py, pz);
+                done = !next_sample<CONE>(P, ray, k, px, py, pz);
             }
             if (done) {
                 alive = false;
@@ -982,12 +1078,18 @@ int d2r_launch_render(d2r_ctx *ctx, const d2r_nerf *m, const ViewParams &V, cons
     }
     const uint32_t tiles = ((V.W + 15) / 16) * ((V.H + 15) / 16);
     size_t tr = ctx->timing_begin(D2R_T_RAYGEN);
-    if (composite && ctx->raygen_rect)
-        hipLaunchKernelGGL(k_raygen_rect, dim3(n, 4), dim3(256), 0, ctx->stream, m->P, V, cams_dev, (uint2 *)ctx->queue.p, cnt);
-    else
-        hipLaunchKernelGGL(k_raygen, dim3(tiles, n), dim3(256), 0, ctx->stream, m->P, V, cams_dev,
-                           (uint2 *)ctx->queue.p, cnt, composite ? nullptr : rgba_dev,
-                           composite ? nullptr : depth_dev);
+    const bool cone = m->P.aabb_scale == 2;          // two occupancy cascades + cone stepping
+    if (composite && ctx->raygen_rect) {
+        if (cone) hipLaunchKernelGGL(k_raygen_rect<true>, dim3(n, 4), dim3(256), 0, ctx->stream, m->P, V, cams_dev, (uint2 *)ctx->queue.p, cnt);
+        else hipLaunchKernelGGL(k_raygen_rect<false>, dim3(n, 4), dim3(256), 0, ctx->stream, m->P, V, cams_dev, (uint2 *)ctx->queue.p, cnt);
+    } else {
+        if (cone)
+            hipLaunchKernelGGL(k_raygen<true>, dim3(tiles, n), dim3(256), 0, ctx->stream, m->P, V, cams_dev, (uint2 *)ctx->queue.p,
+                               cnt, composite ? nullptr : rgba_dev, composite ? nullptr : depth_dev);
+        else
+            hipLaunchKernelGGL(k_raygen<false>, dim3(tiles, n), dim3(256), 0, ctx->stream, m->P, V, cams_dev, (uint2 *)ctx->queue.p,
+                               cnt, composite ? nullptr : rgba_dev, composite ? nullptr : depth_dev);
+    }
     ctx->timing_end(tr);
     size_t tm = ctx->timing_begin(D2R_T_MARCH);
     int blocks = ctx->march_blocks > 0 ? (int)ctx->march_blocks : 256;     // persistent: one per CU
@@ -999,20 +1101,25 @@ int d2r_launch_render(d2r_ctx *ctx, const d2r_nerf *m, const ViewParams &V, cons
     PP.refill_min = (uint32_t)ctx->refill_min;
     const size_t lds = (size_t)D2R_N_WFRAG * 64 * 16 + (nb ? (size_t)m->P.brick_words * 4 : 0);
     uint32_t ngb = nb == 5 ? std::min<uint32_t>((uint32_t)ctx->gbrick_slots, m->P.n_gbrick_slots) : 0;
-#define D2R_MARCH(COMP, NB, NGB, ND)                                                                              \
+#define D2R_MARCH(COMP, NB, NGB, ND) D2R_MARCH_C(COMP, NB, NGB, ND, false)
+#define D2R_MARCH_C(COMP, NB, NGB, ND, CONE)                                                                      \
     do {                                                                                                          \
         static bool attr = false;                                                                                 \
         if (!attr) {                                                                                              \
-            (void)hipFuncSetAttribute((const void *)k_march<COMP, NB, NGB, ND>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            (void)hipFuncSetAttribute((const void *)k_march<COMP, NB, NGB, ND, CONE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             attr = true;                                                                                          \
         }                                                                                                         \
-        hipLaunchKernelGGL((k_march<COMP, NB, NGB, ND>), dim3(blocks), dim3(D2R_MARCH_THREADS), lds, ctx->stream, PP, V, cams_dev, q, \
+        hipLaunchKernelGGL((k_march<COMP, NB, NGB, ND, CONE>), dim3(blocks), dim3(D2R_MARCH_THREADS), lds, ctx->stream, PP, V, cams_dev, q, \
                            cnt, cnt + 1, COMP ? nullptr : rgba_dev, COMP ? nullptr : depth_dev,                   \
                            COMP ? bgd : nullptr, COMP ? frames_dev : nullptr, sc);                                \
     } while (0)
     // compile-time slot kinds: the usual tables have 5 leading dense levels; small objects get 4 or
     // 5 LDS-bricked slots (+ up to 2 HBM-bricked); anything else takes the generic instantiation
-    if (composite) {
+    if (cone) {
+        // aabb_scale 2 models go through the generic slot kinds (no bricks are built for them)
+        if (composite) D2R_MARCH_C(true, 0, 0, -1, true);
+        else D2R_MARCH_C(false, 0, 0, -1, true);
+    } else if (composite) {
         if (m->P.n_dense != 5) D2R_MARCH(true, 0, 0, -1);
         else if (nb == 5 && ngb == 3) D2R_MARCH(true, 5, 3, 5);
         else if (nb == 5 && ngb == 2) D2R_MARCH(true, 5, 2, 5);
@@ -1030,6 +1137,7 @@ int d2r_launch_render(d2r_ctx *ctx, const d2r_nerf *m, const ViewParams &V, cons
         else D2R_MARCH(false, 0, 0, 5);
     }
 #undef D2R_MARCH
+#undef D2R_MARCH_C
     ctx->timing_end(tm);
     D2R_HIP(ctx, hipGetLastError());
     return D2R_OK;

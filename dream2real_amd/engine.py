@@ -106,7 +106,7 @@ class Testbed:
         desc = _lib.NerfDesc(lv.n_levels, lv.n_features, _lib.ptr(k["scale"]), _lib.ptr(k["res"]),
                              _lib.ptr(k["size"]), _lib.ptr(k["offset"]), lv.n_entries, _lib.ptr(k["grid"]),
                              _lib.ptr(k["dw1"]), _lib.ptr(k["dw2"]), _lib.ptr(k["cw1"]), _lib.ptr(k["cw2"]),
-                             _lib.ptr(k["cw3"]), _lib.ptr(k["occ"]))
+                             _lib.ptr(k["cw3"]), _lib.ptr(k["occ"]), int(getattr(model, "aabb_scale", 1)))
         h = C.c_void_p()
         ctx.check(ctx.lib.d2r_nerf_create(ctx.h, C.byref(desc), C.byref(h)))
         self.h = h

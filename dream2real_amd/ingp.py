@@ -66,8 +66,9 @@ def load_ingp(path: str):
     nerf = snap.get("nerf", {})
     ds = nerf.get("dataset", {})
     aabb_scale = int(nerf.get("aabb_scale", ds.get("aabb_scale", 1)))
-    if aabb_scale != 1:
-        raise NotImplementedError("aabb_scale > 1 (several occupancy cascades) is not implemented yet")
+    if aabb_scale not in (1, 2):
+        raise NotImplementedError("aabb_scale > 2 (more than two occupancy cascades) is not implemented")
+    n_casc = aabb_scale.bit_length()
     L, F = int(enc.get("n_levels", 16)), int(enc.get("n_features_per_level", 2))
     levels = grid_levels(L, F, int(enc.get("log2_hashmap_size", 19)), int(enc.get("base_resolution", 16)),
                          enc.get("per_level_scale"), aabb_scale)
@@ -85,14 +86,14 @@ def load_ingp(path: str):
     if int(snap.get("density_grid_size", GRID)) != GRID:
         raise ValueError("density_grid_size must be 128")
     dens = np.frombuffer(snap["density_grid_binary"], np.float16).astype(np.float32)
-    if dens.size != GRID ** 3:
-        raise ValueError("density grid must hold one 128^3 cascade")
+    if dens.size != n_casc * GRID ** 3:
+        raise ValueError(f"density grid must hold {n_casc} cascade(s) of 128^3 values")
     pos = dens[dens > 0]
     thresh = min(float(pos.mean()) if pos.size else 0.0, NERF_MIN_OPTICAL_THICKNESS)
-    occ_lin = np.zeros(GRID ** 3, bool)
-    occ_lin[_morton_order()] = dens > thresh
+    occ_lin = np.zeros((n_casc, GRID ** 3), bool)
+    occ_lin[:, _morton_order()] = dens.reshape(n_casc, -1) > thresh           # Morton order within a cascade
     model = NerfModel(levels, grid.copy(), dw1.copy(), dw2.copy(), cw1.copy(), cw2.copy(), cw3.copy(),
-                      np.packbits(occ_lin.astype(np.uint8), bitorder="little"))
+                      np.packbits(occ_lin.reshape(-1).astype(np.uint8), bitorder="little"), aabb_scale)
     views = []
     for md in ds.get("metadata", []):
         w, h = md["resolution"]
@@ -113,8 +114,9 @@ def save_ingp(path: str, model: NerfModel, training_views=None, dataset_scale: f
     lv = model.levels
     params = np.concatenate([np.asarray(a, np.float16).reshape(-1) for a in
                              (model.dw1, model.dw2, model.cw1, model.cw2, model.cw3, model.grid)])
-    occ_lin = np.unpackbits(model.occ_bits, bitorder="little").astype(bool)
-    dens = np.where(occ_lin[_morton_order()], density_value, 0.0).astype(np.float16)
+    n_casc = int(getattr(model, "aabb_scale", 1)).bit_length()
+    occ_lin = np.unpackbits(model.occ_bits, bitorder="little").astype(bool).reshape(n_casc, -1)
+    dens = np.where(occ_lin[:, _morton_order()], density_value, 0.0).astype(np.float16).reshape(-1)
     views = training_views or [dict(fx=924.66912, fy=926.49735, cx=654.51953, cy=355.18523, w=1280, h=720)]
     cfg = {
         "encoding": {"otype": "HashGrid", "n_levels": lv.n_levels, "n_features_per_level": lv.n_features,
@@ -127,8 +129,9 @@ def save_ingp(path: str, model: NerfModel, training_views=None, dataset_scale: f
         "snapshot": {
             "version": 1, "mode": "nerf", "n_params": int(params.size), "params_type": "__half",
             "params_binary": params.tobytes(), "density_grid_size": GRID, "density_grid_binary": dens.tobytes(),
-            "nerf": {"aabb_scale": 1, "dataset": {
-                "n_images": len(views), "scale": dataset_scale, "offset": list(dataset_offset), "aabb_scale": 1,
+            "nerf": {"aabb_scale": int(getattr(model, "aabb_scale", 1)), "dataset": {
+                "n_images": len(views), "scale": dataset_scale, "offset": list(dataset_offset),
+                "aabb_scale": int(getattr(model, "aabb_scale", 1)),
                 "metadata": [{"resolution": [v["w"], v["h"]], "focal_length": [v["fx"], v["fy"]],
                               "principal_point": [v["cx"] / v["w"], v["cy"] / v["h"]]} for v in views]}},
         },

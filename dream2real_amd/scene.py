@@ -80,11 +80,17 @@ class NerfModel:
     cw1: np.ndarray        # [64, 32] float16   colour layer 1 (in = [density out | SH])
     cw2: np.ndarray        # [64, 64] float16
     cw3: np.ndarray        # [16, 64] float16   rows 0..2 = rgb
-    occ_bits: np.ndarray   # [128^3/8] uint8, bit (x + 128*(y + 128*z)), LSB first
+    occ_bits: np.ndarray   # [n_cascades * 128^3/8] uint8, bit (x + 128*(y + 128*z)) per cascade, LSB first
+    aabb_scale: int = 1    # 1, or 2: the box is the cube of that side centred at 0.5; cascade c covers side 2^c
+
+    @property
+    def n_cascades(self) -> int:
+        return int(self.aabb_scale).bit_length()
 
     def occupancy_bool(self) -> np.ndarray:
-        """[z, y, x] boolean view of the bitfield."""
-        return np.unpackbits(self.occ_bits, bitorder="little").astype(bool).reshape(GRID, GRID, GRID)
+        """[z, y, x] boolean view of the bitfield ([cascade, z, y, x] when aabb_scale > 1)."""
+        b = np.unpackbits(self.occ_bits, bitorder="little").astype(bool)
+        return b.reshape(GRID, GRID, GRID) if self.aabb_scale == 1 else b.reshape(self.n_cascades, GRID, GRID, GRID)
 
 
 @dataclasses.dataclass
@@ -128,7 +134,8 @@ def _xavier(rng: np.random.Generator, n_out: int, n_in: int) -> np.ndarray:
 
 
 def make_synthetic_nerf(occ_zyx: np.ndarray, *, seed_grid: int, seed_mlp: int,
-                        levels: Optional[GridLevels] = None, log_sigma: float = 5.0) -> NerfModel:
+                        levels: Optional[GridLevels] = None, log_sigma: float = 5.0,
+                        aabb_scale: int = 1) -> NerfModel:
     """Seeded random NeRF with a controllable opacity.
 
     Tables are U(-0.5, 0.5) (PCG64); feature 0 of level 0 is pinned to 0.5 so that a
@@ -152,17 +159,19 @@ def make_synthetic_nerf(occ_zyx: np.ndarray, *, seed_grid: int, seed_mlp: int,
     dw2[0, 0] = log_sigma      # out0 = log_sigma + noise
     f16 = lambda a: a.astype(np.float16)
     return NerfModel(levels, f16(grid), f16(dw1), f16(dw2), f16(cw1), f16(cw2), f16(cw3),
-                     pack_bits(occ_zyx))
+                     pack_bits(occ_zyx), aabb_scale)
 
 
-def _cell_centres():
-    c = (np.arange(GRID, dtype=np.float64) + 0.5) / GRID
+def _cell_centres(cascade: int = 0):
+    """ngp-space centres of the 128^3 cells of an occupancy cascade (side 2^cascade about 0.5)."""
+    side = float(1 << cascade)
+    c = (np.arange(GRID, dtype=np.float64) + 0.5) / GRID * side + 0.5 - side / 2
     z, y, x = np.meshgrid(c, c, c, indexing="ij")
     return x, y, z
 
 
-def ellipsoid_occupancy(centre_ngp, radii_ngp) -> np.ndarray:
-    x, y, z = _cell_centres()
+def ellipsoid_occupancy(centre_ngp, radii_ngp, cascade: int = 0) -> np.ndarray:
+    x, y, z = _cell_centres(cascade)
     cx, cy, cz = centre_ngp
     rx, ry, rz = radii_ngp
     return ((x - cx) / rx) ** 2 + ((y - cy) / ry) ** 2 + ((z - cz) / rz) ** 2 <= 1.0
@@ -200,7 +209,11 @@ class SyntheticScene:
 
 def make_scene(kind: str = "shopping") -> SyntheticScene:
     """Seeded scenes of SURVEY.md §8(d).  kind: 'shopping' (apple-sized ellipsoid, scene
-    type 3) or 'pool_triangle' (2.8 cm sphere, scene type 0)."""
+    type 3), 'pool_triangle' (2.8 cm sphere, scene type 0) or 'shelf' (aabb_scale 2 like
+    configs/shelf_demo.json:62: two occupancy cascades, cone stepping; the object sits outside
+    the unit cube and the camera 1.3 m away)."""
+    if kind == "shelf":
+        return _make_shelf_scene()
     levels = grid_levels()
     scene_centre = np.array([0.5, 0.0, 0.035])          # configs/shopping_demo.json:29
     if kind == "shopping":
@@ -229,6 +242,33 @@ def make_scene(kind: str = "shopping") -> SyntheticScene:
                      look_at_opencv(eye + np.array([0.1, 0.0, 0.02]), scene_centre)])
     return SyntheticScene(kind, scene_type, scene_centre, fg, bg, obj_pose, cams,
                           fg_background=(0.0, 0.0, 0.0, 1.0))
+
+
+def _make_shelf_scene() -> SyntheticScene:
+    levels = grid_levels(aabb_scale=2)
+    scene_centre = np.array([0.45, 0.85, 0.20])                 # world; ngp (1.15, 0.70, 0.45): outside the unit cube
+    obj_t = scene_centre + np.array([0.02, -0.03, 0.06])
+    obj_pose = np.eye(4)
+    obj_pose[:3, 3] = obj_t
+    radii_ngp = (0.06, 0.08, 0.06)
+
+    def cascades(fn):
+        return np.stack([fn(c) for c in range(2)])
+    fg = make_synthetic_nerf(cascades(lambda c: ellipsoid_occupancy(world_to_ngp(obj_t), radii_ngp, c)),
+                             seed_grid=1, seed_mlp=3, levels=levels, aabb_scale=2)
+
+    def bg_occ(c):
+        x, y, z = _cell_centres(c)
+        occ = (y >= 0.50) & (y < 0.58) & (x > -0.2) & (x < 1.3)                      # a shelf board
+        occ |= (z >= 1.20) & (z < 1.28) & (y > 0.3) & (y < 1.2)                      # the back panel
+        for d, r in (((0.20, -0.15, 0.05), 0.09), ((-0.25, 0.10, 0.02), 0.07)):
+            occ |= ellipsoid_occupancy(world_to_ngp(scene_centre + np.array(d)), (r, r, r), c)
+        return occ
+    bg = make_synthetic_nerf(cascades(bg_occ), seed_grid=2, seed_mlp=4, levels=levels, aabb_scale=2)
+    eye = scene_centre + 1.3 * np.array([-0.55, -0.35, 0.75]) / np.linalg.norm([-0.55, -0.35, 0.75])
+    cams = np.stack([look_at_opencv(eye, scene_centre),
+                     look_at_opencv(eye + np.array([0.15, 0.0, 0.05]), scene_centre)])
+    return SyntheticScene("shelf", 1, scene_centre, fg, bg, obj_pose, cams, fg_background=(0.0, 0.0, 0.0, 1.0))
 
 
 def scene_text_embeds(image_embed, n_caps: int = 2, seed: int = 5, noise: float = 0.8) -> np.ndarray:

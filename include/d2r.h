@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 #define D2R_API __attribute__((visibility("default")))
-#define D2R_ABI_VERSION 1
+#define D2R_ABI_VERSION 2
 
 typedef enum {
     D2R_OK = 0,
@@ -63,7 +63,7 @@ D2R_API const char *d2r_last_error(d2r_ctx *ctx);
 /* --------------------------------------------------------------- NeRF model */
 
 /* State a pyngp.Testbed holds after load_snapshot (reference ngp_visual_model.py:24-28):
- * tiny-cuda-nn hash grid + density/colour MLPs + 128^3 occupancy bitfield. */
+ * tiny-cuda-nn hash grid + density/colour MLPs + 128^3 occupancy bitfield(s). */
 typedef struct {
     uint32_t n_levels;          /* L (16) */
     uint32_t n_features;        /* F (2) */
@@ -78,7 +78,10 @@ typedef struct {
     const uint16_t *cw1_fp16;   /* host [64][32]   colour layer 1, in = [density out 16 | SH 16] */
     const uint16_t *cw2_fp16;   /* host [64][64] */
     const uint16_t *cw3_fp16;   /* host [16][64]   rows 0..2 = rgb */
-    const uint8_t *occupancy_bits; /* host [128^3/8], bit x+128*(y+128*z), LSB first */
+    const uint8_t *occupancy_bits; /* host [n_cascades][128^3/8], bit x+128*(y+128*z), LSB first */
+    uint32_t aabb_scale;        /* 1 or 2 (0 is read as 1): the model's box is the cube of that side centred at
+                                 * 0.5; n_cascades = log2(aabb_scale)+1 occupancy grids, cascade c covering side
+                                 * 2^c; aabb_scale 2 marches with cone-angle 1/256 steps */
 } d2r_nerf_desc;
 
 /* replaces Testbed(mode=Nerf) + load_snapshot */

@@ -19,6 +19,9 @@
  *     (Mueller et al. 2022 and SURVEY.md Appendix A).  PARITY UNPINNED for
  *     this part: no golden frame of the real renderer exists in the reference
  *     tree, so this file is the specification the HIP kernels are held to.
+ *     That covers both model kinds: aabb_scale 1 (constant step, one occupancy
+ *     grid) and aabb_scale 2 (configs/shelf_demo.json:62: two cascades, cone-angle
+ *     stepping, positions normalised to the box).
  *   - rot90 + CLIP image preprocessing (PIL antialiased bicubic resize in
  *     fixed point, centre crop, rescale, normalise)
  *                                  clip_scoring.py:145,177 (HF CLIPImageProcessor,
@@ -56,8 +59,10 @@ typedef struct {
     const uint16_t *cw1;      /* colour  64 x 32  (in = [density out 16 | SH 16]) */
     const uint16_t *cw2;      /* colour  64 x 64 */
     const uint16_t *cw3;      /* colour  16 x 64  (rows 0..2 used) */
-    /* occupancy, 128^3 bits, linear index x + 128*y + 128*128*z, LSB first */
+    /* occupancy, 128^3 bits per cascade, linear index x + 128*y + 128*128*z, LSB first;
+     * cascade c (c < n_cascades = log2(aabb_scale)+1) covers the cube of side 2^c centred at 0.5 */
     const uint8_t *occ_bits;
+    uint32_t aabb_scale;      /* 1, or 2 (cascades + cone stepping) */
 } d2r_oracle_nerf;
 
 typedef struct {
@@ -281,6 +286,40 @@ static inline int cell_of(float p)
     return c < 0 ? 0 : (c > D2R_GRID - 1 ? D2R_GRID - 1 : c);
 }
 
+/* ---- aabb_scale 2: two occupancy cascades and cone stepping (as believed) ----
+ * instant-ngp advances every ray by dt(t) = clamp(t * cone_angle, dt_min, dt_max) per step whether or
+ * not the cell is occupied, so the possible sample distances of a ray are the fixed sequence
+ *     t_{k+1} = t_k + max(dt_min, t_k / 256)
+ * (dt_max = 16 dt_min is never reached inside a cube of side 2).  It is used here in closed form so
+ * that the HIP kernels can jump along it: t_k = t0 + k dt_min up to k1 (the first k with
+ * t_k >= 256 dt_min), t_k = t_{k1} (1 + 1/256)^(k - k1) after it.  The power is a fixed-order product
+ * of the fp32 constants (1+1/256)^(2^i), the same on both sides. */
+#define D2R_CONE 0.00390625f                     /* 1/256 */
+#define D2R_T_LINEAR (D2R_DT * 256.0f)           /* below this distance the step is dt_min */
+static const float d2r_cone_pow[12] = {      /* float((1 + 1/256)^(2^i)), i = 0..11 */
+    1.00390625f,         1.0078277587890625f, 1.015716791152954f,  1.0316805839538574f,
+    1.0643649101257324f, 1.1328725814819336f, 1.2834001779556274f, 1.6471161842346191f,
+    2.712991714477539f,  7.360323429107666f,  54.17436218261719f,  2934.861572265625f};
+
+static inline float cone_pow(uint32_t n)
+{
+    float r = 1.0f;
+    for (int i = 0; i < 12; i++)
+        if ((n >> i) & 1u) r = r * d2r_cone_pow[i];
+    return r;
+}
+
+/* distance of lattice point k of a ray that starts at t0; k1 / t1 from cone_split() */
+static inline void cone_split(float t0, uint32_t *k1, float *t1)
+{
+    *k1 = t0 >= D2R_T_LINEAR ? 0u : (uint32_t)ceilf((D2R_T_LINEAR - t0) * (1.0f / D2R_DT));
+    *t1 = fmaf((float)*k1, D2R_DT, t0);
+}
+static inline float cone_t(uint32_t k, float t0, uint32_t k1, float t1)
+{
+    return k <= k1 ? fmaf((float)k, D2R_DT, t0) : t1 * cone_pow(k - k1);
+}
+
 /*
  * One frame: Testbed.render(w, h, spp=1, linear=True) in Shade AND Depth mode at once.
  *   cam_nerf : 3x4 row-major, the matrix handed to set_nerf_camera_matrix
@@ -319,35 +358,59 @@ D2R_ORACLE_API void d2r_oracle_render(const d2r_oracle_nerf *m, const d2r_oracle
             const float fwd[3] = {cam[2], cam[6], cam[10]};
             const float org[3] = {cam[3], cam[7], cam[11]};
 
-            /* unit-cube AABB slab test */
+            /* AABB slab test: the cube of side aabb_scale centred at 0.5 */
+            const int cone = m->aabb_scale > 1;
+            const float half = 0.5f * (float)(m->aabb_scale ? m->aabb_scale : 1);
+            const float box_lo = 0.5f - half, box_hi = 0.5f + half, inv_side = 1.0f / (2.0f * half);
             float tmin = -INFINITY, tmax = INFINITY;
             for (int i = 0; i < 3; i++) {
                 float inv = 1.0f / d[i];
-                float t0 = (0.0f - o[i]) * inv, t1 = (1.0f - o[i]) * inv;
+                float t0 = (box_lo - o[i]) * inv, t1 = (box_hi - o[i]) * inv;
                 float lo = fminf(t0, t1), hi = fmaxf(t0, t1);
                 tmin = fmaxf(tmin, lo);
                 tmax = fminf(tmax, hi);
             }
             if (tmax >= tmin && tmax > 0.f) {
                 const float t0 = fmaxf(tmin, 0.0f) + 1e-6f;
-                /* lattice t_k = t0 + k*dt; k runs until the sample leaves the cube */
-                for (uint32_t k = 0; k < 4096; k++) {
-                    float t = fmaf((float)k, D2R_DT, t0);
-                    float p[3];
-                    for (int i = 0; i < 3; i++) p[i] = fmaf(t, d[i], o[i]);
+                uint32_t k1 = 0;
+                float t1 = t0;
+                if (cone) cone_split(t0, &k1, &t1);
+                float on[3], dn[3];
+                for (int i = 0; i < 3; i++) {
+                    on[i] = cone ? fmaf(o[i] - 0.5f, inv_side, 0.5f) : o[i];
+                    dn[i] = cone ? d[i] * inv_side : d[i];
+                }
+                /* lattice t_k (constant step, or the cone sequence); k runs until the sample leaves the box */
+                for (uint32_t k = 0; k < 8192; k++) {
+                    float t = cone ? cone_t(k, t0, k1, t1) : fmaf((float)k, D2R_DT, t0);
+                    float dt = cone ? fmaxf(D2R_DT, t * D2R_CONE) : D2R_DT;
+                    /* position in the unit cube of the box (ray pre-scaled into it), and in world (ngp) space */
+                    float pw[3], p[3];
+                    for (int i = 0; i < 3; i++) p[i] = fmaf(t, dn[i], on[i]);
+                    for (int i = 0; i < 3; i++) pw[i] = cone ? fmaf(p[i] - 0.5f, 2.0f * half, 0.5f) : p[i];
                     if (p[0] < 0.f || p[0] > 1.f || p[1] < 0.f || p[1] > 1.f || p[2] < 0.f ||
                         p[2] > 1.f)
                         break;
-                    if (!occ_test(m->occ_bits, cell_of(p[0]), cell_of(p[1]), cell_of(p[2])))
-                        continue;
+                    if (!cone) {
+                        if (!occ_test(m->occ_bits, cell_of(p[0]), cell_of(p[1]), cell_of(p[2])))
+                            continue;
+                    } else {
+                        /* cascade: 1 outside the unit cube or once the step spans a cell of cascade 0 */
+                        float mx = fmaxf(fmaxf(fabsf(pw[0] - 0.5f), fabsf(pw[1] - 0.5f)), fabsf(pw[2] - 0.5f));
+                        int mip = (mx >= 0.5f || dt * 256.0f >= 1.0f) ? 1 : 0;
+                        const uint8_t *bits = m->occ_bits + (size_t)mip * (D2R_GRID * D2R_GRID * D2R_GRID / 8);
+                        const float *q = mip ? p : pw;     /* cascade 1 spans the whole box, cascade 0 the unit cube */
+                        if (!occ_test(bits, cell_of(q[0]), cell_of(q[1]), cell_of(q[2])))
+                            continue;
+                    }
                     float sigma, rgb[3];
                     nerf_eval(m, p, d, &sigma, rgb);
                     total++;
                     float T = 1.0f - A;
-                    float alpha = 1.0f - expf(-sigma * D2R_DT);
+                    float alpha = 1.0f - expf(-sigma * dt);
                     float wgt = alpha * T;
-                    float z = ((p[0] - org[0]) * fwd[0] + (p[1] - org[1]) * fwd[1] +
-                               (p[2] - org[2]) * fwd[2]) * inv_scale;
+                    float z = ((pw[0] - org[0]) * fwd[0] + (pw[1] - org[1]) * fwd[1] +
+                               (pw[2] - org[2]) * fwd[2]) * inv_scale;
                     for (int i = 0; i < 3; i++) C[i] = fmaf(wgt, rgb[i], C[i]);
                     Z = fmaf(wgt, z, Z);
                     A += wgt;

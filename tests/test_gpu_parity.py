@@ -94,6 +94,55 @@ def test_background_render_matches_oracle(gpu):
     np.testing.assert_allclose(depth[0], odepth, rtol=0, atol=2e-3)
 
 
+def test_aabb_scale_2_model_renders_like_the_oracle():
+    """The shelf scene (configs/shelf_demo.json:62 has aabb_scale 2): two occupancy cascades, cone-angle
+    stepping, positions normalised to the box of side 2.  Object outside the unit cube (cascade 1 only),
+    camera 1.3 m away (steps grow past t = 0.43, the cascade switches with the step size at t = 1).
+    Direct render of fg and bg, composited candidates, and the rect-culled ray generator."""
+    from dream2real_amd import engine
+    scene = make_scene("shelf")
+    assert scene.fg.aabb_scale == 2 and scene.fg.occupancy_bool().shape[0] == 2
+    assert scene.fg.occupancy_bool()[0].sum() == 0 and scene.fg.occupancy_bool()[1].sum() > 100
+    ctx = engine.Context(0)
+    fg, bg = engine.Testbed(ctx, scene.fg), engine.Testbed(ctx, scene.bg)
+    fg.background_color = list(scene.fg_background)
+    W, H = 128, 72
+    pipe = OraclePipeline(scene, W, H)
+    cam = host_ref.converter(np.asarray(scene.cam_poses, np.float32))[0]
+    # background: long rays through both cascades
+    rgba, depth = bg.render_batch(cam[None, :3], W, H)
+    orgba, odepth = pipe.background()
+    assert (odepth > 0).sum() > 1000
+    assert ((depth[0] > 0) != (odepth > 0)).mean() < 2e-3        # lattice points within an ulp of a cell face
+    ok = (depth[0] > 0) == (odepth > 0)
+    assert np.abs(rgba[0] - orgba)[ok].max() < 2e-2 and np.abs(depth[0] - odepth)[ok].max() < 1e-2
+    assert np.abs(rgba[0] - orgba)[ok].mean() < 5e-4
+    assert bg.last_samples > 10000
+    # foreground candidates, composited
+    poses = host_ref.sample_poses_grid(scene.scene_centre, [3, 2, 1, 1, 1, 1], scene.scene_type).reshape(-1, 4, 4)
+    view = fg.view(W, H)
+    ctx.set_background(view, orgba, odepth)
+    T1 = host_ref.converter(np.asarray(scene.obj_pose, np.float32)[None])[0]
+    out = {}
+    for flag in (1, 0):
+        ctx.set_option("raygen_rect", flag)
+        out[flag] = fg.render_composite(view, T1, cam, host_ref.converter(poses.astype(np.float32)))
+    ctx.set_option("raygen_rect", 1)
+    np.testing.assert_array_equal(out[0], out[1])
+    want = pipe.frames(poses, bg=(orgba, odepth))
+    diff = np.abs(out[1].astype(int) - want.astype(int)).max(-1)
+    assert (want != want[:1]).any() and (diff > 1).mean() < 1e-3 and (diff > 0).mean() < 0.02
+    # field queries take positions in the unit cube of the box
+    r = np.random.Generator(np.random.PCG64(4))
+    xyz = r.random((777, 3)).astype(np.float32)
+    d = r.standard_normal((777, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    got, ref = fg.eval_points(xyz, d), render_ref.eval_points(render_ref.OracleNerf(scene.fg), xyz, d)
+    np.testing.assert_allclose(got[:, 0], ref[:, 0], rtol=1e-2, atol=1e-3)
+    np.testing.assert_allclose(got[:, 1:], ref[:, 1:], rtol=0, atol=1e-2)
+    fg.close(); bg.close(); ctx.close()
+
+
 def test_testbed_surface_shade_and_depth(gpu):
     """pyngp-style stateful calls return the same frames as the batched entry point."""
     scene, fg, engine = gpu["scene"], gpu["fg"], gpu["engine"]

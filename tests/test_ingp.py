@@ -37,7 +37,20 @@ def test_rejects_unknown_layouts(tmp_path):
     open(path, "wb").write(zlib.compress(msgpack.packb(cfg, use_bin_type=True)))
     with pytest.raises(ValueError):
         ingp.load_ingp(path)
-    cfg["snapshot"]["nerf"]["aabb_scale"] = 2
+    cfg["snapshot"]["nerf"]["aabb_scale"] = 4            # three cascades: not implemented
     open(path, "wb").write(zlib.compress(msgpack.packb(cfg, use_bin_type=True)))
     with pytest.raises(NotImplementedError):
         ingp.load_ingp(path)
+
+
+def test_aabb_scale_2_snapshot_round_trip(tmp_path):
+    """two Morton-ordered occupancy cascades and the wider level spacing (2048 * aabb_scale at the
+    finest level) survive save -> load"""
+    scene = make_scene("shelf")
+    path = str(tmp_path / "shelf.ingp")
+    ingp.save_ingp(path, scene.bg)
+    model, info = ingp.load_ingp(path)
+    assert model.aabb_scale == 2 and info["aabb_scale"] == 2
+    np.testing.assert_array_equal(model.occ_bits, scene.bg.occ_bits)
+    np.testing.assert_array_equal(model.levels.res, scene.bg.levels.res)
+    np.testing.assert_array_equal(model.grid, scene.bg.grid)
