@@ -320,6 +320,15 @@ static inline float cone_t(uint32_t k, float t0, uint32_t k1, float t1)
     return k <= k1 ? fmaf((float)k, D2R_DT, t0) : t1 * cone_pow(k - k1);
 }
 
+/* test hook: the first n lattice distances of a ray whose lattice starts at t0 */
+D2R_ORACLE_API void d2r_oracle_cone_lattice(float t0, uint32_t n, float *out)
+{
+    uint32_t k1;
+    float t1;
+    cone_split(t0, &k1, &t1);
+    for (uint32_t k = 0; k < n; k++) out[k] = cone_t(k, t0, k1, t1);
+}
+
 /*
  * One frame: Testbed.render(w, h, spp=1, linear=True) in Shade AND Depth mode at once.
  *   cam_nerf : 3x4 row-major, the matrix handed to set_nerf_camera_matrix

@@ -99,6 +99,13 @@ def render(model: OracleNerf, view, cam_nerf):
     return rgba, depth, int(n.value)
 
 
+def cone_lattice(t0: float, n: int) -> np.ndarray:
+    """sample distances t_0..t_{n-1} of an aabb_scale-2 ray whose lattice starts at t0"""
+    out = np.zeros(n, np.float32)
+    lib().d2r_oracle_cone_lattice(C.c_float(t0), C.c_uint32(n), C.c_void_p(_ptr(out)))
+    return out
+
+
 def composite(fg_rgba, fg_depth, bg_rgba, bg_depth) -> np.ndarray:
     """reference reconstruction/combined_rendering.py:133-155 -> uint8 [H,W,3]."""
     H, W = fg_depth.shape

@@ -88,3 +88,24 @@ def test_g5_clip_vit_b16(goldens):
     r = np.random.Generator(np.random.PCG64(77))
     pv = r.standard_normal((2, 3, cfg["image_size"], cfg["image_size"]), dtype=np.float32)
     _check_clip(goldens, "vit_b16", pv, 2e-5)
+
+
+def test_cone_stepping_lattice_follows_the_step_recurrence():
+    """aabb_scale 2: t_{k+1} = t_k + clamp(t_k / 256, dt_min, .) — the closed form the
+    oracle and the kernels share must reproduce that recurrence, stay monotone, and be a pure
+    geometric sequence for rays that start beyond 256 dt_min."""
+    from oracle import render_ref
+    dt = np.float32(np.sqrt(3.0) / 1024.0)
+    for t0 in (1e-6, 0.05, 0.3, 0.4329, 0.5, 1.7):
+        t = render_ref.cone_lattice(t0, 1500).astype(np.float64)
+        assert t[0] == np.float32(t0) and (np.diff(t) > 0).all()
+        step = np.maximum(dt, t[:-1] / 256.0)
+        np.testing.assert_allclose(np.diff(t), step, rtol=2e-3, atol=2e-7)
+        seq = [float(np.float32(t0))]                      # the recurrence itself, in float64
+        for _ in range(1499):
+            seq.append(seq[-1] + max(float(dt), seq[-1] / 256.0))
+        # the closed form switches to geometric growth at the first lattice point past 256 dt_min, the
+        # recurrence a fraction of a step earlier or later: they agree to a fraction of one step
+        assert np.max(np.abs(t - np.array(seq)) / np.maximum(dt, np.array(seq) / 256.0)) < 1.0
+    far = render_ref.cone_lattice(0.9, 600).astype(np.float64)
+    np.testing.assert_allclose(far[1:] / far[:-1], 1.0 + 1.0 / 256.0, rtol=1e-6)
