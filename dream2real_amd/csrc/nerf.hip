@@ -1117,8 +1117,13 @@ int d2r_launch_render(d2r_ctx *ctx, const d2r_nerf *m, const ViewParams &V, cons
     // 5 LDS-bricked slots (+ up to 2 HBM-bricked); anything else takes the generic instantiation
     if (cone) {
         // aabb_scale 2 models go through the generic slot kinds (no bricks are built for them)
-        if (composite) D2R_MARCH_C(true, 0, 0, -1, true);
-        else D2R_MARCH_C(false, 0, 0, -1, true);
+        if (composite) {
+            if (m->P.n_dense == 5) D2R_MARCH_C(true, 0, 0, 5, true);
+            else D2R_MARCH_C(true, 0, 0, -1, true);
+        } else {
+            if (m->P.n_dense == 5) D2R_MARCH_C(false, 0, 0, 5, true);
+            else D2R_MARCH_C(false, 0, 0, -1, true);
+        }
     } else if (composite) {
         if (m->P.n_dense != 5) D2R_MARCH(true, 0, 0, -1);
         else if (nb == 5 && ngb == 3) D2R_MARCH(true, 5, 3, 5);
