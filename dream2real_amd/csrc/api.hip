@@ -319,7 +319,6 @@ int d2r_nerf_create(d2r_ctx *ctx, const d2r_nerf_desc *d, d2r_nerf **out)
     P.aabb_scale = aabb;
     std::vector<uint64_t> bricks((size_t)n_casc * 32 * 32 * 32, 0);
     float blo[3] = {2.f, 2.f, 2.f}, bhi[3] = {-2.f, -2.f, -2.f};
-    int lo[3] = {D2R_GRID, D2R_GRID, D2R_GRID}, hi[3] = {-1, -1, -1};     // cascade-0 cell range (aabb_scale 1 bricks)
     for (uint32_t cs = 0; cs < n_casc; cs++) {
         const uint8_t *bits = d->occupancy_bits + (size_t)cs * (D2R_GRID * D2R_GRID * D2R_GRID / 8);
         const float side = (float)(1u << cs) / (float)aabb, org = 0.5f - 0.5f * side;   // of the cascade, normalised
@@ -331,10 +330,6 @@ int d2r_nerf_create(d2r_ctx *ctx, const d2r_nerf_desc *d, d2r_nerf **out)
                         bricks[(size_t)cs * 32768 + (x >> 2) + 32 * ((y >> 2) + 32 * (z >> 2))] |= 1ull << ((x & 3) + 4 * (y & 3) + 16 * (z & 3));
                         int c[3] = {x, y, z};
                         for (int a = 0; a < 3; a++) {
-                            if (cs == 0) {
-                                lo[a] = std::min(lo[a], c[a]);
-                                hi[a] = std::max(hi[a], c[a]);
-                            }
                             blo[a] = std::min(blo[a], org + side * (float)c[a] / D2R_GRID);
                             bhi[a] = std::max(bhi[a], org + side * (float)(c[a] + 1) / D2R_GRID);
                         }
@@ -364,8 +359,8 @@ int d2r_nerf_create(d2r_ctx *ctx, const d2r_nerf_desc *d, d2r_nerf **out)
         int g0[3], n[3];
         for (int a = 0; a < 3; a++) {
             // same correctly-rounded fma the kernels use: monotone, so these bound every sample
-            float plo = fmaf(L.scale, (float)lo[a] / (float)D2R_GRID, 0.5f);
-            float phi = fmaf(L.scale, (float)(hi[a] + 1) / (float)D2R_GRID, 0.5f);
+            float plo = fmaf(L.scale, blo[a], 0.5f);
+            float phi = fmaf(L.scale, bhi[a], 0.5f);
             g0[a] = (int)floorf(plo);
             n[a] = (int)floorf(phi) + 1 - g0[a] + 1;
         }
@@ -388,7 +383,7 @@ int d2r_nerf_create(d2r_ctx *ctx, const d2r_nerf_desc *d, d2r_nerf **out)
                 }
         return true;
     };
-    if (aabb == 1u && hi[0] >= 0 && P.n_dense >= 0) {
+    if (bhi[0] >= blo[0] && P.n_dense >= 0) {
         const size_t budget_words = (160 * 1024 - (size_t)D2R_N_WFRAG * 64 * 16) / 4;
         std::vector<uint32_t> words;
         for (uint32_t i = 0; i < d->n_levels / 2 && i < 5; i++) {

@@ -1114,33 +1114,25 @@ int d2r_launch_render(d2r_ctx *ctx, const d2r_nerf *m, const ViewParams &V, cons
                            COMP ? bgd : nullptr, COMP ? frames_dev : nullptr, sc);                                \
     } while (0)
     // compile-time slot kinds: the usual tables have 5 leading dense levels; small objects get 4 or
-    // 5 LDS-bricked slots (+ up to 2 HBM-bricked); anything else takes the generic instantiation
+    // 5 LDS-bricked slots (+ up to 3 HBM-bricked); anything else takes the generic instantiation
+#define D2R_MARCH_PICK(COMP, CONE)                                      \
+    do {                                                                \
+        if (m->P.n_dense != 5) D2R_MARCH_C(COMP, 0, 0, -1, CONE);       \
+        else if (nb == 5 && ngb == 3) D2R_MARCH_C(COMP, 5, 3, 5, CONE); \
+        else if (nb == 5 && ngb == 2) D2R_MARCH_C(COMP, 5, 2, 5, CONE); \
+        else if (nb == 5 && ngb == 1) D2R_MARCH_C(COMP, 5, 1, 5, CONE); \
+        else if (nb == 5) D2R_MARCH_C(COMP, 5, 0, 5, CONE);             \
+        else if (nb == 4) D2R_MARCH_C(COMP, 4, 0, 5, CONE);             \
+        else D2R_MARCH_C(COMP, 0, 0, 5, CONE);                          \
+    } while (0)
     if (cone) {
-        // aabb_scale 2 models go through the generic slot kinds (no bricks are built for them)
-        if (composite) {
-            if (m->P.n_dense == 5) D2R_MARCH_C(true, 0, 0, 5, true);
-            else D2R_MARCH_C(true, 0, 0, -1, true);
-        } else {
-            if (m->P.n_dense == 5) D2R_MARCH_C(false, 0, 0, 5, true);
-            else D2R_MARCH_C(false, 0, 0, -1, true);
-        }
-    } else if (composite) {
-        if (m->P.n_dense != 5) D2R_MARCH(true, 0, 0, -1);
-        else if (nb == 5 && ngb == 3) D2R_MARCH(true, 5, 3, 5);
-        else if (nb == 5 && ngb == 2) D2R_MARCH(true, 5, 2, 5);
-        else if (nb == 5 && ngb == 1) D2R_MARCH(true, 5, 1, 5);
-        else if (nb == 5) D2R_MARCH(true, 5, 0, 5);
-        else if (nb == 4) D2R_MARCH(true, 4, 0, 5);
-        else D2R_MARCH(true, 0, 0, 5);
+        if (composite) D2R_MARCH_PICK(true, true);
+        else D2R_MARCH_PICK(false, true);
     } else {
-        if (m->P.n_dense != 5) D2R_MARCH(false, 0, 0, -1);
-        else if (nb == 5 && ngb == 3) D2R_MARCH(false, 5, 3, 5);
-        else if (nb == 5 && ngb == 2) D2R_MARCH(false, 5, 2, 5);
-        else if (nb == 5 && ngb == 1) D2R_MARCH(false, 5, 1, 5);
-        else if (nb == 5) D2R_MARCH(false, 5, 0, 5);
-        else if (nb == 4) D2R_MARCH(false, 4, 0, 5);
-        else D2R_MARCH(false, 0, 0, 5);
+        if (composite) D2R_MARCH_PICK(true, false);
+        else D2R_MARCH_PICK(false, false);
     }
+#undef D2R_MARCH_PICK
 #undef D2R_MARCH
 #undef D2R_MARCH_C
     ctx->timing_end(tm);
