@@ -124,6 +124,16 @@ class Testbed:
         self._view_idx = 0
         self._cam = np.eye(4, dtype=np.float32)[:3]
 
+    @classmethod
+    def from_snapshot(cls, ctx: "Context", path: str) -> "Testbed":
+        """`ngp.Testbed(ngp.TestbedMode.Nerf)` + `load_snapshot(path)` (reference
+        reconstruction/ngp_visual_model.py:24-28): tables, MLPs, occupancy, training-view intrinsics and
+        the dataset scale/offset come from the `.ingp` file (dream2real_amd.ingp.load_ingp)."""
+        from . import ingp
+        model, info = ingp.load_ingp(path)
+        return cls(ctx, model, training_views=info["training_views"] or None,
+                   dataset_scale=info["dataset_scale"], dataset_offset=info["dataset_offset"])
+
     def close(self):
         if getattr(self, "h", None):
             self.ctx.lib.d2r_nerf_destroy(self.h)

@@ -143,6 +143,25 @@ def test_aabb_scale_2_model_renders_like_the_oracle():
     fg.close(); bg.close(); ctx.close()
 
 
+def test_testbed_from_snapshot_renders_like_the_model_it_was_saved_from(gpu, tmp_path):
+    """Testbed.from_snapshot = Testbed(mode) + load_snapshot: a model written by ingp.save_ingp and read
+    back renders bit-identically, with the snapshot's intrinsics and dataset offset in the view."""
+    from dream2real_amd import ingp
+    scene, fg, ctx, engine = gpu["scene"], gpu["fg"], gpu["ctx"], gpu["engine"]
+    path = str(tmp_path / "fg_base.ingp")
+    ingp.save_ingp(path, scene.fg)
+    tb = engine.Testbed.from_snapshot(ctx, path)
+    tb.background_color = list(scene.fg_background)
+    W, H = 96, 54
+    cam = OraclePipeline(scene, W, H).fg_camera(scene.obj_pose)
+    a = fg.render_batch(cam[None], W, H)
+    b = tb.render_batch(cam[None], W, H)
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
+    assert (a[1] > 0).sum() > 50
+    tb.close()
+
+
 def test_testbed_surface_shade_and_depth(gpu):
     """pyngp-style stateful calls return the same frames as the batched entry point."""
     scene, fg, engine = gpu["scene"], gpu["fg"], gpu["engine"]
