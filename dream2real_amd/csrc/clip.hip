@@ -653,8 +653,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
         asm volatile("" ::: "memory");
     };
 
-    // positions 0..7 (both K-tiles of the first pair) of the first tile are requested at once; for later
-    // tiles the same requests are issued in front of the previous tile's epilogue
+    // positions 0..7 (both K-tiles of the first pair) of the first tile are requested at once; later tiles
+    // get theirs from the previous tile's last K-tile pair
     uint32_t t = t_begin + loc;
     if (t >= t_end) return;
     tile_origin(t, m0, n0);
@@ -670,9 +670,13 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
     STAMP(ts0);
-    // everything in flight is drained ONCE per tile: the eight half-tiles requested a whole epilogue ago
-    // and that epilogue's stores (stores share the vmcnt counter and may retire out of order with loads,
+    // everything in flight is drained ONCE per tile: the eight half-tiles staged during the previous tile's
+    // last K-tile pair and that tile's epilogue stores (stores share the vmcnt counter and may retire out of order with loads,
     // so the counted waits below are only sound with no store outstanding)
+    // (the builtin, not inline asm: hipcc's own wait-count bookkeeping must also learn that the
+    // epilogue's loads and stores have retired, or it protects their registers with a vmcnt(0) of its
+    // own inside the K loop)
+    __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0), lgkmcnt / expcnt untouched
     wait_vmcnt<0>();
     bar();
     read_pos(0);
@@ -686,13 +690,21 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
     // group 0's next read section: after the MFMAs for wm = 0, after the DMA issue for wm = 1.
     if (wm == 1) bar();
 
+    // The ring runs on across tile boundaries: the last K-tile pair of a tile stages the first pair of the
+    // workgroup's NEXT tile, so the memory pipe (the resource this kernel is bound by) is not left idle
+    // while the last pair is consumed, and the epilogue's stores do not share it with a burst of requests.
+    const uint32_t t_next = t + per_xcd;
+    const bool has_next = t_next < t_end;             // block-uniform
+    uint32_t m0n = 0, n0n = 0;
+    if (has_next) tile_origin(t_next, m0n, n0n);
     const uint32_t n_iter = nk / 2;
     for (uint32_t u = 0; u < n_iter; u++) {
         const bool last = u + 1 == n_iter;            // block-uniform
+        const bool tail = last && !has_next;          // nothing left to stage: the queue drains
 #pragma unroll
         for (int P = 0; P < 8; P++) {
             auto wait_next = [&]() {                  // position 8u+P+3 must have landed; younger ones stay in flight
-                if (!last) {
+                if (!tail) {
                     wait_vmcnt<10>();
                 } else {
                     if (P == 0) wait_vmcnt<8>();
@@ -703,9 +715,9 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
                 }
             };
             // read section: position 8u+P+2 (kind (P+2) mod 8) for the next phase's MFMAs; stage position
-            // 8u+P+8 (kind P) of K-tile 2(u+1) + (P >= 4) -- nothing is left to stage in the last pair
+            // 8u+P+8 (kind P): K-tile 2(u+1) + (P >= 4) of this tile, or K-tile (P >= 4) of the next one
             if (!(last && P >= 6)) read_pos((P + 2) & 7);
-            if (!last) stage_pos(P, 2 * (u + 1) + (P >= 4 ? 1u : 0u));
+            if (!tail) stage_pos_at(P, (last ? 0u : 2 * (u + 1)) + (P >= 4 ? 1u : 0u), last ? m0n : m0, last ? n0n : n0);
             if (wm == 1) wait_next();
             __builtin_amdgcn_sched_barrier(0);
             bar();
@@ -721,19 +733,10 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
     }
     if (wm == 0) bar();
     STAMP(ts2);
-    // every wave is past its last fragment read and every DMA of this tile has landed: the ring is free.
-    // Request the next tile's first eight half-tiles now; they land while this tile's epilogue runs.
-    const uint32_t t_next = t + per_xcd;
+    // every wave is past its last fragment read of this tile; the ring already holds (or is receiving)
+    // the next tile's first K-tile pair
     const uint32_t em = m0 + wm * 128, en = n0 + wn * 64;
-    auto request_next = [&]() {
-        if (t_next < t_end) {
-            tile_origin(t_next, m0, n0);
-#pragma unroll
-            for (int kind = 0; kind < 8; kind++) stage_pos(kind, kind >= 4 ? 1u : 0u);
-        }
-    };
 #if (D2R_GEMM_ABLATE & 4) && defined(__HIP_DEVICE_COMPILE__)
-    request_next();
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
@@ -741,7 +744,10 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
 #pragma unroll
             for (int r = 0; r < 16; r++) asm volatile("" ::"v"(acc[i][j][r]));
 #else
-    gemm_epilogue<EPI, 4>(acc, ep, lane, em, en, bias, Cout, N, request_next);
+    // a freshly computed lane id (mbcnt) instead of the one derived from threadIdx at kernel entry: that
+    // one would stay live across the K loop for the epilogue's sake, and at 250+ registers it gets spilled
+    const uint32_t lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    gemm_epilogue<EPI, 4>(acc, ep, lane_e, em, en, bias, Cout, N);
 #endif
 #ifdef D2R_GEMM_STAMPS
     {
@@ -754,8 +760,10 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
         }
     }
 #endif
-    if (t_next >= t_end) break;
+    if (!has_next) break;
     t = t_next;
+    m0 = m0n;
+    n0 = n0n;
     }
 }
 

@@ -48,11 +48,19 @@ def test_no_spill_stores_inside_the_counted_vmcnt_k_loop(clip_isa):
 
 
 def test_k_loop_waits_are_counted_not_drained(clip_isa):
-    """between the MFMAs of the steady-state loop the only vmcnt waits are the hand-placed counted ones
-    (10 outstanding) plus the tail's 8/6/4/2/0; a compiler-inserted vmcnt(0) in the steady state would
-    show up as more than a handful of vmcnt(0)."""
+    """between the MFMAs of the K loop every vmcnt wait is one of the hand-placed ones (inline asm: counted,
+    10 outstanding, plus the 8/6/4/2/0 of a workgroup's final tile); a compiler-placed vmcnt wait there
+    would mean a load it knows about (a spill reload, an address it re-fetches) inside the counted ring."""
     for name, lines in kernels(clip_isa, "k_gemm8"):
         mf = [i for i, l in enumerate(lines) if "v_mfma" in l]
-        body = "\n".join(lines[mf[0]:mf[-1] + 1])
-        assert body.count("vmcnt(10)") >= 8, name
-        assert len(re.findall(r"vmcnt\(0\)", body)) <= 4, name
+        body = lines[mf[0]:mf[-1] + 1]
+        assert sum("vmcnt(10)" in l for l in body) >= 8, name
+        in_asm, compiler_waits = False, []
+        for l in body:
+            if "#ASMSTART" in l:
+                in_asm = True
+            elif "#ASMEND" in l:
+                in_asm = False
+            elif "vmcnt" in l and not in_asm:
+                compiler_waits.append(l.strip())
+        assert not compiler_waits, f"{name}: {compiler_waits[:3]}"
