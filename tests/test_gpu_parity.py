@@ -502,6 +502,45 @@ def test_optimise_pose_grid_end_to_end(gpu, tmp_path):
     sc.close()
 
 
+def test_optimise_pose_grid_with_templates_tokenizer_and_text_tower(gpu, tmp_path):
+    """The use_templates branch end to end inside the library's own pieces: 9 templates x (goal + 1
+    normalising caption) -> ClipBpeTokenizer -> GPU text tower -> logits -> mean over templates ->
+    goal / norm (reference clip_scoring.py:153-163,188-195).  Checked against the oracle text tower on
+    the same ids and the oracle image pipeline."""
+    import os
+    from dream2real_amd import clip_scoring, combined_rendering
+    from dream2real_amd.tokenizer import ClipBpeTokenizer
+    engine, ctx, scene, fg, bg = gpu["engine"], gpu["ctx"], gpu["scene"], gpu["fg"], gpu["bg"]
+    g = os.path.join(os.path.dirname(__file__), "golden")
+    tok = ClipBpeTokenizer.from_files(os.path.join(g, "bpe_vocab.json"), os.path.join(g, "bpe_merges.txt"), context_length=32)
+    cfg = dict(CLIP_CONFIGS["vit_tiny"], vocab=len(tok.vocab), ctx=32)
+    sd = random_clip_state_dict(cfg, seed=6)
+    sc, enc = engine.ClipScorer(ctx, cfg, sd), engine.TextEncoder(ctx, cfg, sd)
+    W, H = 160, 90
+    task = make_task(scene, fg, bg)
+    sample_res = [4, 2, 1, 1, 1, 1]
+    rend = combined_rendering.renderer(str(tmp_path), task, resolution=(W, H))
+    best, pose_batch, scores = clip_scoring.optimise_pose_grid(
+        rend, None, [0], task, str(tmp_path), sample_res=sample_res, phys_check=lambda p, t, v: v,
+        use_templates=True, scene_type=scene.scene_type, smoothing=False, scorer=sc, text_encoder=enc, tokenizer=tok)
+    # oracle side: same captions, same ids, numpy text tower, numpy ViT on oracle frames
+    caps, n_goal = clip_scoring.build_captions(task.goal_caption, task.norm_captions, True)
+    assert len(caps) == 18 and n_goal == 9 and caps[1] == "a photo of " + task.goal_caption
+    ids, _ = tok(caps)
+    text = clip_ref.text_embeds(ids, sd, cfg)
+    frames = OraclePipeline(scene, W, H).frames(pose_batch.numpy())
+    lg, _ = oracle_logits(frames, cfg, sd, text)
+    want = clip_scoring.reduce_logits(lg, n_goal, True)
+    got = scores.numpy()
+    # random text embeddings give small logits of either sign, so compare the means the ratio is made
+    # of rather than the ratio: rebuild them from the GPU logits of the same frames
+    lg_gpu = sc.score_frames(frames, enc.encode(ids))
+    assert np.abs(lg_gpu - lg).max() / sc.logit_scale < 2.5e-3
+    np.testing.assert_allclose(got, clip_scoring.reduce_logits(lg_gpu, n_goal, True), rtol=2e-2, atol=1e-3)
+    assert np.isfinite(want).all() and tuple(best.shape) == (4, 4)
+    sc.close(); enc.close()
+
+
 def test_renderer_with_sensor_depth_background(gpu, tmp_path):
     """depths_gt branch of renderer.render (reference combined_rendering.py:107-110): background
     depth from the rectified sensor depth, pushed far where the rectified movable mask is 0."""
