@@ -1257,10 +1257,10 @@ static int launch_gemm_cfg(d2r_ctx *ctx, const uint16_t *A, const uint16_t *W, c
     constexpr uint32_t TBM = WGM * MT * 32, TBN = WGN * 64, LDS = STAGES * (TBM + TBN) * BK * 2;
     const uint32_t M_pad = round_up(M_real, BM);
     const uint32_t nwg = (M_pad / TBM) * (N / TBN);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[D2R_MAX_DEVICES] = {};          // per device: a process may hold contexts on several GPUs
+    if (!attr_set[ctx->device % D2R_MAX_DEVICES]) {
         (void)hipFuncSetAttribute((const void *)k_gemm<EPI, WGM, WGN, MT, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
+        attr_set[ctx->device % D2R_MAX_DEVICES] = true;
     }
     hipLaunchKernelGGL((k_gemm<EPI, WGM, WGN, MT, STAGES>), dim3(nwg), dim3(WGM * WGN * 64), LDS, ctx->stream, A, W, bias, C,
                        M_pad, N, K);
@@ -1283,10 +1283,10 @@ static int launch_gemm(d2r_ctx *ctx, const uint16_t *A, const uint16_t *W, const
     if (N % 256 == 0 && (N >= 2048 || tiles256 >= 1024)) {
         if (K % 128 == 0 && ctx->gemm_cfg != 1) {         // gemm_cfg 1 = the two-stage K loop (kept for comparison)
             const uint32_t M_pad = round_up(M_real, BM);
-            static bool attr8 = false;
-            if (!attr8) {
+            static bool attr8[D2R_MAX_DEVICES] = {};
+            if (!attr8[ctx->device % D2R_MAX_DEVICES]) {
                 (void)hipFuncSetAttribute((const void *)k_gemm8<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024 + 8 * EP_WAVE_FLOATS * 4);
-                attr8 = true;
+                attr8[ctx->device % D2R_MAX_DEVICES] = true;
             }
             constexpr uint32_t LDS8 = 128 * 1024 + 8 * EP_WAVE_FLOATS * 4;
             hipLaunchKernelGGL((k_gemm8<EPI>), dim3(256), dim3(512), LDS8, ctx->stream, A, W, bias, C, M_pad, N, K);
@@ -1324,11 +1324,11 @@ int d2r_clip_forward(d2r_ctx *ctx, const d2r_clip *clip, const uint16_t *patches
                        clip->w.pos, clip->w.pre_w, clip->w.pre_b, X, rows, T, d);
     const uint32_t T_pad = round_up(T, 32);
     const size_t attn_lds = (size_t)T_pad * 128 + (size_t)64 * (T_pad + 4) * 2;
-    static bool attn_attr = false;
-    if (!attn_attr) {
+    static bool attn_attr[D2R_MAX_DEVICES] = {};
+    if (!attn_attr[ctx->device % D2R_MAX_DEVICES]) {
         (void)hipFuncSetAttribute((const void *)k_attention<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void *)k_attention<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attn_attr = true;
+        attn_attr[ctx->device % D2R_MAX_DEVICES] = true;
     }
     if (attn_lds > 160 * 1024) return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "sequence too long for the attention LDS layout");
     for (uint32_t l = 0; l < D.num_layers; l++) {

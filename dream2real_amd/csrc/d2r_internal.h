@@ -10,6 +10,7 @@
 #include "../../include/d2r.h"
 
 #define D2R_MAX_LEVELS 16
+#define D2R_MAX_DEVICES 64              // per-device "kernel attribute already set" flags
 #define D2R_GRID 128
 #define D2R_DT 0.0016914558f           // sqrt(3)/1024
 #define D2R_INV_DT (1.0f / D2R_DT)

@@ -1104,10 +1104,10 @@ int d2r_launch_render(d2r_ctx *ctx, const d2r_nerf *m, const ViewParams &V, cons
 #define D2R_MARCH(COMP, NB, NGB, ND) D2R_MARCH_C(COMP, NB, NGB, ND, false)
 #define D2R_MARCH_C(COMP, NB, NGB, ND, CONE)                                                                      \
     do {                                                                                                          \
-        static bool attr = false;                                                                                 \
-        if (!attr) {                                                                                              \
+        static bool attr[D2R_MAX_DEVICES] = {};                                                                   \
+        if (!attr[ctx->device % D2R_MAX_DEVICES]) {                                                               \
             (void)hipFuncSetAttribute((const void *)k_march<COMP, NB, NGB, ND, CONE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-            attr = true;                                                                                          \
+            attr[ctx->device % D2R_MAX_DEVICES] = true;                                                           \
         }                                                                                                         \
         hipLaunchKernelGGL((k_march<COMP, NB, NGB, ND, CONE>), dim3(blocks), dim3(D2R_MARCH_THREADS), lds, ctx->stream, PP, V, cams_dev, q, \
                            cnt, cnt + 1, COMP ? nullptr : rgba_dev, COMP ? nullptr : depth_dev,                   \
