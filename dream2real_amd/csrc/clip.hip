@@ -79,7 +79,13 @@ __device__ __forceinline__ uint16_t f2bf(float x)
 }
 __device__ __forceinline__ uint32_t pack2(float a, float b)
 {
-    return (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);
+    // the two-element vector form compiles to ONE v_cvt_pk_bf16_f32; converting the halves separately
+    // and or-ing them costs two conversions plus shift/or fix-ups
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    union { bf16x2 v; uint32_t u; } r;
+    r.v[0] = (__bf16)a;
+    r.v[1] = (__bf16)b;
+    return r.u;
 }
 __device__ __forceinline__ float wave_sum(float v)
 {
