@@ -938,6 +938,13 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void k_attention(const uint16_t *_
         float m_run = -INFINITY, l_run = 0.f;
         // causal: key tiles beyond the last query row of this tile are fully masked
         const uint32_t kt_end = CAUSAL ? min(n_kt, qt + 1) : n_kt;
+        // LDS addresses of this lane's fragments advance by a constant per key tile (32 K rows = 4096 B
+        // with an unchanged swizzle term, 32 keys = 64 B along a V^T row): two running pointers and
+        // immediate offsets instead of a dozen address computations per tile (the kernel is VALU-bound)
+        const uint8_t *kp[4];
+#pragma unroll
+        for (int s = 0; s < 4; s++) kp[s] = Ks + lds_off(li, 2 * s + hi);
+        const uint16_t *vp0 = Vt + (size_t)li * vstride + 4 * hi, *vp1 = Vt + (size_t)(32 + li) * vstride + 4 * hi;
         for (uint32_t kt = 0; kt < kt_end; kt++) {
             f32x16 sacc;
 #pragma unroll
@@ -945,7 +952,7 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void k_attention(const uint16_t *_
 #pragma unroll
             for (int s = 0; s < 4; s++) {
                 union { uint4 u; bf16x8 v; } a, b;
-                a.u = *(const uint4 *)(Ks + lds_off(kt * 32 + li, 2 * s + hi));
+                a.u = *(const uint4 *)(kp[s] + kt * 4096u);
                 b.u = qf[s];
                 sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, sacc, 0, 0, 0);
             }
@@ -986,6 +993,7 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void k_attention(const uint16_t *_
             }
             l_run += psum;
             // O^T[d][q] += V^T[d][key] P^T[key][q]; P regs 8s..8s+7 are the B fragment of k-step s
+            const uint16_t *vq0 = vp0 + kt * 32, *vq1 = vp1 + kt * 32;
 #pragma unroll
             for (int s = 0; s < 2; s++) {
                 union { uint4 u; bf16x8 v; } pb, va0, va1;
@@ -994,11 +1002,10 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void k_attention(const uint16_t *_
                 pb.u.z = pack2(sacc[8 * s + 4], sacc[8 * s + 5]);
                 pb.u.w = pack2(sacc[8 * s + 6], sacc[8 * s + 7]);
                 // A slot (hi, j) <-> key kt*32 + 16s + 8(j>>2) + 4hi + (j&3)
-                const uint32_t kb = kt * 32 + 16 * s + 4 * hi;
-                const uint2 a00 = *(const uint2 *)(Vt + (size_t)li * vstride + kb);
-                const uint2 a01 = *(const uint2 *)(Vt + (size_t)li * vstride + kb + 8);
-                const uint2 a10 = *(const uint2 *)(Vt + (size_t)(32 + li) * vstride + kb);
-                const uint2 a11 = *(const uint2 *)(Vt + (size_t)(32 + li) * vstride + kb + 8);
+                const uint2 a00 = *(const uint2 *)(vq0 + 16 * s);
+                const uint2 a01 = *(const uint2 *)(vq0 + 16 * s + 8);
+                const uint2 a10 = *(const uint2 *)(vq1 + 16 * s);
+                const uint2 a11 = *(const uint2 *)(vq1 + 16 * s + 8);
                 va0.u = make_uint4(a00.x, a00.y, a01.x, a01.y);
                 va1.u = make_uint4(a10.x, a10.y, a11.x, a11.y);
                 o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va0.v, pb.v, o0, 0, 0, 0);
