@@ -984,14 +984,20 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void k_attention(const uint16_t *_
                 }
                 m_run = m_new;
             }
-            float psum = 0.f;
+            // s*c - m on packed pairs (v_pk_fma_f32), 16 exp2, pairwise tree sum (v_pk_add_f32)
+            {
+                typedef float f32x8 __attribute__((ext_vector_type(8)));
+                typedef float f32x4 __attribute__((ext_vector_type(4)));
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                const f32x16 cv = sm_c, mv = -m_new;
+                const f32x16 t = __builtin_elementwise_fma(sacc, cv, mv);
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[r], sm_c, -m_new));
-                sacc[r] = pr;
-                psum += pr;
+                for (int r = 0; r < 16; r++) sacc[r] = __builtin_amdgcn_exp2f(t[r]);
+                const f32x8 s8 = sacc.lo + sacc.hi;
+                const f32x4 s4 = s8.lo + s8.hi;
+                const f32x2 s2 = s4.lo + s4.hi;
+                l_run += s2.x + s2.y;
             }
-            l_run += psum;
             // O^T[d][q] += V^T[d][key] P^T[key][q]; P regs 8s..8s+7 are the B fragment of k-step s
             const uint16_t *vq0 = vp0 + kt * 32, *vq1 = vp1 + kt * 32;
 #pragma unroll
