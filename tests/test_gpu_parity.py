@@ -387,6 +387,22 @@ def test_vit_large_batch_is_deterministic_and_matches_oracle_at_both_ends(gpu):
     sc.close()
 
 
+def test_vit_with_a_single_k_tile_pair_in_the_persistent_gemm(gpu):
+    """hidden 128, MLP 2048: fc1 runs the persistent 256x256 kernel with K = 128, i.e. ONE K-tile pair per
+    tile -- the pair that is first and last at once, during which the ring already stages the next tile."""
+    engine, ctx = gpu["engine"], gpu["ctx"]
+    cfg = dict(CLIP_CONFIGS["vit_tiny"], mlp=2048)
+    sd = random_clip_state_dict(cfg, seed=8, text=False)
+    sc = engine.ClipScorer(ctx, cfg, sd)
+    r = np.random.Generator(np.random.PCG64(5))
+    pv = r.standard_normal((40, 3, cfg["image_size"], cfg["image_size"]), dtype=np.float32)   # 680 rows: 3 row panels x 8 column tiles
+    got = sc.embed_pixels(pv)
+    want = clip_ref.vision_embeds(pv, sd, cfg)
+    assert (1.0 - cosine(got, want)).max() < 2e-4
+    assert np.array_equal(got, sc.embed_pixels(pv))
+    sc.close()
+
+
 def test_vit_golden_image_embeds(gpu, goldens):
     """HIP ViT-B/16 against the committed Hugging Face golden embeddings."""
     engine, ctx = gpu["engine"], gpu["ctx"]
