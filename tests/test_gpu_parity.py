@@ -395,10 +395,12 @@ def test_vit_with_a_single_k_tile_pair_in_the_persistent_gemm(gpu):
     sd = random_clip_state_dict(cfg, seed=8, text=False)
     sc = engine.ClipScorer(ctx, cfg, sd)
     r = np.random.Generator(np.random.PCG64(5))
-    pv = r.standard_normal((40, 3, cfg["image_size"], cfg["image_size"]), dtype=np.float32)   # 680 rows: 3 row panels x 8 column tiles
+    # 1400 images = 23 800 rows = 93 row panels x 8 column tiles = 744 tiles: up to three per workgroup
+    pv = r.standard_normal((1400, 3, cfg["image_size"], cfg["image_size"]), dtype=np.float32)
     got = sc.embed_pixels(pv)
-    want = clip_ref.vision_embeds(pv, sd, cfg)
-    assert (1.0 - cosine(got, want)).max() < 2e-4
+    ends = np.r_[0:12, 700:706, 1388:1400]
+    want = clip_ref.vision_embeds(pv[ends], sd, cfg)
+    assert (1.0 - cosine(got[ends], want)).max() < 2e-4
     assert np.array_equal(got, sc.embed_pixels(pv))
     sc.close()
 
