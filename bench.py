@@ -8,11 +8,15 @@ embeddings, then (N>1) ONE all-gather of logits, ratio, smoothing, argmax.
 
 Workload (config.workload): BASELINE.json configs[1] — synthetic "shopping" scene (seeded,
 SURVEY.md §8(d)), 4 096 candidate poses per GPU, 640x360 renders, ViT-B/16, bf16 MFMA with
-fp32 accumulation.  N>1: one process per GPU (torchrun), every rank renders+scores its own
-contiguous 4 096-pose block of a [64,64,N] grid (weak scaling), no data-path collective
-except the all-gather of scores.
+fp32 accumulation.  N>1: one process per GPU; every rank renders+scores its own contiguous block of
+the pose grid, no data-path collective except ONE all-gather of the logits (d2r_allgather_scores:
+RCCL over xGMI behind the C ABI).
+  --scaling weak   (default) 4 096 poses per GPU, grid [64,64,N]
+  --scaling strong --poses-total 131072: BASELINE.json configs[3], grid [128,128,8] split over N GPUs
 
 python bench.py [--gpus N] [--steps K] [--warmup W]
+With --gpus N > 1 and no launcher environment (WORLD_SIZE unset) the script re-executes itself under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`.
 """
 import argparse
 import json
@@ -62,6 +66,26 @@ def cpu_baseline(scene, W, H, cfg, sd, text, poses_world, n_sample):
                       f"(BLAS threads, {t_clip:.1f}s)"}, frames, lg, idx
 
 
+def self_launch(n: int):
+    """`python bench.py --gpus N` outside a launcher: become `torch.distributed.run` with N ranks."""
+    import socket
+    import torch
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    if torch.cuda.device_count() < n:
+        # fewer GPUs than ranks (a 1-GPU box): ranks share GPUs, which RCCL refuses -> gloo process group and
+        # the torch fallback of the gather; the JSON line says so ("collective")
+        env.setdefault("D2R_DIST_BACKEND", "gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execve(sys.executable, cmd, env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -69,13 +93,18 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=360)
-    ap.add_argument("--poses-per-gpu", type=int, default=4096)
+    ap.add_argument("--poses-per-gpu", type=int, default=4096, help="weak scaling: candidates per GPU (a square)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--poses-total", type=int, default=131072,
+                    help="strong scaling: total candidates = x*x*8 (131072 = BASELINE.json configs[3])")
     ap.add_argument("--clip", default="vit_b16")
     ap.add_argument("--scene", default="shopping")
     ap.add_argument("--chunk", type=int, default=4096, help="candidates per pass (the library caps it per model/view)")
     ap.add_argument("--opt", action="append", default=[], help="library tunable key=value (repeatable)")
     ap.add_argument("--cpu-sample", type=int, default=6, help="candidates in the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)
 
     import torch
     from dream2real_amd import dist as d2r_dist
@@ -84,7 +113,7 @@ def main():
     from dream2real_amd.clip_model import CLIP_CONFIGS, random_clip_state_dict
     from dream2real_amd.clip_scoring import reduce_logits
     from dream2real_amd.geometry_utils import spatially_smooth_heatmap
-    from dream2real_amd.scene import make_scene, make_task, scene_text_embeds
+    from tests.scenes import make_scene, make_task, scene_text_embeds
 
     rank, world, local = d2r_dist.init_from_env()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
@@ -105,16 +134,21 @@ def main():
     fg, bg = engine.Testbed(ctx, scene.fg), engine.Testbed(ctx, scene.bg)
     fg.background_color = list(scene.fg_background)
     scorer = engine.ClipScorer(ctx, cfg, sd)
-    side = int(round(np.sqrt(args.poses_per_gpu)))
-    assert side * side == args.poses_per_gpu
-    sample_res = [side, side, world, 1, 1, 1]
+    if args.scaling == "weak":
+        side, nz = int(round(np.sqrt(args.poses_per_gpu))), world
+        assert side * side == args.poses_per_gpu, "--poses-per-gpu must be a square"
+    else:
+        nz = 8
+        side = int(round(np.sqrt(args.poses_total / nz)))
+        assert side * side * nz == args.poses_total, "--poses-total must be x*x*8"
+    sample_res = [side, side, nz, 1, 1, 1]
     task = make_task(scene)
     pose_batch = obj_pose_opt.sample_poses_grid(task, sample_res, scene.scene_type)       # [N,16] world
     N = pose_batch.shape[0]
     lo, hi = d2r_dist.shard_range(N, rank, world)
-    # contiguous in (x, y, z) order means z interleaves: shard by z-slice so every rank gets a full
-    # (x, y) sheet -> permute to z-major for sharding, remember the inverse for the gather
-    order = np.arange(N).reshape(side, side, world).transpose(2, 0, 1).reshape(-1)
+    # contiguous in (x, y, z) order means z interleaves: shard in z-major order so a rank gets whole
+    # (x, y) sheets -> permute for sharding, remember the inverse for the gather
+    order = np.arange(N).reshape(side, side, nz).transpose(2, 0, 1).reshape(-1)
     my_idx = order[lo:hi]
     poses_ngp = converter(pose_batch[my_idx].reshape(-1, 4, 4)).reshape(-1, 16).astype(np.float32)
     poses_dev = torch.from_numpy(poses_ngp).to(dev)
@@ -129,17 +163,20 @@ def main():
     frame0 = fg.render_composite(view, T1, cam_ngp, T1[None])
     _, e0 = scorer.score_frames(frame0, np.zeros((1, cfg["proj"]), np.float32), return_embeds=True)
     text = scene_text_embeds(e0[0])
-    logits_dev = torch.zeros((K_local, text.shape[0]), dtype=torch.float32, device=dev)
-    # run the library on a torch-owned (non-null) stream so torch copies/collectives order after it
+    # run the library on a torch-owned (non-null) stream so torch copies order after it
     stream = torch.cuda.Stream(dev)
     torch.cuda.set_stream(stream)
     ctx.set_stream(stream.cuda_stream)
+    # the one collective: the C-ABI communicator (RCCL over xGMI); torch.distributed only bootstraps it
+    # (id blob) and provides the timing barrier
+    c_abi_comm = d2r_dist.init_comm(ctx, rank, world)
+    gather = d2r_dist.ShardGather(ctx, N, text.shape[0], rank, world, dev, c_abi_comm)
+    logits_dev = gather.local
 
     def step():
         engine.render_score_device(ctx, fg, scorer, view, T1, cam_ngp, poses_dev.data_ptr(), K_local, text,
                                    logits_dev.data_ptr())
-        full = d2r_dist.allgather_logits(logits_dev, N, rank, world)      # one RCCL all-gather (N>1)
-        lg = full.cpu().numpy()                                            # [N, C], z-major order
+        lg = gather.gather()                                               # [N, C], z-major order (ONE all-gather at N>1)
         scores = np.zeros(N, np.float32)
         scores[order] = reduce_logits(lg, 1, True)
         scores = spatially_smooth_heatmap(scores, sample_res)
@@ -165,6 +202,11 @@ def main():
                          device=dev if torch.distributed.get_backend() == "nccl" else "cpu")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
+    ranks_seen = 1
+    if world > 1:
+        t = torch.ones(1, dtype=torch.int32, device=dev if torch.distributed.get_backend() == "nccl" else "cpu")
+        torch.distributed.all_reduce(t)
+        ranks_seen = int(t.item())
     timing = ctx.timing()
     ctx.set_option("timing", 0)
     stats = ctx.render_stats(collect_K=K_local)          # counters of the last step
@@ -196,11 +238,20 @@ def main():
         out = {
             "metric": "candidate renders scored/sec (640x360)", "value": round(value, 2), "unit": "candidates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"BASELINE.json configs[1]: {args.scene} scene, {args.poses_per_gpu} candidate poses per GPU, "
-                                   f"{W}x{H}, bf16 MLP + {args.clip}", "poses_total": N, "chunk": per_launch,
-                       "parallelism": f"pose-shard x{world}" if world > 1 else "single GPU"},
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling,
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic", "ranks_seen": ranks_seen,
+            "config": {"workload": (f"BASELINE.json configs[1]: {args.scene} scene, {args.poses_per_gpu} candidate poses per GPU, "
+                                    f"{W}x{H}, bf16 MLP + {args.clip}") if args.scaling == "weak" else
+                                   (f"BASELINE.json configs[3]: {args.scene} scene, {N} candidates over {world} GPU(s), "
+                                    f"{W}x{H}, bf16 MLP + {args.clip}"),
+                       "poses_total": N, "sample_res": sample_res, "chunk": per_launch,
+                       "parallelism": f"pose-shard x{world}" if world > 1 else "single GPU",
+                       "collective": ("none (single GPU)" if world == 1 else
+                                      "d2r_allgather_scores: one ncclAllGather (RCCL) of fp32 logits per step" if c_abi_comm else
+                                      f"torch.distributed all_gather ({torch.distributed.get_backend()}): ranks share a GPU, RCCL unavailable"),
+                       "text_embeds": "2 seeded unit vectors correlated with the scene's image embedding (random-weight "
+                                      "towers give uncorrelated text: the goal/norm ratio needs positive logits); "
+                                      "throughput does not depend on their values"},
             "roofline": {"bound": "hbm", "kernel": "k_march (hash-grid fetch + fused MLP + compositing)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
@@ -222,7 +273,9 @@ def main():
             cb, frames_o, lg_o, idx = cpu_baseline(scene, W, H, cfg, sd, text, pose_batch, args.cpu_sample)
             out["cpu_baseline"] = cb
             # same candidates through the GPU path: parity of the benchmark itself
-            lg_gpu = logits_dev.cpu().numpy()[np.searchsorted(my_idx, idx)] if world == 1 else None
+            pos = np.empty(N, np.int64)
+            pos[my_idx] = np.arange(K_local)
+            lg_gpu = logits_dev[:K_local].cpu().numpy()[pos[idx]] if world == 1 else None
             if lg_gpu is not None:
                 out["parity_vs_oracle"] = {"max_cosine_err": float(np.abs(lg_gpu - lg_o).max() / scorer.logit_scale),
                                            "n": int(len(idx))}
@@ -231,6 +284,7 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()
+        ctx.comm_destroy()
         torch.distributed.destroy_process_group()
 
 

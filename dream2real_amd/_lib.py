@@ -9,14 +9,16 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libd2r.so")
-ABI_VERSION = 2          # D2R_ABI_VERSION of include/d2r.h this binding was written against
+ABI_VERSION = 3          # D2R_ABI_VERSION of include/d2r.h this binding was written against
 
 EXPORTS = [
     "d2r_abi_version", "d2r_ctx_create", "d2r_ctx_destroy", "d2r_ctx_set_stream", "d2r_ctx_synchronize",
     "d2r_last_error", "d2r_nerf_create", "d2r_nerf_destroy", "d2r_render", "d2r_nerf_eval_points",
     "d2r_set_background", "d2r_render_composite", "d2r_clip_create", "d2r_clip_destroy",
     "d2r_clip_score_frames", "d2r_clip_preprocess", "d2r_clip_embed_pixels", "d2r_render_score",
-    "d2r_get_render_stats", "d2r_collect_render_stats", "d2r_ctx_set_option", "d2r_get_timing", "d2r_text_create", "d2r_text_destroy", "d2r_text_encode",
+    "d2r_get_render_stats", "d2r_collect_render_stats", "d2r_ctx_set_option", "d2r_get_timing", "d2r_text_create",
+    "d2r_text_destroy", "d2r_text_encode", "d2r_comm_get_unique_id", "d2r_comm_init", "d2r_comm_destroy",
+    "d2r_allgather_scores",
 ]
 
 
@@ -61,6 +63,8 @@ class Timing(C.Structure):
                 ("raygen_launches", C.c_uint64), ("prep_ms", C.c_double), ("prep_launches", C.c_uint64),
                 ("clip_ms", C.c_double), ("clip_launches", C.c_uint64)]
 
+
+COMM_ID_BYTES = 128      # D2R_COMM_ID_BYTES
 
 _lib = None
 

@@ -53,10 +53,21 @@ def build_captions(goal_caption, norm_captions, use_templates):
     return ([goal_caption] if norm_captions is None else [goal_caption] + list(norm_captions)), 1
 
 
+def save_pose_outputs(data_dir, best_pose, pose_batch, pose_scores):
+    """What the reference's caller persists after optimise_pose_grid (dream2real.py:356-358):
+    goal_pose.txt, pose_batch.txt, pose_scores.txt in np.savetxt's text format — the files a later
+    run with use_cache_goal_pose / use_cache_renders reads back."""
+    def arr(x):
+        return x.detach().cpu().numpy() if hasattr(x, "detach") else np.asarray(x)
+    np.savetxt(os.path.join(data_dir, "goal_pose.txt"), arr(best_pose))
+    np.savetxt(os.path.join(data_dir, "pose_batch.txt"), arr(pose_batch))
+    np.savetxt(os.path.join(data_dir, "pose_scores.txt"), arr(pose_scores))
+
+
 def optimise_pose_grid(renderer, depths_gt, render_cam_pose_idx, task_model, data_dir, sample_res=None,
                        phys_check=None, use_templates=False, scene_type=0, use_vis_pcds=False,
                        use_cache_renders=False, smoothing=True, physics_only=False, *, scorer=None,
-                       text_embeds=None, text_encoder=None, tokenizer=None, show=False):
+                       text_embeds=None, text_encoder=None, tokenizer=None, show=False, save_renders=True):
     import torch
 
     if sample_res is None:
@@ -91,7 +102,7 @@ def optimise_pose_grid(renderer, depths_gt, render_cam_pose_idx, task_model, dat
         render_poses_ngp = accio2ngp.converter(render_poses)
         valid_poses_ngp = accio2ngp.converter(valid_poses.reshape(-1, 4, 4))
         renders = renderer.render(valid_poses_ngp, render_poses_ngp, render_cam_pose_idx, depths_gt,
-                                  getattr(task_model, "movable_masks", None), save=False)
+                                  getattr(task_model, "movable_masks", None), save=save_renders)   # reference :135-140: save=True
 
     if hasattr(task_model, "free_visual_models"):
         pass    # the reference frees the NeRFs here to make room for CLIP; 288 GB makes that unnecessary
@@ -129,5 +140,7 @@ def optimise_pose_grid(renderer, depths_gt, render_cam_pose_idx, task_model, dat
     img.save(os.path.join(data_dir, "best_render.png"))
     if show:
         img.show()
+    if hasattr(renderer, "wait_saved"):
+        renderer.wait_saved()          # cb_render/*.png are complete when the call returns, as in the reference
     return (torch.from_numpy(best_pose.reshape(4, 4).copy()), torch.from_numpy(pose_batch),
             torch.from_numpy(pose_scores))

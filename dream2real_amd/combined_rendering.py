@@ -140,7 +140,26 @@ class renderer:
             frames = fg.render_composite(view, T_WO_1, cam_matrix, valid_poses)
             render_imgs.extend(list(frames))
         if save and render_idx == 0:
-            from PIL import Image
-            for i, img in enumerate(render_imgs):
-                Image.fromarray(img).save(os.path.join(self.out_render_path, f"cb_rgb_{i:04d}.png"))
+            # the reference writes cb_rgb_%04d.png inline (:157-159); here PNG encoding runs on a worker
+            # thread so that scoring starts at once — wait_saved() joins it (optimise_pose_grid does)
+            self._start_writer(list(render_imgs))
         return render_imgs
+
+    def _start_writer(self, imgs):
+        import threading
+        out_dir = self.out_render_path
+
+        def work():
+            from PIL import Image
+            for i, img in enumerate(imgs):
+                Image.fromarray(img).save(os.path.join(out_dir, f"cb_rgb_{i:04d}.png"), compress_level=1)
+        self.wait_saved()
+        self._writer = threading.Thread(target=work, name="d2r-png-writer", daemon=False)
+        self._writer.start()
+
+    def wait_saved(self):
+        """Block until the PNGs of the last render(save=True) are on disk."""
+        t = getattr(self, "_writer", None)
+        if t is not None:
+            t.join()
+            self._writer = None

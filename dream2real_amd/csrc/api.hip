@@ -122,6 +122,12 @@ int d2r_ctx_create(int device, d2r_ctx **out)
     if (hipSetDevice(device) != hipSuccess) return d2r_fail(nullptr, D2R_ERR_DEVICE, "hipSetDevice failed");
     d2r_ctx *c = new d2r_ctx();
     c->device = device;
+    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    int xcc = 0;
+    if (hipDeviceGetAttribute(&xcc, hipDeviceAttributeNumberOfXccs, device) == hipSuccess && xcc > 0 && c->n_cu % xcc == 0)
+        c->n_xcd = xcc;
+    else
+        c->n_xcd = c->n_cu % 8 == 0 ? 8 : 1;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return d2r_fail(nullptr, D2R_ERR_DEVICE, "hipStreamCreate failed");
@@ -136,6 +142,7 @@ void d2r_ctx_destroy(d2r_ctx *c)
     if (!c) return;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
+    (void)d2r_comm_destroy(c);
     d2r_ctx::Buf *bufs[] = {&c->cams, &c->queue, &c->counters, &c->frames, &c->rgba, &c->depth, &c->poses,
                             &c->text, &c->logits, &c->pix, &c->bg_rgba, &c->bg_depth, &c->bg_u8};
     for (auto *b : bufs)
@@ -255,6 +262,8 @@ int d2r_nerf_create(d2r_ctx *ctx, const d2r_nerf_desc *d, d2r_nerf **out)
     if (!d->level_scale || !d->level_res || !d->level_size || !d->level_offset || !d->grid_fp16 || !d->dw1_fp16 ||
         !d->dw2_fp16 || !d->cw1_fp16 || !d->cw2_fp16 || !d->cw3_fp16 || !d->occupancy_bits)
         return d2r_fail(ctx, D2R_ERR_INVALID, "null field in d2r_nerf_desc");
+    const uint32_t aabb = d->aabb_scale ? d->aabb_scale : 1u;
+    if (aabb != 1u && aabb != 2u) return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "aabb_scale must be 1 or 2");
     hipSetDevice(ctx->device);
     d2r_nerf *m = new d2r_nerf();
     m->ctx = ctx;
@@ -312,9 +321,6 @@ int d2r_nerf_create(d2r_ctx *ctx, const d2r_nerf_desc *d, d2r_nerf **out)
     }
     // occupancy -> 4x4x4 bricks per cascade + bounding box of occupied cells, in the unit cube of
     // the model's box (cascade c spans side 2^c / aabb_scale of it, centred)
-    const uint32_t aabb = d->aabb_scale ? d->aabb_scale : 1u;
-    if (aabb != 1u && aabb != 2u)
-        return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "aabb_scale must be 1 or 2");
     const uint32_t n_casc = aabb == 2u ? 2u : 1u;
     P.aabb_scale = aabb;
     std::vector<uint64_t> bricks((size_t)n_casc * 32 * 32 * 32, 0);
@@ -498,6 +504,7 @@ int d2r_render(d2r_ctx *ctx, const d2r_nerf *model, const d2r_view *view, const 
     const ViewParams V = d2r_view_params(view);
     const size_t px = (size_t)V.W * V.H;
     ctx->stats = d2r_render_stats{0, 0, 0, 0};
+    ctx->last_chunks = 0;
     // bound the pass size: 2^31 rays and ~1 GiB of fp32 frames
     uint32_t per = (uint32_t)std::max<size_t>(1, std::min<size_t>(n, (64u << 20) / px + 1));
     for (uint32_t c0 = 0; c0 < n; c0 += per) {
@@ -570,6 +577,7 @@ int d2r_render_composite(d2r_ctx *ctx, const d2r_nerf *fg, const d2r_view *view,
     const ViewParams V = d2r_view_params(view);
     const size_t px = (size_t)V.W * V.H;
     ctx->stats = d2r_render_stats{0, 0, 0, 0};
+    ctx->last_chunks = 0;
     const uint32_t per = pass_size(ctx, nullptr, px);
     for (uint32_t c0 = 0; c0 < K; c0 += per) {
         uint32_t nc = std::min(per, K - c0);
@@ -691,6 +699,7 @@ int d2r_render_score(d2r_ctx *ctx, const d2r_nerf *fg, const d2r_clip *clip, con
     const size_t px = (size_t)V.W * V.H;
     const uint32_t per = pass_size(ctx, clip, px);
     ctx->last_pass = per;
+    ctx->last_chunks = (K + per - 1) / per;
     // workspaces are sized once for a full chunk so that no allocation happens inside the loop
     const uint32_t cap = std::min(per, K);
     if ((rc = d2r_reserve(ctx, ctx->cams, (size_t)cap * 48))) return rc;
@@ -729,8 +738,11 @@ int d2r_render_score(d2r_ctx *ctx, const d2r_nerf *fg, const d2r_clip *clip, con
 int d2r_collect_render_stats(d2r_ctx *ctx, uint32_t K)
 {
     if (!ctx) return d2r_fail(nullptr, D2R_ERR_INVALID, "null ctx");
-    const uint32_t per = std::max<uint32_t>(1, ctx->last_pass);
-    const uint32_t nchunks = (K + per - 1) / per;
+    // K is kept in the signature for ABI stability; the chunk count is the one the last d2r_render_score stored
+    (void)K;
+    const uint32_t nchunks = ctx->last_chunks;
+    if (nchunks == 0 || !ctx->counters.p || 64 + 32 * (size_t)nchunks > ctx->counters.cap)
+        return d2r_fail(ctx, D2R_ERR_INVALID, "d2r_collect_render_stats needs a preceding d2r_render_score on this context");
     std::vector<uint32_t> c((size_t)nchunks * 8);
     D2R_HIP(ctx, hipMemcpyAsync(c.data(), (uint8_t *)ctx->counters.p + 64, c.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
     D2R_HIP(ctx, hipStreamSynchronize(ctx->stream));

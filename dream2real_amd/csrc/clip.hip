@@ -24,6 +24,8 @@
 #include <math.h>
 
 #include <algorithm>
+#include <deque>
+#include <mutex>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -68,7 +70,8 @@ struct d2r_clip {
     std::vector<void *> allocs;
     ClipWeights w;
     std::vector<ClipWeights::Layer> layers;
-    std::vector<PrepCache> prep;     // resampling tables per (w, h, rot90), built on first use
+    std::deque<PrepCache> prep;      // resampling tables per (w, h, rot90), built on first use (deque: stable references)
+    std::mutex prep_mu;              // two threads may score different frame sizes with one model
 };
 
 __device__ __forceinline__ uint16_t f2bf(float x)
@@ -381,7 +384,7 @@ template <int EPI, int WGM, int WGN, int MT, int STAGES>
 __global__ __launch_bounds__(WGM * WGN * 64, 2) void k_gemm(const uint16_t *__restrict__ A,
                                                           const uint16_t *__restrict__ W,
                                                           const float *__restrict__ bias, void *__restrict__ Cout,
-                                                          uint32_t M_pad, uint32_t N, uint32_t K)
+                                                          uint32_t M_pad, uint32_t N, uint32_t K, uint32_t n_xcd)
 {
     constexpr uint32_t TBM = WGM * MT * 32, TBN = WGN * 64;
     constexpr uint32_t STAGE_BYTES = (TBM + TBN) * BK * 2;
@@ -389,10 +392,10 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void k_gemm(const uint16_t *__re
     constexpr int A_PER_WAVE = TBM / 8 / NWAVE, B_PER_WAVE = TBN / 8 / NWAVE;   // 1 KiB copies per wave per stage
     constexpr int PER_STAGE = A_PER_WAVE + B_PER_WAVE;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    // XCD-aware tile order (bijective): blocks b, b+8, ... share an L2; give each XCD a
+    // XCD-aware tile order (bijective): blocks b, b+n_xcd, ... share an L2; give each XCD a
     // contiguous run of tiles, n fastest so neighbours reuse the same A row panel.
     const uint32_t nwg = gridDim.x, tiles_n = N / TBN;
-    const uint32_t xcd = blockIdx.x & 7u, loc = blockIdx.x >> 3, q = nwg >> 3, rr = nwg & 7u;
+    const uint32_t xcd = blockIdx.x % n_xcd, loc = blockIdx.x / n_xcd, q = nwg / n_xcd, rr = nwg % n_xcd;
     const uint32_t tile = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
     const uint32_t m0 = (tile / tiles_n) * TBM, n0 = (tile % tiles_n) * TBN;
 
@@ -551,16 +554,16 @@ extern "C" __attribute__((visibility("default"))) int d2r_debug_gemm_stamps(unsi
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A, const uint16_t *__restrict__ W,
                                                  const float *__restrict__ bias, void *__restrict__ Cout,
-                                                 uint32_t M_pad, uint32_t N, uint32_t K)
+                                                 uint32_t M_pad, uint32_t N, uint32_t K, uint32_t n_xcd)
 {
     constexpr uint32_t SLOT = 128 * BK * 2;          // 16 KiB
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     // persistent: gridDim.x workgroups (one per CU) walk the tiles.  Tiles are numbered n-fastest; XCD x
-    // (blockIdx & 7) owns the contiguous range [x T/8, (x+1) T/8) and its 32 workgroups take
+    // (blockIdx mod n_xcd) owns the contiguous range [x T/n_xcd, (x+1) T/n_xcd) and its workgroups take
     // consecutive tiles of it in every round, so the CUs behind one L2 share A row panels.
     const uint32_t tiles_n = N / 256, n_tiles = (M_pad / 256) * tiles_n;
-    const uint32_t xcd = blockIdx.x & 7u, loc = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
-    const uint32_t t_begin = (uint32_t)((uint64_t)n_tiles * xcd / 8), t_end = (uint32_t)((uint64_t)n_tiles * (xcd + 1) / 8);
+    const uint32_t xcd = blockIdx.x % n_xcd, loc = blockIdx.x / n_xcd, per_xcd = gridDim.x / n_xcd;
+    const uint32_t t_begin = (uint32_t)((uint64_t)n_tiles * xcd / n_xcd), t_end = (uint32_t)((uint64_t)n_tiles * (xcd + 1) / n_xcd);
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t wm = wave >> 2, wn = wave & 3;
@@ -1198,6 +1201,7 @@ static int resample_coeffs(int in_size, int out_size, std::vector<int> &bounds, 
 // Resampling geometry + Pillow coefficient tables for one frame size, uploaded once.
 static int prep_tables(d2r_ctx *ctx, d2r_clip *clip, uint32_t w, uint32_t h, int rot90, const PrepCache **out)
 {
+    std::lock_guard<std::mutex> lock(clip->prep_mu);
     for (const PrepCache &pc : clip->prep)
         if (pc.w == w && pc.h == h && pc.rot90 == rot90) {
             *out = &pc;
@@ -1261,8 +1265,10 @@ int d2r_launch_preprocess(d2r_ctx *ctx, d2r_clip *clip, const uint8_t *frames_de
     const uint32_t band = P;
     size_t lds = (size_t)R.max_rows * S * 3;
     if (lds > 150 * 1024) return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "preprocess band does not fit in LDS");
-    if (lds > 64 * 1024)
-        hipFuncSetAttribute((const void *)k_preprocess, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    static PerDeviceOnce prep_attr;
+    prep_attr.run(ctx->device, [] {
+        (void)hipFuncSetAttribute((const void *)k_preprocess, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    });
     hipLaunchKernelGGL(k_preprocess, dim3((S + band - 1) / band, n), dim3(256), lds, ctx->stream, frames_dev, w, h,
                        rot90, R, S, P, band, patches_dev, clip->Kp_pad, pixel_values_dev);
     D2R_HIP(ctx, hipGetLastError());
@@ -1276,13 +1282,12 @@ static int launch_gemm_cfg(d2r_ctx *ctx, const uint16_t *A, const uint16_t *W, c
     constexpr uint32_t TBM = WGM * MT * 32, TBN = WGN * 64, LDS = STAGES * (TBM + TBN) * BK * 2;
     const uint32_t M_pad = round_up(M_real, BM);
     const uint32_t nwg = (M_pad / TBM) * (N / TBN);
-    static bool attr_set[D2R_MAX_DEVICES] = {};          // per device: a process may hold contexts on several GPUs
-    if (!attr_set[ctx->device % D2R_MAX_DEVICES]) {
+    static PerDeviceOnce attr_set;                       // per device: a process may hold contexts on several GPUs
+    attr_set.run(ctx->device, [] {
         (void)hipFuncSetAttribute((const void *)k_gemm<EPI, WGM, WGN, MT, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set[ctx->device % D2R_MAX_DEVICES] = true;
-    }
+    });
     hipLaunchKernelGGL((k_gemm<EPI, WGM, WGN, MT, STAGES>), dim3(nwg), dim3(WGM * WGN * 64), LDS, ctx->stream, A, W, bias, C,
-                       M_pad, N, K);
+                       M_pad, N, K, (uint32_t)ctx->n_xcd);
     D2R_HIP(ctx, hipGetLastError());
     return D2R_OK;
 }
@@ -1302,19 +1307,36 @@ static int launch_gemm(d2r_ctx *ctx, const uint16_t *A, const uint16_t *W, const
     if (N % 256 == 0 && (N >= 2048 || tiles256 >= 1024)) {
         if (K % 128 == 0 && ctx->gemm_cfg != 1) {         // gemm_cfg 1 = the two-stage K loop (kept for comparison)
             const uint32_t M_pad = round_up(M_real, BM);
-            static bool attr8[D2R_MAX_DEVICES] = {};
-            if (!attr8[ctx->device % D2R_MAX_DEVICES]) {
-                (void)hipFuncSetAttribute((const void *)k_gemm8<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024 + 8 * EP_WAVE_FLOATS * 4);
-                attr8[ctx->device % D2R_MAX_DEVICES] = true;
-            }
             constexpr uint32_t LDS8 = 128 * 1024 + 8 * EP_WAVE_FLOATS * 4;
-            hipLaunchKernelGGL((k_gemm8<EPI>), dim3(256), dim3(512), LDS8, ctx->stream, A, W, bias, C, M_pad, N, K);
+            static PerDeviceOnce attr8;
+            attr8.run(ctx->device, [] {
+                (void)hipFuncSetAttribute((const void *)k_gemm8<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS8);
+            });
+            // persistent: one workgroup per CU (a multiple of the XCD count, so every XCD gets the same number)
+            const uint32_t nwg8 = (uint32_t)(ctx->n_cu / ctx->n_xcd * ctx->n_xcd);
+            hipLaunchKernelGGL((k_gemm8<EPI>), dim3(nwg8), dim3(512), LDS8, ctx->stream, A, W, bias, C, M_pad, N, K,
+                               (uint32_t)ctx->n_xcd);
             D2R_HIP(ctx, hipGetLastError());
             return D2R_OK;
         }
         return launch_gemm_cfg<EPI, 2, 4, 4, 2>(ctx, A, W, bias, C, M_real, N, K);
     }
     return launch_gemm_cfg<EPI, 4, 2, 2, 3>(ctx, A, W, bias, C, M_real, N, K);
+}
+
+// LDS footprint of k_attention for a padded sequence length, and the one-time opt-in to more than 64 KiB
+// of dynamic LDS (both the vision and the text tower go through here)
+static int attention_setup(d2r_ctx *ctx, uint32_t T_pad, size_t *lds_out)
+{
+    const size_t attn_lds = (size_t)T_pad * 128 + (size_t)64 * (T_pad + 4) * 2;
+    if (attn_lds > 160 * 1024) return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "sequence too long for the attention LDS layout");
+    static PerDeviceOnce attn_attr;
+    attn_attr.run(ctx->device, [] {
+        (void)hipFuncSetAttribute((const void *)k_attention<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_attention<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    *lds_out = attn_lds;
+    return D2R_OK;
 }
 
 // patches (bf16 [n*(T-1) padded to 128][Kp_pad]) -> logits/embeds.  Workspaces:
@@ -1342,14 +1364,8 @@ int d2r_clip_forward(d2r_ctx *ctx, const d2r_clip *clip, const uint16_t *patches
     hipLaunchKernelGGL(k_embed_ln, dim3((rows + 3) / 4), dim3(256), 0, ctx->stream, patch_out, clip->w.cls,
                        clip->w.pos, clip->w.pre_w, clip->w.pre_b, X, rows, T, d);
     const uint32_t T_pad = round_up(T, 32);
-    const size_t attn_lds = (size_t)T_pad * 128 + (size_t)64 * (T_pad + 4) * 2;
-    static bool attn_attr[D2R_MAX_DEVICES] = {};
-    if (!attn_attr[ctx->device % D2R_MAX_DEVICES]) {
-        (void)hipFuncSetAttribute((const void *)k_attention<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void *)k_attention<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attn_attr[ctx->device % D2R_MAX_DEVICES] = true;
-    }
-    if (attn_lds > 160 * 1024) return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "sequence too long for the attention LDS layout");
+    size_t attn_lds = 0;
+    if ((rc = attention_setup(ctx, T_pad, &attn_lds))) return rc;
     for (uint32_t l = 0; l < D.num_layers; l++) {
         const ClipWeights::Layer &L = clip->layers[l];
         hipLaunchKernelGGL(k_layernorm, dim3((rows + 3) / 4), dim3(256), 0, ctx->stream, X, L.ln1_w, L.ln1_b, Xn,
@@ -1604,7 +1620,8 @@ extern "C" int d2r_text_encode(d2r_ctx *ctx, const d2r_text *tt, const int32_t *
     hipLaunchKernelGGL(k_text_embed, dim3(rows), dim3(128), 0, ctx->stream, ids_dev, tt->tok, tt->pos, X, pool, Cn, T, d,
                        D.vocab_size);
     const uint32_t T_pad = round_up(T, 32);
-    const size_t attn_lds = (size_t)T_pad * 128 + (size_t)64 * (T_pad + 4) * 2;
+    size_t attn_lds = 0;
+    if ((rc = attention_setup(ctx, T_pad, &attn_lds))) return rc;
     for (uint32_t l = 0; l < D.num_layers; l++) {
         const ClipWeights::Layer &L = tt->layers[l];
         hipLaunchKernelGGL(k_layernorm, dim3((rows + 3) / 4), dim3(256), 0, ctx->stream, X, L.ln1_w, L.ln1_b, Xn, rows, d);

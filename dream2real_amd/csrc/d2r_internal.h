@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -85,6 +86,13 @@ struct d2r_ctx {
     Buf bg_rgba, bg_depth, bg_u8;
     uint32_t bg_w = 0, bg_h = 0;
     d2r_render_stats stats{};
+    // device geometry (hipDeviceProp_t / hipDeviceAttributeNumberOfXccs): persistent kernels launch one
+    // workgroup per CU and map tiles to XCDs (one L2 each)
+    int n_cu = 256, n_xcd = 8;
+    // pose-shard communicator (comm.hip): an ncclComm_t, or null at world size 1
+    void *comm = nullptr;
+    int comm_rank = 0, comm_world = 1;
+    uint32_t last_chunks = 0;   // chunks of the last d2r_render_score (its per-chunk counters are behind counters+64)
     int64_t chunk = 4096;       // candidates per pass (capped per model/view by pass_size() in api.hip)
     uint32_t last_pass = 0;     // pass size the last d2r_render_score used (for its stats read-back)
     int64_t march_blocks = 0;  // 0 = auto
@@ -108,6 +116,14 @@ struct d2r_nerf {
     d2r_ctx *ctx;
     NerfParams P{};
     void *d_grid = nullptr, *d_bricks = nullptr, *d_wfrag = nullptr, *d_brick_tab = nullptr, *d_gbrick_tab = nullptr;
+};
+
+// hipFuncSetAttribute once per (kernel instantiation, device), safe when different contexts are driven from
+// different threads: one static instance per call site
+struct PerDeviceOnce {
+    std::once_flag flag[D2R_MAX_DEVICES];
+    template <class F>
+    void run(int device, F &&fn) { std::call_once(flag[device % D2R_MAX_DEVICES], fn); }
 };
 
 int d2r_fail(d2r_ctx *ctx, int code, const std::string &msg);

@@ -1092,7 +1092,7 @@ int d2r_launch_render(d2r_ctx *ctx, const d2r_nerf *m, const ViewParams &V, cons
     }
     ctx->timing_end(tr);
     size_t tm = ctx->timing_begin(D2R_T_MARCH);
-    int blocks = ctx->march_blocks > 0 ? (int)ctx->march_blocks : 256;     // persistent: one per CU
+    int blocks = ctx->march_blocks > 0 ? (int)ctx->march_blocks : ctx->n_cu;     // persistent: one per CU
     const float *bgd = (const float *)ctx->bg_depth.p;
     unsigned long long *sc = (unsigned long long *)(cnt + 2);
     const uint2 *q = (const uint2 *)ctx->queue.p;
@@ -1104,11 +1104,10 @@ int d2r_launch_render(d2r_ctx *ctx, const d2r_nerf *m, const ViewParams &V, cons
 #define D2R_MARCH(COMP, NB, NGB, ND) D2R_MARCH_C(COMP, NB, NGB, ND, false)
 #define D2R_MARCH_C(COMP, NB, NGB, ND, CONE)                                                                      \
     do {                                                                                                          \
-        static bool attr[D2R_MAX_DEVICES] = {};                                                                   \
-        if (!attr[ctx->device % D2R_MAX_DEVICES]) {                                                               \
+        static PerDeviceOnce attr;                                                                                \
+        attr.run(ctx->device, [] {                                                                                \
             (void)hipFuncSetAttribute((const void *)k_march<COMP, NB, NGB, ND, CONE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-            attr[ctx->device % D2R_MAX_DEVICES] = true;                                                           \
-        }                                                                                                         \
+        });                                                                                                       \
         hipLaunchKernelGGL((k_march<COMP, NB, NGB, ND, CONE>), dim3(blocks), dim3(D2R_MARCH_THREADS), lds, ctx->stream, PP, V, cams_dev, q, \
                            cnt, cnt + 1, COMP ? nullptr : rgba_dev, COMP ? nullptr : depth_dev,                   \
                            COMP ? bgd : nullptr, COMP ? frames_dev : nullptr, sc);                                \

@@ -63,6 +63,74 @@ def allgather_logits(local_logits, n_total: int, rank: int, world: int):
     return torch.cat(parts, 0)
 
 
+def init_comm(ctx, rank: int, world: int) -> bool:
+    """Bring up the C-ABI communicator of `ctx` (d2r_comm_init: RCCL over xGMI): rank 0 draws the id
+    blob, torch.distributed (whatever backend the process group has) hands it to the other ranks.
+    Returns True when d2r_allgather_scores is usable; False when RCCL cannot be (several ranks
+    sharing one GPU in a smoke run, no RCCL installed) — every rank takes the same branch, and the
+    caller then gathers through torch.distributed instead."""
+    import torch
+    import torch.distributed as dist
+    from . import _lib
+    if world == 1:
+        ctx.comm_init(None, 0, 1)
+        return True
+    # all ranks must agree before anyone enters ncclCommInitRank (it blocks on the others)
+    shared = torch.cuda.device_count() < world
+    blob = [None]
+    if rank == 0 and not shared:
+        try:
+            blob[0] = ctx.comm_unique_id()
+        except _lib.D2RError:
+            blob[0] = None
+    dist.broadcast_object_list(blob, src=0)
+    if blob[0] is None:
+        return False
+    ok = 1
+    try:
+        ctx.comm_init(blob[0], rank, world)
+    except _lib.D2RError:
+        ok = 0
+    t = torch.tensor([ok], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    if int(t.item()) == 0:
+        ctx.comm_destroy()
+        return False
+    return True
+
+
+class ShardGather:
+    """Device buffers of the one collective: every rank writes its logits into `local`
+    ([n_max, C], zero padded when its shard is one short), `gather()` returns [n_total, C] on the
+    host in shard order.  With a C-ABI communicator the exchange is d2r_allgather_scores on the
+    context's stream (no torch op on the data path); otherwise torch.distributed moves it."""
+
+    def __init__(self, ctx, n_total: int, n_caps: int, rank: int, world: int, device, use_c_abi: bool):
+        import torch
+        self.ctx, self.rank, self.world, self.n_total, self.C = ctx, rank, world, n_total, n_caps
+        self.n_max = -(-n_total // world)
+        self.lo, self.hi = shard_range(n_total, rank, world)
+        self.local = torch.zeros((self.n_max, n_caps), dtype=torch.float32, device=device)
+        self.full = torch.zeros((world, self.n_max, n_caps), dtype=torch.float32, device=device) if world > 1 else None
+        self.use_c_abi = use_c_abi
+        sizes = [shard_range(n_total, r, world) for r in range(world)]
+        self._rows = np.concatenate([r * self.n_max + np.arange(b - a) for r, (a, b) in enumerate(sizes)]) if world > 1 else None
+
+    def gather(self) -> np.ndarray:
+        import torch.distributed as dist
+        if self.world == 1:
+            return self.local[: self.n_total].cpu().numpy()
+        if self.use_c_abi:
+            self.ctx.allgather_scores(self.local.data_ptr(), self.n_max * self.C, self.full.data_ptr())
+            out = self.full.cpu().numpy()
+        else:
+            loc = self.local.cpu() if dist.get_backend() == "gloo" else self.local
+            full = self.full.cpu() if dist.get_backend() == "gloo" else self.full
+            dist.all_gather_into_tensor(full.view(-1, self.C), loc)
+            out = full.cpu().numpy()
+        return out.reshape(-1, self.C)[self._rows]
+
+
 def score_sharded(pose_batch: np.ndarray, score_fn, sample_res, has_norm: bool, n_goal: int = 1,
                   smoothing: bool = True, rank: int = 0, world: int = 1, is_valid=None):
     """The multi-GPU form of optimise_pose_grid's scoring half.

@@ -68,6 +68,26 @@ class Context:
         self.check(self.lib.d2r_get_timing(self.h, C.byref(t)))
         return {k: getattr(t, k) for k, _ in t._fields_}
 
+    # --- pose-shard communicator (RCCL behind the C ABI) ------------------------
+    def comm_unique_id(self) -> bytes:
+        """Rank 0: the bootstrap blob every rank hands to comm_init (ncclGetUniqueId)."""
+        buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
+        _lib.check(self.lib.d2r_comm_get_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, id_blob: bytes | None, rank: int, world: int):
+        if id_blob is not None:
+            assert len(id_blob) == _lib.COMM_ID_BYTES
+        self.check(self.lib.d2r_comm_init(self.h, id_blob, C.c_int(rank), C.c_int(world)))
+
+    def comm_destroy(self):
+        self.check(self.lib.d2r_comm_destroy(self.h))
+
+    def allgather_scores(self, local_dev_ptr: int, n_local: int, global_dev_ptr: int):
+        """d2r_allgather_scores: [n_local] fp32 on every rank -> [world][n_local], async on the stream."""
+        self.check(self.lib.d2r_allgather_scores(self.h, C.c_void_p(local_dev_ptr), C.c_size_t(n_local),
+                                                 C.c_void_p(global_dev_ptr)))
+
     def set_background(self, view: View, bg_rgba: np.ndarray, bg_depth: np.ndarray):
         a = np.ascontiguousarray(bg_rgba, np.float32)
         d = np.ascontiguousarray(bg_depth, np.float32)

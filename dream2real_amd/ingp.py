@@ -1,9 +1,9 @@
-"""Reader (and test writer) for instant-ngp `.ingp` NeRF snapshots.
+"""Reader for instant-ngp `.ingp` NeRF snapshots.
 
 The reference loads `fg_base.ingp` / `bg_base.ingp` through `pyngp.Testbed.load_snapshot`
 (reference reconstruction/ngp_visual_model.py:24-28).  No snapshot and no instant-ngp source is
 available offline, so this module is written against the format as believed (SURVEY.md §3.4 and
-Appendix A) and is exercised on snapshots produced by `save_ingp` below in the same layout.
+Appendix A) and is exercised on snapshots produced by tests/ingp_writer.py in the same layout.
 UNPINNED against real files: every constant is taken from the snapshot's embedded config, and
 anything unexpected raises instead of guessing.
 
@@ -50,6 +50,28 @@ def _decompress(raw: bytes) -> bytes:
         return raw          # uncompressed .msgpack
 
 
+def occupancy_from_density(dens_morton: np.ndarray) -> np.ndarray:
+    """instant-ngp's update_density_grid_mean_and_bitfield, as published: [n_cascades, 128^3] fp32
+    densities in Morton order -> [n_cascades, 128^3] bool in linear order (x + 128*(y + 128*z)).
+
+      mean   = sum(max(density, 0)) over the cells of cascade 0 / 128^3
+      thresh = min(NERF_MIN_OPTICAL_THICKNESS = 0.01, mean)
+      bit    = density > thresh                      (every cascade, the one threshold)
+      then cascade c >= 1 ORs in the 2x2x2 max-pool of cascade c-1 over its central 64^3 cells.
+    """
+    n_casc = dens_morton.shape[0]
+    mean = float(np.maximum(dens_morton[0], 0.0).sum(dtype=np.float64) / GRID ** 3)
+    thresh = min(NERF_MIN_OPTICAL_THICKNESS, mean)
+    occ = np.zeros((n_casc, GRID ** 3), bool)
+    occ[:, _morton_order()] = dens_morton > thresh
+    occ = occ.reshape(n_casc, GRID, GRID, GRID)                       # [c, z, y, x]
+    h, q = GRID // 2, GRID // 4
+    for c in range(1, n_casc):
+        pooled = occ[c - 1].reshape(h, 2, h, 2, h, 2).any(axis=(1, 3, 5))
+        occ[c, q:q + h, q:q + h, q:q + h] |= pooled
+    return occ.reshape(n_casc, -1)
+
+
 def load_ingp(path: str):
     """-> (NerfModel, info) where info carries training_views (intrinsics per image), dataset
     scale/offset, aabb_scale and the snapshot's background colour if present."""
@@ -88,10 +110,7 @@ def load_ingp(path: str):
     dens = np.frombuffer(snap["density_grid_binary"], np.float16).astype(np.float32)
     if dens.size != n_casc * GRID ** 3:
         raise ValueError(f"density grid must hold {n_casc} cascade(s) of 128^3 values")
-    pos = dens[dens > 0]
-    thresh = min(float(pos.mean()) if pos.size else 0.0, NERF_MIN_OPTICAL_THICKNESS)
-    occ_lin = np.zeros((n_casc, GRID ** 3), bool)
-    occ_lin[:, _morton_order()] = dens.reshape(n_casc, -1) > thresh           # Morton order within a cascade
+    occ_lin = occupancy_from_density(dens.reshape(n_casc, -1))
     model = NerfModel(levels, grid.copy(), dw1.copy(), dw2.copy(), cw1.copy(), cw2.copy(), cw3.copy(),
                       np.packbits(occ_lin.reshape(-1).astype(np.uint8), bitorder="little"), aabb_scale)
     views = []
@@ -104,37 +123,3 @@ def load_ingp(path: str):
                 dataset_offset=tuple(ds.get("offset", (0.5, 0.5, 0.5))), aabb_scale=aabb_scale,
                 background_color=snap.get("background_color"), training_step=snap.get("training_step"))
     return model, info
-
-
-def save_ingp(path: str, model: NerfModel, training_views=None, dataset_scale: float = 1.0,
-              dataset_offset=(0.0, 0.3, 0.5), density_value: float = 1.0):
-    """Write `model` in the layout load_ingp reads (test fixture writer; occupied cells get
-    `density_value`, the rest 0)."""
-    import msgpack
-    lv = model.levels
-    params = np.concatenate([np.asarray(a, np.float16).reshape(-1) for a in
-                             (model.dw1, model.dw2, model.cw1, model.cw2, model.cw3, model.grid)])
-    n_casc = int(getattr(model, "aabb_scale", 1)).bit_length()
-    occ_lin = np.unpackbits(model.occ_bits, bitorder="little").astype(bool).reshape(n_casc, -1)
-    dens = np.where(occ_lin[:, _morton_order()], density_value, 0.0).astype(np.float16).reshape(-1)
-    views = training_views or [dict(fx=924.66912, fy=926.49735, cx=654.51953, cy=355.18523, w=1280, h=720)]
-    cfg = {
-        "encoding": {"otype": "HashGrid", "n_levels": lv.n_levels, "n_features_per_level": lv.n_features,
-                     "log2_hashmap_size": lv.log2_hashmap_size, "base_resolution": lv.base_resolution},
-        "network": {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None",
-                    "n_neurons": 64, "n_hidden_layers": 1},
-        "rgb_network": {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None",
-                        "n_neurons": 64, "n_hidden_layers": 2},
-        "dir_encoding": {"otype": "Composite", "nested": [{"n_dims_to_encode": 3, "otype": "SphericalHarmonics", "degree": 4}]},
-        "snapshot": {
-            "version": 1, "mode": "nerf", "n_params": int(params.size), "params_type": "__half",
-            "params_binary": params.tobytes(), "density_grid_size": GRID, "density_grid_binary": dens.tobytes(),
-            "nerf": {"aabb_scale": int(getattr(model, "aabb_scale", 1)), "dataset": {
-                "n_images": len(views), "scale": dataset_scale, "offset": list(dataset_offset),
-                "aabb_scale": int(getattr(model, "aabb_scale", 1)),
-                "metadata": [{"resolution": [v["w"], v["h"]], "focal_length": [v["fx"], v["fy"]],
-                              "principal_point": [v["cx"] / v["w"], v["cy"] / v["h"]]} for v in views]}},
-        },
-    }
-    with open(path, "wb") as f:
-        f.write(zlib.compress(msgpack.packb(cfg, use_bin_type=True), 1))

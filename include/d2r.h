@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 #define D2R_API __attribute__((visibility("default")))
-#define D2R_ABI_VERSION 2
+#define D2R_ABI_VERSION 3
 
 typedef enum {
     D2R_OK = 0,
@@ -282,6 +282,32 @@ D2R_API int d2r_get_timing(d2r_ctx *ctx, d2r_timing *out);
  *     one persistent workgroup per CU), "gemm_cfg" (0 default, 1 plain-K-loop 256x256 kernel, 2 force
  *     256x128): development switches. */
 D2R_API int d2r_ctx_set_option(d2r_ctx *ctx, const char *key, int64_t value);
+
+/* ------------------------------------------------------ multi-GPU (one process per GPU) */
+
+/*
+ * The path's only collective: candidate poses are sharded in contiguous
+ * blocks over the GPUs of a node and every rank needs ALL logits before spatially_smooth_heatmap
+ * (reference vision_3d/geometry_utils.py:252-269) and the argmax (clip_scoring.py:218).  The reference
+ * itself is single-GPU (README.md:27) and has no counterpart.  Implemented on RCCL (ncclAllGather
+ * over xGMI), bound at run time; bootstrap is the caller's: rank 0 obtains an id blob and hands it to
+ * the other ranks by any means (torch.distributed, MPI, a file).
+ */
+#define D2R_COMM_ID_BYTES 128
+/* rank 0 only: fills id_out[D2R_COMM_ID_BYTES] (ncclGetUniqueId) */
+D2R_API int d2r_comm_get_unique_id(void *id_out);
+/* every rank, collectively: joins the communicator on the context's device (ncclCommInitRank).
+ * world == 1 with a NULL id needs no RCCL: the gather degenerates to a device copy (with an id, a
+ * one-rank RCCL communicator is created all the same). */
+D2R_API int d2r_comm_init(d2r_ctx *ctx, const void *id_blob, int rank, int world);
+D2R_API int d2r_comm_destroy(d2r_ctx *ctx);
+/*
+ *   local_dev   DEVICE [n_local] fp32: this rank's logits (K_local * C values; ranks with a shorter
+ *               shard pad to the common n_local)
+ *   global_dev  DEVICE [world][n_local] fp32, rank-major
+ * Asynchronous on the context's stream, ordered after the d2r_render_score that produced local_dev.
+ */
+D2R_API int d2r_allgather_scores(d2r_ctx *ctx, const float *local_dev, size_t n_local, float *global_dev);
 
 #ifdef __cplusplus
 }

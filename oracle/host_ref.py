@@ -151,3 +151,92 @@ def score_logits_templates(all_logits, n_templates, has_norm):
     if not has_norm:
         return a.mean(axis=1, dtype=np.float32)
     return a[:, :n_templates].mean(axis=1, dtype=np.float32) / a[:, n_templates:].mean(axis=1, dtype=np.float32)
+
+
+# ---- cv2.resize(..., interpolation=cv2.INTER_CUBIC) as published (OpenCV imgproc/resize.cpp), scalar ----
+# Independent of the product's vectorised dream2real_amd.combined_rendering.resize_cubic: per-pixel loops,
+# tap table built the way OpenCV's resize() builds xofs/alpha, float and 8-bit fixed-point paths.
+# cv2 is not installed in this image: pinned by hand-derived vectors (tests/test_rectify.py), not by cv2.
+
+def _cv_cubic_coeffs(x):
+    """interpolateCubic(): Keys kernel, A = -0.75, float32 arithmetic in OpenCV's expression order
+    (numpy float32 scalars: every intermediate is rounded to float32)."""
+    f = np.float32
+    A, x, one = f(-0.75), f(x), f(1.0)
+    x1 = x + one
+    c0 = ((A * x1 - f(5) * A) * x1 + f(8) * A) * x1 - f(4) * A
+    c1 = ((A + f(2)) * x - (A + f(3))) * x * x + one
+    xm = one - x
+    c2 = ((A + f(2)) * xm - (A + f(3))) * xm * xm + one
+    c3 = one - c0 - c1 - c2
+    return [f(c0), f(c1), f(c2), f(c3)]
+
+
+def _cv_axis_table(src, dst):
+    """resize(): for every destination index the 4 source taps (border-replicated) and coefficients.
+    scale = 1 / (dst / src) in double (inv_scale first, as resize() derives it from dsize);
+    fx = (float)((d + 0.5) * scale - 0.5); s = floor(fx); fx -= s."""
+    inv_scale = float(dst) / float(src)
+    scale = 1.0 / inv_scale
+    taps, coeffs = [], []
+    for d in range(dst):
+        fx = np.float32((d + 0.5) * scale - 0.5)
+        s = int(math.floor(float(fx)))
+        fx = np.float32(fx - np.float32(s))
+        taps.append([min(max(s - 1 + k, 0), src - 1) for k in range(4)])
+        coeffs.append(_cv_cubic_coeffs(fx))
+    return taps, coeffs
+
+
+def resize_cubic_ref(img, dsize):
+    """cv2.resize(img, (w, h), interpolation=cv2.INTER_CUBIC) for a 2-D float32 or uint8 image.
+    float32: HResizeCubic then VResizeCubic in float (left-to-right sums).
+    uint8:   coefficients -> saturate_cast<short>(c * 2048) (round half to even), integer horizontal and
+             vertical sums, FixedPtCast<int, uchar, 22>: (v + 2^21) >> 22 saturated to [0, 255]."""
+    dw, dh = int(dsize[0]), int(dsize[1])
+    sh, sw = img.shape
+    xt, xc = _cv_axis_table(sw, dw)
+    yt, yc = _cv_axis_table(sh, dh)
+    if img.dtype == np.uint8:
+        xi = [[int(min(max(np.rint(np.float32(c) * np.float32(2048.0)), -32768), 32767)) for c in cs] for cs in xc]
+        yi = [[int(min(max(np.rint(np.float32(c) * np.float32(2048.0)), -32768), 32767)) for c in cs] for cs in yc]
+        rows = [[sum(int(img[y, xt[d][k]]) * xi[d][k] for k in range(4)) for d in range(dw)] for y in range(sh)]
+        out = np.zeros((dh, dw), np.uint8)
+        for e in range(dh):
+            for d in range(dw):
+                v = sum(rows[yt[e][k]][d] * yi[e][k] for k in range(4))
+                out[e, d] = min(max((v + (1 << 21)) >> 22, 0), 255)
+        return out
+    src = img.astype(np.float32)
+    rows = np.zeros((sh, dw), np.float32)
+    for y in range(sh):
+        for d in range(dw):
+            acc = np.float32(src[y, xt[d][0]] * xc[d][0])
+            for k in range(1, 4):
+                acc = np.float32(acc + np.float32(src[y, xt[d][k]] * xc[d][k]))
+            rows[y, d] = acc
+    out = np.zeros((dh, dw), np.float32)
+    for e in range(dh):
+        for d in range(dw):
+            acc = np.float32(rows[yt[e][0], d] * yc[e][0])
+            for k in range(1, 4):
+                acc = np.float32(acc + np.float32(rows[yt[e][k], d] * yc[e][k]))
+            out[e, d] = acc
+    return out
+
+
+def rectify_depth_ref(depth, resolution):
+    """reconstruction/combined_rendering.py:166-187: centre crop to a square, cubic resize (channel 0 of
+    the 4-channel repeat is all the caller reads)."""
+    d = np.asarray(depth).astype(np.float32)
+    h, w = d.shape
+    d = d[(h - w) // 2:(h - w) // 2 + w, :] if h > w else d[:, (w - h) // 2:(w - h) // 2 + h]
+    return resize_cubic_ref(np.ascontiguousarray(d), resolution)
+
+
+def rectify_mask_ref(mask, resolution):
+    """reconstruction/combined_rendering.py:189-209: same crop + cubic resize on the uint8 mask."""
+    m = np.asarray(mask).astype(np.uint8)
+    h, w = m.shape
+    m = m[(h - w) // 2:(h - w) // 2 + w, :] if h > w else m[:, (w - h) // 2:(w - h) // 2 + h]
+    return resize_cubic_ref(np.ascontiguousarray(m), resolution)

@@ -8,7 +8,7 @@ import types
 import numpy as np
 
 from dream2real_amd.clip_model import CLIP_CONFIGS, random_clip_state_dict
-from dream2real_amd.scene import make_scene, make_task, scene_text_embeds  # noqa: F401 (re-exported)
+from tests.scenes import make_scene, make_task, scene_text_embeds  # noqa: F401 (re-exported)
 from oracle import clip_ref, host_ref, render_ref
 
 

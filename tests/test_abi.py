@@ -23,7 +23,7 @@ def test_header_symbols_are_exported():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in d2r.h but not exported"
     assert sorted(_lib.EXPORTS) == syms
-    assert lib.d2r_abi_version() == 2
+    assert lib.d2r_abi_version() == _lib.ABI_VERSION == int(re.search(r"#define D2R_ABI_VERSION (\d+)", open(os.path.join(REPO, "include", "d2r.h")).read()).group(1))
 
 
 def test_no_cpu_fallback():

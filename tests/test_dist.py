@@ -25,6 +25,11 @@ def score_fn(p):      # deterministic fake scorer: logits depend only on the pos
 best, scores = dd.score_sharded(poses, score_fn, res, True, rank=rank, world=world, is_valid=valid)
 np.save(os.path.join(os.environ["D2R_OUT"], f"scores_{rank}.npy"), scores)
 open(os.path.join(os.environ["D2R_OUT"], f"best_{rank}.txt"), "w").write(str(best))
+# the bench's gather object (torch fallback of d2r_allgather_scores; ragged shards: 7 rows over 2 ranks)
+assert dd.init_comm(None, rank, world) is False          # no GPU here: every rank agrees on the fallback
+g = dd.ShardGather(None, 7, 2, rank, world, "cpu", False)
+g.local[: g.hi - g.lo] = torch.arange(g.lo, g.hi, dtype=torch.float32)[:, None] * torch.tensor([1.0, 10.0])
+np.save(os.path.join(os.environ["D2R_OUT"], f"gather_{rank}.npy"), g.gather())
 '''
 
 
@@ -60,3 +65,6 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
     np.testing.assert_array_equal(s0, want)
     assert int((tmp_path / "best_0.txt").read_text()) == best
     assert want[3] == 0 and want[17] == 0
+    want_g = np.arange(7, dtype=np.float32)[:, None] * np.array([1.0, 10.0], np.float32)
+    np.testing.assert_array_equal(np.load(tmp_path / "gather_0.npy"), want_g)
+    np.testing.assert_array_equal(np.load(tmp_path / "gather_1.npy"), want_g)

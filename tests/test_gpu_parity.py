@@ -8,13 +8,16 @@ Tolerances (measured headroom in tools/gpu_diag.py, gpurun_out/diag1.log):
   preprocess bit-exact uint8 resampling (integer arithmetic), pixel_values within 1e-6
   scores     cosine error <= 1e-3 (north_star), i.e. |dlogit| <= 0.1 at logit scale 100
 """
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
 from dream2real_amd.clip_model import CLIP_CONFIGS, random_clip_state_dict
-from dream2real_amd.scene import make_scene
+from tests.ingp_writer import save_ingp
+from tests.scenes import make_scene
 from oracle import clip_ref, host_ref, render_ref
 from tests.parity_utils import (OraclePipeline, cosine, make_task, oracle_logits, random_unit_text_embeds,
                                 scene_text_embeds, seeded_text_embeds)
@@ -149,7 +152,7 @@ def test_testbed_from_snapshot_renders_like_the_model_it_was_saved_from(gpu, tmp
     from dream2real_amd import ingp
     scene, fg, ctx, engine = gpu["scene"], gpu["fg"], gpu["ctx"], gpu["engine"]
     path = str(tmp_path / "fg_base.ingp")
-    ingp.save_ingp(path, scene.fg)
+    save_ingp(path, scene.fg)
     tb = engine.Testbed.from_snapshot(ctx, path)
     tb.background_color = list(scene.fg_background)
     W, H = 96, 54
@@ -266,7 +269,8 @@ def test_other_kernel_instantiations(gpu, variant):
     table with 3 dense levels (2^15-entry tables), 4 LDS-bricked slots for a bigger object, no
     bricks for an object filling a quarter of the cube.  Each against the oracle."""
     import dataclasses
-    from dream2real_amd.scene import NerfModel, ellipsoid_occupancy, grid_levels, make_synthetic_nerf, world_to_ngp
+    from dream2real_amd.scene import NerfModel, grid_levels, world_to_ngp
+    from tests.scenes import ellipsoid_occupancy, make_synthetic_nerf
     engine, ctx, scene = gpu["engine"], gpu["ctx"], gpu["scene"]
     centre = world_to_ngp(scene.obj_pose[:3, 3])
     if variant == "small_tables":
@@ -578,8 +582,13 @@ def test_renderer_with_sensor_depth_background(gpu, tmp_path):
     # oracle with the same rectified background depth
     pipe = OraclePipeline(scene, W, H)
     bg_rgba, _ = pipe.background()
-    d = combined_rendering.rectify_depth(depth[0], (W, H))
-    d[combined_rendering.rectify_mask(masks[0], (W, H)) == 0] = 100.0
+    # the checker's own restatement of cv2.resize(INTER_CUBIC) (oracle/host_ref.py, scalar, pinned by
+    # hand-derived vectors in tests/test_rectify.py) — not the product's rectify_*
+    d = host_ref.rectify_depth_ref(depth[0], (W, H))
+    omask = host_ref.rectify_mask_ref(masks[0], (W, H))
+    d[omask == 0] = 100.0
+    np.testing.assert_allclose(combined_rendering.rectify_depth(depth[0], (W, H)), host_ref.rectify_depth_ref(depth[0], (W, H)), atol=2e-6)
+    np.testing.assert_array_equal(combined_rendering.rectify_mask(masks[0], (W, H)), omask)
     want = pipe.frames(poses, bg=(bg_rgba, d))
     # here the background itself is rendered by each side (bf16 vs fp32 MLP, |d| ~ 1e-3 = 0.3 LSB),
     # so single-LSB flips are spread over the whole frame; nothing may differ by more
@@ -588,7 +597,7 @@ def test_renderer_with_sensor_depth_background(gpu, tmp_path):
     # the near half hides the object, the far half shows it
     base = render_ref.composite(np.zeros((H, W, 4), np.float32), np.zeros((H, W), np.float32), bg_rgba, d)
     changed = np.abs(np.stack(frames).astype(int) - base[None].astype(int)).max(-1) > 1
-    hole = combined_rendering.rectify_mask(masks[0], (W, H)) == 0        # pushed to "far": object may show
+    hole = omask == 0                                                    # pushed to "far": object may show
     assert hole.sum() > 100
     # (semi-transparent silhouette pixels report an under-estimated depth — sum of w*z with A < 1,
     # SURVEY A.8 — and may still win the test against the 0.2 m plane, exactly as in the oracle)
@@ -662,3 +671,209 @@ def test_full_size_properties(gpu):
     st = ctx.render_stats()
     assert st["rays_total"] == len(poses) * W * H
     assert 5 < st["samples"] / max(st["rays_alive"], 1) < 60          # ~18 samples per hit ray
+
+
+def test_allgather_scores_c_abi(gpu):
+    """d2r_allgather_scores: world 1 without an id is a device copy; with an id a
+    one-rank RCCL communicator runs the real ncclAllGather on the context's stream."""
+    import torch
+    from dream2real_amd import _lib
+    engine = gpu["engine"]
+    ctx = engine.Context(0)
+    src = torch.arange(4096 * 2, dtype=torch.float32, device="cuda").reshape(4096, 2) * 0.5
+    dst = torch.zeros_like(src)
+    ctx.comm_init(None, 0, 1)
+    ctx.allgather_scores(src.data_ptr(), src.numel(), dst.data_ptr())
+    ctx.synchronize()
+    assert torch.equal(src, dst)
+    ctx.comm_destroy()
+    try:
+        blob = ctx.comm_unique_id()
+        ctx.comm_init(blob, 0, 1)
+    except _lib.D2RError as e:
+        ctx.close()
+        pytest.skip(f"RCCL unavailable: {e}")
+    dst.zero_()
+    ctx.allgather_scores(src.data_ptr(), src.numel(), dst.data_ptr())
+    ctx.synchronize()
+    assert torch.equal(src, dst)
+    with pytest.raises(_lib.D2RError):
+        ctx.comm_init(blob, 0, 1)             # already has a communicator
+    ctx.comm_destroy()
+    ctx.close()
+
+
+def test_bench_two_ranks_self_launch():
+    """`python bench.py --gpus 2` with no launcher environment: the script spawns its own ranks, the
+    ranks share GPU 0 here (gloo bootstrap, torch fallback of the gather) and rank 0 prints ONE JSON line
+    with ranks_seen = 2."""
+    import json, os, subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                        "--poses-per-gpu", "64", "--width", "160", "--height", "90", "--clip", "vit_tiny"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=repo)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["ranks_seen"] == 2 and out["n_gpus"] == 2 and out["config"]["poses_total"] == 128
+    assert out["value"] > 0 and out["cpu_baseline"] is None
+
+
+# ---------------------------------------------------------------- BASELINE.json configs[2] / [4] shapes
+
+def test_pool_triangle_scene_matches_oracle_and_full_size_properties():
+    """BASELINE.json configs[2]: the pool_triangle scene (2.8 cm sphere, scene type 0).  Small size
+    against the oracle (direct render + composited candidates), then 640x360 through size-independent
+    properties (determinism, sparse footprint, sample statistics)."""
+    from dream2real_amd import engine
+    scene = make_scene("pool_triangle")
+    ctx = engine.Context(0)
+    fg, bg = engine.Testbed(ctx, scene.fg), engine.Testbed(ctx, scene.bg)
+    fg.background_color = list(scene.fg_background)
+    W, H = 160, 90
+    pipe = OraclePipeline(scene, W, H)
+    poses = host_ref.sample_poses_grid(scene.scene_centre, [4, 3, 2, 1, 1, 1], scene.scene_type).reshape(-1, 4, 4)
+    cams = np.stack([pipe.fg_camera(p) for p in poses[:4]])
+    rgba, depth = fg.render_batch(cams, W, H)
+    hits = 0
+    for i in range(4):
+        orgba, odepth = pipe.fg_render(poses[i])
+        assert ((depth[i] > 0) == (odepth > 0)).all()
+        hits += int((odepth > 0).sum())
+        np.testing.assert_allclose(rgba[i], orgba, rtol=0, atol=5e-3)
+        np.testing.assert_allclose(depth[i], odepth, rtol=0, atol=2e-3)
+    assert hits > 100
+    obg = pipe.background()
+    view = fg.view(W, H)
+    ctx.set_background(view, obg[0], obg[1])
+    T1 = host_ref.converter(np.asarray(scene.obj_pose, np.float32)[None])[0]
+    TC = host_ref.converter(np.asarray(scene.cam_poses, np.float32))[0]
+    frames = fg.render_composite(view, T1, TC, host_ref.converter(poses.astype(np.float32)))
+    want = pipe.frames(poses, bg=obg)
+    diff = np.abs(frames.astype(int) - want.astype(int)).max(-1)
+    assert diff.max() <= 1 and (diff > 0).mean() < 0.02
+    assert (frames != frames[0][None]).any()
+    # full size
+    W, H = 640, 360
+    brgba, bdepth = bg.render_batch(TC[None, :3], W, H)
+    view = fg.view(W, H)
+    ctx.set_background(view, brgba[0], bdepth[0])
+    big = host_ref.sample_poses_grid(scene.scene_centre, [4, 4, 1, 1, 1, 1], scene.scene_type).reshape(-1, 4, 4)
+    far = np.array(scene.obj_pose, np.float32)
+    far[:3, 3] += (5.0, 5.0, 0.0)
+    pn = host_ref.converter(np.concatenate([big, far[None]]).astype(np.float32))
+    a = fg.render_composite(view, T1, TC, pn)
+    b = fg.render_composite(view, T1, TC, pn)
+    np.testing.assert_array_equal(a, b)
+    changed = (a[:-1] != a[-1][None]).any(-1).reshape(len(big), -1).mean(1)
+    assert (changed < 0.03).all() and changed.max() > 0.0005
+    st = ctx.render_stats()
+    assert st["rays_total"] == len(pn) * W * H and 5 < st["samples"] / max(st["rays_alive"], 1) < 60
+    fg.close(); bg.close(); ctx.close()
+
+
+def test_six_dof_pose_grid_on_the_shelf_scene_matches_oracle():
+    """BASELINE.json configs[4] geometry: scene type 1 (obj_pose_opt.py:22-29: eulers linspace(-pi, pi/2))
+    on the aabb_scale-2 shelf scene, sample_res [2,2,2,3,2,2] = 96 six-DoF candidates through
+    render_composite (virtual cameras all around the object, many looking from behind or below)."""
+    from dream2real_amd import engine, obj_pose_opt
+    scene = make_scene("shelf")
+    assert scene.scene_type == 1
+    ctx = engine.Context(0)
+    fg = engine.Testbed(ctx, scene.fg)
+    fg.background_color = list(scene.fg_background)
+    W, H = 128, 72
+    pipe = OraclePipeline(scene, W, H)
+    sample_res = [2, 2, 2, 3, 2, 2]
+    poses = host_ref.sample_poses_grid(scene.scene_centre, sample_res, 1)
+    np.testing.assert_array_equal(obj_pose_opt.sample_poses_grid(make_task(scene), sample_res, 1), poses)
+    R = poses.reshape(-1, 4, 4)[:, :3, :3]
+    assert (np.abs(R - np.eye(3)).reshape(len(R), -1).max(1) > 0.5).mean() > 0.9   # (rx,ry,rz) = (-pi,-pi,-pi) is the identity
+    obg = pipe.background()
+    view = fg.view(W, H)
+    ctx.set_background(view, obg[0], obg[1])
+    T1 = host_ref.converter(np.asarray(scene.obj_pose, np.float32)[None])[0]
+    TC = host_ref.converter(np.asarray(scene.cam_poses, np.float32))[0]
+    frames = fg.render_composite(view, T1, TC, host_ref.converter(poses.reshape(-1, 4, 4)))
+    st = ctx.render_stats()
+    want = pipe.frames(poses.reshape(-1, 4, 4), bg=obg)
+    diff = np.abs(frames.astype(int) - want.astype(int)).max(-1)
+    # cone-stepped lattice points within an ulp of a cell face may fall either side (see the aabb_scale-2
+    # test above): a handful of pixels may differ by more than 1 LSB
+    assert (diff > 1).mean() < 5e-4 and (diff > 0).mean() < 0.02
+    base = render_ref.composite(np.zeros((H, W, 4), np.float32), np.zeros((H, W), np.float32), obg[0], obg[1])
+    n_visible = sum(bool((f != base).any()) for f in want)
+    assert 10 < n_visible <= len(want) and st["samples"] > 10000
+    fg.close(); ctx.close()
+
+
+def test_full_depth_vit_l14_336_matches_oracle(gpu):
+    """The reference's own model geometry (clip_scoring.py:150: openai/clip-vit-large-patch14-336: 24
+    layers, d 1024, 16 heads, 577 tokens) at FULL depth, one image, against the numpy fp32 oracle."""
+    engine, ctx = gpu["engine"], gpu["ctx"]
+    cfg = CLIP_CONFIGS["vit_l14_336"]
+    assert cfg["num_layers"] == 24 and cfg["image_size"] == 336 and cfg["hidden_size"] == 1024
+    sd = random_clip_state_dict(cfg, seed=6, text=False)
+    sc = engine.ClipScorer(ctx, cfg, sd)
+    r = np.random.Generator(np.random.PCG64(4))
+    frames = r.integers(0, 256, size=(2, 336, 336, 3), dtype=np.uint8)         # the reference's render size
+    text = random_unit_text_embeds(cfg["proj"], 2)
+    lg, emb = sc.score_frames(frames, text, return_embeds=True)
+    olg, oemb = oracle_logits(frames[:1], cfg, sd, text)
+    assert (1.0 - cosine(emb[:1], oemb)).max() < 2e-4
+    assert np.abs(lg[:1] - olg).max() / sc.logit_scale <= 1e-3                  # north_star: 1e-3 cosine
+    assert np.isfinite(lg).all()
+    sc.close()
+
+
+def test_argmax_pose_identical_with_vit_b16_on_a_16x16_grid(gpu, tmp_path):
+    """north_star: "argmax-pose identical on the shopping scene" — 256 candidates (16 x 16 grid, 160x90)
+    through optimise_pose_grid with the full ViT-B/16, smoothing on, against the oracle pipeline.  The
+    goal caption embedding points from the mean image embedding towards one candidate's, so the score
+    landscape has a genuine peak (random-weight towers have no language prior to provide one)."""
+    from dream2real_amd import clip_scoring, combined_rendering
+    engine, ctx, scene, fg, bg = gpu["engine"], gpu["ctx"], gpu["scene"], gpu["fg"], gpu["bg"]
+    cfg = CLIP_CONFIGS["vit_b16"]
+    sd = random_clip_state_dict(cfg, seed=6, text=False)
+    W, H = 160, 90
+    sample_res = [16, 16, 1, 1, 1, 1]
+    pipe = OraclePipeline(scene, W, H)
+    poses = host_ref.sample_poses_grid(scene.scene_centre, sample_res, scene.scene_type)
+    oframes = pipe.frames(poses.reshape(-1, 4, 4))
+    _, oemb = oracle_logits(oframes, cfg, sd, np.zeros((1, cfg["proj"]), np.float32))
+    target = 16 * 6 + 9
+    mean = oemb.mean(0) / np.linalg.norm(oemb.mean(0))
+    d = oemb[target] - mean
+    d /= np.linalg.norm(d)
+    goal = mean + d
+    text = np.stack([goal / np.linalg.norm(goal), mean]).astype(np.float32)
+    olg = clip_ref.logits_per_image(oemb, text, sd["logit_scale"])
+    ratio = host_ref.score_logits(olg, True)
+    want = host_ref.spatially_smooth_heatmap(ratio.copy(), sample_res)
+    sc = engine.ClipScorer(ctx, cfg, sd)
+    task = make_task(scene, fg, bg)
+    task.text_embeds = text
+    rend = combined_rendering.renderer(str(tmp_path), task, resolution=(W, H))
+    best, pose_batch, scores = clip_scoring.optimise_pose_grid(
+        rend, None, [0], task, str(tmp_path), sample_res=sample_res, phys_check=lambda p, t, v: v,
+        scene_type=scene.scene_type, smoothing=True, scorer=sc)
+    got = scores.numpy()
+    tol = float((0.1 * (1.0 + np.abs(ratio)) / np.abs(olg[:, 1])).max())        # 1e-3 cosine per logit, propagated
+    np.testing.assert_allclose(got, want, rtol=0, atol=tol)
+    top = np.sort(want)[::-1]
+    assert top[0] - top[1] > 2 * tol, "fixture must have a distinct peak"
+    assert int(np.argmax(got)) == int(np.argmax(want))
+    np.testing.assert_array_equal(best.numpy().reshape(16), poses[int(np.argmax(want))])
+    # f3: the frames the GPU path wrote (cb_render/*.png, save=True like the reference) re-scored through
+    # use_cache_renders give the same scores (reference clip_scoring.py:89-104, dream2real.py:356-358)
+    assert len(os.listdir(tmp_path / "cb_render")) == 256
+    clip_scoring.save_pose_outputs(str(tmp_path), best, pose_batch, scores)
+    best2, _, scores2 = clip_scoring.optimise_pose_grid(
+        rend, None, [0], task, str(tmp_path), sample_res=sample_res, phys_check=None,
+        scene_type=scene.scene_type, smoothing=True, use_cache_renders=True, scorer=sc)
+    np.testing.assert_allclose(scores2.numpy(), got, rtol=0, atol=1e-5)
+    np.testing.assert_array_equal(best2.numpy(), best.numpy())
+    assert np.loadtxt(tmp_path / "goal_pose.txt").shape == (4, 4)
+    sc.close()

@@ -5,7 +5,8 @@ import pytest
 import types
 
 from dream2real_amd import accio2ngp, clip_scoring, combined_rendering, geometry_utils, obj_pose_opt
-from dream2real_amd.scene import grid_levels, make_scene
+from dream2real_amd.scene import grid_levels
+from tests.scenes import make_scene
 from oracle import host_ref
 
 

@@ -4,14 +4,15 @@ import numpy as np
 import pytest
 
 from dream2real_amd import ingp
-from dream2real_amd.scene import make_scene
+from tests.ingp_writer import save_ingp
+from tests.scenes import make_scene
 
 
 def test_roundtrip(tmp_path):
     scene = make_scene("pool_triangle")
     views = [dict(fx=900.0, fy=910.0, cx=640.0, cy=350.0, w=1280, h=720), dict(fx=450.0, fy=455.0, cx=320.0, cy=175.0, w=640, h=360)]
     path = str(tmp_path / "fg_base.ingp")
-    ingp.save_ingp(path, scene.fg, training_views=views, dataset_scale=1.0, dataset_offset=(0.0, 0.3, 0.5))
+    save_ingp(path, scene.fg, training_views=views, dataset_scale=1.0, dataset_offset=(0.0, 0.3, 0.5))
     model, info = ingp.load_ingp(path)
     for name in ("grid", "dw1", "dw2", "cw1", "cw2", "cw3", "occ_bits"):
         np.testing.assert_array_equal(getattr(model, name), getattr(scene.fg, name))
@@ -31,7 +32,7 @@ def test_rejects_unknown_layouts(tmp_path):
     import msgpack, zlib
     scene = make_scene("pool_triangle")
     path = str(tmp_path / "x.ingp")
-    ingp.save_ingp(path, scene.fg)
+    save_ingp(path, scene.fg)
     cfg = msgpack.unpackb(zlib.decompress(open(path, "rb").read()), raw=False)
     cfg["snapshot"]["params_binary"] = cfg["snapshot"]["params_binary"][:-2]
     open(path, "wb").write(zlib.compress(msgpack.packb(cfg, use_bin_type=True)))
@@ -48,9 +49,35 @@ def test_aabb_scale_2_snapshot_round_trip(tmp_path):
     finest level) survive save -> load"""
     scene = make_scene("shelf")
     path = str(tmp_path / "shelf.ingp")
-    ingp.save_ingp(path, scene.bg)
+    save_ingp(path, scene.bg)
     model, info = ingp.load_ingp(path)
     assert model.aabb_scale == 2 and info["aabb_scale"] == 2
     np.testing.assert_array_equal(model.occ_bits, scene.bg.occ_bits)
     np.testing.assert_array_equal(model.levels.res, scene.bg.levels.res)
     np.testing.assert_array_equal(model.grid, scene.bg.grid)
+
+
+def test_occupancy_threshold_follows_instant_ngp():
+    """Graded densities: the threshold is min(0.01, mean of max(d, 0) over ALL cells of cascade 0) — for a
+    sparse object the mean is far below 0.01 — and coarser cascades OR in the max-pool of the finer one."""
+    r = np.random.Generator(np.random.PCG64(11))
+    order = ingp._morton_order()
+    lin = np.zeros((2, 128, 128, 128), np.float32)              # [c, z, y, x]
+    lin[0, 60:68, 60:68, 60:68] = r.uniform(0.0, 0.02, (8, 8, 8)).astype(np.float32)
+    lin[0, 10, 10, 10] = -3.0                                   # negative densities count as 0 in the mean
+    lin[1, 5, 6, 7] = 0.5
+    dens = lin.reshape(2, -1)[:, order]                         # Morton order, as stored
+    occ = ingp.occupancy_from_density(dens).reshape(2, 128, 128, 128)
+    mean = np.maximum(lin[0], 0).sum(dtype=np.float64) / 128 ** 3
+    assert mean < 1e-5                                          # sparse object: threshold = mean, not 0.01
+    np.testing.assert_array_equal(occ[0], lin[0] > mean)
+    assert occ[0].sum() > 400                                   # nearly all 512 graded cells (min(0.01, positive-mean) would keep ~half)
+    want1 = lin[1] > mean
+    want1[32:96, 32:96, 32:96] |= occ[0].reshape(64, 2, 64, 2, 64, 2).any(axis=(1, 3, 5))
+    np.testing.assert_array_equal(occ[1], want1)
+    assert occ[1, 5, 6, 7] and occ[1, 32 + 30, 32 + 30, 32 + 30]
+    # a dense scene: mean above 0.01 -> the constant threshold
+    dens2 = np.full((1, 128 ** 3), 0.05, np.float32)
+    dens2[0, :1000] = 0.009
+    occ2 = ingp.occupancy_from_density(dens2)
+    assert occ2.sum() == 128 ** 3 - 1000

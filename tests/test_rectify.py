@@ -45,3 +45,58 @@ def test_rectify_shapes_and_crop():
     m = rectify_mask(mask, (336, 336))
     assert m.dtype == np.uint8 and set(np.unique(m)) <= {0, 1}
     assert m[160, 160] == 1 and m[10, 10] == 0
+
+
+# ---- the independent scalar restatement in oracle/host_ref.py (the checker of the GPU-side test) ----
+
+def test_oracle_cubic_hand_derived_vectors():
+    """Known answers worked out by hand from OpenCV's published INTER_CUBIC definition."""
+    from oracle import host_ref
+    # 2x -> 1x: fx = 2d + 0.5, frac 0.5 -> Keys(A=-0.75) taps [-3/32, 19/32, 19/32, -3/32] on s-1..s+2
+    c = host_ref._cv_cubic_coeffs(0.5)
+    np.testing.assert_allclose(c, [-3 / 32, 19 / 32, 19 / 32, -3 / 32], atol=1e-7)
+    row = np.array([[10, 20, 40, 80, 160, 320, 640, 1280]], np.float32)
+    out = host_ref.resize_cubic_ref(np.repeat(row, 2, 0), (4, 1))
+    # d=0: taps (0,0,1,2) border-replicated; d=1: (1,2,3,4); d=2: (3,4,5,6); d=3: (5,6,7,7)
+    want = [(-3 * 10 + 19 * 10 + 19 * 20 - 3 * 40) / 32, (-3 * 20 + 19 * 40 + 19 * 80 - 3 * 160) / 32,
+            (-3 * 80 + 19 * 160 + 19 * 320 - 3 * 640) / 32, (-3 * 320 + 19 * 640 + 19 * 1280 - 3 * 1280) / 32]
+    np.testing.assert_allclose(out[0], want, rtol=1e-6)
+    # same size: frac 0 -> taps [0, 1, 0, 0]: identity, float and uint8
+    r = np.random.default_rng(3)
+    f = r.random((5, 7), dtype=np.float32)
+    np.testing.assert_array_equal(host_ref.resize_cubic_ref(f, (7, 5)), f)
+    u = r.integers(0, 256, (5, 7), dtype=np.uint8)
+    np.testing.assert_array_equal(host_ref.resize_cubic_ref(u, (7, 5)), u)
+    # uint8 fixed point, 2x -> 1x on a step edge 0|255: coefficients round(c*2048) = [-192, 1216, 1216, -192]
+    e = np.zeros((2, 8), np.uint8)
+    e[:, 4:] = 255
+    got = host_ref.resize_cubic_ref(e, (4, 1))
+    # rows identical -> vertical pass multiplies by (-192+1216+1216-192) = 2048: v = h * 2048
+    h = [0, -192 * 255, (1216 + 1216 - 192) * 255 + 0 * -192, 2048 * 255]      # d=1: taps (1,2,3,4) -> only tap 4 is 255
+    want8 = [min(max((x * 2048 + (1 << 21)) >> 22, 0), 255) for x in h]
+    assert got[0].tolist() == want8 == [0, 0, 255, 255]
+    # upscale 1 -> 3 (non-integer phase): fx = (d+0.5)/3 - 0.5 = -1/3, 0, 1/3 around each source pixel
+    one = host_ref.resize_cubic_ref(np.array([[0, 0, 6, 0, 0]], np.float32).repeat(2, 0), (15, 2))
+    assert abs(one[0, 7] - 6.0) < 1e-6                        # phase 0 at the centre of the impulse
+    c13 = host_ref._cv_cubic_coeffs(np.float32(1 / 3))
+    np.testing.assert_allclose(one[0, 8], 6 * c13[1], rtol=1e-6)   # fx = 2 + 1/3: tap s (=2) weight c1
+    np.testing.assert_allclose(one[0, 6], 6 * c13[1], rtol=1e-5)   # mirrored: frac 2/3, impulse on tap s+1, weight c2(2/3) = c1(1/3)
+    np.testing.assert_allclose(one[0, 9], 6 * host_ref._cv_cubic_coeffs(np.float32(2 / 3))[1], rtol=1e-5)   # d=9: fx = 2 + 2/3
+
+
+def test_product_resize_agrees_with_the_independent_oracle():
+    """The product's vectorised resize_cubic / rectify_* against the scalar restatement: float within
+    rounding, uint8 bit-exact, down- and up-scaling, non-integer ratios, centre crop."""
+    from oracle import host_ref
+    r = np.random.default_rng(7)
+    for (sh, sw), (dw, dh) in [((37, 53), (20, 13)), ((16, 16), (41, 23)), ((45, 45), (21, 21)), ((9, 30), (30, 9))]:
+        f = (r.random((sh, sw), dtype=np.float32) * 3).astype(np.float32)
+        np.testing.assert_allclose(resize_cubic(f, (dw, dh)), host_ref.resize_cubic_ref(f, (dw, dh)), rtol=0, atol=2e-6)
+        u = r.integers(0, 256, (sh, sw), dtype=np.uint8)
+        np.testing.assert_array_equal(resize_cubic(u, (dw, dh)), host_ref.resize_cubic_ref(u, (dw, dh)))
+    depth = (r.random((72, 128), dtype=np.float32) * 2).astype(np.float16)
+    mask = r.random((72, 128)) > 0.4
+    np.testing.assert_allclose(rectify_depth(depth, (33, 33)), host_ref.rectify_depth_ref(depth, (33, 33)), rtol=0, atol=2e-6)
+    np.testing.assert_array_equal(rectify_mask(mask, (33, 33)), host_ref.rectify_mask_ref(mask, (33, 33)))
+    tall = r.random((90, 40), dtype=np.float32)              # h > w: crop rows
+    np.testing.assert_allclose(rectify_depth(tall, (17, 17)), host_ref.rectify_depth_ref(tall, (17, 17)), rtol=0, atol=2e-6)

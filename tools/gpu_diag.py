@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from dream2real_amd import engine
 from dream2real_amd.clip_model import CLIP_CONFIGS, random_clip_state_dict
-from dream2real_amd.scene import make_scene
+from tests.scenes import make_scene
 from oracle import clip_ref, host_ref, render_ref
 from tests.parity_utils import OraclePipeline, cosine, oracle_logits, random_unit_text_embeds
 
