@@ -39,6 +39,10 @@ struct ClipWeights {
         const float *ln1_w, *ln1_b, *ln2_w, *ln2_b;
         const uint16_t *w_qkv, *w_o, *w_fc1, *w_fc2;
         const float *b_qkv, *b_o, *b_fc1, *b_fc2;
+        // LayerNorm-folded operands of the two Linears that follow a LayerNorm (vision tower; see EPI_LN_*)
+        const uint16_t *wf_qkv = nullptr, *wf_fc1 = nullptr;       // bf16(W * gamma)
+        const float *cs_qkv = nullptr, *cs_fc1 = nullptr;          // column sums of the folded weight
+        const float *bf_qkv = nullptr, *bf_fc1 = nullptr;          // b + W beta
     };
     const float *post_w, *post_b;
     const float *proj;         // fp32 [D][d]
@@ -220,7 +224,25 @@ __global__ void k_patchify(const float *__restrict__ pv, uint32_t n, uint32_t S,
 
 // ------------------------------------------------------------------ GEMM
 
-enum { EPI_F32 = 0, EPI_BIAS_BF16 = 1, EPI_BIAS_GELU_BF16 = 2, EPI_BIAS_RESID_F32 = 3 };
+// Epilogues.  0-3: the plain ones.  4-7: the LayerNorm-folded transformer block —
+//   LN(x) W^T + b = rstd (x (gamma o W)^T - mu colsum(gamma o W)) + (b + W beta)
+// so the GEMM that follows a LayerNorm takes the RAW residual row (bf16) as its A operand and applies
+// the row statistics in its epilogue (EPI_LN_*), and the GEMM that produces the residual writes the bf16
+// operand copy and per-row partial sums (EPI_RESID_STATS_*): no LayerNorm kernel, no LN round trip
+// through HBM.  _F32X keeps the fp32 residual stream next to the bf16 copy, _BF16 keeps only bf16.
+enum { EPI_F32 = 0, EPI_BIAS_BF16 = 1, EPI_BIAS_GELU_BF16 = 2, EPI_BIAS_RESID_F32 = 3,
+       EPI_LN_BIAS_BF16 = 4, EPI_LN_BIAS_GELU_BF16 = 5, EPI_RESID_STATS_F32X = 6, EPI_RESID_STATS_BF16 = 7, EPI_KINDS = 8 };
+#define EPI_IS_LN(E) ((E) == EPI_LN_BIAS_BF16 || (E) == EPI_LN_BIAS_GELU_BF16)
+#define EPI_IS_STATS(E) ((E) == EPI_RESID_STATS_F32X || (E) == EPI_RESID_STATS_BF16)
+#define EPI_IS_F32_LAYOUT(E) ((E) == EPI_F32 || (E) == EPI_BIAS_RESID_F32 || EPI_IS_STATS(E))
+
+// operands of the folded epilogues
+struct EpiAux {
+    const float *cs;       // EPI_LN_*: [N] column sums of the folded (bf16-rounded) weight
+    const float2 *ab;      // EPI_LN_*: [M_pad] per row (rstd, -rstd * mean) of the residual row
+    uint16_t *xb;          // EPI_RESID_STATS_*: [M_pad][N] bf16 residual (read + written by _BF16, written by _F32X)
+    float2 *part;          // EPI_RESID_STATS_*: [M_pad][N / 64] partial (sum, sum of squares) per 64-column group
+};
 
 // Development-only ablation switches of k_gemm8 and the shared epilogue (bitmask, default 0 = the real
 // kernel): 1 no LDS-DMA, 2 no fragment ds_reads, 4 no epilogue, 8 no MFMA, 128 no global loads/stores in
@@ -272,10 +294,24 @@ struct NoHook { __device__ __forceinline__ void operator()() const {} };
 // `hook` runs once: the persistent kernel requests the next tile's operands there.  It sits where no
 // later compiler-placed wait can also wait for those requests: after the bias values have been
 // consumed (bf16 variants), after the LAST batch of residual loads has been issued (fp32 residual).
+// sum over the 16 lanes of a DPP row (lanes 16r .. 16r+15), result in every lane: four rotate-adds
+__device__ __forceinline__ float row16_sum(float x)
+{
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xf, 0xf, false));   // row_ror:8
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x124, 0xf, 0xf, false));   // row_ror:4
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x122, 0xf, 0xf, false));   // row_ror:2
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x121, 0xf, 0xf, false));   // row_ror:1
+    return x;
+}
+__device__ __forceinline__ float bf_lo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+
+// ab_lds (EPI_LN_* only): this wave's LDS copy of (rstd, -rstd*mean) for the MT*32 rows of its tile.
 template <int EPI, int MT, typename Hook = NoHook>
 __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], float *ep, uint32_t lane,
                                               uint32_t row0, uint32_t col0, const float *__restrict__ bias,
-                                              void *__restrict__ Cout, uint32_t N, Hook hook = Hook())
+                                              void *__restrict__ Cout, uint32_t N, const EpiAux &aux,
+                                              const float2 *ab_lds, Hook hook = Hook())
 {
     // ep: this wave's private 8 x EP_LD float buffer.  Eight rows of the wave tile at a time:
     // acc[i][j][4p..4p+3] of both lane halves are rows 8p..8p+7 of m-tile i.
@@ -287,12 +323,15 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], float *ep, u
 #pragma unroll
             for (int r = 0; r < 4; r++) ep[(r + 4 * hi) * EP_LD + j * 32 + li] = acc[i][j][4 * p8 + r];
     };
-    if (EPI == EPI_F32 || EPI == EPI_BIAS_RESID_F32) {
-        // fp32 outputs: a lane owns 4 columns of a row, 16 lanes a 256-byte row segment.  The residual
-        // rows of TWO 32-row groups (16 float4 per lane) are requested before the first transpose, so
-        // a tile pays two HBM round trips instead of eight.
+    if (EPI_IS_F32_LAYOUT(EPI)) {
+        // fp32 outputs: a lane owns 4 columns of a row, 16 lanes (one DPP row) a 256-byte row segment.  The
+        // residual rows of TWO 32-row groups (16 loads per lane) are requested before the first transpose,
+        // so a tile pays two HBM round trips instead of eight.
         const uint32_t c4 = (lane & 15) * 4, rl0 = lane >> 4;
         const uint32_t col = col0 + c4;
+        constexpr bool RESID_F32 = EPI == EPI_BIAS_RESID_F32 || EPI == EPI_RESID_STATS_F32X;
+        constexpr bool RESID_BF16 = EPI == EPI_RESID_STATS_BF16;
+        constexpr bool STATS = EPI_IS_STATS(EPI);
         float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
         if (EPI != EPI_F32) {
             bv = *(const float4 *)(bias + col);
@@ -300,22 +339,30 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], float *ep, u
         }
         static_assert(MT % 2 == 0, "epilogue handles m-tiles in pairs");
         if (EPI == EPI_F32) hook();
+        const uint32_t np = N >> 6;
+        // m-tiles whose residual rows are requested together (the fp32-residual + statistics variant carries the
+        // most live values: one m-tile at a time keeps it out of scratch)
+        constexpr int G = EPI == EPI_RESID_STATS_F32X ? 1 : 2;
 #pragma unroll
-        for (int ih = 0; ih < MT; ih += 2) {
-            float4 xr[2][8];
-            if (EPI == EPI_BIAS_RESID_F32) {
+        for (int ih = 0; ih < MT; ih += G) {
+            float4 xr[G][8];
+            uint2 xh[G][8];
+            if (RESID_F32 || RESID_BF16) {
 #pragma unroll
-                for (int ii = 0; ii < 2; ii++)
+                for (int ii = 0; ii < G; ii++)
 #pragma unroll
                     for (int k = 0; k < 8; k++) {
                         const uint32_t row = row0 + (ih + ii) * 32 + rl0 + 4 * k;
-                        xr[ii][k] = (D2R_GEMM_ABLATE & 128) ? make_float4(0.f, 0.f, 0.f, 0.f)
-                                                            : *(const float4 *)((const float *)Cout + row * N + col);
+                        if (RESID_F32)
+                            xr[ii][k] = (D2R_GEMM_ABLATE & 128) ? make_float4(0.f, 0.f, 0.f, 0.f)
+                                                                : *(const float4 *)((const float *)Cout + row * N + col);
+                        else
+                            xh[ii][k] = *(const uint2 *)(aux.xb + row * N + col);
                     }
-                if (ih == MT - 2) hook();
+                if (ih == MT - G) hook();
             }
 #pragma unroll
-            for (int ii = 0; ii < 2; ii++)
+            for (int ii = 0; ii < G; ii++)
 #pragma unroll
                 for (int p8 = 0; p8 < 4; p8++) {
                     transpose_in(ih + ii, p8);
@@ -326,22 +373,41 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], float *ep, u
                         float4 v = (D2R_GEMM_ABLATE & 256) ? make_float4(acc[ih + ii][0][k], acc[ih + ii][0][k + 8], acc[ih + ii][1][k], acc[ih + ii][1][k + 8])
                                                            : *(const float4 *)(ep + (rl0 + 4 * qq) * EP_LD + c4);
                         v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-                        if (EPI == EPI_BIAS_RESID_F32) {
+                        if (RESID_F32) {
                             v.x += xr[ii][k].x; v.y += xr[ii][k].y; v.z += xr[ii][k].z; v.w += xr[ii][k].w;
+                        }
+                        if (RESID_BF16) {
+                            v.x += bf_lo(xh[ii][k].x); v.y += bf_hi(xh[ii][k].x); v.z += bf_lo(xh[ii][k].y); v.w += bf_hi(xh[ii][k].y);
                         }
 #if (D2R_GEMM_ABLATE & 128) && defined(__HIP_DEVICE_COMPILE__)
                         asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
                         continue;
 #endif
-                        *(float4 *)((float *)Cout + row * N + col) = v;       // < 2^32 elements (checked on host)
+                        if (!RESID_BF16) *(float4 *)((float *)Cout + row * N + col) = v;       // < 2^32 elements (checked on host)
+                        if (STATS) {
+                            // the bf16 copy the next GEMM reads as its A operand, and this 64-column group's share of
+                            // the row's LayerNorm statistics (of the fp32 values: the rounding averages out over d)
+                            *(uint2 *)(aux.xb + row * N + col) = make_uint2(pack2(v.x, v.y), pack2(v.z, v.w));
+                            const float sm = row16_sum((v.x + v.y) + (v.z + v.w));
+                            const float sq = row16_sum(fmaf(v.x, v.x, v.y * v.y) + fmaf(v.z, v.z, v.w * v.w));
+                            if ((lane & 15) == 0) aux.part[row * np + (col0 >> 6)] = make_float2(sm, sq);
+                        }
                     }
                 }
         }
     } else {
         // bf16 outputs: a lane owns 8 columns (one 16-byte store), 8 lanes a 128-byte row segment
+        constexpr bool LN = EPI_IS_LN(EPI);
+        constexpr bool GELU = EPI == EPI_BIAS_GELU_BF16 || EPI == EPI_LN_BIAS_GELU_BF16;
         const uint32_t c8 = (lane & 7) * 8, rl0 = lane >> 3;
         const uint32_t col = col0 + c8;
         float4 b0 = *(const float4 *)(bias + col), b1 = *(const float4 *)(bias + col + 4);
+        float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+        if (LN) {
+            s0 = *(const float4 *)(aux.cs + col);
+            s1 = *(const float4 *)(aux.cs + col + 4);
+            asm volatile("" : "+v"(s0.x), "+v"(s0.y), "+v"(s0.z), "+v"(s0.w), "+v"(s1.x), "+v"(s1.y), "+v"(s1.z), "+v"(s1.w));
+        }
         asm volatile("" : "+v"(b0.x), "+v"(b0.y), "+v"(b0.z), "+v"(b0.w), "+v"(b1.x), "+v"(b1.y), "+v"(b1.z), "+v"(b1.w));
         hook();
 #pragma unroll
@@ -354,8 +420,18 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], float *ep, u
                                                    : *(const float4 *)(ep + rl0 * EP_LD + c8);
                 float4 w = (D2R_GEMM_ABLATE & 256) ? make_float4(acc[i][0][k + 4], acc[i][0][k + 12], acc[i][1][k + 4], acc[i][1][k + 12])
                                                    : *(const float4 *)(ep + rl0 * EP_LD + c8 + 4);
-                float f[8] = {u.x + b0.x, u.y + b0.y, u.z + b0.z, u.w + b0.w, w.x + b1.x, w.y + b1.y, w.z + b1.z, w.w + b1.w};
-                if (EPI == EPI_BIAS_GELU_BF16) {
+                float f[8];
+                if (LN) {
+                    const float2 ab = ab_lds[i * 32 + rl0 + 8 * k];          // (rstd, -rstd * mean) of this row
+                    f[0] = fmaf(ab.x, u.x, fmaf(ab.y, s0.x, b0.x)); f[1] = fmaf(ab.x, u.y, fmaf(ab.y, s0.y, b0.y));
+                    f[2] = fmaf(ab.x, u.z, fmaf(ab.y, s0.z, b0.z)); f[3] = fmaf(ab.x, u.w, fmaf(ab.y, s0.w, b0.w));
+                    f[4] = fmaf(ab.x, w.x, fmaf(ab.y, s1.x, b1.x)); f[5] = fmaf(ab.x, w.y, fmaf(ab.y, s1.y, b1.y));
+                    f[6] = fmaf(ab.x, w.z, fmaf(ab.y, s1.z, b1.z)); f[7] = fmaf(ab.x, w.w, fmaf(ab.y, s1.w, b1.w));
+                } else {
+                    f[0] = u.x + b0.x; f[1] = u.y + b0.y; f[2] = u.z + b0.z; f[3] = u.w + b0.w;
+                    f[4] = w.x + b1.x; f[5] = w.y + b1.y; f[6] = w.z + b1.z; f[7] = w.w + b1.w;
+                }
+                if (GELU) {
                     // quick_gelu: x * sigmoid(1.702 x) = x / (1 + exp2(-1.702 log2(e) x))
 #pragma unroll
                     for (int e = 0; e < 8; e++)
@@ -384,7 +460,8 @@ template <int EPI, int WGM, int WGN, int MT, int STAGES>
 __global__ __launch_bounds__(WGM * WGN * 64, 2) void k_gemm(const uint16_t *__restrict__ A,
                                                           const uint16_t *__restrict__ W,
                                                           const float *__restrict__ bias, void *__restrict__ Cout,
-                                                          uint32_t M_pad, uint32_t N, uint32_t K, uint32_t n_xcd)
+                                                          uint32_t M_pad, uint32_t N, uint32_t K, uint32_t n_xcd,
+                                                          EpiAux aux)
 {
     constexpr uint32_t TBM = WGM * MT * 32, TBN = WGN * 64;
     constexpr uint32_t STAGE_BYTES = (TBM + TBN) * BK * 2;
@@ -507,7 +584,15 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void k_gemm(const uint16_t *__re
     }
     // the ring is free (the loop ended on a barrier with nothing in flight): its first bytes serve as
     // the epilogue's transpose buffers
-    gemm_epilogue<EPI, MT>(acc, (float *)smem + wave * EP_WAVE_FLOATS, lane, m0 + wm, n0 + wn, bias, Cout, N);
+    // (EPI_LN_*: the rows' (rstd, -rstd*mean) pairs go into a private LDS strip behind the transpose buffers:
+    // written and read by this wave only, LDS operations of one wave execute in order)
+    float2 *abw = (float2 *)(smem + NWAVE * EP_WAVE_FLOATS * 4) + wave * (MT * 32);
+    if (EPI_IS_LN(EPI)) {
+#pragma unroll
+        for (int h = 0; h < MT * 32; h += 64)
+            if (h + lane < MT * 32) abw[h + lane] = aux.ab[m0 + wm + h + lane];
+    }
+    gemm_epilogue<EPI, MT>(acc, (float *)smem + wave * EP_WAVE_FLOATS, lane, m0 + wm, n0 + wn, bias, Cout, N, aux, abw);
 }
 
 // ---- 256x256x64 GEMM with a half-tile staging ring that never drains ("8-phase" K loop) ----
@@ -536,12 +621,12 @@ __device__ __forceinline__ void glds16s(uint32_t voff, const void *sbase, uint32
 #ifdef D2R_GEMM_STAMPS
 // development only: shader-clock cycles wave 0 of every workgroup spends per tile section,
 // [EPI][0 drain wait, 1 K loop, 2 epilogue, 3 tiles]
-__device__ unsigned long long d2r_gemm_stamps[4][4];
+__device__ unsigned long long d2r_gemm_stamps[EPI_KINDS][4];
 extern "C" __attribute__((visibility("default"))) int d2r_debug_gemm_stamps(unsigned long long *out, int reset)
 {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(d2r_gemm_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(d2r_gemm_stamps), sizeof(unsigned long long) * 4 * EPI_KINDS) != hipSuccess) return -1;
     if (reset) {
-        unsigned long long z[16] = {0};
+        unsigned long long z[4 * EPI_KINDS] = {0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(d2r_gemm_stamps), z, sizeof(z)) != hipSuccess) return -1;
     }
     return 0;
@@ -554,7 +639,7 @@ extern "C" __attribute__((visibility("default"))) int d2r_debug_gemm_stamps(unsi
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A, const uint16_t *__restrict__ W,
                                                  const float *__restrict__ bias, void *__restrict__ Cout,
-                                                 uint32_t M_pad, uint32_t N, uint32_t K, uint32_t n_xcd)
+                                                 uint32_t M_pad, uint32_t N, uint32_t K, uint32_t n_xcd, EpiAux aux)
 {
     constexpr uint32_t SLOT = 128 * BK * 2;          // 16 KiB
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -670,6 +755,11 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
 #pragma unroll
     for (int kind = 0; kind < 8; kind++) stage_pos(kind, kind >= 4 ? 1u : 0u);
     float *ep = (float *)(smem + 8 * SLOT) + wave * EP_WAVE_FLOATS;      // transpose buffer behind the ring
+    // EPI_LN_*: 1 KiB per wave behind the transpose buffers for the (rstd, -rstd*mean) pairs of its 128 rows,
+    // fetched by ONE LDS-DMA instruction per tile (16 B = two rows per lane) so that it is ordered by the same
+    // hand-counted vmcnt waits as the operand ring (a compiler-visible load would be waited for with vmcnt(0),
+    // i.e. for the whole next tile's first K-tile pair)
+    const float2 *ab_lds = (const float2 *)(smem + 8 * SLOT + 8 * EP_WAVE_FLOATS * 4) + wave * 128;
 
     for (;;) {
 #pragma unroll
@@ -725,6 +815,10 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
             };
             // read section: position 8u+P+2 (kind (P+2) mod 8) for the next phase's MFMAs; stage position
             // 8u+P+8 (kind P): K-tile 2(u+1) + (P >= 4) of this tile, or K-tile (P >= 4) of the next one
+            if (EPI_IS_LN(EPI) && last && P == 0) {     // older than every request that follows: landed by the last counted wait
+                const uint32_t l16 = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) * 16u;   // not a value kept live across the loop
+                glds16s(l16, aux.ab + m0 + wm * 128, lds0 + 8 * SLOT + 8 * EP_WAVE_FLOATS * 4 + wave * 1024);
+            }
             if (!(last && P >= 6)) read_pos((P + 2) & 7);
             if (!tail) stage_pos_at(P, (last ? 0u : 2 * (u + 1)) + (P >= 4 ? 1u : 0u), last ? m0n : m0, last ? n0n : n0);
             if (wm == 1) wait_next();
@@ -756,7 +850,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
     // a freshly computed lane id (mbcnt) instead of the one derived from threadIdx at kernel entry: that
     // one would stay live across the K loop for the epilogue's sake, and at 250+ registers it gets spilled
     const uint32_t lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    gemm_epilogue<EPI, 4>(acc, ep, lane_e, em, en, bias, Cout, N);
+    gemm_epilogue<EPI, 4>(acc, ep, lane_e, em, en, bias, Cout, N, aux, ab_lds);
 #endif
 #ifdef D2R_GEMM_STAMPS
     {
@@ -782,8 +876,11 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
 __global__ __launch_bounds__(256) void k_embed_ln(const float *__restrict__ patch_out, const float *__restrict__ cls,
                                                   const float *__restrict__ pos, const float *__restrict__ w,
                                                   const float *__restrict__ b, float *__restrict__ X, uint32_t rows,
-                                                  uint32_t T, uint32_t d)
+                                                  uint32_t T, uint32_t d, uint16_t *__restrict__ Xb,
+                                                  float2 *__restrict__ AB)
 {
+    // X (fp32 residual stream) and Xb/AB (LayerNorm-folded path: bf16 operand copy of the row and the
+    // (rstd, -rstd*mean) of the row for the first block's layer_norm1) are each optional
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -819,8 +916,62 @@ __global__ __launch_bounds__(256) void k_embed_ln(const float *__restrict__ patc
             o[i].y = (v[i].y - mu) * rstd * ww.y + bb.y;
             o[i].z = (v[i].z - mu) * rstd * ww.z + bb.z;
             o[i].w = (v[i].w - mu) * rstd * ww.w + bb.w;
-            *(float4 *)(X + (size_t)row * d + c0) = o[i];
+            if (X) *(float4 *)(X + (size_t)row * d + c0) = o[i];
+            if (Xb) *(uint2 *)(Xb + (size_t)row * d + c0) = make_uint2(pack2(o[i].x, o[i].y), pack2(o[i].z, o[i].w));
+        } else {
+            o[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
+    }
+    if (AB) {
+        float s2 = 0.f, q2 = 0.f;
+        for (int i = 0; i < 4; i++) {
+            s2 += (o[i].x + o[i].y) + (o[i].z + o[i].w);
+            q2 += fmaf(o[i].x, o[i].x, o[i].y * o[i].y) + fmaf(o[i].z, o[i].z, o[i].w * o[i].w);
+        }
+        s2 = wave_sum(s2);
+        q2 = wave_sum(q2);
+        const float m2 = s2 / (float)d, r2 = 1.0f / sqrtf(fmaxf(q2 / (float)d - m2 * m2, 0.f) + 1e-5f);
+        if (lane == 0) AB[row] = make_float2(r2, -r2 * m2);
+    }
+}
+
+// per row: the d/64 partial (sum, sum of squares) pairs an EPI_RESID_STATS_* GEMM wrote -> (rstd, -rstd*mean)
+__global__ void k_rowstats(const float2 *__restrict__ part, uint32_t np, uint32_t rows, float inv_d,
+                           float2 *__restrict__ AB)
+{
+    const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    float s = 0.f, q = 0.f;
+    for (uint32_t i = 0; i < np; i++) {
+        const float2 p = part[(size_t)row * np + i];
+        s += p.x;
+        q += p.y;
+    }
+    const float mu = s * inv_d, r = 1.0f / sqrtf(fmaxf(q * inv_d - mu * mu, 0.f) + 1e-5f);
+    AB[row] = make_float2(r, -r * mu);
+}
+
+// LayerNorm folding of a Linear that follows a LayerNorm (weights prepared once at create):
+//   Wf[n][k] = bf16(W[n][k] * gamma[k]);   cs[n] = sum_k float(Wf[n][k]);   bf[n] = b[n] + sum_k W[n][k] * beta[k]
+__global__ void k_fold_ln_weight(const float *__restrict__ W, const float *__restrict__ gamma, const float *__restrict__ beta,
+                                 const float *__restrict__ b, uint16_t *__restrict__ Wf, float *__restrict__ cs,
+                                 float *__restrict__ bf, uint32_t N, uint32_t K)
+{
+    const uint32_t n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= N) return;
+    float s = 0.f, t = 0.f;
+    for (uint32_t k = lane; k < K; k += 64) {
+        const float w = W[(size_t)n * K + k];
+        const uint16_t h = f2bf(w * gamma[k]);
+        Wf[(size_t)n * K + k] = h;
+        s += __uint_as_float((uint32_t)h << 16);
+        t = fmaf(w, beta[k], t);
+    }
+    s = wave_sum(s);
+    t = wave_sum(t);
+    if (lane == 0) {
+        cs[n] = s;
+        bf[n] = b[n] + t;
     }
 }
 
@@ -1046,8 +1197,8 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void k_attention(const uint16_t *_
 // 16 waves and 4 output rows per wave iteration keep ~48 loads per lane in flight: the
 // projection is a latency problem (1.5 MB of fp32 weights per image out of L2), not a flop one.
 #define HEAD_THREADS 1024
-__global__ __launch_bounds__(HEAD_THREADS) void k_head(const float *__restrict__ X, const uint32_t *__restrict__ pool_row,
-                                                       uint32_t T, uint32_t d,
+__global__ __launch_bounds__(HEAD_THREADS) void k_head(const float *__restrict__ X, const uint16_t *__restrict__ Xb,
+                                                       const uint32_t *__restrict__ pool_row, uint32_t T, uint32_t d,
                                                        const float *__restrict__ lw, const float *__restrict__ lb,
                                                        const float *__restrict__ proj, uint32_t D,
                                                        const float *__restrict__ text, uint32_t C, float logit_scale,
@@ -1059,8 +1210,9 @@ __global__ __launch_bounds__(HEAD_THREADS) void k_head(const float *__restrict__
     constexpr uint32_t NW = HEAD_THREADS / 64;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // vision: the class token (row 0 of the image); text: the EOS token's row
-    const float *x = X + ((size_t)blockIdx.x * T + (pool_row ? pool_row[blockIdx.x] : 0u)) * d;
-    const float xv = tid < d ? x[tid] : 0.f;                         // d <= 1024
+    // (the residual stream is fp32 X, or bf16 Xb when the tower runs with a bf16 residual stream)
+    const size_t xoff = ((size_t)blockIdx.x * T + (pool_row ? pool_row[blockIdx.x] : 0u)) * d;
+    const float xv = tid < d ? (Xb ? __uint_as_float((uint32_t)Xb[xoff + tid] << 16) : X[xoff + tid]) : 0.f;      // d <= 1024
     float s = wave_sum(xv);
     if (lane == 0) red[wave] = s;
     __syncthreads();
@@ -1277,7 +1429,7 @@ int d2r_launch_preprocess(d2r_ctx *ctx, d2r_clip *clip, const uint8_t *frames_de
 
 template <int EPI, int WGM, int WGN, int MT, int STAGES>
 static int launch_gemm_cfg(d2r_ctx *ctx, const uint16_t *A, const uint16_t *W, const float *bias, void *C,
-                           uint32_t M_real, uint32_t N, uint32_t K)
+                           uint32_t M_real, uint32_t N, uint32_t K, const EpiAux &aux)
 {
     constexpr uint32_t TBM = WGM * MT * 32, TBN = WGN * 64, LDS = STAGES * (TBM + TBN) * BK * 2;
     const uint32_t M_pad = round_up(M_real, BM);
@@ -1287,27 +1439,27 @@ static int launch_gemm_cfg(d2r_ctx *ctx, const uint16_t *A, const uint16_t *W, c
         (void)hipFuncSetAttribute((const void *)k_gemm<EPI, WGM, WGN, MT, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     });
     hipLaunchKernelGGL((k_gemm<EPI, WGM, WGN, MT, STAGES>), dim3(nwg), dim3(WGM * WGN * 64), LDS, ctx->stream, A, W, bias, C,
-                       M_pad, N, K, (uint32_t)ctx->n_xcd);
+                       M_pad, N, K, (uint32_t)ctx->n_xcd, aux);
     D2R_HIP(ctx, hipGetLastError());
     return D2R_OK;
 }
 
 template <int EPI>
 static int launch_gemm(d2r_ctx *ctx, const uint16_t *A, const uint16_t *W, const float *bias, void *C,
-                       uint32_t M_real, uint32_t N, uint32_t K)
+                       uint32_t M_real, uint32_t N, uint32_t K, const EpiAux &aux = EpiAux{})
 {
     if (N % 128 || K % BK) return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "GEMM N must be a multiple of 128 and K of 64");
     if ((uint64_t)round_up(M_real, BM) * N >= (1ull << 32))
         return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "GEMM output too large for 32-bit indexing");
     // wide outputs: 256x256 tiles (more flops per byte staged); narrow ones keep 256x128 so the tile
     // count still covers the 256 CUs a few times
-    if (ctx->gemm_cfg == 2) return launch_gemm_cfg<EPI, 4, 2, 2, 3>(ctx, A, W, bias, C, M_real, N, K);   // force 256x128
+    if (ctx->gemm_cfg == 2) return launch_gemm_cfg<EPI, 4, 2, 2, 3>(ctx, A, W, bias, C, M_real, N, K, aux);   // force 256x128
     // 256x256 tiles whenever they still cover the 256 CUs at least ~4 times, else 256x128
     const uint64_t tiles256 = (uint64_t)(round_up(M_real, BM) / 256) * (N / 256);
     if (N % 256 == 0 && (N >= 2048 || tiles256 >= 1024)) {
         if (K % 128 == 0 && ctx->gemm_cfg != 1) {         // gemm_cfg 1 = the two-stage K loop (kept for comparison)
             const uint32_t M_pad = round_up(M_real, BM);
-            constexpr uint32_t LDS8 = 128 * 1024 + 8 * EP_WAVE_FLOATS * 4;
+            constexpr uint32_t LDS8 = 128 * 1024 + 8 * EP_WAVE_FLOATS * 4 + 8 * 1024;     // ring + transpose buffers + (rstd, -rstd*mean) strips
             static PerDeviceOnce attr8;
             attr8.run(ctx->device, [] {
                 (void)hipFuncSetAttribute((const void *)k_gemm8<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS8);
@@ -1315,13 +1467,13 @@ static int launch_gemm(d2r_ctx *ctx, const uint16_t *A, const uint16_t *W, const
             // persistent: one workgroup per CU (a multiple of the XCD count, so every XCD gets the same number)
             const uint32_t nwg8 = (uint32_t)(ctx->n_cu / ctx->n_xcd * ctx->n_xcd);
             hipLaunchKernelGGL((k_gemm8<EPI>), dim3(nwg8), dim3(512), LDS8, ctx->stream, A, W, bias, C, M_pad, N, K,
-                               (uint32_t)ctx->n_xcd);
+                               (uint32_t)ctx->n_xcd, aux);
             D2R_HIP(ctx, hipGetLastError());
             return D2R_OK;
         }
-        return launch_gemm_cfg<EPI, 2, 4, 4, 2>(ctx, A, W, bias, C, M_real, N, K);
+        return launch_gemm_cfg<EPI, 2, 4, 4, 2>(ctx, A, W, bias, C, M_real, N, K, aux);
     }
-    return launch_gemm_cfg<EPI, 4, 2, 2, 3>(ctx, A, W, bias, C, M_real, N, K);
+    return launch_gemm_cfg<EPI, 4, 2, 2, 3>(ctx, A, W, bias, C, M_real, N, K, aux);
 }
 
 // LDS footprint of k_attention for a padded sequence length, and the one-time opt-in to more than 64 KiB
@@ -1361,25 +1513,65 @@ int d2r_clip_forward(d2r_ctx *ctx, const d2r_clip *clip, const uint16_t *patches
 
     if ((rc = launch_gemm<EPI_F32>(ctx, patches_dev, clip->w.w_patch, nullptr, patch_out, prow, d, clip->Kp_pad)))
         return rc;
-    hipLaunchKernelGGL(k_embed_ln, dim3((rows + 3) / 4), dim3(256), 0, ctx->stream, patch_out, clip->w.cls,
-                       clip->w.pos, clip->w.pre_w, clip->w.pre_b, X, rows, T, d);
     const uint32_t T_pad = round_up(T, 32);
     size_t attn_lds = 0;
     if ((rc = attention_setup(ctx, T_pad, &attn_lds))) return rc;
+    const int fold = (int)ctx->ln_fold;
+    if (fold == 0) {
+        // separate LayerNorm kernels, fp32 residual stream (also what the text tower runs)
+        hipLaunchKernelGGL(k_embed_ln, dim3((rows + 3) / 4), dim3(256), 0, ctx->stream, patch_out, clip->w.cls,
+                           clip->w.pos, clip->w.pre_w, clip->w.pre_b, X, rows, T, d, (uint16_t *)nullptr, (float2 *)nullptr);
+        for (uint32_t l = 0; l < D.num_layers; l++) {
+            const ClipWeights::Layer &L = clip->layers[l];
+            hipLaunchKernelGGL(k_layernorm, dim3((rows + 3) / 4), dim3(256), 0, ctx->stream, X, L.ln1_w, L.ln1_b, Xn,
+                               rows, d);
+            if ((rc = launch_gemm<EPI_BIAS_BF16>(ctx, Xn, L.w_qkv, L.b_qkv, QKV, rows, 3 * d, d))) return rc;
+            hipLaunchKernelGGL(k_attention<false>, dim3(D.num_heads, n), dim3(ATTN_THREADS), attn_lds, ctx->stream, QKV, AO, T, T_pad, d);
+            if ((rc = launch_gemm<EPI_BIAS_RESID_F32>(ctx, AO, L.w_o, L.b_o, X, rows, d, d))) return rc;
+            hipLaunchKernelGGL(k_layernorm, dim3((rows + 3) / 4), dim3(256), 0, ctx->stream, X, L.ln2_w, L.ln2_b, Xn,
+                               rows, d);
+            if ((rc = launch_gemm<EPI_BIAS_GELU_BF16>(ctx, Xn, L.w_fc1, L.b_fc1, H, rows, mlp, d))) return rc;
+            if ((rc = launch_gemm<EPI_BIAS_RESID_F32>(ctx, H, L.w_fc2, L.b_fc2, X, rows, d, mlp))) return rc;
+        }
+        hipLaunchKernelGGL(k_head, dim3(n), dim3(HEAD_THREADS), 0, ctx->stream, X, (const uint16_t *)nullptr, (const uint32_t *)nullptr, T, d,
+                           clip->w.post_w, clip->w.post_b, clip->w.proj, D.proj_dim, text_dev, C, logit_scale, logits_dev, embeds_dev);
+        D2R_HIP(ctx, hipGetLastError());
+        return D2R_OK;
+    }
+    // LayerNorm folded into the GEMMs (EPI_LN_* / EPI_RESID_STATS_*): Xn holds the RAW residual rows in bf16 (the
+    // A operand of QKV and fc1), the residual GEMMs emit per-row partial sums, k_rowstats turns them into
+    // (rstd, -rstd*mean).  fold 1 keeps the fp32 residual stream next to the bf16 copy, fold 2 keeps bf16 only.
+    const uint32_t np = d / 64;
+    if ((rc = d2r_reserve(ctx, ctx->clipws[7], (size_t)rows_pad * np * 8 + (size_t)rows_pad * 8))) return rc;
+    float2 *part = (float2 *)ctx->clipws[7].p, *AB = part + (size_t)rows_pad * np;
+    const bool xf32 = fold == 1;
+    hipLaunchKernelGGL(k_embed_ln, dim3((rows + 3) / 4), dim3(256), 0, ctx->stream, patch_out, clip->w.cls, clip->w.pos,
+                       clip->w.pre_w, clip->w.pre_b, xf32 ? X : (float *)nullptr, rows, T, d, Xn, AB);
+    EpiAux ln{}, st{};
+    ln.ab = AB;
+    st.xb = Xn;
+    st.part = part;
+    const float inv_d = 1.0f / (float)d;
     for (uint32_t l = 0; l < D.num_layers; l++) {
         const ClipWeights::Layer &L = clip->layers[l];
-        hipLaunchKernelGGL(k_layernorm, dim3((rows + 3) / 4), dim3(256), 0, ctx->stream, X, L.ln1_w, L.ln1_b, Xn,
-                           rows, d);
-        if ((rc = launch_gemm<EPI_BIAS_BF16>(ctx, Xn, L.w_qkv, L.b_qkv, QKV, rows, 3 * d, d))) return rc;
+        ln.cs = L.cs_qkv;
+        if ((rc = launch_gemm<EPI_LN_BIAS_BF16>(ctx, Xn, L.wf_qkv, L.bf_qkv, QKV, rows, 3 * d, d, ln))) return rc;
         hipLaunchKernelGGL(k_attention<false>, dim3(D.num_heads, n), dim3(ATTN_THREADS), attn_lds, ctx->stream, QKV, AO, T, T_pad, d);
-        if ((rc = launch_gemm<EPI_BIAS_RESID_F32>(ctx, AO, L.w_o, L.b_o, X, rows, d, d))) return rc;
-        hipLaunchKernelGGL(k_layernorm, dim3((rows + 3) / 4), dim3(256), 0, ctx->stream, X, L.ln2_w, L.ln2_b, Xn,
-                           rows, d);
-        if ((rc = launch_gemm<EPI_BIAS_GELU_BF16>(ctx, Xn, L.w_fc1, L.b_fc1, H, rows, mlp, d))) return rc;
-        if ((rc = launch_gemm<EPI_BIAS_RESID_F32>(ctx, H, L.w_fc2, L.b_fc2, X, rows, d, mlp))) return rc;
+        if (xf32) rc = launch_gemm<EPI_RESID_STATS_F32X>(ctx, AO, L.w_o, L.b_o, X, rows, d, d, st);
+        else rc = launch_gemm<EPI_RESID_STATS_BF16>(ctx, AO, L.w_o, L.b_o, Xn, rows, d, d, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_rowstats, dim3((rows_pad + 255) / 256), dim3(256), 0, ctx->stream, part, np, rows_pad, inv_d, AB);
+        ln.cs = L.cs_fc1;
+        if ((rc = launch_gemm<EPI_LN_BIAS_GELU_BF16>(ctx, Xn, L.wf_fc1, L.bf_fc1, H, rows, mlp, d, ln))) return rc;
+        if (xf32) rc = launch_gemm<EPI_RESID_STATS_F32X>(ctx, H, L.w_fc2, L.b_fc2, X, rows, d, mlp, st);
+        else rc = launch_gemm<EPI_RESID_STATS_BF16>(ctx, H, L.w_fc2, L.b_fc2, Xn, rows, d, mlp, st);
+        if (rc) return rc;
+        if (l + 1 < D.num_layers)
+            hipLaunchKernelGGL(k_rowstats, dim3((rows_pad + 255) / 256), dim3(256), 0, ctx->stream, part, np, rows_pad, inv_d, AB);
     }
-    hipLaunchKernelGGL(k_head, dim3(n), dim3(HEAD_THREADS), 0, ctx->stream, X, (const uint32_t *)nullptr, T, d, clip->w.post_w, clip->w.post_b,
-                       clip->w.proj, D.proj_dim, text_dev, C, logit_scale, logits_dev, embeds_dev);
+    hipLaunchKernelGGL(k_head, dim3(n), dim3(HEAD_THREADS), 0, ctx->stream, X, xf32 ? (const uint16_t *)nullptr : (const uint16_t *)Xn,
+                       (const uint32_t *)nullptr, T, d, clip->w.post_w, clip->w.post_b, clip->w.proj, D.proj_dim, text_dev, C,
+                       logit_scale, logits_dev, embeds_dev);
     D2R_HIP(ctx, hipGetLastError());
     return D2R_OK;
 }
@@ -1477,12 +1669,31 @@ extern "C" int d2r_clip_create(d2r_ctx *ctx, const d2r_clip_desc *desc, const fl
         }
         L.w_qkv = wqkv;
         L.b_qkv = bqkv;
+        // layer_norm1 folded into q/k/v (EPI_LN_BIAS_BF16): the three [d][d] + [d] pairs sit 3 blocks back in the blob
+        uint16_t *wfq = nullptr, *wf1 = nullptr;
+        float *csq = nullptr, *bfq = nullptr, *cs1 = nullptr, *bf1 = nullptr;
+        if (hipMalloc(&wfq, (size_t)3 * d * d * 2) != hipSuccess || hipMalloc(&csq, (size_t)3 * d * 4) != hipSuccess ||
+            hipMalloc(&bfq, (size_t)3 * d * 4) != hipSuccess || hipMalloc(&wf1, (size_t)mlp * d * 2) != hipSuccess ||
+            hipMalloc(&cs1, (size_t)mlp * 4) != hipSuccess || hipMalloc(&bf1, (size_t)mlp * 4) != hipSuccess) { ok = false; break; }
+        for (void *pp : {(void *)wfq, (void *)csq, (void *)bfq, (void *)wf1, (void *)cs1, (void *)bf1}) c->allocs.push_back(pp);
+        {
+            const float *q0 = blob + off - 3 * ((size_t)d * d + d);
+            for (int j = 0; j < 3; j++) {
+                const float *wj = q0 + (size_t)j * ((size_t)d * d + d), *bj = wj + (size_t)d * d;
+                hipLaunchKernelGGL(k_fold_ln_weight, dim3((d + 3) / 4), dim3(256), 0, ctx->stream, wj, L.ln1_w, L.ln1_b, bj,
+                                   wfq + (size_t)j * d * d, csq + (size_t)j * d, bfq + (size_t)j * d, d, d);
+            }
+        }
+        L.wf_qkv = wfq; L.cs_qkv = csq; L.bf_qkv = bfq;
         L.w_o = bf16(f32((size_t)d * d), d, d, d);
         L.b_o = f32(d);
         L.ln2_w = f32(d);
         L.ln2_b = f32(d);
-        L.w_fc1 = bf16(f32((size_t)mlp * d), mlp, d, d);
+        const float *w1 = f32((size_t)mlp * d);
+        L.w_fc1 = bf16(w1, mlp, d, d);
         L.b_fc1 = f32(mlp);
+        hipLaunchKernelGGL(k_fold_ln_weight, dim3((mlp + 3) / 4), dim3(256), 0, ctx->stream, w1, L.ln2_w, L.ln2_b, L.b_fc1, wf1, cs1, bf1, mlp, d);
+        L.wf_fc1 = wf1; L.cs_fc1 = cs1; L.bf_fc1 = bf1;
         L.w_fc2 = bf16(f32((size_t)d * mlp), d, mlp, mlp);
         L.b_fc2 = f32(d);
     }
@@ -1632,7 +1843,7 @@ extern "C" int d2r_text_encode(d2r_ctx *ctx, const d2r_text *tt, const int32_t *
         if ((rc = launch_gemm<EPI_BIAS_GELU_BF16>(ctx, Xn, L.w_fc1, L.b_fc1, H, rows, mlp, d))) return rc;
         if ((rc = launch_gemm<EPI_BIAS_RESID_F32>(ctx, H, L.w_fc2, L.b_fc2, X, rows, d, mlp))) return rc;
     }
-    hipLaunchKernelGGL(k_head, dim3(Cn), dim3(HEAD_THREADS), 0, ctx->stream, X, (const uint32_t *)pool, T, d, tt->fin_w,
+    hipLaunchKernelGGL(k_head, dim3(Cn), dim3(HEAD_THREADS), 0, ctx->stream, X, (const uint16_t *)nullptr, (const uint32_t *)pool, T, d, tt->fin_w,
                        tt->fin_b, tt->proj, D.proj_dim, (const float *)ctx->text.p, 0u, 1.0f, (float *)nullptr,
                        (float *)ctx->logits.p);
     D2R_HIP(ctx, hipGetLastError());

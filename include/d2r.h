@@ -278,6 +278,11 @@ D2R_API int d2r_get_timing(d2r_ctx *ctx, d2r_timing *out);
  *     level through the global tables.  "gbrick_slots" (default 2, 0..3): slots served from de-hashed
  *     bricks in HBM.  "raygen_rect" (default 1): composite mode generates rays only inside the projected
  *     occupied bounding box.  Results are bit-identical whatever these three are set to.
+ * "ln_fold" (default 1): schedule of the vision tower.  0: LayerNorm kernels between the GEMMs, fp32 residual
+ *     stream.  1: LayerNorm folded into the QKV / fc1 GEMMs (LN(x) W^T + b = rstd (x (gamma o W)^T - mean
+ *     colsum) + b'), row statistics emitted by the residual GEMMs' epilogues, fp32 residual stream kept next
+ *     to the bf16 operand copy.  2: as 1 with a bf16-only residual stream (faster; its accumulated rounding
+ *     puts the logit error past 1e-3 of the logit scale in the tail, so it is not the default).
  * "timing" (0/1): record HIP events per kernel group for d2r_get_timing.  "march_blocks" (default 0 =
  *     one persistent workgroup per CU), "gemm_cfg" (0 default, 1 plain-K-loop 256x256 kernel, 2 force
  *     256x128): development switches. */
