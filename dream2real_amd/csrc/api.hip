@@ -184,7 +184,7 @@ int d2r_ctx_set_option(d2r_ctx *ctx, const char *key, int64_t value)
     } else if (!strcmp(key, "gemm_cfg")) {
         ctx->gemm_cfg = value;
     } else if (!strcmp(key, "ln_fold")) {
-        if (value < 0 || value > 2) return d2r_fail(ctx, D2R_ERR_INVALID, "ln_fold must be 0, 1 or 2");
+        if (value < 0 || value > 3) return d2r_fail(ctx, D2R_ERR_INVALID, "ln_fold must be 0..3");
         ctx->ln_fold = value;
     } else if (!strcmp(key, "gbrick_slots")) {
         if (value < 0 || value > 3) return d2r_fail(ctx, D2R_ERR_INVALID, "gbrick_slots must be in [0, 3]");

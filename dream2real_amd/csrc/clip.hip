@@ -229,11 +229,14 @@ __global__ void k_patchify(const float *__restrict__ pv, uint32_t n, uint32_t S,
 // so the GEMM that follows a LayerNorm takes the RAW residual row (bf16) as its A operand and applies
 // the row statistics in its epilogue (EPI_LN_*), and the GEMM that produces the residual writes the bf16
 // operand copy and per-row partial sums (EPI_RESID_STATS_*): no LayerNorm kernel, no LN round trip
-// through HBM.  _F32X keeps the fp32 residual stream next to the bf16 copy, _BF16 keeps only bf16.
+// through HBM.  _F32X keeps the fp32 residual stream next to the bf16 copy, _BF16 keeps only bf16, _SPLIT keeps
+// the residual as TWO bf16 arrays, x ~ hi + lo with hi = bf16(x) (the operand copy) and lo = bf16(x - hi): 16
+// mantissa bits for the bytes of one fp32 array, i.e. a third less residual traffic than _F32X.
 enum { EPI_F32 = 0, EPI_BIAS_BF16 = 1, EPI_BIAS_GELU_BF16 = 2, EPI_BIAS_RESID_F32 = 3,
-       EPI_LN_BIAS_BF16 = 4, EPI_LN_BIAS_GELU_BF16 = 5, EPI_RESID_STATS_F32X = 6, EPI_RESID_STATS_BF16 = 7, EPI_KINDS = 8 };
+       EPI_LN_BIAS_BF16 = 4, EPI_LN_BIAS_GELU_BF16 = 5, EPI_RESID_STATS_F32X = 6, EPI_RESID_STATS_BF16 = 7,
+       EPI_RESID_STATS_SPLIT = 8, EPI_KINDS = 9 };
 #define EPI_IS_LN(E) ((E) == EPI_LN_BIAS_BF16 || (E) == EPI_LN_BIAS_GELU_BF16)
-#define EPI_IS_STATS(E) ((E) == EPI_RESID_STATS_F32X || (E) == EPI_RESID_STATS_BF16)
+#define EPI_IS_STATS(E) ((E) == EPI_RESID_STATS_F32X || (E) == EPI_RESID_STATS_BF16 || (E) == EPI_RESID_STATS_SPLIT)
 #define EPI_IS_F32_LAYOUT(E) ((E) == EPI_F32 || (E) == EPI_BIAS_RESID_F32 || EPI_IS_STATS(E))
 
 // operands of the folded epilogues
@@ -242,6 +245,7 @@ struct EpiAux {
     const float2 *ab;      // EPI_LN_*: [M_pad] per row (rstd, -rstd * mean) of the residual row
     uint16_t *xb;          // EPI_RESID_STATS_*: [M_pad][N] bf16 residual (read + written by _BF16, written by _F32X)
     float2 *part;          // EPI_RESID_STATS_*: [M_pad][N / 64] partial (sum, sum of squares) per 64-column group
+    uint16_t *xlo;         // EPI_RESID_STATS_SPLIT: [M_pad][N] low half of the split residual
 };
 
 // Development-only ablation switches of k_gemm8 and the shared epilogue (bitmask, default 0 = the real
@@ -330,7 +334,8 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], float *ep, u
         const uint32_t c4 = (lane & 15) * 4, rl0 = lane >> 4;
         const uint32_t col = col0 + c4;
         constexpr bool RESID_F32 = EPI == EPI_BIAS_RESID_F32 || EPI == EPI_RESID_STATS_F32X;
-        constexpr bool RESID_BF16 = EPI == EPI_RESID_STATS_BF16;
+        constexpr bool RESID_BF16 = EPI == EPI_RESID_STATS_BF16 || EPI == EPI_RESID_STATS_SPLIT;
+        constexpr bool SPLIT = EPI == EPI_RESID_STATS_SPLIT;
         constexpr bool STATS = EPI_IS_STATS(EPI);
         float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
         if (EPI != EPI_F32) {
@@ -346,7 +351,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], float *ep, u
 #pragma unroll
         for (int ih = 0; ih < MT; ih += G) {
             float4 xr[G][8];
-            uint2 xh[G][8];
+            uint2 xh[G][8], xl[G][8];
             if (RESID_F32 || RESID_BF16) {
 #pragma unroll
                 for (int ii = 0; ii < G; ii++)
@@ -358,6 +363,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], float *ep, u
                                                                 : *(const float4 *)((const float *)Cout + row * N + col);
                         else
                             xh[ii][k] = *(const uint2 *)(aux.xb + row * N + col);
+                        if (SPLIT) xl[ii][k] = *(const uint2 *)(aux.xlo + row * N + col);
                     }
                 if (ih == MT - G) hook();
             }
@@ -379,6 +385,9 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], float *ep, u
                         if (RESID_BF16) {
                             v.x += bf_lo(xh[ii][k].x); v.y += bf_hi(xh[ii][k].x); v.z += bf_lo(xh[ii][k].y); v.w += bf_hi(xh[ii][k].y);
                         }
+                        if (SPLIT) {
+                            v.x += bf_lo(xl[ii][k].x); v.y += bf_hi(xl[ii][k].x); v.z += bf_lo(xl[ii][k].y); v.w += bf_hi(xl[ii][k].y);
+                        }
 #if (D2R_GEMM_ABLATE & 128) && defined(__HIP_DEVICE_COMPILE__)
                         asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
                         continue;
@@ -387,7 +396,11 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], float *ep, u
                         if (STATS) {
                             // the bf16 copy the next GEMM reads as its A operand, and this 64-column group's share of
                             // the row's LayerNorm statistics (of the fp32 values: the rounding averages out over d)
-                            *(uint2 *)(aux.xb + row * N + col) = make_uint2(pack2(v.x, v.y), pack2(v.z, v.w));
+                            const uint2 hv = make_uint2(pack2(v.x, v.y), pack2(v.z, v.w));
+                            *(uint2 *)(aux.xb + row * N + col) = hv;
+                            if (SPLIT)
+                                *(uint2 *)(aux.xlo + row * N + col) = make_uint2(pack2(v.x - bf_lo(hv.x), v.y - bf_hi(hv.x)),
+                                                                                 pack2(v.z - bf_lo(hv.y), v.w - bf_hi(hv.y)));
                             const float sm = row16_sum((v.x + v.y) + (v.z + v.w));
                             const float sq = row16_sum(fmaf(v.x, v.x, v.y * v.y) + fmaf(v.z, v.z, v.w * v.w));
                             if ((lane & 15) == 0) aux.part[row * np + (col0 >> 6)] = make_float2(sm, sq);
@@ -877,7 +890,7 @@ __global__ __launch_bounds__(256) void k_embed_ln(const float *__restrict__ patc
                                                   const float *__restrict__ pos, const float *__restrict__ w,
                                                   const float *__restrict__ b, float *__restrict__ X, uint32_t rows,
                                                   uint32_t T, uint32_t d, uint16_t *__restrict__ Xb,
-                                                  float2 *__restrict__ AB)
+                                                  float2 *__restrict__ AB, uint16_t *__restrict__ Xlo)
 {
     // X (fp32 residual stream) and Xb/AB (LayerNorm-folded path: bf16 operand copy of the row and the
     // (rstd, -rstd*mean) of the row for the first block's layer_norm1) are each optional
@@ -917,7 +930,13 @@ __global__ __launch_bounds__(256) void k_embed_ln(const float *__restrict__ patc
             o[i].z = (v[i].z - mu) * rstd * ww.z + bb.z;
             o[i].w = (v[i].w - mu) * rstd * ww.w + bb.w;
             if (X) *(float4 *)(X + (size_t)row * d + c0) = o[i];
-            if (Xb) *(uint2 *)(Xb + (size_t)row * d + c0) = make_uint2(pack2(o[i].x, o[i].y), pack2(o[i].z, o[i].w));
+            if (Xb) {
+                const uint2 hv = make_uint2(pack2(o[i].x, o[i].y), pack2(o[i].z, o[i].w));
+                *(uint2 *)(Xb + (size_t)row * d + c0) = hv;
+                if (Xlo)
+                    *(uint2 *)(Xlo + (size_t)row * d + c0) = make_uint2(pack2(o[i].x - bf_lo(hv.x), o[i].y - bf_hi(hv.x)),
+                                                                         pack2(o[i].z - bf_lo(hv.y), o[i].w - bf_hi(hv.y)));
+            }
         } else {
             o[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -1198,6 +1217,7 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void k_attention(const uint16_t *_
 // projection is a latency problem (1.5 MB of fp32 weights per image out of L2), not a flop one.
 #define HEAD_THREADS 1024
 __global__ __launch_bounds__(HEAD_THREADS) void k_head(const float *__restrict__ X, const uint16_t *__restrict__ Xb,
+                                                       const uint16_t *__restrict__ Xlo,
                                                        const uint32_t *__restrict__ pool_row, uint32_t T, uint32_t d,
                                                        const float *__restrict__ lw, const float *__restrict__ lb,
                                                        const float *__restrict__ proj, uint32_t D,
@@ -1212,7 +1232,11 @@ __global__ __launch_bounds__(HEAD_THREADS) void k_head(const float *__restrict__
     // vision: the class token (row 0 of the image); text: the EOS token's row
     // (the residual stream is fp32 X, or bf16 Xb when the tower runs with a bf16 residual stream)
     const size_t xoff = ((size_t)blockIdx.x * T + (pool_row ? pool_row[blockIdx.x] : 0u)) * d;
-    const float xv = tid < d ? (Xb ? __uint_as_float((uint32_t)Xb[xoff + tid] << 16) : X[xoff + tid]) : 0.f;      // d <= 1024
+    float xv = 0.f;                                                                                            // d <= 1024
+    if (tid < d) {
+        xv = Xb ? __uint_as_float((uint32_t)Xb[xoff + tid] << 16) : X[xoff + tid];
+        if (Xb && Xlo) xv += __uint_as_float((uint32_t)Xlo[xoff + tid] << 16);
+    }
     float s = wave_sum(xv);
     if (lane == 0) red[wave] = s;
     __syncthreads();
@@ -1520,7 +1544,7 @@ int d2r_clip_forward(d2r_ctx *ctx, const d2r_clip *clip, const uint16_t *patches
     if (fold == 0) {
         // separate LayerNorm kernels, fp32 residual stream (also what the text tower runs)
         hipLaunchKernelGGL(k_embed_ln, dim3((rows + 3) / 4), dim3(256), 0, ctx->stream, patch_out, clip->w.cls,
-                           clip->w.pos, clip->w.pre_w, clip->w.pre_b, X, rows, T, d, (uint16_t *)nullptr, (float2 *)nullptr);
+                           clip->w.pos, clip->w.pre_w, clip->w.pre_b, X, rows, T, d, (uint16_t *)nullptr, (float2 *)nullptr, (uint16_t *)nullptr);
         for (uint32_t l = 0; l < D.num_layers; l++) {
             const ClipWeights::Layer &L = clip->layers[l];
             hipLaunchKernelGGL(k_layernorm, dim3((rows + 3) / 4), dim3(256), 0, ctx->stream, X, L.ln1_w, L.ln1_b, Xn,
@@ -1533,24 +1557,27 @@ int d2r_clip_forward(d2r_ctx *ctx, const d2r_clip *clip, const uint16_t *patches
             if ((rc = launch_gemm<EPI_BIAS_GELU_BF16>(ctx, Xn, L.w_fc1, L.b_fc1, H, rows, mlp, d))) return rc;
             if ((rc = launch_gemm<EPI_BIAS_RESID_F32>(ctx, H, L.w_fc2, L.b_fc2, X, rows, d, mlp))) return rc;
         }
-        hipLaunchKernelGGL(k_head, dim3(n), dim3(HEAD_THREADS), 0, ctx->stream, X, (const uint16_t *)nullptr, (const uint32_t *)nullptr, T, d,
+        hipLaunchKernelGGL(k_head, dim3(n), dim3(HEAD_THREADS), 0, ctx->stream, X, (const uint16_t *)nullptr, (const uint16_t *)nullptr, (const uint32_t *)nullptr, T, d,
                            clip->w.post_w, clip->w.post_b, clip->w.proj, D.proj_dim, text_dev, C, logit_scale, logits_dev, embeds_dev);
         D2R_HIP(ctx, hipGetLastError());
         return D2R_OK;
     }
     // LayerNorm folded into the GEMMs (EPI_LN_* / EPI_RESID_STATS_*): Xn holds the RAW residual rows in bf16 (the
     // A operand of QKV and fc1), the residual GEMMs emit per-row partial sums, k_rowstats turns them into
-    // (rstd, -rstd*mean).  fold 1 keeps the fp32 residual stream next to the bf16 copy, fold 2 keeps bf16 only.
+    // (rstd, -rstd*mean).
     const uint32_t np = d / 64;
     if ((rc = d2r_reserve(ctx, ctx->clipws[7], (size_t)rows_pad * np * 8 + (size_t)rows_pad * 8))) return rc;
     float2 *part = (float2 *)ctx->clipws[7].p, *AB = part + (size_t)rows_pad * np;
-    const bool xf32 = fold == 1;
+    // fold 1: residual = hi (Xn, the operand copy) + lo (bf16 array in X's workspace); fold 2: hi only; fold 3: fp32 X + hi
+    const bool xf32 = fold == 3, split = fold == 1;
+    uint16_t *Xlo = split ? (uint16_t *)X : (uint16_t *)nullptr;
     hipLaunchKernelGGL(k_embed_ln, dim3((rows + 3) / 4), dim3(256), 0, ctx->stream, patch_out, clip->w.cls, clip->w.pos,
-                       clip->w.pre_w, clip->w.pre_b, xf32 ? X : (float *)nullptr, rows, T, d, Xn, AB);
+                       clip->w.pre_w, clip->w.pre_b, xf32 ? X : (float *)nullptr, rows, T, d, Xn, AB, Xlo);
     EpiAux ln{}, st{};
     ln.ab = AB;
     st.xb = Xn;
     st.part = part;
+    st.xlo = Xlo;
     const float inv_d = 1.0f / (float)d;
     for (uint32_t l = 0; l < D.num_layers; l++) {
         const ClipWeights::Layer &L = clip->layers[l];
@@ -1558,19 +1585,21 @@ int d2r_clip_forward(d2r_ctx *ctx, const d2r_clip *clip, const uint16_t *patches
         if ((rc = launch_gemm<EPI_LN_BIAS_BF16>(ctx, Xn, L.wf_qkv, L.bf_qkv, QKV, rows, 3 * d, d, ln))) return rc;
         hipLaunchKernelGGL(k_attention<false>, dim3(D.num_heads, n), dim3(ATTN_THREADS), attn_lds, ctx->stream, QKV, AO, T, T_pad, d);
         if (xf32) rc = launch_gemm<EPI_RESID_STATS_F32X>(ctx, AO, L.w_o, L.b_o, X, rows, d, d, st);
+        else if (split) rc = launch_gemm<EPI_RESID_STATS_SPLIT>(ctx, AO, L.w_o, L.b_o, Xn, rows, d, d, st);
         else rc = launch_gemm<EPI_RESID_STATS_BF16>(ctx, AO, L.w_o, L.b_o, Xn, rows, d, d, st);
         if (rc) return rc;
         hipLaunchKernelGGL(k_rowstats, dim3((rows_pad + 255) / 256), dim3(256), 0, ctx->stream, part, np, rows_pad, inv_d, AB);
         ln.cs = L.cs_fc1;
         if ((rc = launch_gemm<EPI_LN_BIAS_GELU_BF16>(ctx, Xn, L.wf_fc1, L.bf_fc1, H, rows, mlp, d, ln))) return rc;
         if (xf32) rc = launch_gemm<EPI_RESID_STATS_F32X>(ctx, H, L.w_fc2, L.b_fc2, X, rows, d, mlp, st);
+        else if (split) rc = launch_gemm<EPI_RESID_STATS_SPLIT>(ctx, H, L.w_fc2, L.b_fc2, Xn, rows, d, mlp, st);
         else rc = launch_gemm<EPI_RESID_STATS_BF16>(ctx, H, L.w_fc2, L.b_fc2, Xn, rows, d, mlp, st);
         if (rc) return rc;
         if (l + 1 < D.num_layers)
             hipLaunchKernelGGL(k_rowstats, dim3((rows_pad + 255) / 256), dim3(256), 0, ctx->stream, part, np, rows_pad, inv_d, AB);
     }
     hipLaunchKernelGGL(k_head, dim3(n), dim3(HEAD_THREADS), 0, ctx->stream, X, xf32 ? (const uint16_t *)nullptr : (const uint16_t *)Xn,
-                       (const uint32_t *)nullptr, T, d, clip->w.post_w, clip->w.post_b, clip->w.proj, D.proj_dim, text_dev, C,
+                       (const uint16_t *)Xlo, (const uint32_t *)nullptr, T, d, clip->w.post_w, clip->w.post_b, clip->w.proj, D.proj_dim, text_dev, C,
                        logit_scale, logits_dev, embeds_dev);
     D2R_HIP(ctx, hipGetLastError());
     return D2R_OK;
@@ -1843,7 +1872,7 @@ extern "C" int d2r_text_encode(d2r_ctx *ctx, const d2r_text *tt, const int32_t *
         if ((rc = launch_gemm<EPI_BIAS_GELU_BF16>(ctx, Xn, L.w_fc1, L.b_fc1, H, rows, mlp, d))) return rc;
         if ((rc = launch_gemm<EPI_BIAS_RESID_F32>(ctx, H, L.w_fc2, L.b_fc2, X, rows, d, mlp))) return rc;
     }
-    hipLaunchKernelGGL(k_head, dim3(Cn), dim3(HEAD_THREADS), 0, ctx->stream, X, (const uint16_t *)nullptr, (const uint32_t *)pool, T, d, tt->fin_w,
+    hipLaunchKernelGGL(k_head, dim3(Cn), dim3(HEAD_THREADS), 0, ctx->stream, X, (const uint16_t *)nullptr, (const uint16_t *)nullptr, (const uint32_t *)pool, T, d, tt->fin_w,
                        tt->fin_b, tt->proj, D.proj_dim, (const float *)ctx->text.p, 0u, 1.0f, (float *)nullptr,
                        (float *)ctx->logits.p);
     D2R_HIP(ctx, hipGetLastError());

@@ -279,10 +279,11 @@ D2R_API int d2r_get_timing(d2r_ctx *ctx, d2r_timing *out);
  *     bricks in HBM.  "raygen_rect" (default 1): composite mode generates rays only inside the projected
  *     occupied bounding box.  Results are bit-identical whatever these three are set to.
  * "ln_fold" (default 1): schedule of the vision tower.  0: LayerNorm kernels between the GEMMs, fp32 residual
- *     stream.  1: LayerNorm folded into the QKV / fc1 GEMMs (LN(x) W^T + b = rstd (x (gamma o W)^T - mean
- *     colsum) + b'), row statistics emitted by the residual GEMMs' epilogues, fp32 residual stream kept next
- *     to the bf16 operand copy.  2: as 1 with a bf16-only residual stream (faster; its accumulated rounding
- *     puts the logit error past 1e-3 of the logit scale in the tail, so it is not the default).
+ *     stream.  1-3: LayerNorm folded into the QKV / fc1 GEMMs (LN(x) W^T + b = rstd (x (gamma o W)^T - mean
+ *     colsum) + b'), row statistics emitted by the residual GEMMs' epilogues, which also write the bf16 operand
+ *     copy of the residual row; the residual stream itself is kept as 1: two bf16 arrays hi + lo (16 mantissa
+ *     bits), 2: one bf16 array (fastest; its accumulated rounding puts the logit error past 1e-3 of the logit
+ *     scale in the tail, so it is not the default), 3: fp32 next to the bf16 copy.
  * "timing" (0/1): record HIP events per kernel group for d2r_get_timing.  "march_blocks" (default 0 =
  *     one persistent workgroup per CU), "gemm_cfg" (0 default, 1 plain-K-loop 256x256 kernel, 2 force
  *     256x128): development switches. */
