@@ -31,7 +31,8 @@ class NerfDesc(C.Structure):
                 ("level_res", C.c_void_p), ("level_size", C.c_void_p), ("level_offset", C.c_void_p),
                 ("n_entries", C.c_uint32), ("grid_fp16", C.c_void_p), ("dw1_fp16", C.c_void_p),
                 ("dw2_fp16", C.c_void_p), ("cw1_fp16", C.c_void_p), ("cw2_fp16", C.c_void_p),
-                ("cw3_fp16", C.c_void_p), ("occupancy_bits", C.c_void_p), ("aabb_scale", C.c_uint32)]
+                ("cw3_fp16", C.c_void_p), ("occupancy_bits", C.c_void_p), ("aabb_scale", C.c_uint32),
+                ("render_aabb", C.c_float * 6)]
 
 
 class ViewC(C.Structure):

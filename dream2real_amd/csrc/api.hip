@@ -260,8 +260,8 @@ static void build_frag(std::vector<uint16_t> &dst, int frag, const uint16_t *w, 
 int d2r_nerf_create(d2r_ctx *ctx, const d2r_nerf_desc *d, d2r_nerf **out)
 {
     if (!ctx || !d || !out) return d2r_fail(ctx, D2R_ERR_INVALID, "null argument");
-    if (d->n_levels != 16 || d->n_features != 2)
-        return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "only the L=16, F=2 hash grid layout is implemented");
+    if (!((d->n_levels == 16 && d->n_features == 2) || (d->n_levels == 8 && d->n_features == 4)))
+        return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "hash grid layout must be L=16,F=2 or L=8,F=4 (32 network inputs)");
     if (!d->level_scale || !d->level_res || !d->level_size || !d->level_offset || !d->grid_fp16 || !d->dw1_fp16 ||
         !d->dw2_fp16 || !d->cw1_fp16 || !d->cw2_fp16 || !d->cw3_fp16 || !d->occupancy_bits)
         return d2r_fail(ctx, D2R_ERR_INVALID, "null field in d2r_nerf_desc");
@@ -303,12 +303,24 @@ int d2r_nerf_create(d2r_ctx *ctx, const d2r_nerf_desc *d, d2r_nerf **out)
         if (lm.hashed) prefix = false;
         if (!lm.hashed && !prefix && (int)l >= n_dense) n_dense = -1000;   // dense after hashed: irregular
     }
+    // F = 4: a slot is ONE level and its two halves are feature pairs of the same entries, so the slot kinds
+    // (dense / hashed / mixed, in half-levels) count every level twice
+    const bool f4 = d->n_features == 4;
+    const uint32_t n_slots = 8;
+    if (f4 && n_dense >= 0) n_dense *= 2;
     P.n_dense = n_dense < 0 ? -1 : n_dense;
-    // interleaved slot tables: entry e of level 2i+h at word 2e+h of slot i
+    // slot tables: F = 2: entry e of level 2i+h at word 2e+h of slot i (the two levels interleaved);
+    //              F = 4: the level's own table (entry e = words 2e, 2e+1)
     std::vector<uint32_t> tab;
-    const uint32_t *src = (const uint32_t *)d->grid_fp16;       // half2 per entry
-    for (uint32_t i = 0; i < d->n_levels / 2; i++) {
-        const LevelMeta &a = lv[2 * i], &b = lv[2 * i + 1];
+    const uint32_t *src = (const uint32_t *)d->grid_fp16;       // half2 words: one per entry (F = 2), two per entry (F = 4)
+    // word of (level-half) vertex: F = 2 -> src[offset + idx]; F = 4 -> src[2 (offset + idx) + h]
+    auto half_level = [&](uint32_t slot, int h) -> const LevelMeta & { return f4 ? lv[slot] : lv[2 * slot + h]; };
+    auto src_word = [&](uint32_t slot, int h, uint32_t idx) -> uint32_t {
+        const LevelMeta &L = half_level(slot, h);
+        return f4 ? src[2 * ((size_t)L.offset + idx) + h] : src[(size_t)L.offset + idx];
+    };
+    for (uint32_t i = 0; i < n_slots; i++) {
+        const LevelMeta &a = half_level(i, 0), &b = half_level(i, 1);
         SlotMeta &sm = P.slot[i];
         sm.scale[0] = a.scale; sm.scale[1] = b.scale;
         sm.res[0] = a.res; sm.res[1] = b.res;
@@ -319,8 +331,8 @@ int d2r_nerf_create(d2r_ctx *ctx, const d2r_nerf_desc *d, d2r_nerf **out)
         const uint32_t n = std::max(a.size, b.size);
         const size_t base = tab.size();
         tab.resize(base + (size_t)n * 2, 0u);
-        for (uint32_t e = 0; e < a.size; e++) tab[base + 2 * (size_t)e] = src[a.offset + e];
-        for (uint32_t e = 0; e < b.size; e++) tab[base + 2 * (size_t)e + 1] = src[b.offset + e];
+        for (uint32_t e = 0; e < a.size; e++) tab[base + 2 * (size_t)e] = src_word(i, 0, e);
+        for (uint32_t e = 0; e < b.size; e++) tab[base + 2 * (size_t)e + 1] = src_word(i, 1, e);
     }
     // occupancy -> 4x4x4 bricks per cascade + bounding box of occupied cells, in the unit cube of
     // the model's box (cascade c spans side 2^c / aabb_scale of it, centred)
@@ -354,6 +366,17 @@ int d2r_nerf_create(d2r_ctx *ctx, const d2r_nerf_desc *d, d2r_nerf **out)
             P.bbox_hi[a] = bhi[a] + 1e-4f;
         }
     }
+    {
+        const float half = 0.5f * (float)aabb, box_lo = 0.5f - half, box_hi = 0.5f + half, inv_side = 1.0f / (2.0f * half);
+        bool crop = false;
+        for (int a = 0; a < 6; a++) crop = crop || d->render_aabb[a] != 0.f;
+        for (int a = 0; a < 3; a++) {
+            P.raabb_lo[a] = crop ? fmaxf(box_lo, d->render_aabb[a]) : box_lo;
+            P.raabb_hi[a] = crop ? fminf(box_hi, d->render_aabb[3 + a]) : box_hi;
+            P.rn_lo[a] = aabb == 2u ? fmaf(P.raabb_lo[a] - 0.5f, inv_side, 0.5f) : P.raabb_lo[a];
+            P.rn_hi[a] = aabb == 2u ? fmaf(P.raabb_hi[a] - 0.5f, inv_side, 0.5f) : P.raabb_hi[a];
+        }
+    }
     // De-hashed, bounding-box-local dense bricks of the leading levels (small objects): the
     // vertices a sample inside an occupied cell can touch, with the table value (incl. tiny-cuda-nn's
     // index wrap) resolved here once.  Served from LDS by k_march; values identical to the tables.
@@ -364,7 +387,7 @@ int d2r_nerf_create(d2r_ctx *ctx, const d2r_nerf_desc *d, d2r_nerf **out)
     // appends the brick of level 2i+h to `words`; false when it would exceed `budget_words`
     auto add_level_brick = [&](uint32_t i, int h, std::vector<uint32_t> &words, size_t budget_words, size_t word0) -> bool {
         SlotMeta &sm = P.slot[i];
-        const LevelMeta &L = lv[2 * i + h];
+        const LevelMeta &L = half_level(i, h);
         int g0[3], n[3];
         for (int a = 0; a < 3; a++) {
             // same correctly-rounded fma the kernels use: monotone, so these bound every sample
@@ -388,14 +411,14 @@ int d2r_nerf_create(d2r_ctx *ctx, const d2r_nerf_desc *d, d2r_nerf **out)
                         idx = (uint32_t)(gx ^ (gy * 2654435761u) ^ (gz * 805459861u));
                     else
                         idx = (uint64_t)gx + (uint64_t)gy * L.res + (uint64_t)gz * L.res * L.res;
-                    words.push_back(src[L.offset + (uint32_t)(idx % L.size)]);
+                    words.push_back(src_word(i, h, (uint32_t)(idx % L.size)));
                 }
         return true;
     };
     if (bhi[0] >= blo[0] && P.n_dense >= 0) {
         const size_t budget_words = (160 * 1024 - (size_t)D2R_N_WFRAG * 64 * 16) / 4;
         std::vector<uint32_t> words;
-        for (uint32_t i = 0; i < d->n_levels / 2 && i < 5; i++) {
+        for (uint32_t i = 0; i < n_slots && i < 5; i++) {
             std::vector<uint32_t> trial = words;
             if (!add_level_brick(i, 0, trial, budget_words, 0) || !add_level_brick(i, 1, trial, budget_words, 0)) break;
             words.swap(trial);
@@ -408,7 +431,7 @@ int d2r_nerf_create(d2r_ctx *ctx, const d2r_nerf_desc *d, d2r_nerf **out)
         // slots 5 and 6 as HBM-resident bricks (spatially coherent, no hash scatter) when small enough
         if (P.n_brick_slots == 5) {
             const size_t gbudget = ((size_t)512 << 20) >> 2;    // 512 MiB of words
-            for (uint32_t i = 5; i < 8 && i < d->n_levels / 2; i++) {
+            for (uint32_t i = 5; i < 8 && i < n_slots; i++) {
                 std::vector<uint32_t> trial = gbrick_tab;
                 if (!add_level_brick(i, 0, trial, gbudget, 0) || !add_level_brick(i, 1, trial, gbudget, 0)) break;
                 gbrick_tab.swap(trial);

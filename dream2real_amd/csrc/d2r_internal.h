@@ -47,8 +47,10 @@ struct SlotMeta {
 struct NerfParams {
     const uint32_t *grid;      // interleaved slot tables, half2 entries
     uint32_t grid_bytes;
-    uint32_t n_levels;
-    int32_t n_dense;           // leading dense levels (slot kinds follow from it), -1 = irregular
+    uint32_t n_levels;         // 16 (F = 2: a slot is the level pair 2i, 2i+1) or 8 (F = 4: a slot is level i, its two
+                               // "halves" the feature pairs (0,1) and (2,3) of the 8-byte entries) — either way entry e
+                               // of half h lives at byte 8e + 4h of the slot table and network input 4*slot + 2h + f
+    int32_t n_dense;           // leading dense HALF-levels (2 per level when F = 4; slot kinds follow from it), -1 = irregular
     SlotMeta slot[D2R_MAX_LEVELS / 2];
     uint32_t refill_min;       // free lanes in a wave before it pulls new rays from the queue
     uint32_t n_brick_slots;    // leading slots whose levels are de-hashed into LDS bricks (0, 4 or 5)
@@ -61,6 +63,9 @@ struct NerfParams {
     uint32_t aabb_scale;       // 1, or 2: two cascades, cone stepping, positions normalised to the box (k_*<.., CONE>)
     const uint4 *wfrag;        // [24][64] MFMA A-operand fragments of the MLPs
     float bbox_lo[3], bbox_hi[3];  // bounding box of occupied cells (+margin), unit-cube units
+    // Testbed.render_aabb clipped to the model's box: in ngp coordinates (ray slab test) and in the unit cube of
+    // the box (per-sample containment test); the whole box when none is set
+    float raabb_lo[3], raabb_hi[3], rn_lo[3], rn_hi[3];
 };
 
 struct ViewParams {

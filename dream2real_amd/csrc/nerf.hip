@@ -213,13 +213,12 @@ __device__ __forceinline__ bool make_ray(const NerfParams &P, const ViewParams &
     float inv_len = 1.0f / sqrtf(fmaf(d[2], d[2], fmaf(d[1], d[1], d[0] * d[0])));
 #pragma unroll
     for (int i = 0; i < 3; i++) d[i] *= inv_len;
-    // the model's box: the unit cube, or (CONE) the cube of side 2 centred at 0.5
-    const float box_lo = CONE ? -0.5f : 0.0f, box_hi = CONE ? 1.5f : 1.0f;
+    // the model's box (the unit cube, or (CONE) the cube of side 2 centred at 0.5) cropped to render_aabb
     float tmin = -INFINITY, tmax = INFINITY;
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         float inv = 1.0f / d[i];
-        float t0 = (box_lo - o[i]) * inv, t1 = (box_hi - o[i]) * inv;
+        float t0 = (P.raabb_lo[i] - o[i]) * inv, t1 = (P.raabb_hi[i] - o[i]) * inv;
         tmin = fmaxf(tmin, fminf(t0, t1));
         tmax = fminf(tmax, fmaxf(t0, t1));
     }
@@ -276,7 +275,7 @@ __device__ __forceinline__ bool next_sample(const NerfParams &P, const Ray &r, u
         px = fmaf(t, r.dx, r.ox);
         py = fmaf(t, r.dy, r.oy);
         pz = fmaf(t, r.dz, r.oz);
-        if (px < 0.f || px > 1.f || py < 0.f || py > 1.f || pz < 0.f || pz > 1.f) return false;
+        if (px < P.rn_lo[0] || px > P.rn_hi[0] || py < P.rn_lo[1] || py > P.rn_hi[1] || pz < P.rn_lo[2] || pz > P.rn_hi[2]) return false;
         // occupancy cascade (CONE): 1 outside the unit cube or once the step spans a cell of cascade 0;
         // cascade 1 spans the whole box (cells 1/128 of it), cascade 0 its central half (cells 1/256)
         int mip = 0;

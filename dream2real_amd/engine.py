@@ -126,7 +126,9 @@ class Testbed:
         desc = _lib.NerfDesc(lv.n_levels, lv.n_features, _lib.ptr(k["scale"]), _lib.ptr(k["res"]),
                              _lib.ptr(k["size"]), _lib.ptr(k["offset"]), lv.n_entries, _lib.ptr(k["grid"]),
                              _lib.ptr(k["dw1"]), _lib.ptr(k["dw2"]), _lib.ptr(k["cw1"]), _lib.ptr(k["cw2"]),
-                             _lib.ptr(k["cw3"]), _lib.ptr(k["occ"]), int(getattr(model, "aabb_scale", 1)))
+                             _lib.ptr(k["cw3"]), _lib.ptr(k["occ"]), int(getattr(model, "aabb_scale", 1)),
+                             (C.c_float * 6)(*([0.0] * 6 if getattr(model, "render_aabb", None) is None
+                                               else [float(x) for x in model.render_aabb])))
         h = C.c_void_p()
         ctx.check(ctx.lib.d2r_nerf_create(ctx.h, C.byref(desc), C.byref(h)))
         self.h = h
@@ -151,8 +153,11 @@ class Testbed:
         the dataset scale/offset come from the `.ingp` file (dream2real_amd.ingp.load_ingp)."""
         from . import ingp
         model, info = ingp.load_ingp(path)
-        return cls(ctx, model, training_views=info["training_views"] or None,
-                   dataset_scale=info["dataset_scale"], dataset_offset=info["dataset_offset"])
+        tb = cls(ctx, model, training_views=info["training_views"] or None,
+                 dataset_scale=info["dataset_scale"], dataset_offset=info["dataset_offset"])
+        if info.get("background_color") is not None:          # a Testbed restores the colour the snapshot was saved with
+            tb.background_color = [float(x) for x in info["background_color"]]
+        return tb
 
     def close(self):
         if getattr(self, "h", None):

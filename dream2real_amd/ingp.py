@@ -72,6 +72,21 @@ def occupancy_from_density(dens_morton: np.ndarray) -> np.ndarray:
     return occ.reshape(n_casc, -1)
 
 
+def _render_aabb(ra, aabb_scale):
+    """snapshot.render_aabb ({"min": [x,y,z], "max": [x,y,z]} or six numbers) -> (lo xyz, hi xyz), or None
+    when absent or equal to the model's whole box (the value a snapshot carries unless the GUI cropped it)."""
+    if ra is None:
+        return None
+    v = (list(ra["min"]) + list(ra["max"])) if isinstance(ra, dict) else list(ra)
+    if len(v) != 6:
+        raise ValueError("render_aabb must hold six numbers")
+    v = tuple(float(x) for x in v)
+    half = 0.5 * aabb_scale
+    if all(a <= 0.5 - half for a in v[:3]) and all(b >= 0.5 + half for b in v[3:]):
+        return None
+    return v
+
+
 def load_ingp(path: str):
     """-> (NerfModel, info) where info carries training_views (intrinsics per image), dataset
     scale/offset, aabb_scale and the snapshot's background colour if present."""
@@ -92,6 +107,8 @@ def load_ingp(path: str):
         raise NotImplementedError("aabb_scale > 2 (more than two occupancy cascades) is not implemented")
     n_casc = aabb_scale.bit_length()
     L, F = int(enc.get("n_levels", 16)), int(enc.get("n_features_per_level", 2))
+    if (L, F) not in ((16, 2), (8, 4)):
+        raise ValueError(f"hash grid layout L={L}, F={F}: only L=16,F=2 and L=8,F=4 (32 network inputs) are implemented")
     levels = grid_levels(L, F, int(enc.get("log2_hashmap_size", 19)), int(enc.get("base_resolution", 16)),
                          enc.get("per_level_scale"), aabb_scale)
     if snap.get("params_type", "__half") != "__half":
@@ -112,7 +129,8 @@ def load_ingp(path: str):
         raise ValueError(f"density grid must hold {n_casc} cascade(s) of 128^3 values")
     occ_lin = occupancy_from_density(dens.reshape(n_casc, -1))
     model = NerfModel(levels, grid.copy(), dw1.copy(), dw2.copy(), cw1.copy(), cw2.copy(), cw3.copy(),
-                      np.packbits(occ_lin.reshape(-1).astype(np.uint8), bitorder="little"), aabb_scale)
+                      np.packbits(occ_lin.reshape(-1).astype(np.uint8), bitorder="little"), aabb_scale,
+                      _render_aabb(snap.get("render_aabb"), aabb_scale))
     views = []
     for md in ds.get("metadata", []):
         w, h = md["resolution"]

@@ -65,8 +65,8 @@ D2R_API const char *d2r_last_error(d2r_ctx *ctx);
 /* State a pyngp.Testbed holds after load_snapshot (reference ngp_visual_model.py:24-28):
  * tiny-cuda-nn hash grid + density/colour MLPs + 128^3 occupancy bitfield(s). */
 typedef struct {
-    uint32_t n_levels;          /* L (16) */
-    uint32_t n_features;        /* F (2) */
+    uint32_t n_levels;          /* L: 16, or 8 */
+    uint32_t n_features;        /* F: 2 with L = 16, 4 with L = 8 (the two layouts with L*F = 32 inputs) */
     const float *level_scale;   /* host [L]: exp2(l*log2(b))*N_min - 1 */
     const uint32_t *level_res;  /* host [L]: ceil(scale)+1 */
     const uint32_t *level_size; /* host [L]: entries per level */
@@ -82,6 +82,8 @@ typedef struct {
     uint32_t aabb_scale;        /* 1 or 2 (0 is read as 1): the model's box is the cube of that side centred at
                                  * 0.5; n_cascades = log2(aabb_scale)+1 occupancy grids, cascade c covering side
                                  * 2^c; aabb_scale 2 marches with cone-angle 1/256 steps */
+    float render_aabb[6];       /* Testbed.render_aabb: lo xyz, hi xyz in ngp coordinates — rays start where they
+                                 * enter it and stop where they leave it; all zeros = the model's whole box */
 } d2r_nerf_desc;
 
 /* replaces Testbed(mode=Nerf) + load_snapshot */

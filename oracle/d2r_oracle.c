@@ -63,6 +63,9 @@ typedef struct {
      * cascade c (c < n_cascades = log2(aabb_scale)+1) covers the cube of side 2^c centred at 0.5 */
     const uint8_t *occ_bits;
     uint32_t aabb_scale;      /* 1, or 2 (cascades + cone stepping) */
+    /* Testbed.render_aabb (instant-ngp crops rendering to it: rays start where they enter it and stop
+     * where they leave it), lo xyz then hi xyz in ngp coordinates; all zeros = the model's whole box */
+    float render_aabb[6];
 } d2r_oracle_nerf;
 
 typedef struct {
@@ -371,10 +374,20 @@ D2R_ORACLE_API void d2r_oracle_render(const d2r_oracle_nerf *m, const d2r_oracle
             const int cone = m->aabb_scale > 1;
             const float half = 0.5f * (float)(m->aabb_scale ? m->aabb_scale : 1);
             const float box_lo = 0.5f - half, box_hi = 0.5f + half, inv_side = 1.0f / (2.0f * half);
+            /* cropped to render_aabb when one is set; rn_*: the crop box in the unit cube of the model's box */
+            const int crop = m->render_aabb[0] != 0.f || m->render_aabb[1] != 0.f || m->render_aabb[2] != 0.f ||
+                             m->render_aabb[3] != 0.f || m->render_aabb[4] != 0.f || m->render_aabb[5] != 0.f;
+            float blo[3], bhi[3], rn_lo[3], rn_hi[3];
+            for (int i = 0; i < 3; i++) {
+                blo[i] = crop ? fmaxf(box_lo, m->render_aabb[i]) : box_lo;
+                bhi[i] = crop ? fminf(box_hi, m->render_aabb[3 + i]) : box_hi;
+                rn_lo[i] = cone ? fmaf(blo[i] - 0.5f, inv_side, 0.5f) : blo[i];
+                rn_hi[i] = cone ? fmaf(bhi[i] - 0.5f, inv_side, 0.5f) : bhi[i];
+            }
             float tmin = -INFINITY, tmax = INFINITY;
             for (int i = 0; i < 3; i++) {
                 float inv = 1.0f / d[i];
-                float t0 = (box_lo - o[i]) * inv, t1 = (box_hi - o[i]) * inv;
+                float t0 = (blo[i] - o[i]) * inv, t1 = (bhi[i] - o[i]) * inv;
                 float lo = fminf(t0, t1), hi = fmaxf(t0, t1);
                 tmin = fmaxf(tmin, lo);
                 tmax = fminf(tmax, hi);
@@ -397,8 +410,8 @@ D2R_ORACLE_API void d2r_oracle_render(const d2r_oracle_nerf *m, const d2r_oracle
                     float pw[3], p[3];
                     for (int i = 0; i < 3; i++) p[i] = fmaf(t, dn[i], on[i]);
                     for (int i = 0; i < 3; i++) pw[i] = cone ? fmaf(p[i] - 0.5f, 2.0f * half, 0.5f) : p[i];
-                    if (p[0] < 0.f || p[0] > 1.f || p[1] < 0.f || p[1] > 1.f || p[2] < 0.f ||
-                        p[2] > 1.f)
+                    if (p[0] < rn_lo[0] || p[0] > rn_hi[0] || p[1] < rn_lo[1] || p[1] > rn_hi[1] || p[2] < rn_lo[2] ||
+                        p[2] > rn_hi[2])
                         break;
                     if (!cone) {
                         if (!occ_test(m->occ_bits, cell_of(p[0]), cell_of(p[1]), cell_of(p[2])))

@@ -29,7 +29,7 @@ class _Nerf(C.Structure):
                 ("level_size", C.c_void_p), ("level_offset", C.c_void_p),
                 ("grid", C.c_void_p), ("dw1", C.c_void_p), ("dw2", C.c_void_p),
                 ("cw1", C.c_void_p), ("cw2", C.c_void_p), ("cw3", C.c_void_p),
-                ("occ_bits", C.c_void_p), ("aabb_scale", C.c_uint32)]
+                ("occ_bits", C.c_void_p), ("aabb_scale", C.c_uint32), ("render_aabb", C.c_float * 6)]
 
 
 class _View(C.Structure):
@@ -67,7 +67,9 @@ class OracleNerf:
         for name in ("grid", "dw1", "dw2", "cw1", "cw2", "cw3"):
             self._keep.append(np.ascontiguousarray(getattr(model, name), np.float16))
         self._keep.append(np.ascontiguousarray(model.occ_bits, np.uint8))
-        self.c = _Nerf(lv.n_levels, lv.n_features, *[_ptr(a) for a in self._keep], int(getattr(model, "aabb_scale", 1)))
+        ra = getattr(model, "render_aabb", None)
+        self.c = _Nerf(lv.n_levels, lv.n_features, *[_ptr(a) for a in self._keep], int(getattr(model, "aabb_scale", 1)),
+                       (C.c_float * 6)(*([0.0] * 6 if ra is None else [float(x) for x in ra])))
         self.n_feat = lv.n_levels * lv.n_features
 
 

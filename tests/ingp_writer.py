@@ -11,7 +11,7 @@ from dream2real_amd.scene import GRID, NerfModel
 
 
 def save_ingp(path: str, model: NerfModel, training_views=None, dataset_scale: float = 1.0,
-              dataset_offset=(0.0, 0.3, 0.5), density_value: float = 1.0):
+              dataset_offset=(0.0, 0.3, 0.5), density_value: float = 1.0, background_color=None):
     """Write `model` in the layout load_ingp reads (test fixture writer; occupied cells get
     `density_value`, the rest 0)."""
     import msgpack
@@ -33,6 +33,9 @@ def save_ingp(path: str, model: NerfModel, training_views=None, dataset_scale: f
         "snapshot": {
             "version": 1, "mode": "nerf", "n_params": int(params.size), "params_type": "__half",
             "params_binary": params.tobytes(), "density_grid_size": GRID, "density_grid_binary": dens.tobytes(),
+            **({"background_color": list(background_color)} if background_color is not None else {}),
+            **({"render_aabb": {"min": list(model.render_aabb[:3]), "max": list(model.render_aabb[3:])}}
+               if getattr(model, "render_aabb", None) is not None else {}),
             "nerf": {"aabb_scale": int(getattr(model, "aabb_scale", 1)), "dataset": {
                 "n_images": len(views), "scale": dataset_scale, "offset": list(dataset_offset),
                 "aabb_scale": int(getattr(model, "aabb_scale", 1)),

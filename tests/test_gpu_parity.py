@@ -263,11 +263,13 @@ def test_lds_bricks_are_bit_identical_to_global_tables(gpu):
     assert out[0][2] == out[1][2] > 10000
 
 
-@pytest.mark.parametrize("variant", ["small_tables", "bigger_object", "huge_object"])
+@pytest.mark.parametrize("variant", ["small_tables", "bigger_object", "huge_object", "l8f4", "l8f4_small_tables", "render_aabb"])
 def test_other_kernel_instantiations(gpu, variant):
     """The march kernel is instantiated per table/occupancy shape: generic slot kinds for a level
     table with 3 dense levels (2^15-entry tables), 4 LDS-bricked slots for a bigger object, no
-    bricks for an object filling a quarter of the cube.  Each against the oracle."""
+    bricks for an object filling a quarter of the cube; the other hash-grid layout a snapshot may
+    carry (L = 8 levels x F = 4 features: 8-byte entries, a lane pair splits a level's feature pairs);
+    and a model cropped by Testbed.render_aabb.  Each against the oracle."""
     import dataclasses
     from dream2real_amd.scene import NerfModel, grid_levels, world_to_ngp
     from tests.scenes import ellipsoid_occupancy, make_synthetic_nerf
@@ -280,10 +282,20 @@ def test_other_kernel_instantiations(gpu, variant):
     elif variant == "bigger_object":
         levels = grid_levels()
         occ = ellipsoid_occupancy(centre, (0.09, 0.11, 0.09))
-    else:
+    elif variant == "huge_object":
         levels = grid_levels()
         occ = ellipsoid_occupancy((0.5, 0.5, 0.5), (0.3, 0.3, 0.3))
+    elif variant in ("l8f4", "l8f4_small_tables"):
+        levels = grid_levels(n_levels=8, n_features=4, log2_hashmap_size=19 if variant == "l8f4" else 15)
+        assert levels.n_entries * 4 * 2 < 64 << 20 and abs(levels.per_level_scale - 2.0) < 1e-6
+        assert list(levels.hashed).index(True) == (3 if variant == "l8f4" else 2)
+        occ = ellipsoid_occupancy(centre, (0.04, 0.05, 0.04))
+    else:
+        levels = grid_levels()
+        occ = ellipsoid_occupancy(centre, (0.05, 0.06, 0.05))
     model = make_synthetic_nerf(occ, seed_grid=21, seed_mlp=22, levels=levels)
+    if variant == "render_aabb":         # crop: keep the part of the object on one side of a plane through it, and a slab in z
+        model = dataclasses.replace(model, render_aabb=(0.0, 0.0, float(centre[2]) - 0.02, float(centre[0]) + 0.01, 1.0, float(centre[2]) + 0.03))
     tb = engine.Testbed(ctx, model)
     tb.background_color = [0.0, 0.0, 0.0, 1.0]
     W, H = 96, 54
@@ -298,6 +310,19 @@ def test_other_kernel_instantiations(gpu, variant):
         np.testing.assert_allclose(rgba[i], orgba, rtol=0, atol=5e-3)
         np.testing.assert_allclose(depth[i], odepth, rtol=0, atol=2e-3)
     assert abs(tb.last_samples - pipe.n_samples) <= 0.01 * pipe.n_samples and pipe.n_samples > 2000
+    if variant == "render_aabb":         # the crop really removes samples
+        full = render_ref.OracleNerf(dataclasses.replace(model, render_aabb=None))
+        n_full = sum(render_ref.render(full, pipe.view_fg, pipe.fg_camera(p))[2] for p in poses)
+        assert pipe.n_samples < 0.8 * n_full
+    if variant.startswith("l8f4"):       # the field itself, at arbitrary points (hashed and dense levels, cube corners)
+        r = np.random.Generator(np.random.PCG64(1))
+        xyz = r.random((777, 3)).astype(np.float32)
+        xyz[0], xyz[1] = (0.0, 0.0, 0.0), (1.0, 1.0, 1.0)
+        dirs = r.standard_normal((777, 3)).astype(np.float32)
+        dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+        got, want = tb.eval_points(xyz, dirs), render_ref.eval_points(pipe.fg, xyz, dirs)
+        np.testing.assert_allclose(got[:, 0], want[:, 0], rtol=1e-2, atol=1e-3)
+        np.testing.assert_allclose(got[:, 1:], want[:, 1:], rtol=0, atol=1e-2)
     # bricks on/off bit-identical for this shape too
     ctx.set_option("bricks", 0)
     rgba0, depth0 = tb.render_batch(cams, W, H)
@@ -578,6 +603,7 @@ def test_renderer_with_sensor_depth_background(gpu, tmp_path):
     poses = host_ref.sample_poses_grid(scene.scene_centre, [3, 3, 1, 1, 1, 1], scene.scene_type).reshape(-1, 4, 4)
     frames = rend.render(host_ref.converter(poses), host_ref.converter(np.asarray(scene.cam_poses, np.float32))[:1], [0],
                          depths_gt=depth, movable_masks=masks, save=True)
+    rend.wait_saved()                    # the PNGs are written by a worker thread; optimise_pose_grid joins it the same way
     assert len(frames) == 9 and (tmp_path / "cb_render" / "cb_rgb_0008.png").exists()
     # oracle with the same rectified background depth
     pipe = OraclePipeline(scene, W, H)

@@ -81,3 +81,31 @@ def test_occupancy_threshold_follows_instant_ngp():
     dens2[0, :1000] = 0.009
     occ2 = ingp.occupancy_from_density(dens2)
     assert occ2.sum() == 128 ** 3 - 1000
+
+
+def test_l8f4_layout_background_and_render_aabb_round_trip(tmp_path):
+    """The other layout a snapshot may carry (L = 8, F = 4), the saved background colour and a cropped
+    render_aabb survive save -> load; layouts with another input width are refused."""
+    import dataclasses
+    from dream2real_amd.scene import grid_levels
+    from tests.scenes import ellipsoid_occupancy, make_synthetic_nerf
+    levels = grid_levels(n_levels=8, n_features=4, log2_hashmap_size=14)
+    model = make_synthetic_nerf(ellipsoid_occupancy((0.5, 0.5, 0.5), (0.1, 0.1, 0.1)), seed_grid=3, seed_mlp=4, levels=levels)
+    model = dataclasses.replace(model, render_aabb=(0.1, 0.2, 0.3, 0.9, 0.8, 0.7))
+    path = str(tmp_path / "m.ingp")
+    save_ingp(path, model, background_color=(0.0, 0.0, 0.0, 0.0))
+    got, info = ingp.load_ingp(path)
+    assert (got.levels.n_levels, got.levels.n_features) == (8, 4) and got.grid.shape == (levels.n_entries, 4)
+    np.testing.assert_array_equal(got.grid, model.grid)
+    np.testing.assert_array_equal(got.dw1, model.dw1)
+    np.testing.assert_allclose(got.render_aabb, model.render_aabb, rtol=0, atol=1e-7)
+    assert info["background_color"] == [0.0, 0.0, 0.0, 0.0]
+    # render_aabb equal to the whole box is "no crop"
+    save_ingp(path, dataclasses.replace(model, render_aabb=(0.0, 0.0, 0.0, 1.0, 1.0, 1.0)))
+    assert ingp.load_ingp(path)[0].render_aabb is None
+    import msgpack, zlib
+    cfg = msgpack.unpackb(zlib.decompress(open(path, "rb").read()), raw=False)
+    cfg["encoding"]["n_levels"] = 12
+    open(path, "wb").write(zlib.compress(msgpack.packb(cfg, use_bin_type=True)))
+    with pytest.raises(ValueError):
+        ingp.load_ingp(path)
