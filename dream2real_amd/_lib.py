@@ -18,7 +18,7 @@ EXPORTS = [
     "d2r_clip_score_frames", "d2r_clip_preprocess", "d2r_clip_embed_pixels", "d2r_render_score",
     "d2r_get_render_stats", "d2r_collect_render_stats", "d2r_ctx_set_option", "d2r_get_timing", "d2r_text_create",
     "d2r_text_destroy", "d2r_text_encode", "d2r_comm_get_unique_id", "d2r_comm_init", "d2r_comm_destroy",
-    "d2r_allgather_scores",
+    "d2r_allgather_scores", "d2r_phys_create", "d2r_phys_destroy", "d2r_phys_check",
 ]
 
 
@@ -52,6 +52,12 @@ class TextDesc(C.Structure):
     _fields_ = [("vocab_size", C.c_uint32), ("context_length", C.c_uint32), ("hidden_size", C.c_uint32),
                 ("num_layers", C.c_uint32), ("num_heads", C.c_uint32), ("mlp_size", C.c_uint32),
                 ("proj_dim", C.c_uint32)]
+
+
+class PhysParams(C.Structure):
+    _fields_ = [("sample_res", C.c_uint32 * 6), ("init_pose", C.c_float * 16), ("table_z", C.c_float),
+                ("unsup_thresh", C.c_float), ("gravity", C.c_float * 3), ("perturb", C.c_float),
+                ("stability_check", C.c_int32), ("disallow_regrasp", C.c_int32)]
 
 
 class RenderStats(C.Structure):
@@ -93,6 +99,7 @@ def load() -> C.CDLL:
     lib.d2r_nerf_destroy.restype = None
     lib.d2r_clip_destroy.restype = None
     lib.d2r_text_destroy.restype = None
+    lib.d2r_phys_destroy.restype = None
     for name in EXPORTS:
         getattr(lib, name)          # every declared symbol must be exported
     if lib.d2r_abi_version() != ABI_VERSION:

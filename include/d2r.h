@@ -317,6 +317,40 @@ D2R_API int d2r_comm_destroy(d2r_ctx *ctx);
  */
 D2R_API int d2r_allgather_scores(d2r_ctx *ctx, const float *local_dev, size_t n_local, float *global_dev);
 
+/* ------------------------------------------ batched physics pre-filter */
+
+/*
+ * replaces the per-pose PyBullet loop of unsupcol_check (reference vision_3d/physics_utils.py:248-375), the
+ * phys_check the path calls before rendering (clip_scoring.py:108-113, dream2real.py:304-326): duplicate
+ * orientations (:260-278), optional regrasp rule (:281-301), then per pose collision (:314-321), support
+ * (:329-340) and stability (:349-365).  Shapes are convex hulls given as vertex sets — PyBullet's GEOM_MESH
+ * without the concave flag (:239) is the convex hull of the mesh; "collides / touches" is hull intersection
+ * (GJK, one wavefront per pose).  PyBullet's collision margins are not modelled.
+ *   movable_verts   host [n_movable][3]  movable object's hull, world frame, at the object's initial pose
+ *   static_verts    host [static_offsets[n_static]][3]  hulls of the static objects, concatenated
+ *   static_offsets  host [n_static + 1]  first vertex of each static hull
+ */
+typedef struct d2r_phys d2r_phys;
+D2R_API int d2r_phys_create(d2r_ctx *ctx, const float *movable_verts, uint32_t n_movable, const float *static_verts,
+                            const uint32_t *static_offsets, uint32_t n_static, d2r_phys **out);
+D2R_API void d2r_phys_destroy(d2r_phys *phys);
+typedef struct {
+    uint32_t sample_res[6];   /* the pose grid's resolution: orientations per position = res[3] * res[4] * res[5] */
+    float init_pose[16];      /* task_model.movable_obj.pose, row-major 4x4 (world) */
+    float table_z;            /* scene_centre[2]: a pose below it counts as supported (:332-334) */
+    float unsup_thresh;       /* 0.02: how far the object is lowered for the support test */
+    float gravity[3];         /* GRAVITY_DIRECTION (0, 0, -1) */
+    float perturb;            /* 0.04: sideways offset of the four stability probes */
+    int32_t stability_check;  /* non-zero: run the stability probes */
+    int32_t disallow_regrasp; /* non-zero: keep only orientations whose object z axis faces +z or -y (:281-301) */
+} d2r_phys_params;
+/*
+ *   pose_batch  host [N][16] sampled poses (world, sample_poses_grid order: orientations fastest)
+ *   valid_io    host [N] uint8: valid_so_far in, is_valid out
+ */
+D2R_API int d2r_phys_check(d2r_ctx *ctx, const d2r_phys *phys, const d2r_phys_params *params, const float *pose_batch,
+                           uint32_t N, uint8_t *valid_io);
+
 #ifdef __cplusplus
 }
 #endif
