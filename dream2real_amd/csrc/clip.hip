@@ -1033,15 +1033,185 @@ __global__ __launch_bounds__(256) void k_layernorm(const float *__restrict__ X, 
 
 // ------------------------------------------------------------- attention
 
+// combine the two lanes (l, l ^ 32) that hold the halves of one query's scores: v_permlane32_swap exchanges the
+// upper half of one register with the lower half of the other on the VALU (a __shfl_xor goes through the LDS)
+__device__ __forceinline__ float half_max(float x)
+{
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float half_sum(float x)
+{
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 // QKV [rows][3d] bf16 (q | k | v, head h at columns h*64), out AO [rows][d] bf16.
 // grid (heads, images); block 256; dynamic LDS: K [T_pad][64] swizzled + Vt [64][T_pad+4].
 #define ATTN_THREADS 512
+// One 32-query tile of one (image, head) against all keys staged in LDS (Ks: K rows, swizzled 16-byte chunks;
+// Vt: V^T, [64][vstride]): S^T = K Q^T so that a query's scores are lane-local, online softmax in the exp2
+// domain, P fed back as the MFMA B operand, O^T accumulated; writes the tile's rows of AO.
 template <bool CAUSAL>
-__global__ __launch_bounds__(ATTN_THREADS, 2) void k_attention(const uint16_t *__restrict__ QKV,
+__device__ __forceinline__ void attn_qtile(const uint8_t *__restrict__ Ks, const uint16_t *__restrict__ Vt, uint32_t vstride,
+                                           const uint4 (&qf)[4], uint32_t qt, uint32_t T, uint32_t n_kt, uint32_t li,
+                                           uint32_t hi, uint16_t *__restrict__ AO, size_t row_base, uint32_t d, uint32_t head)
+{
+    const float sm_c = 0.125f * 1.4426950408889634f;   // head_dim^-0.5 * log2(e), head_dim = 64
+    const uint32_t qrow = qt * 32 + li;
+    {
+        f32x16 o0, o1;
+#pragma unroll
+        for (int r = 0; r < 16; r++) o0[r] = o1[r] = 0.f;
+        float m_run = -INFINITY, l_run = 0.f;
+        // causal: key tiles beyond the last query row of this tile are fully masked
+        const uint32_t kt_end = CAUSAL ? min(n_kt, qt + 1) : n_kt;
+        // LDS addresses of this lane's fragments advance by a constant per key tile (32 K rows = 4096 B
+        // with an unchanged swizzle term, 32 keys = 64 B along a V^T row): two running pointers and
+        // immediate offsets instead of a dozen address computations per tile (the kernel is VALU-bound)
+        const uint8_t *kp[4];
+#pragma unroll
+        for (int s = 0; s < 4; s++) kp[s] = Ks + lds_off(li, 2 * s + hi);
+        const uint16_t *vp0 = Vt + (size_t)li * vstride + 4 * hi, *vp1 = Vt + (size_t)(32 + li) * vstride + 4 * hi;
+        // K fragments are software-pipelined: the reads of tile kt+1 are issued right after the S MFMAs of tile
+        // kt (into the registers those MFMAs have just consumed), so their LDS latency hides under the
+        // softmax and the PV MFMAs instead of standing in front of every S chain
+        uint4 ka[4];
+#pragma unroll
+        for (int s = 0; s < 4; s++) ka[s] = *(const uint4 *)(kp[s]);
+        for (uint32_t kt = 0; kt < kt_end; kt++) {
+            f32x16 sacc;
+#pragma unroll
+            for (int r = 0; r < 16; r++) sacc[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                union { uint4 u; bf16x8 v; } a, b;
+                a.u = ka[s];
+                b.u = qf[s];
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, sacc, 0, 0, 0);
+            }
+            if (kt + 1 < kt_end) {
+#pragma unroll
+                for (int s = 0; s < 4; s++) ka[s] = *(const uint4 *)(kp[s] + (kt + 1) * 4096u);
+            }
+            // lane (q, hi), reg r  <->  key kt*32 + (r&3) + 8*(r>>2) + 4*hi.  Softmax in the exp2 domain:
+            // p = exp2(s*c - m) with c = head_dim^-0.5 * log2(e) and m the running maximum of s*c.  Only
+            // the tile that holds keys >= T (and, for the causal text tower, the diagonal tile) needs
+            // the mask; the select keeps garbage in K rows >= T out of the arithmetic.
+            const bool need_mask = (kt + 1) * 32 > T || (CAUSAL && kt == qt);      // wave-uniform
+            if (need_mask) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const uint32_t key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    sacc[r] = (key < T && (!CAUSAL || key <= qrow)) ? sacc[r] : -INFINITY;
+                }
+            }
+            float tmax = sacc[0];
+#pragma unroll
+            for (int r = 1; r < 16; r++) tmax = fmaxf(tmax, sacc[r]);
+            tmax = half_max(tmax) * sm_c;
+            const float m_new = fmaxf(m_run, tmax);
+            // rescale the running sums only when some query's maximum moved (exact: alpha would be 1)
+            if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);      // m_run = -inf on the first tile -> 0
+                l_run *= alpha;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    o0[r] *= alpha;
+                    o1[r] *= alpha;
+                }
+                m_run = m_new;
+            }
+            // s*c - m on packed pairs (v_pk_fma_f32), 16 exp2, pairwise tree sum (v_pk_add_f32)
+            {
+                typedef float f32x8 __attribute__((ext_vector_type(8)));
+                typedef float f32x4 __attribute__((ext_vector_type(4)));
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                const f32x16 cv = sm_c, mv = -m_new;
+                const f32x16 t = __builtin_elementwise_fma(sacc, cv, mv);
+#pragma unroll
+                for (int r = 0; r < 16; r++) sacc[r] = __builtin_amdgcn_exp2f(t[r]);
+                const f32x8 s8 = sacc.lo + sacc.hi;
+                const f32x4 s4 = s8.lo + s8.hi;
+                const f32x2 s2 = s4.lo + s4.hi;
+                l_run += s2.x + s2.y;
+            }
+            // O^T[d][q] += V^T[d][key] P^T[key][q]; P regs 8s..8s+7 are the B fragment of k-step s
+            const uint16_t *vq0 = vp0 + kt * 32, *vq1 = vp1 + kt * 32;
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                union { uint4 u; bf16x8 v; } pb, va0, va1;
+                pb.u.x = pack2(sacc[8 * s + 0], sacc[8 * s + 1]);
+                pb.u.y = pack2(sacc[8 * s + 2], sacc[8 * s + 3]);
+                pb.u.z = pack2(sacc[8 * s + 4], sacc[8 * s + 5]);
+                pb.u.w = pack2(sacc[8 * s + 6], sacc[8 * s + 7]);
+                // A slot (hi, j) <-> key kt*32 + 16s + 8(j>>2) + 4hi + (j&3)
+                const uint2 a00 = *(const uint2 *)(vq0 + 16 * s);
+                const uint2 a01 = *(const uint2 *)(vq0 + 16 * s + 8);
+                const uint2 a10 = *(const uint2 *)(vq1 + 16 * s);
+                const uint2 a11 = *(const uint2 *)(vq1 + 16 * s + 8);
+                va0.u = make_uint4(a00.x, a00.y, a01.x, a01.y);
+                va1.u = make_uint4(a10.x, a10.y, a11.x, a11.y);
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va0.v, pb.v, o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va1.v, pb.v, o1, 0, 0, 0);
+            }
+        }
+        const float l_tot = half_sum(l_run);
+        const float inv_l = 1.0f / l_tot;
+        if (qrow < T) {
+            uint16_t *dst = AO + (row_base + qrow) * d + head * 64;
+            // lane (q, hi), reg r of o{0,1} <-> dim 32*{0,1} + (r&3) + 8*(r>>2) + 4*hi
+#pragma unroll
+            for (int g4 = 0; g4 < 4; g4++) {
+                uint2 w0, w1;
+                w0.x = pack2(o0[4 * g4 + 0] * inv_l, o0[4 * g4 + 1] * inv_l);
+                w0.y = pack2(o0[4 * g4 + 2] * inv_l, o0[4 * g4 + 3] * inv_l);
+                w1.x = pack2(o1[4 * g4 + 0] * inv_l, o1[4 * g4 + 1] * inv_l);
+                w1.y = pack2(o1[4 * g4 + 2] * inv_l, o1[4 * g4 + 3] * inv_l);
+                *(uint2 *)(dst + 8 * g4 + 4 * hi) = w0;
+                *(uint2 *)(dst + 32 + 8 * g4 + 4 * hi) = w1;
+            }
+        }
+    }
+}
+
+#ifdef D2R_ATTN_STAMPS
+// development only: shader-clock cycles per workgroup section seen by wave 0:
+// [0] issue of all loads + V transposes, [1] wait for the K copies, [2] barrier, [3] compute + store, [4] workgroups
+__device__ unsigned long long d2r_attn_stamps[8];
+extern "C" __attribute__((visibility("default"))) int d2r_debug_attn_stamps(unsigned long long *out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(d2r_attn_stamps), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(d2r_attn_stamps), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
+template <bool CAUSAL>
+__global__ __launch_bounds__(ATTN_THREADS, 4) void k_attention(const uint16_t *__restrict__ QKV,
                                                                uint16_t *__restrict__ AO, uint32_t T, uint32_t T_pad,
-                                                               uint32_t d)
+                                                               uint32_t d, uint32_t stagger_lo, uint32_t stagger_hi)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    // Every workgroup does the same work — load Q/K/V, barrier, arithmetic — so a launch whose workgroups all start
+    // together stays in lockstep: the whole chip loads (each CU at its HBM share), then the whole chip computes with
+    // the memory system idle (cycle stamps: 18 k + 13 k cycles per workgroup).  The first generation's second
+    // workgroup per CU starts half a period late; equal durations keep later generations half a period apart, so one
+    // workgroup's loads overlap the other's arithmetic on every CU.
+    {
+        const uint32_t lin = blockIdx.y * gridDim.x + blockIdx.x;
+        if (lin >= stagger_lo && lin < stagger_hi) {
+#pragma unroll 1
+            for (int i = 0; i < 2; i++) __builtin_amdgcn_s_sleep(127);
+        }
+    }
+#ifdef D2R_ATTN_STAMPS
+    const unsigned long long at0 = __builtin_readcyclecounter();
+#endif
     uint8_t *Ks = smem;                                  // T_pad * 128 B
     uint16_t *Vt = (uint16_t *)(smem + (size_t)T_pad * 128);
     const uint32_t vstride = T_pad + 4;
@@ -1094,119 +1264,170 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void k_attention(const uint16_t *_
             *(uint2 *)(Vt + (size_t)(c * 8 + 2 * p + 1) * vstride + kb) = hi2;
         }
     }
+#ifdef D2R_ATTN_STAMPS
+    const unsigned long long at1 = __builtin_readcyclecounter();
+#endif
     wait_vmcnt<0>();              // this wave's K copies have landed
+#ifdef D2R_ATTN_STAMPS
+    const unsigned long long at2 = __builtin_readcyclecounter();
+#endif
     __syncthreads();
+#ifdef D2R_ATTN_STAMPS
+    const unsigned long long at3 = __builtin_readcyclecounter();
+#endif
 
-    const float sm_c = 0.125f * 1.4426950408889634f;   // head_dim^-0.5 * log2(e), head_dim = 64
     for (uint32_t qt = wave; qt < n_qt; qt += ATTN_THREADS / 64) {
-        const uint32_t qrow = qt * 32 + li;
         if (qt != wave) {
+            const uint32_t qrow = qt * 32 + li;
 #pragma unroll
             for (int s = 0; s < 4; s++)
                 qf[s] = qrow < T ? *(const uint4 *)(Qg + (size_t)qrow * ld + 16 * s + 8 * hi) : make_uint4(0, 0, 0, 0);
         }
-        f32x16 o0, o1;
+        attn_qtile<CAUSAL>(Ks, Vt, vstride, qf, qt, T, n_kt, li, hi, AO, row_base, d, head);
+    }
+#ifdef D2R_ATTN_STAMPS
+    {
+        const unsigned long long at4 = __builtin_readcyclecounter();
+        if (threadIdx.x == 0) {
+            atomicAdd(&d2r_attn_stamps[0], at1 - at0);
+            atomicAdd(&d2r_attn_stamps[1], at2 - at1);
+            atomicAdd(&d2r_attn_stamps[2], at3 - at2);
+            atomicAdd(&d2r_attn_stamps[3], at4 - at3);
+            atomicAdd(&d2r_attn_stamps[4], 1ull);
+        }
+    }
+#endif
+}
+
+// ---- persistent, double-buffered attention (vision tower) ----
+//
+// k_attention above gives each (image, head) its own workgroup: load Q/K/V, barrier, compute.  Every workgroup
+// of the launch is in the same phase at the same time (cycle stamps: 18 k cycles of loads at the per-CU HBM share,
+// then 13 k cycles of arithmetic with the memory system idle), so the kernel runs at ~55 % of the HBM rate.  Here one
+// workgroup per CU walks its share of the items with TWO K / V^T buffers in LDS: while item i is computed from
+// one buffer, item i+1's K streams into the other by LDS-DMA and its V and Q rows wait in registers; V is
+// transposed into LDS after the arithmetic.  Loads and arithmetic of different items overlap on every CU.
+// Items are (image, head) pairs, consecutive items = consecutive heads of one image (the same QKV rows).
+#define ATTN_MAX_VTASKS 2          /* V staging tasks per thread: (T_pad / 4) * 8 <= 2 * ATTN_THREADS */
+__global__ __launch_bounds__(ATTN_THREADS, 2) void k_attention_p(const uint16_t *__restrict__ QKV, uint16_t *__restrict__ AO,
+                                                                 uint32_t T, uint32_t T_pad, uint32_t d, uint32_t n_heads,
+                                                                 uint32_t n_items)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t vstride = T_pad + 4;
+    const uint32_t buf_bytes = T_pad * 128u + 64u * vstride * 2u;       // K rows + V^T of one item (a multiple of 16)
+    const uint32_t tid = threadIdx.x, lane = tid & 63, li = lane & 31, hi = lane >> 5;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t ld = 3 * d, n_qt = (T + 31) / 32, n_kt = T_pad / 32;
+    const uint32_t n_vtasks = (T_pad / 4) * 8;
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+
+    auto item_base = [&](uint32_t item, size_t &row_base, uint32_t &head) {
+        const uint32_t img = item / n_heads;
+        head = item - img * n_heads;
+        row_base = (size_t)img * T;
+    };
+    // K rows of `item` -> buffer b by LDS-DMA (rows >= T repeat row T-1: masked by a select, any finite value does)
+    auto issue_k = [&](uint32_t item, uint32_t b) {
+        size_t rb; uint32_t head;
+        item_base(item, rb, head);
+        const uint16_t *Kg = QKV + rb * ld + head * 64 + d;
+        for (uint32_t blk = wave; blk < T_pad / 8; blk += ATTN_THREADS / 64) {
+            const uint32_t row = blk * 8 + (lane >> 3), src_row = row < T ? row : T - 1;
+            glds16(Kg + (size_t)src_row * ld + ((lane & 7) ^ ((row >> 1) & 7u)) * 8, lds0 + b * buf_bytes + blk * 1024);
+        }
+    };
+    // V rows of `item` -> registers: a task takes 4 keys x 8 dims (four 16-byte loads)
+    auto load_v = [&](uint32_t item, uint4 (&v)[ATTN_MAX_VTASKS][4]) {
+        size_t rb; uint32_t head;
+        item_base(item, rb, head);
+        const uint16_t *Vg = QKV + rb * ld + head * 64 + 2 * d;
 #pragma unroll
-        for (int r = 0; r < 16; r++) o0[r] = o1[r] = 0.f;
-        float m_run = -INFINITY, l_run = 0.f;
-        // causal: key tiles beyond the last query row of this tile are fully masked
-        const uint32_t kt_end = CAUSAL ? min(n_kt, qt + 1) : n_kt;
-        // LDS addresses of this lane's fragments advance by a constant per key tile (32 K rows = 4096 B
-        // with an unchanged swizzle term, 32 keys = 64 B along a V^T row): two running pointers and
-        // immediate offsets instead of a dozen address computations per tile (the kernel is VALU-bound)
-        const uint8_t *kp[4];
+        for (int t = 0; t < ATTN_MAX_VTASKS; t++) {
+            const uint32_t i = tid + t * ATTN_THREADS;
+            if (i < n_vtasks) {
+                const uint32_t kb = (i >> 3) * 4, c = i & 7;
 #pragma unroll
-        for (int s = 0; s < 4; s++) kp[s] = Ks + lds_off(li, 2 * s + hi);
-        const uint16_t *vp0 = Vt + (size_t)li * vstride + 4 * hi, *vp1 = Vt + (size_t)(32 + li) * vstride + 4 * hi;
-        for (uint32_t kt = 0; kt < kt_end; kt++) {
-            f32x16 sacc;
-#pragma unroll
-            for (int r = 0; r < 16; r++) sacc[r] = 0.f;
-#pragma unroll
-            for (int s = 0; s < 4; s++) {
-                union { uint4 u; bf16x8 v; } a, b;
-                a.u = *(const uint4 *)(kp[s] + kt * 4096u);
-                b.u = qf[s];
-                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, sacc, 0, 0, 0);
-            }
-            // lane (q, hi), reg r  <->  key kt*32 + (r&3) + 8*(r>>2) + 4*hi.  Softmax in the exp2 domain:
-            // p = exp2(s*c - m) with c = head_dim^-0.5 * log2(e) and m the running maximum of s*c.  Only
-            // the tile that holds keys >= T (and, for the causal text tower, the diagonal tile) needs
-            // the mask; the select keeps garbage in K rows >= T out of the arithmetic.
-            const bool need_mask = (kt + 1) * 32 > T || (CAUSAL && kt == qt);      // wave-uniform
-            if (need_mask) {
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const uint32_t key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    sacc[r] = (key < T && (!CAUSAL || key <= qrow)) ? sacc[r] : -INFINITY;
-                }
-            }
-            float tmax = sacc[0];
-#pragma unroll
-            for (int r = 1; r < 16; r++) tmax = fmaxf(tmax, sacc[r]);
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32)) * sm_c;
-            const float m_new = fmaxf(m_run, tmax);
-            // rescale the running sums only when some query's maximum moved (exact: alpha would be 1)
-            if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {
-                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);      // m_run = -inf on the first tile -> 0
-                l_run *= alpha;
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    o0[r] *= alpha;
-                    o1[r] *= alpha;
-                }
-                m_run = m_new;
-            }
-            // s*c - m on packed pairs (v_pk_fma_f32), 16 exp2, pairwise tree sum (v_pk_add_f32)
-            {
-                typedef float f32x8 __attribute__((ext_vector_type(8)));
-                typedef float f32x4 __attribute__((ext_vector_type(4)));
-                typedef float f32x2 __attribute__((ext_vector_type(2)));
-                const f32x16 cv = sm_c, mv = -m_new;
-                const f32x16 t = __builtin_elementwise_fma(sacc, cv, mv);
-#pragma unroll
-                for (int r = 0; r < 16; r++) sacc[r] = __builtin_amdgcn_exp2f(t[r]);
-                const f32x8 s8 = sacc.lo + sacc.hi;
-                const f32x4 s4 = s8.lo + s8.hi;
-                const f32x2 s2 = s4.lo + s4.hi;
-                l_run += s2.x + s2.y;
-            }
-            // O^T[d][q] += V^T[d][key] P^T[key][q]; P regs 8s..8s+7 are the B fragment of k-step s
-            const uint16_t *vq0 = vp0 + kt * 32, *vq1 = vp1 + kt * 32;
-#pragma unroll
-            for (int s = 0; s < 2; s++) {
-                union { uint4 u; bf16x8 v; } pb, va0, va1;
-                pb.u.x = pack2(sacc[8 * s + 0], sacc[8 * s + 1]);
-                pb.u.y = pack2(sacc[8 * s + 2], sacc[8 * s + 3]);
-                pb.u.z = pack2(sacc[8 * s + 4], sacc[8 * s + 5]);
-                pb.u.w = pack2(sacc[8 * s + 6], sacc[8 * s + 7]);
-                // A slot (hi, j) <-> key kt*32 + 16s + 8(j>>2) + 4hi + (j&3)
-                const uint2 a00 = *(const uint2 *)(vq0 + 16 * s);
-                const uint2 a01 = *(const uint2 *)(vq0 + 16 * s + 8);
-                const uint2 a10 = *(const uint2 *)(vq1 + 16 * s);
-                const uint2 a11 = *(const uint2 *)(vq1 + 16 * s + 8);
-                va0.u = make_uint4(a00.x, a00.y, a01.x, a01.y);
-                va1.u = make_uint4(a10.x, a10.y, a11.x, a11.y);
-                o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va0.v, pb.v, o0, 0, 0, 0);
-                o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va1.v, pb.v, o1, 0, 0, 0);
+                for (int k = 0; k < 4; k++)
+                    v[t][k] = *(const uint4 *)(Vg + (size_t)(kb + k < T ? kb + k : T - 1) * ld + c * 8);   // keys >= T: finite filler, their P is 0
             }
         }
-        const float l_tot = l_run + __shfl_xor(l_run, 32);
-        const float inv_l = 1.0f / l_tot;
-        if (qrow < T) {
-            uint16_t *dst = AO + (row_base + qrow) * d + head * 64;
-            // lane (q, hi), reg r of o{0,1} <-> dim 32*{0,1} + (r&3) + 8*(r>>2) + 4*hi
+    };
+    // ... transposed 4x8 blocks in registers (v_perm_b32) -> V^T of buffer b, 8-byte words of 4 consecutive keys per dim
+    auto store_vt = [&](const uint4 (&v)[ATTN_MAX_VTASKS][4], uint32_t b) {
+        uint16_t *Vt = (uint16_t *)(smem + b * buf_bytes + T_pad * 128u);
 #pragma unroll
-            for (int g4 = 0; g4 < 4; g4++) {
-                uint2 w0, w1;
-                w0.x = pack2(o0[4 * g4 + 0] * inv_l, o0[4 * g4 + 1] * inv_l);
-                w0.y = pack2(o0[4 * g4 + 2] * inv_l, o0[4 * g4 + 3] * inv_l);
-                w1.x = pack2(o1[4 * g4 + 0] * inv_l, o1[4 * g4 + 1] * inv_l);
-                w1.y = pack2(o1[4 * g4 + 2] * inv_l, o1[4 * g4 + 3] * inv_l);
-                *(uint2 *)(dst + 8 * g4 + 4 * hi) = w0;
-                *(uint2 *)(dst + 32 + 8 * g4 + 4 * hi) = w1;
+        for (int t = 0; t < ATTN_MAX_VTASKS; t++) {
+            const uint32_t i = tid + t * ATTN_THREADS;
+            if (i < n_vtasks) {
+                const uint32_t kb = (i >> 3) * 4, c = i & 7;
+                const uint32_t *w0 = (const uint32_t *)&v[t][0], *w1 = (const uint32_t *)&v[t][1];
+                const uint32_t *w2 = (const uint32_t *)&v[t][2], *w3 = (const uint32_t *)&v[t][3];
+#pragma unroll
+                for (int p = 0; p < 4; p++) {      // dims 2p, 2p+1 live in word p of every key's chunk
+                    uint2 lo, hi2;
+                    lo.x = __builtin_amdgcn_perm(w1[p], w0[p], 0x05040100);
+                    lo.y = __builtin_amdgcn_perm(w3[p], w2[p], 0x05040100);
+                    hi2.x = __builtin_amdgcn_perm(w1[p], w0[p], 0x07060302);
+                    hi2.y = __builtin_amdgcn_perm(w3[p], w2[p], 0x07060302);
+                    *(uint2 *)(Vt + (size_t)(c * 8 + 2 * p) * vstride + kb) = lo;
+                    *(uint2 *)(Vt + (size_t)(c * 8 + 2 * p + 1) * vstride + kb) = hi2;
+                }
             }
         }
+    };
+    // this wave's query tile of `item` (B operand of S^T = K Q^T: lane (q, hi) holds Q[q][16s + 8hi .. +8))
+    auto load_q = [&](uint32_t item, uint4 (&q)[4]) {
+        size_t rb; uint32_t head;
+        item_base(item, rb, head);
+        const uint16_t *Qg = QKV + rb * ld + head * 64;
+        const uint32_t qrow = wave * 32 + li;
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+            q[s] = (wave < n_qt && qrow < T) ? *(const uint4 *)(Qg + (size_t)qrow * ld + 16 * s + 8 * hi) : make_uint4(0, 0, 0, 0);
+    };
+
+    uint32_t item = blockIdx.x;
+    if (item >= n_items) return;
+    uint4 qf[4], vreg[ATTN_MAX_VTASKS][4];
+    issue_k(item, 0);
+    load_v(item, vreg);
+    load_q(item, qf);
+    store_vt(vreg, 0);
+    wait_vmcnt<0>();
+    __syncthreads();
+    for (uint32_t b = 0;; b ^= 1u) {
+        const uint32_t next = item + gridDim.x;
+        const bool has_next = next < n_items;                      // block-uniform
+        uint4 qn[4];
+        if (has_next) {
+            // buffer b^1 was last read while the PREVIOUS item was computed; every wave has passed the barrier since
+            issue_k(next, b ^ 1u);
+            load_v(next, vreg);
+            load_q(next, qn);
+        }
+        size_t rb; uint32_t head;
+        item_base(item, rb, head);
+        const uint8_t *Ks = smem + b * buf_bytes;
+        const uint16_t *Vt = (const uint16_t *)(Ks + T_pad * 128u);
+        // one query tile per wave (n_qt <= 8); longer sequences take several rounds (their Q rows are loaded here)
+        for (uint32_t qt = wave; qt < n_qt; qt += ATTN_THREADS / 64) {
+            if (qt != wave) {
+                const uint16_t *Qg = QKV + rb * ld + head * 64;
+                const uint32_t qrow = qt * 32 + li;
+#pragma unroll
+                for (int s = 0; s < 4; s++)
+                    qf[s] = qrow < T ? *(const uint4 *)(Qg + (size_t)qrow * ld + 16 * s + 8 * hi) : make_uint4(0, 0, 0, 0);
+            }
+            attn_qtile<false>(Ks, Vt, vstride, qf, qt, T, n_kt, li, hi, AO, rb, d, head);
+        }
+        if (!has_next) break;
+        store_vt(vreg, b ^ 1u);
+#pragma unroll
+        for (int s = 0; s < 4; s++) qf[s] = qn[s];
+        wait_vmcnt<0>();              // this wave's K copies (and its AO stores) are complete
+        __syncthreads();              // buffer b^1 is complete; buffer b is free for the item after next
+        item = next;
     }
 }
 
@@ -1502,6 +1723,30 @@ static int launch_gemm(d2r_ctx *ctx, const uint16_t *A, const uint16_t *W, const
 
 // LDS footprint of k_attention for a padded sequence length, and the one-time opt-in to more than 64 KiB
 // of dynamic LDS (both the vision and the text tower go through here)
+// vision tower: the persistent double-buffered kernel when two K / V^T buffers fit in LDS (T <= ~270), else one
+// workgroup per (image, head)
+static int attention_setup(d2r_ctx *ctx, uint32_t T_pad, size_t *lds_out);
+static int launch_attention_vision(d2r_ctx *ctx, const uint16_t *QKV, uint16_t *AO, uint32_t T, uint32_t T_pad, uint32_t d,
+                                   uint32_t n_heads, uint32_t n, size_t attn_lds)
+{
+    const size_t two = 2 * attn_lds;
+    const uint32_t n_items = n * n_heads;
+    if (ctx->attn_persistent && two <= 160 * 1024 && (T_pad / 4) * 8 <= ATTN_MAX_VTASKS * ATTN_THREADS && n_items >= (uint32_t)ctx->n_cu) {
+        static PerDeviceOnce attr;
+        attr.run(ctx->device, [] {
+            (void)hipFuncSetAttribute((const void *)k_attention_p, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        });
+        hipLaunchKernelGGL(k_attention_p, dim3((uint32_t)ctx->n_cu), dim3(ATTN_THREADS), two, ctx->stream, QKV, AO, T, T_pad, d,
+                           n_heads, n_items);
+    } else {
+        // (two workgroups per CU when 2 * attn_lds fits: stagger the second one of the first generation)
+        const uint32_t lo = ctx->attn_stagger && 2 * attn_lds <= 160 * 1024 ? (uint32_t)ctx->n_cu : 0u;
+        hipLaunchKernelGGL(k_attention<false>, dim3(n_heads, n), dim3(ATTN_THREADS), attn_lds, ctx->stream, QKV, AO, T, T_pad, d,
+                           lo, lo ? 2u * (uint32_t)ctx->n_cu : 0u);
+    }
+    return D2R_OK;
+}
+
 static int attention_setup(d2r_ctx *ctx, uint32_t T_pad, size_t *lds_out)
 {
     const size_t attn_lds = (size_t)T_pad * 128 + (size_t)64 * (T_pad + 4) * 2;
@@ -1550,7 +1795,7 @@ int d2r_clip_forward(d2r_ctx *ctx, const d2r_clip *clip, const uint16_t *patches
             hipLaunchKernelGGL(k_layernorm, dim3((rows + 3) / 4), dim3(256), 0, ctx->stream, X, L.ln1_w, L.ln1_b, Xn,
                                rows, d);
             if ((rc = launch_gemm<EPI_BIAS_BF16>(ctx, Xn, L.w_qkv, L.b_qkv, QKV, rows, 3 * d, d))) return rc;
-            hipLaunchKernelGGL(k_attention<false>, dim3(D.num_heads, n), dim3(ATTN_THREADS), attn_lds, ctx->stream, QKV, AO, T, T_pad, d);
+            (void)launch_attention_vision(ctx, QKV, AO, T, T_pad, d, D.num_heads, n, attn_lds);
             if ((rc = launch_gemm<EPI_BIAS_RESID_F32>(ctx, AO, L.w_o, L.b_o, X, rows, d, d))) return rc;
             hipLaunchKernelGGL(k_layernorm, dim3((rows + 3) / 4), dim3(256), 0, ctx->stream, X, L.ln2_w, L.ln2_b, Xn,
                                rows, d);
@@ -1583,7 +1828,7 @@ int d2r_clip_forward(d2r_ctx *ctx, const d2r_clip *clip, const uint16_t *patches
         const ClipWeights::Layer &L = clip->layers[l];
         ln.cs = L.cs_qkv;
         if ((rc = launch_gemm<EPI_LN_BIAS_BF16>(ctx, Xn, L.wf_qkv, L.bf_qkv, QKV, rows, 3 * d, d, ln))) return rc;
-        hipLaunchKernelGGL(k_attention<false>, dim3(D.num_heads, n), dim3(ATTN_THREADS), attn_lds, ctx->stream, QKV, AO, T, T_pad, d);
+        (void)launch_attention_vision(ctx, QKV, AO, T, T_pad, d, D.num_heads, n, attn_lds);
         if (xf32) rc = launch_gemm<EPI_RESID_STATS_F32X>(ctx, AO, L.w_o, L.b_o, X, rows, d, d, st);
         else if (split) rc = launch_gemm<EPI_RESID_STATS_SPLIT>(ctx, AO, L.w_o, L.b_o, Xn, rows, d, d, st);
         else rc = launch_gemm<EPI_RESID_STATS_BF16>(ctx, AO, L.w_o, L.b_o, Xn, rows, d, d, st);
@@ -1866,7 +2111,7 @@ extern "C" int d2r_text_encode(d2r_ctx *ctx, const d2r_text *tt, const int32_t *
         const ClipWeights::Layer &L = tt->layers[l];
         hipLaunchKernelGGL(k_layernorm, dim3((rows + 3) / 4), dim3(256), 0, ctx->stream, X, L.ln1_w, L.ln1_b, Xn, rows, d);
         if ((rc = launch_gemm<EPI_BIAS_BF16>(ctx, Xn, L.w_qkv, L.b_qkv, QKV, rows, 3 * d, d))) return rc;
-        hipLaunchKernelGGL(k_attention<true>, dim3(D.num_heads, Cn), dim3(ATTN_THREADS), attn_lds, ctx->stream, QKV, AO, T, T_pad, d);
+        hipLaunchKernelGGL(k_attention<true>, dim3(D.num_heads, Cn), dim3(ATTN_THREADS), attn_lds, ctx->stream, QKV, AO, T, T_pad, d, 0u, 0u);
         if ((rc = launch_gemm<EPI_BIAS_RESID_F32>(ctx, AO, L.w_o, L.b_o, X, rows, d, d))) return rc;
         hipLaunchKernelGGL(k_layernorm, dim3((rows + 3) / 4), dim3(256), 0, ctx->stream, X, L.ln2_w, L.ln2_b, Xn, rows, d);
         if ((rc = launch_gemm<EPI_BIAS_GELU_BF16>(ctx, Xn, L.w_fc1, L.b_fc1, H, rows, mlp, d))) return rc;
