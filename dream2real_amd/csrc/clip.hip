@@ -246,6 +246,12 @@ struct EpiAux {
     uint16_t *xb;          // EPI_RESID_STATS_*: [M_pad][N] bf16 residual (read + written by _BF16, written by _F32X)
     float2 *part;          // EPI_RESID_STATS_*: [M_pad][N / 64] partial (sum, sum of squares) per 64-column group
     uint16_t *xlo;         // EPI_RESID_STATS_SPLIT: [M_pad][N] low half of the split residual
+    // Layout of bf16 activations.  "Tile-major" = [cols / 64][M_pad][64]: the 64-column group a wave tile produces
+    // (one attention head; one K-tile of the GEMM that consumes it) is a contiguous plane, so an epilogue writes
+    // whole 128-byte rows back to back and the consumer's LDS-DMA reads 8 KiB runs, instead of 128-byte pieces
+    // at a row stride of 1.5-6 KiB (HBM delivers about half its streaming rate on those).
+    uint32_t hm_rows;      // bf16 output (and xb / xlo) tile-major with this many rows per plane (M_pad); 0 = row-major
+    uint32_t a_rs, a_ks;   // A operand: elements between rows, and between K-tiles (row-major: K, 64; tile-major: 64, 64 M_pad); 0,0 = row-major
 };
 
 // Development-only ablation switches of k_gemm8 and the shared epilogue (bitmask, default 0 = the real
@@ -345,9 +351,13 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], float *ep, u
         static_assert(MT % 2 == 0, "epilogue handles m-tiles in pairs");
         if (EPI == EPI_F32) hook();
         const uint32_t np = N >> 6;
+        // element offset of this lane's 4 columns of `row` in the bf16 residual arrays (tile-major planes, or row-major)
+        auto xoff = [&](uint32_t row) -> uint32_t {
+            return aux.hm_rows ? ((col0 >> 6) * aux.hm_rows + row) * 64u + c4 : row * N + col;
+        };
         // m-tiles whose residual rows are requested together (the fp32-residual + statistics variant carries the
         // most live values: one m-tile at a time keeps it out of scratch)
-        constexpr int G = EPI == EPI_RESID_STATS_F32X ? 1 : 2;
+        constexpr int G = (EPI == EPI_RESID_STATS_F32X || EPI == EPI_BIAS_RESID_F32) ? 1 : 2;
 #pragma unroll
         for (int ih = 0; ih < MT; ih += G) {
             float4 xr[G][8];
@@ -362,8 +372,8 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], float *ep, u
                             xr[ii][k] = (D2R_GEMM_ABLATE & 128) ? make_float4(0.f, 0.f, 0.f, 0.f)
                                                                 : *(const float4 *)((const float *)Cout + row * N + col);
                         else
-                            xh[ii][k] = *(const uint2 *)(aux.xb + row * N + col);
-                        if (SPLIT) xl[ii][k] = *(const uint2 *)(aux.xlo + row * N + col);
+                            xh[ii][k] = *(const uint2 *)(aux.xb + xoff(row));
+                        if (SPLIT) xl[ii][k] = *(const uint2 *)(aux.xlo + xoff(row));
                     }
                 if (ih == MT - G) hook();
             }
@@ -397,9 +407,9 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], float *ep, u
                             // the bf16 copy the next GEMM reads as its A operand, and this 64-column group's share of
                             // the row's LayerNorm statistics (of the fp32 values: the rounding averages out over d)
                             const uint2 hv = make_uint2(pack2(v.x, v.y), pack2(v.z, v.w));
-                            *(uint2 *)(aux.xb + row * N + col) = hv;
+                            *(uint2 *)(aux.xb + xoff(row)) = hv;
                             if (SPLIT)
-                                *(uint2 *)(aux.xlo + row * N + col) = make_uint2(pack2(v.x - bf_lo(hv.x), v.y - bf_hi(hv.x)),
+                                *(uint2 *)(aux.xlo + xoff(row)) = make_uint2(pack2(v.x - bf_lo(hv.x), v.y - bf_hi(hv.x)),
                                                                                  pack2(v.z - bf_lo(hv.y), v.w - bf_hi(hv.y)));
                             const float sm = row16_sum((v.x + v.y) + (v.z + v.w));
                             const float sq = row16_sum(fmaf(v.x, v.x, v.y * v.y) + fmaf(v.z, v.z, v.w * v.w));
@@ -455,7 +465,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], float *ep, u
                 asm volatile("" ::"v"(pk.x), "v"(pk.y), "v"(pk.z), "v"(pk.w));
                 continue;
 #endif
-                *(uint4 *)((uint16_t *)Cout + row * N + col) = pk;
+                *(uint4 *)((uint16_t *)Cout + (aux.hm_rows ? ((col0 >> 6) * aux.hm_rows + row) * 64u + c8 : row * N + col)) = pk;
             }
         }
     }
@@ -505,11 +515,12 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void k_gemm(const uint16_t *__re
     // staging: an 8-row x 128-byte block per wave instruction.  lane -> (row in block, physical
     // chunk); it fetches the swizzle-inverse logical chunk.
     const uint32_t r_in = lane >> 3, pc = lane & 7;
+    const size_t a_rs = aux.a_rs ? aux.a_rs : K, a_ks = aux.a_rs ? aux.a_ks : BK;       // A operand layout (EpiAux)
     const uint16_t *ag[A_PER_WAVE], *wg[B_PER_WAVE];
 #pragma unroll
     for (int i = 0; i < A_PER_WAVE; i++) {
         const uint32_t row = (wave * A_PER_WAVE + i) * 8 + r_in;
-        ag[i] = A + (size_t)(m0 + row) * K + (pc ^ ((row >> 1) & 7u)) * 8;
+        ag[i] = A + (size_t)(m0 + row) * a_rs + (pc ^ ((row >> 1) & 7u)) * 8;
     }
 #pragma unroll
     for (int i = 0; i < B_PER_WAVE; i++) {
@@ -523,7 +534,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void k_gemm(const uint16_t *__re
         const uint32_t base = lds0 + buf * STAGE_BYTES;
 #pragma unroll
         for (int i = 0; i < A_PER_WAVE; i++)
-            if (idx == i) glds16(ag[i] + (size_t)kt * BK, base + (wave * A_PER_WAVE + i) * 1024);
+            if (idx == i) glds16(ag[i] + (size_t)kt * a_ks, base + (wave * A_PER_WAVE + i) * 1024);
 #pragma unroll
         for (int i = 0; i < B_PER_WAVE; i++)
             if (idx == A_PER_WAVE + i)
@@ -671,12 +682,14 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
 
     // staging: piece qq of a half-tile = 8 slot rows x 128 B per wave instruction
     const uint32_t r_in = lane >> 3, pc = lane & 7;
+    const uint32_t a_rs = aux.a_rs ? aux.a_rs : K;                                      // A operand layout (EpiAux)
+    const size_t a_ks = aux.a_rs ? aux.a_ks : BK;
     uint32_t voffA[2], voffB[2];
 #pragma unroll
     for (int qq = 0; qq < 2; qq++) {
         const uint32_t sr = (wave * 2 + qq) * 8 + r_in;                       // slot row 0..127
         const uint32_t chunk = pc ^ ((sr >> 1) & 7u);
-        voffA[qq] = (((sr >> 6) * 128 + (sr & 63)) * K + chunk * 8) * 2;       // bytes from the half's first row
+        voffA[qq] = (((sr >> 6) * 128 + (sr & 63)) * a_rs + chunk * 8) * 2;    // bytes from the half's first row
         voffB[qq] = (((sr >> 5) * 64 + (sr & 31)) * K + chunk * 8) * 2;
     }
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem));
@@ -686,7 +699,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
     auto stage_pos_at = [&](int kind, uint32_t kt, uint32_t m0, uint32_t n0) {
         const bool isA = kind == 0 || kind == 3 || kind == 4 || kind == 7;
         const uint32_t h = (kind == 2 || kind == 3 || kind == 5 || kind == 7) ? 1u : 0u;
-        const uint16_t *base = isA ? A + (size_t)(m0 + h * 64) * K + (size_t)kt * BK
+        const uint16_t *base = isA ? A + (size_t)(m0 + h * 64) * a_rs + (size_t)kt * a_ks
                                    : W + (size_t)(n0 + h * 32) * K + (size_t)kt * BK;
         if (D2R_GEMM_ABLATE & 1) return;
 #pragma unroll
@@ -890,7 +903,7 @@ __global__ __launch_bounds__(256) void k_embed_ln(const float *__restrict__ patc
                                                   const float *__restrict__ pos, const float *__restrict__ w,
                                                   const float *__restrict__ b, float *__restrict__ X, uint32_t rows,
                                                   uint32_t T, uint32_t d, uint16_t *__restrict__ Xb,
-                                                  float2 *__restrict__ AB, uint16_t *__restrict__ Xlo)
+                                                  float2 *__restrict__ AB, uint16_t *__restrict__ Xlo, uint32_t M_pad)
 {
     // X (fp32 residual stream) and Xb/AB (LayerNorm-folded path: bf16 operand copy of the row and the
     // (rstd, -rstd*mean) of the row for the first block's layer_norm1) are each optional
@@ -932,9 +945,10 @@ __global__ __launch_bounds__(256) void k_embed_ln(const float *__restrict__ patc
             if (X) *(float4 *)(X + (size_t)row * d + c0) = o[i];
             if (Xb) {
                 const uint2 hv = make_uint2(pack2(o[i].x, o[i].y), pack2(o[i].z, o[i].w));
-                *(uint2 *)(Xb + (size_t)row * d + c0) = hv;
+                const size_t xo = ((size_t)(c0 >> 6) * M_pad + row) * 64 + (c0 & 63);       // tile-major [d/64][M_pad][64]
+                *(uint2 *)(Xb + xo) = hv;
                 if (Xlo)
-                    *(uint2 *)(Xlo + (size_t)row * d + c0) = make_uint2(pack2(o[i].x - bf_lo(hv.x), o[i].y - bf_hi(hv.x)),
+                    *(uint2 *)(Xlo + xo) = make_uint2(pack2(o[i].x - bf_lo(hv.x), o[i].y - bf_hi(hv.x)),
                                                                          pack2(o[i].z - bf_lo(hv.y), o[i].w - bf_hi(hv.y)));
             }
         } else {
@@ -1048,16 +1062,23 @@ __device__ __forceinline__ float half_sum(float x)
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-// QKV [rows][3d] bf16 (q | k | v, head h at columns h*64), out AO [rows][d] bf16.
+// QKV bf16, tile-major [3 d / 64][M_pad][64] (plane s*H + h = section s (q, k, v) of head h: what the QKV GEMM's
+// epilogue writes), out AO bf16 tile-major [d / 64][M_pad][64] (the out-projection's A operand): every (image, head)
+// reads and writes contiguous T x 128-byte blocks.
 // grid (heads, images); block 256; dynamic LDS: K [T_pad][64] swizzled + Vt [64][T_pad+4].
 #define ATTN_THREADS 512
+// development only (bitmask, default 0): 1 skip the K copies, 2 skip the V staging, 4 skip the arithmetic, 8 skip the
+// Q loads — results are garbage; tools/attn_ablate.sh rebuilds with each mask to see what a workgroup's time is made of
+#ifndef D2R_ATTN_ABLATE
+#define D2R_ATTN_ABLATE 0
+#endif
 // One 32-query tile of one (image, head) against all keys staged in LDS (Ks: K rows, swizzled 16-byte chunks;
 // Vt: V^T, [64][vstride]): S^T = K Q^T so that a query's scores are lane-local, online softmax in the exp2
 // domain, P fed back as the MFMA B operand, O^T accumulated; writes the tile's rows of AO.
 template <bool CAUSAL>
 __device__ __forceinline__ void attn_qtile(const uint8_t *__restrict__ Ks, const uint16_t *__restrict__ Vt, uint32_t vstride,
                                            const uint4 (&qf)[4], uint32_t qt, uint32_t T, uint32_t n_kt, uint32_t li,
-                                           uint32_t hi, uint16_t *__restrict__ AO, size_t row_base, uint32_t d, uint32_t head)
+                                           uint32_t hi, uint16_t *__restrict__ AO, size_t row_base, uint32_t M_pad, uint32_t head)
 {
     const float sm_c = 0.125f * 1.4426950408889634f;   // head_dim^-0.5 * log2(e), head_dim = 64
     const uint32_t qrow = qt * 32 + li;
@@ -1161,7 +1182,7 @@ __device__ __forceinline__ void attn_qtile(const uint8_t *__restrict__ Ks, const
         const float l_tot = half_sum(l_run);
         const float inv_l = 1.0f / l_tot;
         if (qrow < T) {
-            uint16_t *dst = AO + (row_base + qrow) * d + head * 64;
+            uint16_t *dst = AO + ((size_t)head * M_pad + row_base + qrow) * 64;       // tile-major: head h is plane h of [d/64][M_pad][64]
             // lane (q, hi), reg r of o{0,1} <-> dim 32*{0,1} + (r&3) + 8*(r>>2) + 4*hi
 #pragma unroll
             for (int g4 = 0; g4 < 4; g4++) {
@@ -1194,7 +1215,7 @@ extern "C" __attribute__((visibility("default"))) int d2r_debug_attn_stamps(unsi
 template <bool CAUSAL>
 __global__ __launch_bounds__(ATTN_THREADS, 4) void k_attention(const uint16_t *__restrict__ QKV,
                                                                uint16_t *__restrict__ AO, uint32_t T, uint32_t T_pad,
-                                                               uint32_t d, uint32_t stagger_lo, uint32_t stagger_hi)
+                                                               uint32_t d, uint32_t M_pad, uint32_t stagger_lo, uint32_t stagger_hi)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     // Every workgroup does the same work — load Q/K/V, barrier, arithmetic — so a launch whose workgroups all start
@@ -1218,10 +1239,10 @@ __global__ __launch_bounds__(ATTN_THREADS, 4) void k_attention(const uint16_t *_
     const uint32_t head = blockIdx.x, img = blockIdx.y;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, hi = lane >> 5;
     const size_t row_base = (size_t)img * T;
-    const uint32_t ld = 3 * d;
-    const uint16_t *Qg = QKV + row_base * ld + head * 64;
-    const uint16_t *Kg = Qg + d;
-    const uint16_t *Vg = Qg + 2 * d;
+    const uint32_t ld = 64, H = d >> 6;
+    const uint16_t *Qg = QKV + ((size_t)head * M_pad + row_base) * 64;
+    const uint16_t *Kg = QKV + ((size_t)(H + head) * M_pad + row_base) * 64;
+    const uint16_t *Vg = QKV + ((size_t)(2 * H + head) * M_pad + row_base) * 64;
 
     // this wave's first query tile is requested before the staging so that its latency hides under it
     // (B operand of S^T = K Q^T: lane (q, hi) holds Q[q][16s + 8hi .. +8))
@@ -1231,21 +1252,21 @@ __global__ __launch_bounds__(ATTN_THREADS, 4) void k_attention(const uint16_t *_
         const uint32_t qrow0 = wave * 32 + li;
 #pragma unroll
         for (int s = 0; s < 4; s++)
-            qf[s] = (wave < n_qt && qrow0 < T) ? *(const uint4 *)(Qg + (size_t)qrow0 * ld + 16 * s + 8 * hi) : make_uint4(0, 0, 0, 0);
+            qf[s] = (!(D2R_ATTN_ABLATE & 8) && wave < n_qt && qrow0 < T) ? *(const uint4 *)(Qg + (size_t)qrow0 * ld + 16 * s + 8 * hi) : make_uint4(lane, s, 0, 0);
     }
     // K (row-major, swizzled 16-byte chunks) goes straight to LDS by LDS-DMA, 8 key rows per wave
     // instruction, issued before anything else so it overlaps the V transposes.  Rows >= T repeat row
     // T-1: their scores are masked by a select below, so any finite value does.
     {
         const uint32_t ks0 = __builtin_amdgcn_readfirstlane(lds_addr(Ks));
-        for (uint32_t b = __builtin_amdgcn_readfirstlane(wave); b < T_pad / 8; b += ATTN_THREADS / 64) {
+        for (uint32_t b = __builtin_amdgcn_readfirstlane(wave); b < ((D2R_ATTN_ABLATE & 1) ? 0u : T_pad / 8); b += ATTN_THREADS / 64) {
             const uint32_t row = b * 8 + (lane >> 3), src_row = row < T ? row : T - 1;
             glds16(Kg + (size_t)src_row * ld + ((lane & 7) ^ ((row >> 1) & 7u)) * 8, ks0 + b * 1024);
         }
     }
     // stage V^T: a task takes 4 keys x 8 dims (four 16-byte loads), transposes the 4x8 block in
     // registers (v_perm_b32) and writes one 8-byte word of 4 consecutive keys per dim
-    for (uint32_t i = tid; i < (T_pad / 4) * 8; i += ATTN_THREADS) {
+    for (uint32_t i = tid; i < ((D2R_ATTN_ABLATE & 2) ? 0u : (T_pad / 4) * 8); i += ATTN_THREADS) {
         const uint32_t kb = (i >> 3) * 4, c = i & 7;
         uint4 v[4];
 #pragma unroll
@@ -1276,14 +1297,17 @@ __global__ __launch_bounds__(ATTN_THREADS, 4) void k_attention(const uint16_t *_
     const unsigned long long at3 = __builtin_readcyclecounter();
 #endif
 
-    for (uint32_t qt = wave; qt < n_qt; qt += ATTN_THREADS / 64) {
+    if (D2R_ATTN_ABLATE & 4) {       // keep the loaded values alive
+        if (qf[0].x == 0x12345678u && Ks[tid] == 0x7f && Vt[tid] == 0x1234) AO[tid] = 1;
+    }
+    for (uint32_t qt = wave; qt < ((D2R_ATTN_ABLATE & 4) ? 0u : n_qt); qt += ATTN_THREADS / 64) {
         if (qt != wave) {
             const uint32_t qrow = qt * 32 + li;
 #pragma unroll
             for (int s = 0; s < 4; s++)
                 qf[s] = qrow < T ? *(const uint4 *)(Qg + (size_t)qrow * ld + 16 * s + 8 * hi) : make_uint4(0, 0, 0, 0);
         }
-        attn_qtile<CAUSAL>(Ks, Vt, vstride, qf, qt, T, n_kt, li, hi, AO, row_base, d, head);
+        attn_qtile<CAUSAL>(Ks, Vt, vstride, qf, qt, T, n_kt, li, hi, AO, row_base, M_pad, head);
     }
 #ifdef D2R_ATTN_STAMPS
     {
@@ -1310,15 +1334,15 @@ __global__ __launch_bounds__(ATTN_THREADS, 4) void k_attention(const uint16_t *_
 // Items are (image, head) pairs, consecutive items = consecutive heads of one image (the same QKV rows).
 #define ATTN_MAX_VTASKS 2          /* V staging tasks per thread: (T_pad / 4) * 8 <= 2 * ATTN_THREADS */
 __global__ __launch_bounds__(ATTN_THREADS, 2) void k_attention_p(const uint16_t *__restrict__ QKV, uint16_t *__restrict__ AO,
-                                                                 uint32_t T, uint32_t T_pad, uint32_t d, uint32_t n_heads,
-                                                                 uint32_t n_items)
+                                                                 uint32_t T, uint32_t T_pad, uint32_t d, uint32_t M_pad,
+                                                                 uint32_t n_heads, uint32_t n_items)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const uint32_t vstride = T_pad + 4;
     const uint32_t buf_bytes = T_pad * 128u + 64u * vstride * 2u;       // K rows + V^T of one item (a multiple of 16)
     const uint32_t tid = threadIdx.x, lane = tid & 63, li = lane & 31, hi = lane >> 5;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t ld = 3 * d, n_qt = (T + 31) / 32, n_kt = T_pad / 32;
+    const uint32_t ld = 64, H = d >> 6, n_qt = (T + 31) / 32, n_kt = T_pad / 32;
     const uint32_t n_vtasks = (T_pad / 4) * 8;
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem));
 
@@ -1331,7 +1355,7 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void k_attention_p(const uint16_t 
     auto issue_k = [&](uint32_t item, uint32_t b) {
         size_t rb; uint32_t head;
         item_base(item, rb, head);
-        const uint16_t *Kg = QKV + rb * ld + head * 64 + d;
+        const uint16_t *Kg = QKV + ((size_t)(H + head) * M_pad + rb) * 64;
         for (uint32_t blk = wave; blk < T_pad / 8; blk += ATTN_THREADS / 64) {
             const uint32_t row = blk * 8 + (lane >> 3), src_row = row < T ? row : T - 1;
             glds16(Kg + (size_t)src_row * ld + ((lane & 7) ^ ((row >> 1) & 7u)) * 8, lds0 + b * buf_bytes + blk * 1024);
@@ -1341,7 +1365,7 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void k_attention_p(const uint16_t 
     auto load_v = [&](uint32_t item, uint4 (&v)[ATTN_MAX_VTASKS][4]) {
         size_t rb; uint32_t head;
         item_base(item, rb, head);
-        const uint16_t *Vg = QKV + rb * ld + head * 64 + 2 * d;
+        const uint16_t *Vg = QKV + ((size_t)(2 * H + head) * M_pad + rb) * 64;
 #pragma unroll
         for (int t = 0; t < ATTN_MAX_VTASKS; t++) {
             const uint32_t i = tid + t * ATTN_THREADS;
@@ -1380,7 +1404,7 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void k_attention_p(const uint16_t 
     auto load_q = [&](uint32_t item, uint4 (&q)[4]) {
         size_t rb; uint32_t head;
         item_base(item, rb, head);
-        const uint16_t *Qg = QKV + rb * ld + head * 64;
+        const uint16_t *Qg = QKV + ((size_t)head * M_pad + rb) * 64;
         const uint32_t qrow = wave * 32 + li;
 #pragma unroll
         for (int s = 0; s < 4; s++)
@@ -1413,13 +1437,13 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void k_attention_p(const uint16_t 
         // one query tile per wave (n_qt <= 8); longer sequences take several rounds (their Q rows are loaded here)
         for (uint32_t qt = wave; qt < n_qt; qt += ATTN_THREADS / 64) {
             if (qt != wave) {
-                const uint16_t *Qg = QKV + rb * ld + head * 64;
+                const uint16_t *Qg = QKV + ((size_t)head * M_pad + rb) * 64;
                 const uint32_t qrow = qt * 32 + li;
 #pragma unroll
                 for (int s = 0; s < 4; s++)
                     qf[s] = qrow < T ? *(const uint4 *)(Qg + (size_t)qrow * ld + 16 * s + 8 * hi) : make_uint4(0, 0, 0, 0);
             }
-            attn_qtile<false>(Ks, Vt, vstride, qf, qt, T, n_kt, li, hi, AO, rb, d, head);
+            attn_qtile<false>(Ks, Vt, vstride, qf, qt, T, n_kt, li, hi, AO, rb, M_pad, head);
         }
         if (!has_next) break;
         store_vt(vreg, b ^ 1u);
@@ -1438,7 +1462,7 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void k_attention_p(const uint16_t 
 // projection is a latency problem (1.5 MB of fp32 weights per image out of L2), not a flop one.
 #define HEAD_THREADS 1024
 __global__ __launch_bounds__(HEAD_THREADS) void k_head(const float *__restrict__ X, const uint16_t *__restrict__ Xb,
-                                                       const uint16_t *__restrict__ Xlo,
+                                                       const uint16_t *__restrict__ Xlo, uint32_t M_pad,
                                                        const uint32_t *__restrict__ pool_row, uint32_t T, uint32_t d,
                                                        const float *__restrict__ lw, const float *__restrict__ lb,
                                                        const float *__restrict__ proj, uint32_t D,
@@ -1452,11 +1476,12 @@ __global__ __launch_bounds__(HEAD_THREADS) void k_head(const float *__restrict__
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // vision: the class token (row 0 of the image); text: the EOS token's row
     // (the residual stream is fp32 X, or bf16 Xb when the tower runs with a bf16 residual stream)
-    const size_t xoff = ((size_t)blockIdx.x * T + (pool_row ? pool_row[blockIdx.x] : 0u)) * d;
+    const size_t xrow = (size_t)blockIdx.x * T + (pool_row ? pool_row[blockIdx.x] : 0u);
     float xv = 0.f;                                                                                            // d <= 1024
     if (tid < d) {
-        xv = Xb ? __uint_as_float((uint32_t)Xb[xoff + tid] << 16) : X[xoff + tid];
-        if (Xb && Xlo) xv += __uint_as_float((uint32_t)Xlo[xoff + tid] << 16);
+        const size_t xo = ((size_t)(tid >> 6) * M_pad + xrow) * 64 + (tid & 63);                                // bf16 residual: tile-major
+        xv = Xb ? __uint_as_float((uint32_t)Xb[xo] << 16) : X[xrow * d + tid];
+        if (Xb && Xlo) xv += __uint_as_float((uint32_t)Xlo[xo] << 16);
     }
     float s = wave_sum(xv);
     if (lane == 0) red[wave] = s;
@@ -1727,7 +1752,7 @@ static int launch_gemm(d2r_ctx *ctx, const uint16_t *A, const uint16_t *W, const
 // workgroup per (image, head)
 static int attention_setup(d2r_ctx *ctx, uint32_t T_pad, size_t *lds_out);
 static int launch_attention_vision(d2r_ctx *ctx, const uint16_t *QKV, uint16_t *AO, uint32_t T, uint32_t T_pad, uint32_t d,
-                                   uint32_t n_heads, uint32_t n, size_t attn_lds)
+                                   uint32_t M_pad, uint32_t n_heads, uint32_t n, size_t attn_lds)
 {
     const size_t two = 2 * attn_lds;
     const uint32_t n_items = n * n_heads;
@@ -1737,12 +1762,12 @@ static int launch_attention_vision(d2r_ctx *ctx, const uint16_t *QKV, uint16_t *
             (void)hipFuncSetAttribute((const void *)k_attention_p, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         });
         hipLaunchKernelGGL(k_attention_p, dim3((uint32_t)ctx->n_cu), dim3(ATTN_THREADS), two, ctx->stream, QKV, AO, T, T_pad, d,
-                           n_heads, n_items);
+                           M_pad, n_heads, n_items);
     } else {
         // (two workgroups per CU when 2 * attn_lds fits: stagger the second one of the first generation)
         const uint32_t lo = ctx->attn_stagger && 2 * attn_lds <= 160 * 1024 ? (uint32_t)ctx->n_cu : 0u;
         hipLaunchKernelGGL(k_attention<false>, dim3(n_heads, n), dim3(ATTN_THREADS), attn_lds, ctx->stream, QKV, AO, T, T_pad, d,
-                           lo, lo ? 2u * (uint32_t)ctx->n_cu : 0u);
+                           M_pad, lo, lo ? 2u * (uint32_t)ctx->n_cu : 0u);
     }
     return D2R_OK;
 }
@@ -1786,23 +1811,30 @@ int d2r_clip_forward(d2r_ctx *ctx, const d2r_clip *clip, const uint16_t *patches
     size_t attn_lds = 0;
     if ((rc = attention_setup(ctx, T_pad, &attn_lds))) return rc;
     const int fold = (int)ctx->ln_fold;
+    // bf16 activations between kernels are tile-major ([cols/64][rows_pad][64], see EpiAux): QKV, AO, H and the bf16
+    // residual arrays; only k_layernorm's output (fold 0, text tower) and the patch matrix are row-major
+    EpiAux out_tm{}, a_tm{};
+    out_tm.hm_rows = rows_pad;                    // GEMM whose A is row-major and whose bf16 output is tile-major
+    a_tm.a_rs = 64;                               // GEMM whose A is tile-major (fp32 row-major output)
+    a_tm.a_ks = (uint32_t)64 * rows_pad;
+    if ((uint64_t)64 * rows_pad >= (1ull << 32)) return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "activation plane too large for 32-bit indexing");
     if (fold == 0) {
         // separate LayerNorm kernels, fp32 residual stream (also what the text tower runs)
         hipLaunchKernelGGL(k_embed_ln, dim3((rows + 3) / 4), dim3(256), 0, ctx->stream, patch_out, clip->w.cls,
-                           clip->w.pos, clip->w.pre_w, clip->w.pre_b, X, rows, T, d, (uint16_t *)nullptr, (float2 *)nullptr, (uint16_t *)nullptr);
+                           clip->w.pos, clip->w.pre_w, clip->w.pre_b, X, rows, T, d, (uint16_t *)nullptr, (float2 *)nullptr, (uint16_t *)nullptr, rows_pad);
         for (uint32_t l = 0; l < D.num_layers; l++) {
             const ClipWeights::Layer &L = clip->layers[l];
             hipLaunchKernelGGL(k_layernorm, dim3((rows + 3) / 4), dim3(256), 0, ctx->stream, X, L.ln1_w, L.ln1_b, Xn,
                                rows, d);
-            if ((rc = launch_gemm<EPI_BIAS_BF16>(ctx, Xn, L.w_qkv, L.b_qkv, QKV, rows, 3 * d, d))) return rc;
-            (void)launch_attention_vision(ctx, QKV, AO, T, T_pad, d, D.num_heads, n, attn_lds);
-            if ((rc = launch_gemm<EPI_BIAS_RESID_F32>(ctx, AO, L.w_o, L.b_o, X, rows, d, d))) return rc;
+            if ((rc = launch_gemm<EPI_BIAS_BF16>(ctx, Xn, L.w_qkv, L.b_qkv, QKV, rows, 3 * d, d, out_tm))) return rc;
+            (void)launch_attention_vision(ctx, QKV, AO, T, T_pad, d, rows_pad, D.num_heads, n, attn_lds);
+            if ((rc = launch_gemm<EPI_BIAS_RESID_F32>(ctx, AO, L.w_o, L.b_o, X, rows, d, d, a_tm))) return rc;
             hipLaunchKernelGGL(k_layernorm, dim3((rows + 3) / 4), dim3(256), 0, ctx->stream, X, L.ln2_w, L.ln2_b, Xn,
                                rows, d);
-            if ((rc = launch_gemm<EPI_BIAS_GELU_BF16>(ctx, Xn, L.w_fc1, L.b_fc1, H, rows, mlp, d))) return rc;
-            if ((rc = launch_gemm<EPI_BIAS_RESID_F32>(ctx, H, L.w_fc2, L.b_fc2, X, rows, d, mlp))) return rc;
+            if ((rc = launch_gemm<EPI_BIAS_GELU_BF16>(ctx, Xn, L.w_fc1, L.b_fc1, H, rows, mlp, d, out_tm))) return rc;
+            if ((rc = launch_gemm<EPI_BIAS_RESID_F32>(ctx, H, L.w_fc2, L.b_fc2, X, rows, d, mlp, a_tm))) return rc;
         }
-        hipLaunchKernelGGL(k_head, dim3(n), dim3(HEAD_THREADS), 0, ctx->stream, X, (const uint16_t *)nullptr, (const uint16_t *)nullptr, (const uint32_t *)nullptr, T, d,
+        hipLaunchKernelGGL(k_head, dim3(n), dim3(HEAD_THREADS), 0, ctx->stream, X, (const uint16_t *)nullptr, (const uint16_t *)nullptr, rows_pad, (const uint32_t *)nullptr, T, d,
                            clip->w.post_w, clip->w.post_b, clip->w.proj, D.proj_dim, text_dev, C, logit_scale, logits_dev, embeds_dev);
         D2R_HIP(ctx, hipGetLastError());
         return D2R_OK;
@@ -1817,9 +1849,12 @@ int d2r_clip_forward(d2r_ctx *ctx, const d2r_clip *clip, const uint16_t *patches
     const bool xf32 = fold == 3, split = fold == 1;
     uint16_t *Xlo = split ? (uint16_t *)X : (uint16_t *)nullptr;
     hipLaunchKernelGGL(k_embed_ln, dim3((rows + 3) / 4), dim3(256), 0, ctx->stream, patch_out, clip->w.cls, clip->w.pos,
-                       clip->w.pre_w, clip->w.pre_b, xf32 ? X : (float *)nullptr, rows, T, d, Xn, AB, Xlo);
-    EpiAux ln{}, st{};
+                       clip->w.pre_w, clip->w.pre_b, xf32 ? X : (float *)nullptr, rows, T, d, Xn, AB, Xlo, rows_pad);
+    EpiAux ln = out_tm, st = a_tm;                // LN-folded GEMMs: A = tile-major residual copy, output tile-major
+    ln.a_rs = a_tm.a_rs;
+    ln.a_ks = a_tm.a_ks;
     ln.ab = AB;
+    st.hm_rows = rows_pad;                        // residual GEMMs: A tile-major (AO / H), bf16 residual arrays tile-major
     st.xb = Xn;
     st.part = part;
     st.xlo = Xlo;
@@ -1828,7 +1863,7 @@ int d2r_clip_forward(d2r_ctx *ctx, const d2r_clip *clip, const uint16_t *patches
         const ClipWeights::Layer &L = clip->layers[l];
         ln.cs = L.cs_qkv;
         if ((rc = launch_gemm<EPI_LN_BIAS_BF16>(ctx, Xn, L.wf_qkv, L.bf_qkv, QKV, rows, 3 * d, d, ln))) return rc;
-        (void)launch_attention_vision(ctx, QKV, AO, T, T_pad, d, D.num_heads, n, attn_lds);
+        (void)launch_attention_vision(ctx, QKV, AO, T, T_pad, d, rows_pad, D.num_heads, n, attn_lds);
         if (xf32) rc = launch_gemm<EPI_RESID_STATS_F32X>(ctx, AO, L.w_o, L.b_o, X, rows, d, d, st);
         else if (split) rc = launch_gemm<EPI_RESID_STATS_SPLIT>(ctx, AO, L.w_o, L.b_o, Xn, rows, d, d, st);
         else rc = launch_gemm<EPI_RESID_STATS_BF16>(ctx, AO, L.w_o, L.b_o, Xn, rows, d, d, st);
@@ -1844,7 +1879,7 @@ int d2r_clip_forward(d2r_ctx *ctx, const d2r_clip *clip, const uint16_t *patches
             hipLaunchKernelGGL(k_rowstats, dim3((rows_pad + 255) / 256), dim3(256), 0, ctx->stream, part, np, rows_pad, inv_d, AB);
     }
     hipLaunchKernelGGL(k_head, dim3(n), dim3(HEAD_THREADS), 0, ctx->stream, X, xf32 ? (const uint16_t *)nullptr : (const uint16_t *)Xn,
-                       (const uint16_t *)Xlo, (const uint32_t *)nullptr, T, d, clip->w.post_w, clip->w.post_b, clip->w.proj, D.proj_dim, text_dev, C,
+                       (const uint16_t *)Xlo, rows_pad, (const uint32_t *)nullptr, T, d, clip->w.post_w, clip->w.post_b, clip->w.proj, D.proj_dim, text_dev, C,
                        logit_scale, logits_dev, embeds_dev);
     D2R_HIP(ctx, hipGetLastError());
     return D2R_OK;
@@ -2107,17 +2142,21 @@ extern "C" int d2r_text_encode(d2r_ctx *ctx, const d2r_text *tt, const int32_t *
     const uint32_t T_pad = round_up(T, 32);
     size_t attn_lds = 0;
     if ((rc = attention_setup(ctx, T_pad, &attn_lds))) return rc;
+    EpiAux out_tm{}, a_tm{};                      // tile-major bf16 activations, as in the vision tower
+    out_tm.hm_rows = rows_pad;
+    a_tm.a_rs = 64;
+    a_tm.a_ks = (uint32_t)64 * rows_pad;
     for (uint32_t l = 0; l < D.num_layers; l++) {
         const ClipWeights::Layer &L = tt->layers[l];
         hipLaunchKernelGGL(k_layernorm, dim3((rows + 3) / 4), dim3(256), 0, ctx->stream, X, L.ln1_w, L.ln1_b, Xn, rows, d);
-        if ((rc = launch_gemm<EPI_BIAS_BF16>(ctx, Xn, L.w_qkv, L.b_qkv, QKV, rows, 3 * d, d))) return rc;
-        hipLaunchKernelGGL(k_attention<true>, dim3(D.num_heads, Cn), dim3(ATTN_THREADS), attn_lds, ctx->stream, QKV, AO, T, T_pad, d, 0u, 0u);
-        if ((rc = launch_gemm<EPI_BIAS_RESID_F32>(ctx, AO, L.w_o, L.b_o, X, rows, d, d))) return rc;
+        if ((rc = launch_gemm<EPI_BIAS_BF16>(ctx, Xn, L.w_qkv, L.b_qkv, QKV, rows, 3 * d, d, out_tm))) return rc;
+        hipLaunchKernelGGL(k_attention<true>, dim3(D.num_heads, Cn), dim3(ATTN_THREADS), attn_lds, ctx->stream, QKV, AO, T, T_pad, d, rows_pad, 0u, 0u);
+        if ((rc = launch_gemm<EPI_BIAS_RESID_F32>(ctx, AO, L.w_o, L.b_o, X, rows, d, d, a_tm))) return rc;
         hipLaunchKernelGGL(k_layernorm, dim3((rows + 3) / 4), dim3(256), 0, ctx->stream, X, L.ln2_w, L.ln2_b, Xn, rows, d);
-        if ((rc = launch_gemm<EPI_BIAS_GELU_BF16>(ctx, Xn, L.w_fc1, L.b_fc1, H, rows, mlp, d))) return rc;
-        if ((rc = launch_gemm<EPI_BIAS_RESID_F32>(ctx, H, L.w_fc2, L.b_fc2, X, rows, d, mlp))) return rc;
+        if ((rc = launch_gemm<EPI_BIAS_GELU_BF16>(ctx, Xn, L.w_fc1, L.b_fc1, H, rows, mlp, d, out_tm))) return rc;
+        if ((rc = launch_gemm<EPI_BIAS_RESID_F32>(ctx, H, L.w_fc2, L.b_fc2, X, rows, d, mlp, a_tm))) return rc;
     }
-    hipLaunchKernelGGL(k_head, dim3(Cn), dim3(HEAD_THREADS), 0, ctx->stream, X, (const uint16_t *)nullptr, (const uint16_t *)nullptr, (const uint32_t *)pool, T, d, tt->fin_w,
+    hipLaunchKernelGGL(k_head, dim3(Cn), dim3(HEAD_THREADS), 0, ctx->stream, X, (const uint16_t *)nullptr, (const uint16_t *)nullptr, rows_pad, (const uint32_t *)pool, T, d, tt->fin_w,
                        tt->fin_b, tt->proj, D.proj_dim, (const float *)ctx->text.p, 0u, 1.0f, (float *)nullptr,
                        (float *)ctx->logits.p);
     D2R_HIP(ctx, hipGetLastError());

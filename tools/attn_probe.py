@@ -1,0 +1,13 @@
+"""Two ViT-B/16 layers over 2048 images (one k_attention launch per layer at bench geometry); run under rocprofv3 by tools/attn_ablate.sh."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from dream2real_amd import engine
+from dream2real_amd.clip_model import CLIP_CONFIGS, random_clip_state_dict
+ctx = engine.Context(0)
+cfg = dict(CLIP_CONFIGS["vit_b16"], num_layers=2)
+sc = engine.ClipScorer(ctx, cfg, random_clip_state_dict(cfg, seed=6, text=False))
+pv = np.random.default_rng(0).standard_normal((2048, 3, 224, 224), dtype=np.float32)
+ctx.set_option("chunk", 4096)
+sc.embed_pixels(pv)
+sc.embed_pixels(pv)
