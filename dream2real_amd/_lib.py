@@ -18,7 +18,7 @@ EXPORTS = [
     "d2r_clip_score_frames", "d2r_clip_preprocess", "d2r_clip_embed_pixels", "d2r_render_score",
     "d2r_get_render_stats", "d2r_collect_render_stats", "d2r_ctx_set_option", "d2r_get_timing", "d2r_text_create",
     "d2r_text_destroy", "d2r_text_encode", "d2r_comm_get_unique_id", "d2r_comm_init", "d2r_comm_destroy",
-    "d2r_allgather_scores", "d2r_phys_create", "d2r_phys_destroy", "d2r_phys_check",
+    "d2r_allgather_scores", "d2r_phys_create", "d2r_phys_destroy", "d2r_phys_check", "d2r_nerf_load_ingp",
 ]
 
 
@@ -58,6 +58,16 @@ class PhysParams(C.Structure):
     _fields_ = [("sample_res", C.c_uint32 * 6), ("init_pose", C.c_float * 16), ("table_z", C.c_float),
                 ("unsup_thresh", C.c_float), ("gravity", C.c_float * 3), ("perturb", C.c_float),
                 ("stability_check", C.c_int32), ("disallow_regrasp", C.c_int32)]
+
+
+class IngpView(C.Structure):
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("w", C.c_uint32), ("h", C.c_uint32)]
+
+
+class IngpInfo(C.Structure):
+    _fields_ = [("n_levels", C.c_uint32), ("n_features", C.c_uint32), ("aabb_scale", C.c_uint32),
+                ("has_background", C.c_int32), ("dataset_scale", C.c_double), ("dataset_offset", C.c_double * 3),
+                ("background_color", C.c_float * 4), ("n_views", C.c_uint32), ("n_views_written", C.c_uint32)]
 
 
 class RenderStats(C.Structure):

@@ -132,6 +132,9 @@ class Testbed:
         h = C.c_void_p()
         ctx.check(ctx.lib.d2r_nerf_create(ctx.h, C.byref(desc), C.byref(h)))
         self.h = h
+        self._init_state(training_views, dataset_scale, dataset_offset)
+
+    def _init_state(self, training_views, dataset_scale, dataset_offset):
         # pyngp.Testbed attributes the path reads/writes
         self.background_color = [0.0, 0.0, 0.0, 1.0]
         self.render_ground_truth = False
@@ -149,14 +152,24 @@ class Testbed:
     @classmethod
     def from_snapshot(cls, ctx: "Context", path: str) -> "Testbed":
         """`ngp.Testbed(ngp.TestbedMode.Nerf)` + `load_snapshot(path)` (reference
-        reconstruction/ngp_visual_model.py:24-28): tables, MLPs, occupancy, training-view intrinsics and
-        the dataset scale/offset come from the `.ingp` file (dream2real_amd.ingp.load_ingp)."""
-        from . import ingp
-        model, info = ingp.load_ingp(path)
-        tb = cls(ctx, model, training_views=info["training_views"] or None,
-                 dataset_scale=info["dataset_scale"], dataset_offset=info["dataset_offset"])
-        if info.get("background_color") is not None:          # a Testbed restores the colour the snapshot was saved with
-            tb.background_color = [float(x) for x in info["background_color"]]
+        reconstruction/ngp_visual_model.py:24-28) through the C ABI: d2r_nerf_load_ingp parses the file's bytes
+        (zlib/gzip msgpack) in the library and returns the model handle plus the state a Testbed keeps beside it
+        (training-view intrinsics, dataset scale/offset, saved background colour)."""
+        data = open(path, "rb").read()
+        buf = np.frombuffer(data, np.uint8)
+        h = C.c_void_p()
+        info = _lib.IngpInfo()
+        cap = 4096
+        views = (_lib.IngpView * cap)()
+        ctx.check(ctx.lib.d2r_nerf_load_ingp(ctx.h, _lib.ptr(buf), C.c_size_t(buf.size), C.byref(h), C.byref(info), views,
+                                             C.c_uint32(cap)))
+        tv = [dict(fx=float(v.fx), fy=float(v.fy), cx=float(v.cx), cy=float(v.cy), w=int(v.w), h=int(v.h))
+              for v in views[: info.n_views_written]]
+        tb = cls.__new__(cls)
+        tb.ctx, tb.model, tb._keep, tb.h = ctx, None, {}, h
+        tb._init_state(tv or None, float(info.dataset_scale), tuple(float(x) for x in info.dataset_offset))
+        if info.has_background:            # a Testbed restores the colour the snapshot was saved with
+            tb.background_color = [float(x) for x in info.background_color]
         return tb
 
     def close(self):

@@ -51,14 +51,16 @@ def grid_levels(n_levels: int = 16, n_features: int = 2, log2_hashmap_size: int 
     if per_level_scale is None:
         # instant-ngp: desired resolution 2048*aabb_scale at the finest level
         per_level_scale = math.exp(math.log(2048.0 * aabb_scale / base_resolution) / (n_levels - 1))
-    log2_pls = np.float32(np.log2(np.float32(per_level_scale)))
+    # log2 / exp2 in double, rounded to float32 (= a correctly rounded log2f / exp2f; dream2real_amd/csrc/ingp.hip
+    # d2r_grid_levels does the same, so the C-ABI snapshot loader derives the same table bit for bit)
+    log2_pls = np.float32(math.log2(float(np.float32(per_level_scale))))
     scale = np.zeros(n_levels, np.float32)
     res = np.zeros(n_levels, np.uint32)
     size = np.zeros(n_levels, np.uint32)
     offset = np.zeros(n_levels, np.uint32)
     off = 0
     for l in range(n_levels):
-        s = np.float32(np.exp2(np.float32(l) * log2_pls)) * np.float32(base_resolution) - np.float32(1.0)
+        s = np.float32(2.0 ** float(np.float32(l) * log2_pls)) * np.float32(base_resolution) - np.float32(1.0)
         r = int(math.ceil(float(s))) + 1
         max_params = (2 ** 32 - 1) // 2
         p = max_params if float(r) ** 3 > float(max_params) else r ** 3

@@ -90,6 +90,25 @@ typedef struct {
 D2R_API int d2r_nerf_create(d2r_ctx *ctx, const d2r_nerf_desc *desc, d2r_nerf **out);
 D2R_API void d2r_nerf_destroy(d2r_nerf *m);
 
+/*
+ * replaces Testbed(mode=Nerf) + load_snapshot(path) on the bytes of an instant-ngp `.ingp` file (reference
+ * reconstruction/ngp_visual_model.py:24-28): zlib/gzip msgpack -> level table, fp16 tables and MLPs, occupancy
+ * bitfield (instant-ngp's threshold rule and cascade max-pool), render_aabb -> d2r_nerf_create.  `info` / `views`
+ * (optional) receive what a Testbed keeps beside the model: dataset scale/offset for nerf_matrix_to_ngp, the saved
+ * background colour, per-training-view intrinsics for set_camera_to_training_view.
+ */
+typedef struct { double fx, fy, cx, cy; uint32_t w, h; } d2r_ingp_view;   /* pixels at the training resolution */
+typedef struct {
+    uint32_t n_levels, n_features, aabb_scale;
+    int32_t has_background;
+    double dataset_scale, dataset_offset[3];
+    float background_color[4];
+    uint32_t n_views;            /* training views in the snapshot */
+    uint32_t n_views_written;    /* how many of them went into `views` (at most views_cap) */
+} d2r_ingp_info;
+D2R_API int d2r_nerf_load_ingp(d2r_ctx *ctx, const void *bytes, size_t len, d2r_nerf **out, d2r_ingp_info *info,
+                               d2r_ingp_view *views, uint32_t views_cap);
+
 /* Camera state set on a Testbed before render(): set_camera_to_training_view (intrinsics),
  * background_color, nerf.render_min_transmittance, dataset scale/offset used by
  * set_nerf_camera_matrix (reference combined_rendering.py:98-105,116,123-127). */

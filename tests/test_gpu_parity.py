@@ -147,13 +147,22 @@ def test_aabb_scale_2_model_renders_like_the_oracle():
 
 
 def test_testbed_from_snapshot_renders_like_the_model_it_was_saved_from(gpu, tmp_path):
-    """Testbed.from_snapshot = Testbed(mode) + load_snapshot: a model written by ingp.save_ingp and read
-    back renders bit-identically, with the snapshot's intrinsics and dataset offset in the view."""
+    """Testbed.from_snapshot = Testbed(mode) + load_snapshot through the C ABI (d2r_nerf_load_ingp: zlib + msgpack
+    parsed in the library): a model written by tests/ingp_writer.py and read back renders bit-identically to the one
+    it was saved from AND to the one the Python reader (dream2real_amd.ingp.load_ingp) builds — for both hash-grid
+    layouts, an aabb_scale-2 model, graded densities, a cropped render_aabb and a saved background colour."""
+    import dataclasses
     from dream2real_amd import ingp
+    from dream2real_amd.scene import grid_levels
+    from tests.scenes import ellipsoid_occupancy, make_synthetic_nerf
     scene, fg, ctx, engine = gpu["scene"], gpu["fg"], gpu["ctx"], gpu["engine"]
     path = str(tmp_path / "fg_base.ingp")
-    save_ingp(path, scene.fg)
+    views = [dict(fx=900.0, fy=910.0, cx=640.0, cy=350.0, w=1280, h=720), dict(fx=450.0, fy=455.0, cx=320.0, cy=175.0, w=640, h=360)]
+    save_ingp(path, scene.fg, training_views=views, dataset_offset=(0.0, 0.3, 0.5), background_color=(0.0, 0.0, 0.0, 0.0))
     tb = engine.Testbed.from_snapshot(ctx, path)
+    assert tb.background_color == [0.0, 0.0, 0.0, 0.0] and len(tb.training_views) == 2
+    assert abs(tb.training_views[1]["cx"] - 320.0) < 1e-4 and np.allclose(tb.dataset_offset, (0.0, 0.3, 0.5), atol=1e-7)
+    tb.training_views = fg.training_views
     tb.background_color = list(scene.fg_background)
     W, H = 96, 54
     cam = OraclePipeline(scene, W, H).fg_camera(scene.obj_pose)
@@ -163,6 +172,31 @@ def test_testbed_from_snapshot_renders_like_the_model_it_was_saved_from(gpu, tmp
     np.testing.assert_array_equal(a[1], b[1])
     assert (a[1] > 0).sum() > 50
     tb.close()
+    # the other layouts / fields: C loader == Python loader, bit for bit
+    centre = (0.5, 0.5, 0.5)
+    l8 = make_synthetic_nerf(ellipsoid_occupancy(centre, (0.08, 0.1, 0.08)), seed_grid=5, seed_mlp=6,
+                             levels=grid_levels(n_levels=8, n_features=4, log2_hashmap_size=15))
+    l8 = dataclasses.replace(l8, render_aabb=(0.0, 0.0, 0.0, 0.52, 1.0, 1.0))
+    shelf = make_scene("shelf").fg
+    cam2 = np.array([[1, 0, 0, 0.5], [0, 1, 0, 0.5], [0, 0, 1, -0.4]], np.float32)        # looking along +z at the cube centre (ngp coords after the cycle)
+    shelf_scene = make_scene("shelf")
+    for model, kw in ((l8, dict(density_value=0.004)), (shelf, dict())):
+        save_ingp(path, model, **kw)
+        c_tb = engine.Testbed.from_snapshot(ctx, path)
+        py_model, info = ingp.load_ingp(path)
+        py_tb = engine.Testbed(ctx, py_model, training_views=info["training_views"], dataset_scale=info["dataset_scale"],
+                               dataset_offset=info["dataset_offset"])
+        cams = np.stack([OraclePipeline(scene, W, H).fg_camera(scene.obj_pose), cam2,
+                         OraclePipeline(shelf_scene, W, H).fg_camera(shelf_scene.obj_pose)])
+        ra, rb = c_tb.render_batch(cams, W, H), py_tb.render_batch(cams, W, H)
+        np.testing.assert_array_equal(ra[0], rb[0])
+        np.testing.assert_array_equal(ra[1], rb[1])
+        assert c_tb.last_samples == py_tb.last_samples > 100
+        c_tb.close(); py_tb.close()
+    # malformed input fails loudly
+    open(path, "wb").write(b"\x78\x9c not a snapshot")
+    with pytest.raises(Exception):
+        engine.Testbed.from_snapshot(ctx, path)
 
 
 def test_testbed_surface_shade_and_depth(gpu):
