@@ -324,15 +324,30 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], float *ep, u
                                               const float2 *ab_lds, Hook hook = Hook())
 {
     // ep: this wave's private 8 x EP_LD float buffer.  Eight rows of the wave tile at a time:
-    // acc[i][j][4p..4p+3] of both lane halves are rows 8p..8p+7 of m-tile i.
+    // acc[i][j][4p..4p+3] of both lane halves are rows 8p..8p+7 of m-tile i.  Register (j, r) of all 64 lanes is two
+    // rows (r and r + 4, one per lane half) of 32 consecutive columns: exactly the lane-linear image
+    // ds_write_addtid_b32 stores (address = M0 + offset + 4 lane, no address VGPR, 128 B/clk where ds_write_b32 does
+    // 64 — the transposes' LDS writes were what an epilogue's time was made of: 256 KiB per tile at 64 B/clk).
+    // Buffer layout: dword (4 j + r) * EP_LD + 32 hi + li, i.e. logical row R = r + 4 hi of the 8-row group sits in
+    // row-pair slot R & 3, half R >> 2.
     const uint32_t li = lane & 31, hi = lane >> 5;
+    const uint32_t ep_addr = __builtin_amdgcn_readfirstlane(lds_addr(ep));
     auto transpose_in = [&](int i, int p8) {
         if (D2R_GEMM_ABLATE & 256) return;
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) ep[(r + 4 * hi) * EP_LD + j * 32 + li] = acc[i][j][4 * p8 + r];
+        asm volatile("s_mov_b32 m0, %8\n\ts_nop 0\n\t"
+                     "ds_write_addtid_b32 %0 offset:0\n\tds_write_addtid_b32 %1 offset:272\n\t"
+                     "ds_write_addtid_b32 %2 offset:544\n\tds_write_addtid_b32 %3 offset:816\n\t"
+                     "ds_write_addtid_b32 %4 offset:1088\n\tds_write_addtid_b32 %5 offset:1360\n\t"
+                     "ds_write_addtid_b32 %6 offset:1632\n\tds_write_addtid_b32 %7 offset:1904"
+                     :
+                     : "v"(acc[i][0][4 * p8 + 0]), "v"(acc[i][0][4 * p8 + 1]), "v"(acc[i][0][4 * p8 + 2]), "v"(acc[i][0][4 * p8 + 3]),
+                       "v"(acc[i][1][4 * p8 + 0]), "v"(acc[i][1][4 * p8 + 1]), "v"(acc[i][1][4 * p8 + 2]), "v"(acc[i][1][4 * p8 + 3]),
+                       "s"(ep_addr)
+                     : "memory");
     };
+    static_assert(EP_LD == 68u, "the ds_write_addtid offsets above are (4 j + r) * EP_LD * 4 bytes");
+    // float offset of logical row R (0..7), column c (0..63) of the 8-row group in ep
+    auto ep_at = [](uint32_t R, uint32_t c) -> uint32_t { return ((c >> 5) * 4u + (R & 3u)) * EP_LD + (R >> 2) * 32u + (c & 31u); };
     if (EPI_IS_F32_LAYOUT(EPI)) {
         // fp32 outputs: a lane owns 4 columns of a row, 16 lanes (one DPP row) a 256-byte row segment.  The
         // residual rows of TWO 32-row groups (16 loads per lane) are requested before the first transpose,
@@ -387,7 +402,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], float *ep, u
                         const int k = 2 * p8 + qq;
                         const uint32_t row = row0 + (ih + ii) * 32 + rl0 + 4 * k;
                         float4 v = (D2R_GEMM_ABLATE & 256) ? make_float4(acc[ih + ii][0][k], acc[ih + ii][0][k + 8], acc[ih + ii][1][k], acc[ih + ii][1][k + 8])
-                                                           : *(const float4 *)(ep + (rl0 + 4 * qq) * EP_LD + c4);
+                                                           : *(const float4 *)(ep + ep_at(rl0 + 4 * qq, c4));
                         v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
                         if (RESID_F32) {
                             v.x += xr[ii][k].x; v.y += xr[ii][k].y; v.z += xr[ii][k].z; v.w += xr[ii][k].w;
@@ -440,9 +455,9 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], float *ep, u
                 transpose_in(i, k);
                 const uint32_t row = row0 + i * 32 + rl0 + 8 * k;
                 float4 u = (D2R_GEMM_ABLATE & 256) ? make_float4(acc[i][0][k], acc[i][0][k + 8], acc[i][1][k], acc[i][1][k + 8])
-                                                   : *(const float4 *)(ep + rl0 * EP_LD + c8);
+                                                   : *(const float4 *)(ep + ep_at(rl0, c8));
                 float4 w = (D2R_GEMM_ABLATE & 256) ? make_float4(acc[i][0][k + 4], acc[i][0][k + 12], acc[i][1][k + 4], acc[i][1][k + 12])
-                                                   : *(const float4 *)(ep + rl0 * EP_LD + c8 + 4);
+                                                   : *(const float4 *)(ep + ep_at(rl0, c8) + 4);
                 float f[8];
                 if (LN) {
                     const float2 ab = ab_lds[i * 32 + rl0 + 8 * k];          // (rstd, -rstd * mean) of this row
@@ -663,7 +678,8 @@ extern "C" __attribute__((visibility("default"))) int d2r_debug_gemm_stamps(unsi
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A, const uint16_t *__restrict__ W,
                                                  const float *__restrict__ bias, void *__restrict__ Cout,
-                                                 uint32_t M_pad, uint32_t N, uint32_t K, uint32_t n_xcd, EpiAux aux)
+                                                 uint32_t M_pad, uint32_t N, uint32_t K, uint32_t n_xcd, EpiAux aux,
+                                                 uint32_t stagger_sleeps)
 {
     constexpr uint32_t SLOT = 128 * BK * 2;          // 16 KiB
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -780,6 +796,12 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
     tile_origin(t, m0, n0);
 #pragma unroll
     for (int kind = 0; kind < 8; kind++) stage_pos(kind, kind >= 4 ? 1u : 0u);
+    // Every tile of a launch costs the same, so workgroups that start together stay together: the whole chip runs K
+    // loops (HBM nearly idle), then the whole chip runs epilogues (HBM saturated: the epilogues' loads and stores
+    // took 30 of a step's 145 GEMM ms at exactly the HBM rate).  Workgroup `loc` of each XCD starts (loc mod 8) / 8
+    // of a tile period late, once; equal tile times keep the eight phases apart for the rest of the launch, so at
+    // any moment an eighth of the CUs are in their epilogue and the memory system sees a steady stream.
+    for (uint32_t i = 0, n = (loc & 7u) * stagger_sleeps; i < n; i++) __builtin_amdgcn_s_sleep(127);
     float *ep = (float *)(smem + 8 * SLOT) + wave * EP_WAVE_FLOATS;      // transpose buffer behind the ring
     // EPI_LN_*: 1 KiB per wave behind the transpose buffers for the (rstd, -rstd*mean) pairs of its 128 rows,
     // fetched by ONE LDS-DMA instruction per tile (16 B = two rows per lane) so that it is ordered by the same
@@ -1736,8 +1758,12 @@ static int launch_gemm(d2r_ctx *ctx, const uint16_t *A, const uint16_t *W, const
             });
             // persistent: one workgroup per CU (a multiple of the XCD count, so every XCD gets the same number)
             const uint32_t nwg8 = (uint32_t)(ctx->n_cu / ctx->n_xcd * ctx->n_xcd);
+            // one eighth of a tile period in s_sleep(127) units (8 128 cycles each): a K-tile costs ~2.9 k cycles, an epilogue 5-18 k
+            const uint32_t tiles_per_wg = (uint32_t)((tiles256 + nwg8 - 1) / nwg8);
+            const uint32_t period = (K / BK) * 2900u + 9000u;
+            const uint32_t sleeps = (ctx->gemm_stagger && tiles_per_wg >= 4) ? std::max(1u, period / 8u / 8128u) : 0u;
             hipLaunchKernelGGL((k_gemm8<EPI>), dim3(nwg8), dim3(512), LDS8, ctx->stream, A, W, bias, C, M_pad, N, K,
-                               (uint32_t)ctx->n_xcd, aux);
+                               (uint32_t)ctx->n_xcd, aux, sleeps);
             D2R_HIP(ctx, hipGetLastError());
             return D2R_OK;
         }
