@@ -244,7 +244,7 @@ struct EpiAux {
     const float *cs;       // EPI_LN_*: [N] column sums of the folded (bf16-rounded) weight
     const float2 *ab;      // EPI_LN_*: [M_pad] per row (rstd, -rstd * mean) of the residual row
     uint16_t *xb;          // EPI_RESID_STATS_*: [M_pad][N] bf16 residual (read + written by _BF16, written by _F32X)
-    float2 *part;          // EPI_RESID_STATS_*: [M_pad][N / 64] partial (sum, sum of squares) per 64-column group
+    float2 *part;          // EPI_RESID_STATS_*: [N / 64][M_pad] partial (sum, sum of squares) per 64-column group (needs hm_rows = M_pad)
     uint16_t *xlo;         // EPI_RESID_STATS_SPLIT: [M_pad][N] low half of the split residual
     // Layout of bf16 activations.  "Tile-major" = [cols / 64][M_pad][64]: the 64-column group a wave tile produces
     // (one attention head; one K-tile of the GEMM that consumes it) is a contiguous plane, so an epilogue writes
@@ -365,7 +365,6 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], float *ep, u
         }
         static_assert(MT % 2 == 0, "epilogue handles m-tiles in pairs");
         if (EPI == EPI_F32) hook();
-        const uint32_t np = N >> 6;
         // element offset of this lane's 4 columns of `row` in the bf16 residual arrays (tile-major planes, or row-major)
         auto xoff = [&](uint32_t row) -> uint32_t {
             return aux.hm_rows ? ((col0 >> 6) * aux.hm_rows + row) * 64u + c4 : row * N + col;
@@ -428,7 +427,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], float *ep, u
                                                                                  pack2(v.z - bf_lo(hv.y), v.w - bf_hi(hv.y)));
                             const float sm = row16_sum((v.x + v.y) + (v.z + v.w));
                             const float sq = row16_sum(fmaf(v.x, v.x, v.y * v.y) + fmaf(v.z, v.z, v.w * v.w));
-                            if ((lane & 15) == 0) aux.part[row * np + (col0 >> 6)] = make_float2(sm, sq);
+                            if ((lane & 15) == 0) aux.part[(col0 >> 6) * aux.hm_rows + row] = make_float2(sm, sq);      // [N / 64][M_pad]: coalesced for k_rowstats
                         }
                     }
                 }
@@ -990,7 +989,7 @@ __global__ __launch_bounds__(256) void k_embed_ln(const float *__restrict__ patc
     }
 }
 
-// per row: the d/64 partial (sum, sum of squares) pairs an EPI_RESID_STATS_* GEMM wrote -> (rstd, -rstd*mean)
+// per row: the d/64 partial (sum, sum of squares) pairs an EPI_RESID_STATS_* GEMM wrote ([d/64][rows]) -> (rstd, -rstd*mean)
 __global__ void k_rowstats(const float2 *__restrict__ part, uint32_t np, uint32_t rows, float inv_d,
                            float2 *__restrict__ AB)
 {
@@ -998,7 +997,7 @@ __global__ void k_rowstats(const float2 *__restrict__ part, uint32_t np, uint32_
     if (row >= rows) return;
     float s = 0.f, q = 0.f;
     for (uint32_t i = 0; i < np; i++) {
-        const float2 p = part[(size_t)row * np + i];
+        const float2 p = part[(size_t)i * rows + row];
         s += p.x;
         q += p.y;
     }
