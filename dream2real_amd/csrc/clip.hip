@@ -678,16 +678,21 @@ template <int EPI>
 __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A, const uint16_t *__restrict__ W,
                                                  const float *__restrict__ bias, void *__restrict__ Cout,
                                                  uint32_t M_pad, uint32_t N, uint32_t K, uint32_t n_xcd, EpiAux aux,
-                                                 uint32_t stagger_sleeps)
+                                                 uint32_t stagger_sleeps, uint32_t gn)
 {
     constexpr uint32_t SLOT = 128 * BK * 2;          // 16 KiB
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    // persistent: gridDim.x workgroups (one per CU) walk the tiles.  Tiles are numbered n-fastest; XCD x
-    // (blockIdx mod n_xcd) owns the contiguous range [x T/n_xcd, (x+1) T/n_xcd) and its workgroups take
-    // consecutive tiles of it in every round, so the CUs behind one L2 share A row panels.
-    const uint32_t tiles_n = N / 256, n_tiles = (M_pad / 256) * tiles_n;
+    // persistent: gridDim.x workgroups (one per CU) walk the tiles.  XCD x (blockIdx mod n_xcd: one L2) owns the row
+    // panels [x MP/n_xcd, (x+1) MP/n_xcd) with all their column tiles, and walks them column GROUP by column group
+    // (`gn` column tiles at a time, the row panels swept inside a group, column fastest), its workgroups taking
+    // consecutive tiles of that order in every round.  With gn = 4 a round of 32 workgroups is 8 row panels x 4
+    // column tiles: the group's W panels (gn x K x 512 B = 1.5 MB at K = 768) are touched every round and stay in
+    // the 4 MiB L2 while the A panels stream past — with the plain column-fastest order every round cycled ALL of W
+    // (3.5-4.7 MB for the QKV / fc1 products) through the L2 and a quarter of the operand reads missed it.
+    const uint32_t tiles_n = N / 256, mp_all = M_pad / 256;
     const uint32_t xcd = blockIdx.x % n_xcd, loc = blockIdx.x / n_xcd, per_xcd = gridDim.x / n_xcd;
-    const uint32_t t_begin = (uint32_t)((uint64_t)n_tiles * xcd / n_xcd), t_end = (uint32_t)((uint64_t)n_tiles * (xcd + 1) / n_xcd);
+    const uint32_t mp_lo = (uint32_t)((uint64_t)mp_all * xcd / n_xcd), mp_cnt = (uint32_t)((uint64_t)mp_all * (xcd + 1) / n_xcd) - mp_lo;
+    const uint32_t t_begin = 0, t_end = mp_cnt * tiles_n;          // local tile ids of this XCD
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint32_t wm = wave >> 2, wn = wave & 3;
@@ -723,8 +728,12 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
     };
     auto stage_pos = [&](int kind, uint32_t kt) { stage_pos_at(kind, kt, m0, n0); };
     auto tile_origin = [&](uint32_t t, uint32_t &tm, uint32_t &tn) {
-        tm = (t / tiles_n) * 256;
-        tn = (t % tiles_n) * 256;
+        const uint32_t per_group = mp_cnt * gn;                    // tiles of a full column group
+        const uint32_t g = t / per_group, r = t - g * per_group;
+        const uint32_t gw = min(gn, tiles_n - g * gn);             // the last group may be narrower
+        const uint32_t mi = r / gw;
+        tm = (mp_lo + mi) * 256;
+        tn = (g * gn + (r - mi * gw)) * 256;
     };
     // fragment read addresses: the swizzle term is the same for every row this lane reads
     // ((row >> 1) & 7 == (li >> 1) & 7), so four byte offsets per operand serve all kinds; the slot and
@@ -1761,8 +1770,23 @@ static int launch_gemm(d2r_ctx *ctx, const uint16_t *A, const uint16_t *W, const
             const uint32_t tiles_per_wg = (uint32_t)((tiles256 + nwg8 - 1) / nwg8);
             const uint32_t period = (K / BK) * 2900u + 9000u;
             const uint32_t sleeps = (ctx->gemm_stagger && tiles_per_wg >= 4) ? std::max(1u, period / 8u / 8128u) : 0u;
+            // column tiles per group of the tile order: the choice that misses the L2 least by a simple model —
+            // every group re-reads A once; a group whose W panels (gn * K * 512 B) fit beside the streaming A stays
+            // resident, a wider one is re-read every round of workgroups
+            uint32_t gn = (uint32_t)ctx->gemm_group;
+            if (gn == 0) {
+                const uint32_t tn = N / 256;
+                const double a_bytes = (double)M_pad * K * 2.0, w_bytes = (double)N * K * 2.0;
+                const double rounds = (double)tiles256 / (double)nwg8 * ctx->n_xcd, l2_budget = 2.0 * 1024 * 1024;
+                double best = 1e300;
+                for (uint32_t g = 1; g <= tn; g++) {
+                    const double cost = a_bytes * ((tn + g - 1) / g) + ((double)g * K * 512.0 <= l2_budget ? w_bytes : w_bytes * rounds);
+                    if (cost < best) { best = cost; gn = g; }
+                }
+            }
+            gn = std::max(1u, std::min(gn, N / 256));
             hipLaunchKernelGGL((k_gemm8<EPI>), dim3(nwg8), dim3(512), LDS8, ctx->stream, A, W, bias, C, M_pad, N, K,
-                               (uint32_t)ctx->n_xcd, aux, sleeps);
+                               (uint32_t)ctx->n_xcd, aux, sleeps, gn);
             D2R_HIP(ctx, hipGetLastError());
             return D2R_OK;
         }
