@@ -330,7 +330,6 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], float *ep, u
     // 64 — the transposes' LDS writes were what an epilogue's time was made of: 256 KiB per tile at 64 B/clk).
     // Buffer layout: dword (4 j + r) * EP_LD + 32 hi + li, i.e. logical row R = r + 4 hi of the 8-row group sits in
     // row-pair slot R & 3, half R >> 2.
-    const uint32_t li = lane & 31, hi = lane >> 5;
     const uint32_t ep_addr = __builtin_amdgcn_readfirstlane(lds_addr(ep));
     auto transpose_in = [&](int i, int p8) {
         if (D2R_GEMM_ABLATE & 256) return;
