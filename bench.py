@@ -35,13 +35,20 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0       # dense bf16
 MLP_FLOP_PER_SAMPLE = 20480
 
 
-def vit_gflop(cfg) -> float:
-    """Forward FLOPs per image of the vision tower (35.1 GFLOP for ViT-B/16)."""
+def vit_gflop(cfg, executed: bool = False) -> float:
+    """Forward FLOPs per image of the vision tower (35.1 GFLOP for ViT-B/16).
+    executed=True: what the library actually issues — its last block computes q/k/v for every token but
+    attention output, out-projection and MLP for the class token only (the head reads nothing else;
+    the other rows of the last block are dead code), 2.2 GFLOP less for ViT-B/16."""
     P, d, mlp, L = cfg["patch_size"], cfg["hidden_size"], cfg["mlp"], cfg["num_layers"]
     npatch = (cfg["image_size"] // P) ** 2
     T = npatch + 1
     per_layer = 2 * T * (4 * d * d + 2 * d * mlp) + 4 * T * T * d
-    return (2 * npatch * d * 3 * P * P + L * per_layer + 2 * d * cfg["proj"]) / 1e9
+    total = 2 * npatch * d * 3 * P * P + L * per_layer + 2 * d * cfg["proj"]
+    if executed:
+        last = 2 * T * 3 * d * d + 4 * T * d + 2 * (d * d + 2 * d * mlp)
+        total += last - per_layer
+    return total / 1e9
 
 
 def cpu_baseline(scene, W, H, cfg, sd, text, poses_world, n_sample):
@@ -234,7 +241,10 @@ def main():
         march_avg_s = timing["march_ms"] / max(1, timing["march_launches"]) * 1e-3
         achieved = samples_per_launch * ALGO_BYTES_PER_SAMPLE / march_avg_s / 1e9 if march_avg_s > 0 else 0.0
         n_img = K_local * args.steps
-        clip_tflops = vit_gflop(cfg) * 1e9 * n_img / (timing["clip_ms"] * 1e-3) / 1e12 if timing["clip_ms"] > 0 else None
+        # MFMA utilisation is priced on the flops the library issues (class-token-only last block), not on the
+        # textbook count of the architecture
+        cls_last = "cls_last=0" not in args.opt
+        clip_tflops = vit_gflop(cfg, executed=cls_last) * 1e9 * n_img / (timing["clip_ms"] * 1e-3) / 1e12 if timing["clip_ms"] > 0 else None
         out = {
             "metric": "candidate renders scored/sec (640x360)", "value": round(value, 2), "unit": "candidates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -261,7 +271,9 @@ def main():
                          "lane_utilisation": round(stats["samples"] / max(1, 64 * stats["wave_iters"]), 4),
                          "avg_launch_ms": round(march_avg_s * 1e3, 4),
                          "mlp_tflops": round(samples_per_launch * MLP_FLOP_PER_SAMPLE / march_avg_s / 1e12, 3) if march_avg_s > 0 else None},
-            "roofline_vit": {"bound": "mfma", "gflop_per_image": round(vit_gflop(cfg), 2),
+            "roofline_vit": {"bound": "mfma", "gflop_per_image": round(vit_gflop(cfg, executed=cls_last), 2),
+                             "gflop_per_image_architecture": round(vit_gflop(cfg), 2),
+                             "note": "last block: attention output / out-proj / MLP on the class token only (exact: the head reads nothing else)",
                              "achieved": round(clip_tflops, 2) if clip_tflops else None,
                              "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": round(clip_tflops / MFMA_BF16_PEAK_TFLOPS, 5) if clip_tflops else None},

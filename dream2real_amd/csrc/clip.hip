@@ -1484,6 +1484,88 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void k_attention_p(const uint16_t 
     }
 }
 
+// ---- last transformer block: only the class token feeds the head ----
+//
+// post_layernorm and the projection read token 0 of every image and nothing else (reference clip_scoring.py:180-181:
+// CLIPModel's pooled output), so in the LAST block only that row's attention output, out-projection and MLP are
+// live: 1 query instead of T per (image, head), M = n rows instead of n*T for three of the four GEMMs.  The other
+// rows of the last block are dead code; the result is the same function of the inputs (K and V still come from
+// all tokens).  k_attention_cls: one wave per (image, head); fp32 softmax over the T keys.
+__global__ __launch_bounds__(256) void k_attention_cls(const uint16_t *__restrict__ QKV, uint16_t *__restrict__ AO_cls,
+                                                       uint32_t T, uint32_t d, uint32_t M_pad, uint32_t n_heads, uint32_t n_items)
+{
+    __shared__ float ps[4][1024];
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t item = blockIdx.x * 4 + w;
+    if (item >= n_items) return;
+    const uint32_t img = item / n_heads, head = item - img * n_heads, H = d >> 6;
+    const size_t row0 = (size_t)img * T;
+    const uint16_t *Qg = QKV + ((size_t)head * M_pad + row0) * 64;                 // tile-major planes (see k_attention)
+    const uint16_t *Kg = QKV + ((size_t)(H + head) * M_pad + row0) * 64;
+    const uint16_t *Vg = QKV + ((size_t)(2 * H + head) * M_pad + row0) * 64;
+    // q (token 0) as 64 floats, same in every lane
+    float q[64];
+    {
+        const uint4 *qp = (const uint4 *)Qg;
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const uint4 v = qp[c];
+            q[8 * c + 0] = bf_lo(v.x); q[8 * c + 1] = bf_hi(v.x); q[8 * c + 2] = bf_lo(v.y); q[8 * c + 3] = bf_hi(v.y);
+            q[8 * c + 4] = bf_lo(v.z); q[8 * c + 5] = bf_hi(v.z); q[8 * c + 6] = bf_lo(v.w); q[8 * c + 7] = bf_hi(v.w);
+        }
+    }
+    // scores: lane takes keys lane, lane + 64, ... (T <= 1024), kept in LDS
+    float mx = -INFINITY;
+    for (uint32_t key = lane; key < T; key += 64) {
+        const uint4 *kp = (const uint4 *)(Kg + (size_t)key * 64);
+        float a = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const uint4 v = kp[c];
+            a = fmaf(q[8 * c + 0], bf_lo(v.x), a); a = fmaf(q[8 * c + 1], bf_hi(v.x), a);
+            a = fmaf(q[8 * c + 2], bf_lo(v.y), a); a = fmaf(q[8 * c + 3], bf_hi(v.y), a);
+            a = fmaf(q[8 * c + 4], bf_lo(v.z), a); a = fmaf(q[8 * c + 5], bf_hi(v.z), a);
+            a = fmaf(q[8 * c + 6], bf_lo(v.w), a); a = fmaf(q[8 * c + 7], bf_hi(v.w), a);
+        }
+        a *= 0.125f;                                              // head_dim^-0.5
+        ps[w][key] = a;
+        mx = fmaxf(mx, a);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+    for (uint32_t key = lane; key < T; key += 64) {
+        const float p = __expf(ps[w][key] - mx);
+        ps[w][key] = p;
+        sum += p;
+    }
+    sum = wave_sum(sum);
+    __builtin_amdgcn_wave_barrier();
+    // o[dim = lane] = sum_key p[key] V[key][lane] / sum
+    float o = 0.f;
+    for (uint32_t key = 0; key < T; key++) o = fmaf(ps[w][key], __uint_as_float((uint32_t)Vg[(size_t)key * 64 + lane] << 16), o);
+    AO_cls[(size_t)img * d + head * 64 + lane] = f2bf(o / sum);
+}
+
+// class-token rows of the residual stream -> compact fp32 [n][d] (bf16 hi (+ lo) tile-major planes, or fp32 row-major X)
+__global__ void k_gather_cls(const float *__restrict__ X, const uint16_t *__restrict__ Xhi, const uint16_t *__restrict__ Xlo,
+                             uint32_t M_pad, uint32_t T, uint32_t d, uint32_t n, float *__restrict__ X_cls)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * d) return;
+    const uint32_t img = i / d, c = i - img * d;
+    const size_t row = (size_t)img * T;
+    float v;
+    if (Xhi) {
+        const size_t xo = ((size_t)(c >> 6) * M_pad + row) * 64 + (c & 63);
+        v = __uint_as_float((uint32_t)Xhi[xo] << 16);
+        if (Xlo) v += __uint_as_float((uint32_t)Xlo[xo] << 16);
+    } else {
+        v = X[row * d + c];
+    }
+    X_cls[i] = v;
+}
+
 // ------------------------------------------------------------------ head
 
 // one 1024-thread block per image: post_layernorm(X[b*T]) -> proj -> L2 normalise -> logits.
@@ -1833,6 +1915,25 @@ static int attention_setup(d2r_ctx *ctx, uint32_t T_pad, size_t *lds_out)
     return D2R_OK;
 }
 
+// The last block on class-token rows only (see k_attention_cls).  QKV must already hold the block's q/k/v (tile-major);
+// the residual stream is X (fp32 row-major) or Xhi (+ Xlo) (bf16 tile-major).  Leaves the block's output rows in
+// Xc (compact fp32 [n][d]) for k_head with T = 1.  Workspaces: Xc, AOc (bf16 [n_pad][d]), Xnc (bf16 [n_pad][d]),
+// Hc (bf16 [n_pad][mlp]) — all row-major, padded rows hold finite leftovers.
+static int last_block_cls(d2r_ctx *ctx, const d2r_clip_desc &D, const ClipWeights::Layer &L, uint32_t n, uint32_t T, uint32_t rows_pad,
+                          const uint16_t *QKV, const float *X, const uint16_t *Xhi, const uint16_t *Xlo, float *Xc, uint16_t *AOc,
+                          uint16_t *Xnc, uint16_t *Hc)
+{
+    const uint32_t d = D.hidden_size, mlp = D.mlp_size, items = n * D.num_heads;
+    int rc;
+    hipLaunchKernelGGL(k_attention_cls, dim3((items + 3) / 4), dim3(256), 0, ctx->stream, QKV, AOc, T, d, rows_pad, D.num_heads, items);
+    hipLaunchKernelGGL(k_gather_cls, dim3((n * d + 255) / 256), dim3(256), 0, ctx->stream, X, Xhi, Xlo, rows_pad, T, d, n, Xc);
+    if ((rc = launch_gemm<EPI_BIAS_RESID_F32>(ctx, AOc, L.w_o, L.b_o, Xc, n, d, d))) return rc;
+    hipLaunchKernelGGL(k_layernorm, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, Xc, L.ln2_w, L.ln2_b, Xnc, n, d);
+    if ((rc = launch_gemm<EPI_BIAS_GELU_BF16>(ctx, Xnc, L.w_fc1, L.b_fc1, Hc, n, mlp, d))) return rc;
+    if ((rc = launch_gemm<EPI_BIAS_RESID_F32>(ctx, Hc, L.w_fc2, L.b_fc2, Xc, n, d, mlp))) return rc;
+    return D2R_OK;
+}
+
 // patches (bf16 [n*(T-1) padded to 128][Kp_pad]) -> logits/embeds.  Workspaces:
 //  clipws[0] patch_out f32, [1] X f32, [2] Xn bf16, [3] QKV bf16, [4] AO bf16, [5] H bf16
 int d2r_clip_forward(d2r_ctx *ctx, const d2r_clip *clip, const uint16_t *patches_dev, uint32_t n,
@@ -1859,6 +1960,8 @@ int d2r_clip_forward(d2r_ctx *ctx, const d2r_clip *clip, const uint16_t *patches
     size_t attn_lds = 0;
     if ((rc = attention_setup(ctx, T_pad, &attn_lds))) return rc;
     const int fold = (int)ctx->ln_fold;
+    // the last block runs on the class-token rows only (last_block_cls); needs its small workspaces to fit what exists
+    const bool cls_last = ctx->cls_last && D.num_layers >= 1 && T <= 1024 && round_up(n, BM) <= round_up(prow, BM);
     // bf16 activations between kernels are tile-major ([cols/64][rows_pad][64], see EpiAux): QKV, AO, H and the bf16
     // residual arrays; only k_layernorm's output (fold 0, text tower) and the patch matrix are row-major
     EpiAux out_tm{}, a_tm{};
@@ -1875,6 +1978,10 @@ int d2r_clip_forward(d2r_ctx *ctx, const d2r_clip *clip, const uint16_t *patches
             hipLaunchKernelGGL(k_layernorm, dim3((rows + 3) / 4), dim3(256), 0, ctx->stream, X, L.ln1_w, L.ln1_b, Xn,
                                rows, d);
             if ((rc = launch_gemm<EPI_BIAS_BF16>(ctx, Xn, L.w_qkv, L.b_qkv, QKV, rows, 3 * d, d, out_tm))) return rc;
+            if (cls_last && l + 1 == D.num_layers) {
+                if ((rc = last_block_cls(ctx, D, L, n, T, rows_pad, QKV, X, nullptr, nullptr, patch_out, AO, Xn, H))) return rc;
+                break;
+            }
             (void)launch_attention_vision(ctx, QKV, AO, T, T_pad, d, rows_pad, D.num_heads, n, attn_lds);
             if ((rc = launch_gemm<EPI_BIAS_RESID_F32>(ctx, AO, L.w_o, L.b_o, X, rows, d, d, a_tm))) return rc;
             hipLaunchKernelGGL(k_layernorm, dim3((rows + 3) / 4), dim3(256), 0, ctx->stream, X, L.ln2_w, L.ln2_b, Xn,
@@ -1882,7 +1989,8 @@ int d2r_clip_forward(d2r_ctx *ctx, const d2r_clip *clip, const uint16_t *patches
             if ((rc = launch_gemm<EPI_BIAS_GELU_BF16>(ctx, Xn, L.w_fc1, L.b_fc1, H, rows, mlp, d, out_tm))) return rc;
             if ((rc = launch_gemm<EPI_BIAS_RESID_F32>(ctx, H, L.w_fc2, L.b_fc2, X, rows, d, mlp, a_tm))) return rc;
         }
-        hipLaunchKernelGGL(k_head, dim3(n), dim3(HEAD_THREADS), 0, ctx->stream, X, (const uint16_t *)nullptr, (const uint16_t *)nullptr, rows_pad, (const uint32_t *)nullptr, T, d,
+        hipLaunchKernelGGL(k_head, dim3(n), dim3(HEAD_THREADS), 0, ctx->stream, cls_last ? patch_out : X, (const uint16_t *)nullptr, (const uint16_t *)nullptr, rows_pad,
+                           (const uint32_t *)nullptr, cls_last ? 1u : T, d,
                            clip->w.post_w, clip->w.post_b, clip->w.proj, D.proj_dim, text_dev, C, logit_scale, logits_dev, embeds_dev);
         D2R_HIP(ctx, hipGetLastError());
         return D2R_OK;
@@ -1911,6 +2019,11 @@ int d2r_clip_forward(d2r_ctx *ctx, const d2r_clip *clip, const uint16_t *patches
         const ClipWeights::Layer &L = clip->layers[l];
         ln.cs = L.cs_qkv;
         if ((rc = launch_gemm<EPI_LN_BIAS_BF16>(ctx, Xn, L.wf_qkv, L.bf_qkv, QKV, rows, 3 * d, d, ln))) return rc;
+        if (cls_last && l + 1 == D.num_layers) {
+            // (the gather reads the residual rows out of Xn / Xlo before Xn's first rows are reused for the LayerNorm output)
+            if ((rc = last_block_cls(ctx, D, L, n, T, rows_pad, QKV, X, xf32 ? nullptr : Xn, Xlo, patch_out, AO, Xn, H))) return rc;
+            break;
+        }
         (void)launch_attention_vision(ctx, QKV, AO, T, T_pad, d, rows_pad, D.num_heads, n, attn_lds);
         if (xf32) rc = launch_gemm<EPI_RESID_STATS_F32X>(ctx, AO, L.w_o, L.b_o, X, rows, d, d, st);
         else if (split) rc = launch_gemm<EPI_RESID_STATS_SPLIT>(ctx, AO, L.w_o, L.b_o, Xn, rows, d, d, st);
@@ -1926,6 +2039,11 @@ int d2r_clip_forward(d2r_ctx *ctx, const d2r_clip *clip, const uint16_t *patches
         if (l + 1 < D.num_layers)
             hipLaunchKernelGGL(k_rowstats, dim3((rows_pad + 255) / 256), dim3(256), 0, ctx->stream, part, np, rows_pad, inv_d, AB);
     }
+    if (cls_last)
+        hipLaunchKernelGGL(k_head, dim3(n), dim3(HEAD_THREADS), 0, ctx->stream, patch_out, (const uint16_t *)nullptr, (const uint16_t *)nullptr, rows_pad,
+                           (const uint32_t *)nullptr, 1u, d, clip->w.post_w, clip->w.post_b, clip->w.proj, D.proj_dim, text_dev, C, logit_scale, logits_dev,
+                           embeds_dev);
+    else
     hipLaunchKernelGGL(k_head, dim3(n), dim3(HEAD_THREADS), 0, ctx->stream, X, xf32 ? (const uint16_t *)nullptr : (const uint16_t *)Xn,
                        (const uint16_t *)Xlo, rows_pad, (const uint32_t *)nullptr, T, d, clip->w.post_w, clip->w.post_b, clip->w.proj, D.proj_dim, text_dev, C,
                        logit_scale, logits_dev, embeds_dev);
