@@ -150,6 +150,10 @@ void d2r_ctx_destroy(d2r_ctx *c)
     for (auto &b : c->clipws)
         if (b.p) hipFree(b.p);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+    for (int k = 0; k < 2; k++) {
+        if (c->text_ev[k]) (void)hipEventDestroy(c->text_ev[k]);
+        if (c->text_host[k]) (void)hipHostFree(c->text_host[k]);
+    }
     (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -640,7 +644,22 @@ static int upload_text(d2r_ctx *ctx, const d2r_clip *clip, const float *text, ui
     size_t bytes = (size_t)C * d2r_clip_proj_dim(clip) * 4;
     int rc = d2r_reserve(ctx, ctx->text, bytes);
     if (rc) return rc;
-    D2R_HIP(ctx, hipMemcpyAsync(ctx->text.p, text, bytes, hipMemcpyHostToDevice, ctx->stream));
+    // staged through a pinned slot: the caller's buffer is fully read before this returns (d2r.h: "host pointers are
+    // read before the call returns"), and the copy itself stays asynchronous on the context's stream
+    const uint32_t slot = ctx->text_turn++ & 1u;
+    if (ctx->text_ev[slot]) D2R_HIP(ctx, hipEventSynchronize(ctx->text_ev[slot]));        // the slot's previous copy has left it
+    else D2R_HIP(ctx, hipEventCreateWithFlags(&ctx->text_ev[slot], hipEventDisableTiming));
+    if (ctx->text_host_cap[slot] < bytes) {
+        if (ctx->text_host[slot]) (void)hipHostFree(ctx->text_host[slot]);
+        ctx->text_host[slot] = nullptr;
+        ctx->text_host_cap[slot] = 0;
+        if (hipHostMalloc(&ctx->text_host[slot], bytes + 4096, hipHostMallocDefault) != hipSuccess)
+            return d2r_fail(ctx, D2R_ERR_MEMORY, "hipHostMalloc failed for the text staging buffer");
+        ctx->text_host_cap[slot] = bytes + 4096;
+    }
+    memcpy(ctx->text_host[slot], text, bytes);
+    D2R_HIP(ctx, hipMemcpyAsync(ctx->text.p, ctx->text_host[slot], bytes, hipMemcpyHostToDevice, ctx->stream));
+    D2R_HIP(ctx, hipEventRecord(ctx->text_ev[slot], ctx->stream));
     return D2R_OK;
 }
 

@@ -87,6 +87,13 @@ struct d2r_ctx {
     // growable device workspaces (one per role so sizes are independent)
     struct Buf { void *p = nullptr; size_t cap = 0; };
     Buf cams, queue, counters, frames, rgba, depth, poses, clipws[8], text, logits, pix;
+    // host -> device uploads of small caller buffers on asynchronous entry points (text embeddings of d2r_render_score)
+    // go through two library-owned pinned slots, so the caller's memory is consumed before the call returns whatever
+    // the runtime does with pageable copies; an event per slot guards its reuse
+    void *text_host[2] = {nullptr, nullptr};
+    size_t text_host_cap[2] = {0, 0};
+    hipEvent_t text_ev[2] = {nullptr, nullptr};
+    uint32_t text_turn = 0;
     // background of the current view
     Buf bg_rgba, bg_depth, bg_u8;
     uint32_t bg_w = 0, bg_h = 0;

@@ -305,6 +305,10 @@ D2R_API int d2r_get_timing(d2r_ctx *ctx, d2r_timing *out);
  *     copy of the residual row; the residual stream itself is kept as 1: two bf16 arrays hi + lo (16 mantissa
  *     bits), 2: one bf16 array (fastest; its accumulated rounding puts the logit error past 1e-3 of the logit
  *     scale in the tail, so it is not the default), 3: fp32 next to the bf16 copy.
+ * "cls_last" (default 1): the last transformer block of the vision tower runs on the class-token rows only (the head
+ *     reads nothing else; same result, ~6 % less ViT work).  "attn_persistent", "attn_stagger", "gemm_stagger",
+ *     "gemm_group": alternative schedules of the attention / persistent-GEMM kernels that were measured no faster
+ *     and are kept switchable; results do not depend on them.
  * "timing" (0/1): record HIP events per kernel group for d2r_get_timing.  "march_blocks" (default 0 =
  *     one persistent workgroup per CU), "gemm_cfg" (0 default, 1 plain-K-loop 256x256 kernel, 2 force
  *     256x128): development switches. */
