@@ -281,7 +281,7 @@ int d2r_nerf_create(d2r_ctx *ctx, const d2r_nerf_desc *d, d2r_nerf **out)
         !d->dw2_fp16 || !d->cw1_fp16 || !d->cw2_fp16 || !d->cw3_fp16 || !d->occupancy_bits)
         return d2r_fail(ctx, D2R_ERR_INVALID, "null field in d2r_nerf_desc");
     const uint32_t aabb = d->aabb_scale ? d->aabb_scale : 1u;
-    if (aabb != 1u && aabb != 2u) return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "aabb_scale must be 1 or 2");
+    if ((aabb & (aabb - 1u)) || aabb > 128u) return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "aabb_scale must be a power of two <= 128");
     hipSetDevice(ctx->device);
     d2r_nerf *m = new d2r_nerf();
     m->ctx = ctx;
@@ -351,8 +351,12 @@ int d2r_nerf_create(d2r_ctx *ctx, const d2r_nerf_desc *d, d2r_nerf **out)
     }
     // occupancy -> 4x4x4 bricks per cascade + bounding box of occupied cells, in the unit cube of
     // the model's box (cascade c spans side 2^c / aabb_scale of it, centred)
-    const uint32_t n_casc = aabb == 2u ? 2u : 1u;
+    uint32_t n_casc = 1;
+    while ((1u << (n_casc - 1)) < aabb) n_casc++;
     P.aabb_scale = aabb;
+    P.n_casc = n_casc;
+    P.side = (float)aabb;
+    P.inv_side = 1.0f / (float)aabb;
     std::vector<uint64_t> bricks((size_t)n_casc * 32 * 32 * 32, 0);
     float blo[3] = {2.f, 2.f, 2.f}, bhi[3] = {-2.f, -2.f, -2.f};
     for (uint32_t cs = 0; cs < n_casc; cs++) {
@@ -388,8 +392,8 @@ int d2r_nerf_create(d2r_ctx *ctx, const d2r_nerf_desc *d, d2r_nerf **out)
         for (int a = 0; a < 3; a++) {
             P.raabb_lo[a] = crop ? fmaxf(box_lo, d->render_aabb[a]) : box_lo;
             P.raabb_hi[a] = crop ? fminf(box_hi, d->render_aabb[3 + a]) : box_hi;
-            P.rn_lo[a] = aabb == 2u ? fmaf(P.raabb_lo[a] - 0.5f, inv_side, 0.5f) : P.raabb_lo[a];
-            P.rn_hi[a] = aabb == 2u ? fmaf(P.raabb_hi[a] - 0.5f, inv_side, 0.5f) : P.raabb_hi[a];
+            P.rn_lo[a] = aabb >= 2u ? fmaf(P.raabb_lo[a] - 0.5f, inv_side, 0.5f) : P.raabb_lo[a];
+            P.rn_hi[a] = aabb >= 2u ? fmaf(P.raabb_hi[a] - 0.5f, inv_side, 0.5f) : P.raabb_hi[a];
         }
     }
     // De-hashed, bounding-box-local dense bricks of the leading levels (small objects): the

@@ -60,7 +60,9 @@ struct NerfParams {
     uint32_t gbrick_bytes;
     const uint32_t *gbrick_tab;
     const uint64_t *bricks;    // [n_cascades][32^3] 4x4x4-cell occupancy bricks
-    uint32_t aabb_scale;       // 1, or 2: two cascades, cone stepping, positions normalised to the box (k_*<.., CONE>)
+    uint32_t aabb_scale;       // 1, or a power of two up to 128: log2 + 1 cascades, cone stepping, positions normalised to the box (k_*<.., CONE>)
+    uint32_t n_casc;
+    float side, inv_side;      // aabb_scale and its reciprocal as floats
     const uint4 *wfrag;        // [24][64] MFMA A-operand fragments of the MLPs
     float bbox_lo[3], bbox_hi[3];  // bounding box of occupied cells (+margin), unit-cube units
     // Testbed.render_aabb clipped to the model's box: in ngp coordinates (ray slab test) and in the unit cube of

@@ -213,8 +213,9 @@ extern "C" int d2r_nerf_load_ingp(d2r_ctx *ctx, const void *bytes, size_t len, d
         return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "snapshot: only the 32->64->16 density and 32->64->64->16 colour MLPs are implemented");
     const Node *nerf = snap->get("nerf"), *ds = nerf ? nerf->get("dataset") : nullptr;
     const uint32_t aabb = (uint32_t)num(nerf, "aabb_scale", num(ds, "aabb_scale", 1));
-    if (aabb != 1 && aabb != 2) return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "snapshot: aabb_scale > 2 (more than two occupancy cascades) is not implemented");
-    const uint32_t n_casc = aabb == 2 ? 2 : 1;
+    if (aabb == 0 || (aabb & (aabb - 1)) || aabb > 128) return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "snapshot: aabb_scale must be a power of two <= 128");
+    uint32_t n_casc = 1;
+    while ((1u << (n_casc - 1)) < aabb) n_casc++;
     const uint32_t L = (uint32_t)num(enc, "n_levels", 16), F = (uint32_t)num(enc, "n_features_per_level", 2);
     if (!((L == 16 && F == 2) || (L == 8 && F == 4))) return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "snapshot: hash grid layout must be L=16,F=2 or L=8,F=4");
     std::vector<float> scale;

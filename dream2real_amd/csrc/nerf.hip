@@ -162,7 +162,7 @@ struct Ray {
     float t1;
 };
 
-// aabb_scale 2 (template parameter CONE): the lattice of a ray is the cone-stepping sequence
+// aabb_scale >= 2 (template parameter CONE): the lattice of a ray is the cone-stepping sequence
 // t_{k+1} = t_k + max(dt, t_k / 256) in closed form -- t0 + k dt up to k1, t1 (1 + 1/256)^(k - k1) after it,
 // the power as the fixed-order product of fp32 constants that oracle/d2r_oracle.c uses (same bits).
 __device__ __forceinline__ float cone_pow(uint32_t n)
@@ -223,11 +223,11 @@ __device__ __forceinline__ bool make_ray(const NerfParams &P, const ViewParams &
         tmax = fminf(tmax, fmaxf(t0, t1));
     }
     if (CONE) {
-        // from here on in the unit cube of the box; distances stay world distances
+        // from here on in the unit cube of the box (side aabb_scale about 0.5); distances stay world distances
 #pragma unroll
         for (int i = 0; i < 3; i++) {
-            o[i] = fmaf(o[i] - 0.5f, 0.5f, 0.5f);
-            d[i] *= 0.5f;
+            o[i] = fmaf(o[i] - 0.5f, P.inv_side, 0.5f);
+            d[i] *= P.inv_side;
         }
     }
     float bmin = -INFINITY, bmax = INFINITY;
@@ -276,19 +276,29 @@ __device__ __forceinline__ bool next_sample(const NerfParams &P, const Ray &r, u
         py = fmaf(t, r.dy, r.oy);
         pz = fmaf(t, r.dz, r.oz);
         if (px < P.rn_lo[0] || px > P.rn_hi[0] || py < P.rn_lo[1] || py > P.rn_hi[1] || pz < P.rn_lo[2] || pz > P.rn_hi[2]) return false;
-        // occupancy cascade (CONE): 1 outside the unit cube or once the step spans a cell of cascade 0;
-        // cascade 1 spans the whole box (cells 1/128 of it), cascade 0 its central half (cells 1/256)
+        // occupancy cascade (CONE; n_casc = log2(aabb_scale) + 1 of them, cascade c the cube of side 2^c about 0.5 with
+        // cells 2^c / 128): the smallest one that contains the sample, or a coarser one once the step has grown to
+        // its cells (step * 256 >= 2^(c-1)) — instant-ngp's max(mip_from_pos, mip_from_dt) as believed
         int mip = 0;
         float qx = px, qy = py, qz = pz, cell = 1.0f / (float)D2R_GRID, corg = 0.f;
         if (CONE) {
-            const float mx = fmaxf(fmaxf(fabsf(px - 0.5f), fabsf(py - 0.5f)), fabsf(pz - 0.5f));
-            mip = (mx >= 0.25f || lattice_dt<CONE>(t) * 256.0f >= 1.0f) ? 1 : 0;
-            if (mip == 0) {
-                qx = fmaf(px - 0.5f, 2.0f, 0.5f);
-                qy = fmaf(py - 0.5f, 2.0f, 0.5f);
-                qz = fmaf(pz - 0.5f, 2.0f, 0.5f);
-                cell = 0.5f / (float)D2R_GRID;
-                corg = 0.25f;
+            const float mxw = fmaxf(fmaxf(fabsf(px - 0.5f), fabsf(py - 0.5f)), fabsf(pz - 0.5f)) * P.side;   // world units
+            const float dt256 = lattice_dt<CONE>(t) * 256.0f;
+            const int top = (int)P.n_casc - 1;
+            float half = 0.5f, step = 1.0f;
+            for (int c = 1; c <= top; c++) {
+                if (mxw >= half || dt256 >= step) mip = c;
+                half *= 2.0f;
+                step *= 2.0f;
+            }
+            if (mip != top) {
+                // the sample in the unit cube of cascade `mip`: scale about the centre by aabb_scale / 2^mip
+                const float sc = P.side / (float)(1 << mip);
+                qx = fmaf(px - 0.5f, sc, 0.5f);
+                qy = fmaf(py - 0.5f, sc, 0.5f);
+                qz = fmaf(pz - 0.5f, sc, 0.5f);
+                cell = 1.0f / ((float)D2R_GRID * sc);
+                corg = 0.5f - 0.5f / sc;
             }
         }
         int cx = min(max((int)(qx * (float)D2R_GRID), 0), D2R_GRID - 1);
@@ -308,11 +318,15 @@ __device__ __forceinline__ bool next_sample(const NerfParams &P, const Ray &r, u
         float tz = ((r.dz > 0.f ? lz + cs : lz) - pz) * iz;
         float dist = fminf(fminf(tx, ty), tz);
         // whole steps that surely stay inside the skipped region: the steps only grow along the ray, so
-        // sizing them by the step at the far end is conservative; and never across the distance at which
-        // the cascade choice changes with the step size (t = 1)
+        // sizing them by the step at the far end is conservative; and never across a distance at which
+        // the cascade choice changes with the step size (t = 1, 2, 4, ...)
         int n;
         if (CONE) {
-            if (mip == 0) dist = fminf(dist, 1.0f - t);
+            if (mip != (int)P.n_casc - 1) {
+                float tb = 1.0f;
+                while (tb <= t) tb *= 2.0f;
+                dist = fminf(dist, tb - t);
+            }
             n = (int)floorf(dist / lattice_dt<CONE>(t + fmaxf(dist, 0.f)));
         } else {
             n = (int)floorf(dist * D2R_INV_DT);
@@ -406,9 +420,9 @@ __global__ __launch_bounds__(256) void k_raygen_rect(NerfParams P, ViewParams V,
             // box-unit corner -> world (CONE: the box is the cube of side 2 about 0.5)
             const float wx = (c & 1) ? P.bbox_hi[0] : P.bbox_lo[0], wy = (c & 2) ? P.bbox_hi[1] : P.bbox_lo[1];
             const float wz = (c & 4) ? P.bbox_hi[2] : P.bbox_lo[2];
-            const float qx = (CONE ? fmaf(wx - 0.5f, 2.0f, 0.5f) : wx) - cam[3];
-            const float qy = (CONE ? fmaf(wy - 0.5f, 2.0f, 0.5f) : wy) - cam[7];
-            const float qz = (CONE ? fmaf(wz - 0.5f, 2.0f, 0.5f) : wz) - cam[11];
+            const float qx = (CONE ? fmaf(wx - 0.5f, P.side, 0.5f) : wx) - cam[3];
+            const float qy = (CONE ? fmaf(wy - 0.5f, P.side, 0.5f) : wy) - cam[7];
+            const float qz = (CONE ? fmaf(wz - 0.5f, P.side, 0.5f) : wz) - cam[11];
             const float cx = cam[0] * qx + cam[4] * qy + cam[8] * qz;      // R^T (p - t)
             const float cy = cam[1] * qx + cam[5] * qy + cam[9] * qz;
             const float cz = cam[2] * qx + cam[6] * qy + cam[10] * qz;
@@ -883,9 +897,9 @@ __global__ __launch_bounds__(D2R_MARCH_THREADS) void k_march(NerfParams P, ViewP
                     py = fmaf(t, ray.dy, ray.oy);
                     pz = fmaf(t, ray.dz, ray.oz);
                     // world-space ray for the depth (CONE: the stored ray lives in the unit cube of the box)
-                    const float wdx = CONE ? ray.dx * 2.0f : ray.dx, wdy = CONE ? ray.dy * 2.0f : ray.dy, wdz = CONE ? ray.dz * 2.0f : ray.dz;
-                    const float wox = CONE ? fmaf(ray.ox - 0.5f, 2.0f, 0.5f) : ray.ox, woy = CONE ? fmaf(ray.oy - 0.5f, 2.0f, 0.5f) : ray.oy;
-                    const float woz = CONE ? fmaf(ray.oz - 0.5f, 2.0f, 0.5f) : ray.oz;
+                    const float wdx = CONE ? ray.dx * P.side : ray.dx, wdy = CONE ? ray.dy * P.side : ray.dy, wdz = CONE ? ray.dz * P.side : ray.dz;
+                    const float wox = CONE ? fmaf(ray.ox - 0.5f, P.side, 0.5f) : ray.ox, woy = CONE ? fmaf(ray.oy - 0.5f, P.side, 0.5f) : ray.oy;
+                    const float woz = CONE ? fmaf(ray.oz - 0.5f, P.side, 0.5f) : ray.oz;
                     zslope = (wdx * cam[2] + wdy * cam[6] + wdz * cam[10]) * V.inv_scale;
                     zbase = ((wox - cam[3]) * cam[2] + (woy - cam[7]) * cam[6] + (woz - cam[11]) * cam[10]) * V.inv_scale;
                     C0 = C1 = C2 = A = Z = 0.f;
@@ -894,7 +908,7 @@ __global__ __launch_bounds__(D2R_MARCH_THREADS) void k_march(NerfParams P, ViewP
             }
             // ray directions changed in some lanes: refresh the wave's SH fragments (all lanes
             // take part: a lane's fragment also carries its partner's direction)
-            if (CONE) sh_fragments(lane, ray.dx * 2.0f, ray.dy * 2.0f, ray.dz * 2.0f, shfA, shfB);     // unit direction
+            if (CONE) sh_fragments(lane, ray.dx * P.side, ray.dy * P.side, ray.dz * P.side, shfA, shfB);     // unit direction
             else sh_fragments(lane, ray.dx, ray.dy, ray.dz, shfA, shfB);
         }
         if (!__any(alive)) break;
@@ -1077,7 +1091,7 @@ int d2r_launch_render(d2r_ctx *ctx, const d2r_nerf *m, const ViewParams &V, cons
     }
     const uint32_t tiles = ((V.W + 15) / 16) * ((V.H + 15) / 16);
     size_t tr = ctx->timing_begin(D2R_T_RAYGEN);
-    const bool cone = m->P.aabb_scale == 2;          // two occupancy cascades + cone stepping
+    const bool cone = m->P.aabb_scale >= 2;          // occupancy cascades + cone stepping
     if (composite && ctx->raygen_rect) {
         if (cone) hipLaunchKernelGGL(k_raygen_rect<true>, dim3(n, 4), dim3(256), 0, ctx->stream, m->P, V, cams_dev, (uint2 *)ctx->queue.p, cnt);
         else hipLaunchKernelGGL(k_raygen_rect<false>, dim3(n, 4), dim3(256), 0, ctx->stream, m->P, V, cams_dev, (uint2 *)ctx->queue.p, cnt);

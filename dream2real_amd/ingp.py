@@ -103,8 +103,8 @@ def load_ingp(path: str):
     nerf = snap.get("nerf", {})
     ds = nerf.get("dataset", {})
     aabb_scale = int(nerf.get("aabb_scale", ds.get("aabb_scale", 1)))
-    if aabb_scale not in (1, 2):
-        raise NotImplementedError("aabb_scale > 2 (more than two occupancy cascades) is not implemented")
+    if aabb_scale < 1 or aabb_scale & (aabb_scale - 1) or aabb_scale > 128:
+        raise NotImplementedError("aabb_scale must be a power of two <= 128")
     n_casc = aabb_scale.bit_length()
     L, F = int(enc.get("n_levels", 16)), int(enc.get("n_features_per_level", 2))
     if (L, F) not in ((16, 2), (8, 4)):

@@ -84,7 +84,7 @@ class NerfModel:
     cw2: np.ndarray        # [64, 64] float16
     cw3: np.ndarray        # [16, 64] float16   rows 0..2 = rgb
     occ_bits: np.ndarray   # [n_cascades * 128^3/8] uint8, bit (x + 128*(y + 128*z)) per cascade, LSB first
-    aabb_scale: int = 1    # 1, or 2: the box is the cube of that side centred at 0.5; cascade c covers side 2^c
+    aabb_scale: int = 1    # a power of two: the box is the cube of that side centred at 0.5; cascade c (0 .. log2) covers side 2^c
     render_aabb: Optional[tuple] = None   # Testbed.render_aabb (lo xyz, hi xyz, ngp coordinates); None = the whole box
 
     @property

@@ -79,9 +79,9 @@ typedef struct {
     const uint16_t *cw2_fp16;   /* host [64][64] */
     const uint16_t *cw3_fp16;   /* host [16][64]   rows 0..2 = rgb */
     const uint8_t *occupancy_bits; /* host [n_cascades][128^3/8], bit x+128*(y+128*z), LSB first */
-    uint32_t aabb_scale;        /* 1 or 2 (0 is read as 1): the model's box is the cube of that side centred at
-                                 * 0.5; n_cascades = log2(aabb_scale)+1 occupancy grids, cascade c covering side
-                                 * 2^c; aabb_scale 2 marches with cone-angle 1/256 steps */
+    uint32_t aabb_scale;        /* a power of two, 1..128 (0 is read as 1): the model's box is the cube of that side
+                                 * centred at 0.5; n_cascades = log2(aabb_scale)+1 occupancy grids, cascade c covering
+                                 * side 2^c; aabb_scale >= 2 marches with cone-angle 1/256 steps */
     float render_aabb[6];       /* Testbed.render_aabb: lo xyz, hi xyz in ngp coordinates — rays start where they
                                  * enter it and stop where they leave it; all zeros = the model's whole box */
 } d2r_nerf_desc;

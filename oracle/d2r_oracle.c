@@ -62,7 +62,7 @@ typedef struct {
     /* occupancy, 128^3 bits per cascade, linear index x + 128*y + 128*128*z, LSB first;
      * cascade c (c < n_cascades = log2(aabb_scale)+1) covers the cube of side 2^c centred at 0.5 */
     const uint8_t *occ_bits;
-    uint32_t aabb_scale;      /* 1, or 2 (cascades + cone stepping) */
+    uint32_t aabb_scale;      /* 1, or a power of two up to 128 (log2 + 1 cascades + cone stepping) */
     /* Testbed.render_aabb (instant-ngp crops rendering to it: rays start where they enter it and stop
      * where they leave it), lo xyz then hi xyz in ngp coordinates; all zeros = the model's whole box */
     float render_aabb[6];
@@ -372,6 +372,8 @@ D2R_ORACLE_API void d2r_oracle_render(const d2r_oracle_nerf *m, const d2r_oracle
 
             /* AABB slab test: the cube of side aabb_scale centred at 0.5 */
             const int cone = m->aabb_scale > 1;
+            int n_casc = 1;
+            while ((1u << (n_casc - 1)) < (m->aabb_scale ? m->aabb_scale : 1u)) n_casc++;
             const float half = 0.5f * (float)(m->aabb_scale ? m->aabb_scale : 1);
             const float box_lo = 0.5f - half, box_hi = 0.5f + half, inv_side = 1.0f / (2.0f * half);
             /* cropped to render_aabb when one is set; rn_*: the crop box in the unit cube of the model's box */
@@ -417,11 +419,25 @@ D2R_ORACLE_API void d2r_oracle_render(const d2r_oracle_nerf *m, const d2r_oracle
                         if (!occ_test(m->occ_bits, cell_of(p[0]), cell_of(p[1]), cell_of(p[2])))
                             continue;
                     } else {
-                        /* cascade: 1 outside the unit cube or once the step spans a cell of cascade 0 */
-                        float mx = fmaxf(fmaxf(fabsf(pw[0] - 0.5f), fabsf(pw[1] - 0.5f)), fabsf(pw[2] - 0.5f));
-                        int mip = (mx >= 0.5f || dt * 256.0f >= 1.0f) ? 1 : 0;
+                        /* cascade: the smallest one (cube of side 2^c about 0.5) that contains the sample, or a coarser
+                         * one once the step has grown to its cells: step * 256 >= 2^(c-1) */
+                        const int top = n_casc - 1;
+                        float mx = fmaxf(fmaxf(fabsf(p[0] - 0.5f), fabsf(p[1] - 0.5f)), fabsf(p[2] - 0.5f)) * (2.0f * half);
+                        float dt256 = dt * 256.0f, hw = 0.5f, st = 1.0f;
+                        int mip = 0;
+                        for (int c = 1; c <= top; c++) {
+                            if (mx >= hw || dt256 >= st) mip = c;
+                            hw *= 2.0f;
+                            st *= 2.0f;
+                        }
                         const uint8_t *bits = m->occ_bits + (size_t)mip * (D2R_GRID * D2R_GRID * D2R_GRID / 8);
-                        const float *q = mip ? p : pw;     /* cascade 1 spans the whole box, cascade 0 the unit cube */
+                        float q[3];
+                        if (mip == top) {
+                            for (int i = 0; i < 3; i++) q[i] = p[i];          /* the top cascade spans the whole box */
+                        } else {
+                            const float sc = (2.0f * half) / (float)(1 << mip);
+                            for (int i = 0; i < 3; i++) q[i] = fmaf(p[i] - 0.5f, sc, 0.5f);
+                        }
                         if (!occ_test(bits, cell_of(q[0]), cell_of(q[1]), cell_of(q[2])))
                             continue;
                     }

@@ -102,6 +102,8 @@ def make_scene(kind: str = "shopping") -> SyntheticScene:
     the unit cube and the camera 1.3 m away)."""
     if kind == "shelf":
         return _make_shelf_scene()
+    if kind == "room":
+        return _make_shelf_scene(aabb_scale=4)
     levels = grid_levels()
     scene_centre = np.array([0.5, 0.0, 0.035])          # configs/shopping_demo.json:29
     if kind == "shopping":
@@ -132,8 +134,12 @@ def make_scene(kind: str = "shopping") -> SyntheticScene:
                           fg_background=(0.0, 0.0, 0.0, 1.0))
 
 
-def _make_shelf_scene() -> SyntheticScene:
-    levels = grid_levels(aabb_scale=2)
+def _make_shelf_scene(aabb_scale: int = 2) -> SyntheticScene:
+    """aabb_scale 2: the 'shelf' scene.  aabb_scale 4 ('room'): the same geometry in a box of side 4 with three
+    occupancy cascades, a far wall that only cascade 2 holds, and the camera 2.3 m away (steps grow past the
+    cascade thresholds at t = 1 and t = 2)."""
+    levels = grid_levels(aabb_scale=aabb_scale)
+    n_casc = int(aabb_scale).bit_length()
     scene_centre = np.array([0.45, 0.85, 0.20])                 # world; ngp (1.15, 0.70, 0.45): outside the unit cube
     obj_t = scene_centre + np.array([0.02, -0.03, 0.06])
     obj_pose = np.eye(4)
@@ -143,13 +149,15 @@ def _make_shelf_scene() -> SyntheticScene:
     def cascades(fn):
         # as instant-ngp builds its bitfield: cascade 1 also holds the 2x2x2 max-pool of cascade 0 in its
         # central half (dream2real_amd.ingp.occupancy_from_density), so a snapshot round trip is the identity
-        c0, c1 = fn(0), fn(1)
         h, q = GRID // 2, GRID // 4
-        c1 = c1.copy()
-        c1[q:q + h, q:q + h, q:q + h] |= c0.reshape(h, 2, h, 2, h, 2).any(axis=(1, 3, 5))
-        return np.stack([c0, c1])
+        out = [fn(0)]
+        for c in range(1, n_casc):
+            cc = fn(c).copy()
+            cc[q:q + h, q:q + h, q:q + h] |= out[-1].reshape(h, 2, h, 2, h, 2).any(axis=(1, 3, 5))
+            out.append(cc)
+        return np.stack(out)
     fg = make_synthetic_nerf(cascades(lambda c: ellipsoid_occupancy(world_to_ngp(obj_t), radii_ngp, c)),
-                             seed_grid=1, seed_mlp=3, levels=levels, aabb_scale=2)
+                             seed_grid=1, seed_mlp=3, levels=levels, aabb_scale=aabb_scale)
 
     def bg_occ(c):
         x, y, z = _cell_centres(c)
@@ -157,12 +165,16 @@ def _make_shelf_scene() -> SyntheticScene:
         occ |= (z >= 1.20) & (z < 1.28) & (y > 0.3) & (y < 1.2)                      # the back panel
         for d, r in (((0.20, -0.15, 0.05), 0.09), ((-0.25, 0.10, 0.02), 0.07)):
             occ |= ellipsoid_occupancy(world_to_ngp(scene_centre + np.array(d)), (r, r, r), c)
+        if aabb_scale > 2:
+            occ |= (z >= 1.95) & (z < 2.10) & (y > -0.5) & (y < 1.8) & (x > -1.0) & (x < 2.0)      # a far wall: outside cascades 0 and 1
         return occ
-    bg = make_synthetic_nerf(cascades(bg_occ), seed_grid=2, seed_mlp=4, levels=levels, aabb_scale=2)
-    eye = scene_centre + 1.3 * np.array([-0.55, -0.35, 0.75]) / np.linalg.norm([-0.55, -0.35, 0.75])
+    bg = make_synthetic_nerf(cascades(bg_occ), seed_grid=2, seed_mlp=4, levels=levels, aabb_scale=aabb_scale)
+    dist = 1.3 if aabb_scale == 2 else 2.3
+    eye = scene_centre + dist * np.array([-0.55, -0.35, 0.75]) / np.linalg.norm([-0.55, -0.35, 0.75])
     cams = np.stack([look_at_opencv(eye, scene_centre),
                      look_at_opencv(eye + np.array([0.15, 0.0, 0.05]), scene_centre)])
-    return SyntheticScene("shelf", 1, scene_centre, fg, bg, obj_pose, cams, fg_background=(0.0, 0.0, 0.0, 1.0))
+    return SyntheticScene("shelf" if aabb_scale == 2 else "room", 1, scene_centre, fg, bg, obj_pose, cams,
+                          fg_background=(0.0, 0.0, 0.0, 1.0))
 
 
 def scene_text_embeds(image_embed, n_caps: int = 2, seed: int = 5, noise: float = 0.8) -> np.ndarray:

@@ -97,6 +97,50 @@ def test_background_render_matches_oracle(gpu):
     np.testing.assert_allclose(depth[0], odepth, rtol=0, atol=2e-3)
 
 
+def test_aabb_scale_4_model_renders_like_the_oracle(tmp_path):
+    """Three occupancy cascades (aabb_scale 4, the 'room' fixture): the object outside the unit cube, a wall that only
+    the coarsest cascade holds, the camera 2.3 m away so that the cone step crosses the cascade thresholds at t = 1
+    and t = 2.  Background + foreground renders, composited candidates, and the snapshot round trip through the C
+    loader."""
+    from dream2real_amd import engine
+    scene = make_scene("room")
+    assert scene.bg.aabb_scale == 4 and scene.bg.occupancy_bool().shape[0] == 3
+    occ = scene.bg.occupancy_bool()
+    assert occ[2].sum() > occ[1][32:96, 32:96, 32:96].any() and occ[2][:, :, :].sum() > 1000
+    ctx = engine.Context(0)
+    fg, bg = engine.Testbed(ctx, scene.fg), engine.Testbed(ctx, scene.bg)
+    fg.background_color = list(scene.fg_background)
+    W, H = 128, 72
+    pipe = OraclePipeline(scene, W, H)
+    cam = host_ref.converter(np.asarray(scene.cam_poses, np.float32))[0]
+    rgba, depth = bg.render_batch(cam[None, :3], W, H)
+    orgba, odepth = pipe.background()
+    assert (odepth > 0).sum() > 1000 and odepth.max() > 2.0          # the far wall is seen
+    assert ((depth[0] > 0) != (odepth > 0)).mean() < 2e-3
+    ok = (depth[0] > 0) == (odepth > 0)
+    assert np.abs(rgba[0] - orgba)[ok].max() < 2e-2 and np.abs(depth[0] - odepth)[ok].max() < 1.5e-2
+    assert np.abs(rgba[0] - orgba)[ok].mean() < 5e-4
+    poses = host_ref.sample_poses_grid(scene.scene_centre, [2, 2, 2, 1, 1, 1], scene.scene_type).reshape(-1, 4, 4)
+    view = fg.view(W, H)
+    ctx.set_background(view, orgba, odepth)
+    T1 = host_ref.converter(np.asarray(scene.obj_pose, np.float32)[None])[0]
+    frames = fg.render_composite(view, T1, cam, host_ref.converter(poses.astype(np.float32)))
+    want = pipe.frames(poses, bg=(orgba, odepth))
+    diff = np.abs(frames.astype(int) - want.astype(int)).max(-1)
+    assert (diff > 1).mean() < 5e-4 and (diff > 0).mean() < 0.02
+    assert ctx.render_stats()["samples"] > 1000
+    # snapshot round trip with three Morton-ordered cascades (C loader)
+    path = str(tmp_path / "room.ingp")
+    save_ingp(path, scene.bg)
+    tb = engine.Testbed.from_snapshot(ctx, path)
+    r2 = tb.render_batch(cam[None, :3], W, H)
+    np.testing.assert_array_equal(r2[0], rgba)
+    np.testing.assert_array_equal(r2[1], depth)
+    for t in (tb, fg, bg):
+        t.close()
+    ctx.close()
+
+
 def test_aabb_scale_2_model_renders_like_the_oracle():
     """The shelf scene (configs/shelf_demo.json:62 has aabb_scale 2): two occupancy cascades, cone-angle
     stepping, positions normalised to the box of side 2.  Object outside the unit cube (cascade 1 only),

@@ -38,7 +38,7 @@ def test_rejects_unknown_layouts(tmp_path):
     open(path, "wb").write(zlib.compress(msgpack.packb(cfg, use_bin_type=True)))
     with pytest.raises(ValueError):
         ingp.load_ingp(path)
-    cfg["snapshot"]["nerf"]["aabb_scale"] = 4            # three cascades: not implemented
+    cfg["snapshot"]["nerf"]["aabb_scale"] = 3            # not a power of two
     open(path, "wb").write(zlib.compress(msgpack.packb(cfg, use_bin_type=True)))
     with pytest.raises(NotImplementedError):
         ingp.load_ingp(path)
