@@ -10,7 +10,8 @@
 // implemented in clip.hip / nerf.hip
 struct d2r_clip;
 int d2r_launch_preprocess(d2r_ctx *, d2r_clip *, const uint8_t *frames_dev, uint32_t n, uint32_t w, uint32_t h,
-                          int rot90, uint16_t *patches_dev, float *pixel_values_dev);
+                          int rot90, uint16_t *patches_dev, float *pixel_values_dev, const void *rects_dev = nullptr,
+                          const uint16_t *bg_patches_dev = nullptr);
 int d2r_clip_forward(d2r_ctx *, const d2r_clip *, const uint16_t *patches_dev, uint32_t n, const float *text_dev,
                      uint32_t C, float logit_scale, float *logits_dev, float *embeds_dev);
 int d2r_launch_patchify(d2r_ctx *, const d2r_clip *, const float *pv_dev, uint32_t n, uint16_t *patches_dev);
@@ -144,7 +145,7 @@ void d2r_ctx_destroy(d2r_ctx *c)
     hipStreamSynchronize(c->stream);
     (void)d2r_comm_destroy(c);
     d2r_ctx::Buf *bufs[] = {&c->cams, &c->queue, &c->counters, &c->frames, &c->rgba, &c->depth, &c->poses,
-                            &c->text, &c->logits, &c->pix, &c->bg_rgba, &c->bg_depth, &c->bg_u8};
+                            &c->text, &c->logits, &c->pix, &c->bg_rgba, &c->bg_depth, &c->bg_u8, &c->rects, &c->bg_patches};
     for (auto *b : bufs)
         if (b->p) hipFree(b->p);
     for (auto &b : c->clipws)
@@ -190,6 +191,8 @@ int d2r_ctx_set_option(d2r_ctx *ctx, const char *key, int64_t value)
     } else if (!strcmp(key, "ln_fold")) {
         if (value < 0 || value > 3) return d2r_fail(ctx, D2R_ERR_INVALID, "ln_fold must be 0..3");
         ctx->ln_fold = value;
+    } else if (!strcmp(key, "prep_reuse")) {
+        ctx->prep_reuse = value != 0;
     } else if (!strcmp(key, "cls_last")) {
         ctx->cls_last = value != 0;
     } else if (!strcmp(key, "gemm_group")) {
@@ -608,6 +611,7 @@ int d2r_set_background(d2r_ctx *ctx, const d2r_view *view, const float *bg_rgba,
     D2R_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->bg_w = view->width;
     ctx->bg_h = view->height;
+    ctx->bg_patches_for = nullptr;          // the background's CLIP patches are recomputed on the next d2r_render_score
     return D2R_OK;
 }
 
@@ -766,12 +770,26 @@ int d2r_render_score(d2r_ctx *ctx, const d2r_nerf *fg, const d2r_clip *clip, con
     if ((rc = d2r_reserve(ctx, ctx->frames, (size_t)cap * px * 3))) return rc;
     if ((rc = d2r_reserve(ctx, ctx->clipws[6], d2r_clip_patch_bytes(clip, cap)))) return rc;
     if ((rc = d2r_reserve(ctx, ctx->counters, 64 + 32 * (size_t)((K + per - 1) / per)))) return rc;
+    // the background frame's own patches, once per (background, CLIP model): bands of a candidate that its rays cannot
+    // have touched are copies of these (k_preprocess)
+    const bool reuse_bg = ctx->prep_reuse && ctx->raygen_rect && ctx->bg_w == V.W && ctx->bg_h == V.H && ctx->bg_u8.p;
+    if (reuse_bg) {
+        if ((rc = d2r_reserve(ctx, ctx->rects, (size_t)cap * 16))) return rc;
+        if (ctx->bg_patches_for != (const void *)clip) {
+            if ((rc = d2r_reserve(ctx, ctx->bg_patches, d2r_clip_patch_bytes(clip, 1)))) return rc;
+            if ((rc = d2r_launch_preprocess(ctx, (d2r_clip *)clip, (const uint8_t *)ctx->bg_u8.p, 1, V.W, V.H, 1,
+                                            (uint16_t *)ctx->bg_patches.p, nullptr)))
+                return rc;
+            ctx->bg_patches_for = (const void *)clip;
+        }
+    }
     ctx->stats = d2r_render_stats{0, 0, 0, 0};
     for (uint32_t c0 = 0; c0 < K; c0 += per) {
         uint32_t nc = std::min(per, K - c0);
         if ((rc = d2r_launch_cameras_virtual(ctx, V, obj_pose_now, cam_pose, obj_poses_dev + (size_t)c0 * 16, nc, (float *)ctx->cams.p)))
             return rc;
-        if ((rc = d2r_launch_render(ctx, fg, V, (const float *)ctx->cams.p, nc, true, nullptr, nullptr, (uint8_t *)ctx->frames.p)))
+        if ((rc = d2r_launch_render(ctx, fg, V, (const float *)ctx->cams.p, nc, true, nullptr, nullptr, (uint8_t *)ctx->frames.p,
+                                    reuse_bg ? ctx->rects.p : nullptr)))
             return rc;
         // keep this chunk's counters for the stats read-back at the end
         D2R_HIP(ctx, hipMemcpyAsync((uint8_t *)ctx->counters.p + 64 + 32 * (size_t)(c0 / per), ctx->counters.p, 32,
@@ -780,7 +798,8 @@ int d2r_render_score(d2r_ctx *ctx, const d2r_nerf *fg, const d2r_clip *clip, con
             D2R_HIP(ctx, hipMemcpyAsync(frames_out + (size_t)c0 * px * 3, ctx->frames.p, (size_t)nc * px * 3, hipMemcpyDeviceToHost, ctx->stream));
         size_t tp = ctx->timing_begin(D2R_T_PREP);
         if ((rc = d2r_launch_preprocess(ctx, (d2r_clip *)clip, (const uint8_t *)ctx->frames.p, nc, V.W, V.H, 1,
-                                        (uint16_t *)ctx->clipws[6].p, nullptr)))
+                                        (uint16_t *)ctx->clipws[6].p, nullptr, reuse_bg ? ctx->rects.p : nullptr,
+                                        reuse_bg ? (const uint16_t *)ctx->bg_patches.p : nullptr)))
             return rc;
         ctx->timing_end(tp);
         size_t tc = ctx->timing_begin(D2R_T_CLIP);

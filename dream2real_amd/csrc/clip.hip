@@ -117,12 +117,41 @@ __device__ __forceinline__ uint32_t clip8(int v)
 __global__ __launch_bounds__(256) void k_preprocess(const uint8_t *__restrict__ frames, uint32_t w, uint32_t h,
                                                     int rot90, ResampleTables R, uint32_t S, uint32_t P,
                                                     uint32_t band, uint16_t *__restrict__ patches,
-                                                    uint32_t Kp_pad, float *__restrict__ pixel_values)
+                                                    uint32_t Kp_pad, float *__restrict__ pixel_values,
+                                                    const int4 *__restrict__ rects, const uint16_t *__restrict__ bg_patches)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t tmp[];
     const uint32_t img = blockIdx.y;
     const uint32_t row0 = blockIdx.x * band;                 // first output row (cropped coords)
     const uint32_t nrows = min(band, S - row0);
+    // Composited candidates differ from the background frame only inside the rectangle their rays were generated in
+    // (rects[img] = x0, y0, x1, y1 in frame pixels, inclusive; k_raygen_rect).  A band (= one row of patches) whose
+    // source rows do not meet that rectangle resamples background pixels only: it is the background's own patch row
+    // (computed once per view with this same kernel), copied.  Exact by construction; ~3/4 of the bands of a
+    // candidate with a 60-pixel object.
+    if (rects && bg_patches && patches && !pixel_values && band == P) {
+        int ys, ye;                                          // rotated-source rows this band reads: [ys, ye)
+        if (R.need_v) {
+            ys = R.bounds_v[2 * (R.top + row0)];
+            const int lastrow = R.top + row0 + nrows - 1;
+            ye = R.bounds_v[2 * lastrow] + R.bounds_v[2 * lastrow + 1];
+        } else {
+            ys = R.top + row0;
+            ye = ys + nrows;
+        }
+        const int4 rc = rects[img];
+        // the rectangle's rows in the (rotated) source: rot90 maps frame column x to row w-1-x
+        const int rlo = rot90 ? (int)w - 1 - rc.z : rc.y, rhi = rot90 ? (int)w - 1 - rc.x : rc.w;
+        const bool untouched = rc.x > rc.z || rc.y > rc.w || rhi < ys || rlo >= ye;
+        if (untouched) {
+            const uint32_t g = S / P;
+            const size_t n16 = (size_t)g * Kp_pad * 2 / 16;                         // one patch row, in 16-byte words
+            const uint4 *src16 = (const uint4 *)(bg_patches + (size_t)blockIdx.x * g * Kp_pad);
+            uint4 *dst16 = (uint4 *)(patches + ((size_t)img * g * g + (size_t)blockIdx.x * g) * Kp_pad);
+            for (size_t i = threadIdx.x; i < n16; i += blockDim.x) dst16[i] = src16[i];
+            return;
+        }
+    }
     const uint8_t *src = frames + (size_t)img * w * h * 3;
     // rows of the horizontally-resampled image this band needs
     int y_first, y_last;
@@ -1788,7 +1817,8 @@ static int prep_tables(d2r_ctx *ctx, d2r_clip *clip, uint32_t w, uint32_t h, int
 
 // frames (device, [n][h][w][3] u8) -> patches (bf16 [n*g*g][Kp_pad]) and/or pixel_values
 int d2r_launch_preprocess(d2r_ctx *ctx, d2r_clip *clip, const uint8_t *frames_dev, uint32_t n, uint32_t w,
-                          uint32_t h, int rot90, uint16_t *patches_dev, float *pixel_values_dev)
+                          uint32_t h, int rot90, uint16_t *patches_dev, float *pixel_values_dev, const void *rects_dev,
+                          const uint16_t *bg_patches_dev)
 {
     const uint32_t S = clip->desc.image_size, P = clip->desc.patch_size;
     const PrepCache *pc = nullptr;
@@ -1803,7 +1833,7 @@ int d2r_launch_preprocess(d2r_ctx *ctx, d2r_clip *clip, const uint8_t *frames_de
         (void)hipFuncSetAttribute((const void *)k_preprocess, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     });
     hipLaunchKernelGGL(k_preprocess, dim3((S + band - 1) / band, n), dim3(256), lds, ctx->stream, frames_dev, w, h,
-                       rot90, R, S, P, band, patches_dev, clip->Kp_pad, pixel_values_dev);
+                       rot90, R, S, P, band, patches_dev, clip->Kp_pad, pixel_values_dev, (const int4 *)rects_dev, bg_patches_dev);
     D2R_HIP(ctx, hipGetLastError());
     return D2R_OK;
 }
@@ -2186,6 +2216,7 @@ extern "C" int d2r_clip_create(d2r_ctx *ctx, const d2r_clip_desc *desc, const fl
 extern "C" void d2r_clip_destroy(d2r_clip *c)
 {
     if (!c) return;
+    if (c->ctx && c->ctx->bg_patches_for == (const void *)c) c->ctx->bg_patches_for = nullptr;   // a later model may reuse the address
     for (void *p : c->allocs) hipFree(p);
     delete c;
 }

@@ -98,6 +98,10 @@ struct d2r_ctx {
     uint32_t text_turn = 0;
     // background of the current view
     Buf bg_rgba, bg_depth, bg_u8;
+    Buf rects;                   // per candidate of a pass: frame rectangle (x0, y0, x1, y1) its rays were generated in
+    Buf bg_patches;              // CLIP patches of the background frame itself (one image)
+    const void *bg_patches_for = nullptr;   // the d2r_clip they were computed with (nullptr = stale)
+    int64_t prep_reuse = 1;      // k_preprocess copies the background's patch rows for bands a candidate cannot have touched
     uint32_t bg_w = 0, bg_h = 0;
     d2r_render_stats stats{};
     // device geometry (hipDeviceProp_t / hipDeviceAttributeNumberOfXccs): persistent kernels launch one
@@ -165,6 +169,6 @@ int d2r_launch_cameras_virtual(d2r_ctx *, const ViewParams &, const float *obj_n
                                float *cams_out);
 int d2r_launch_render(d2r_ctx *, const d2r_nerf *, const ViewParams &, const float *cams_dev,
                       uint32_t n, bool composite, float *rgba_dev, float *depth_dev,
-                      uint8_t *frames_dev);
+                      uint8_t *frames_dev, void *rects_dev = nullptr);
 int d2r_launch_bg_quantize(d2r_ctx *, uint32_t w, uint32_t h);
 ViewParams d2r_view_params(const d2r_view *v);

@@ -397,7 +397,8 @@ __global__ __launch_bounds__(256) void k_raygen(NerfParams P, ViewParams V, cons
 // grid: (n_cams, parts); block 256 = 4 waves, each wave an 8x8 pixel tile.
 template <bool CONE>
 __global__ __launch_bounds__(256) void k_raygen_rect(NerfParams P, ViewParams V, const float *__restrict__ cams,
-                                                     uint2 *__restrict__ queue, uint32_t *__restrict__ qcount)
+                                                     uint2 *__restrict__ queue, uint32_t *__restrict__ qcount,
+                                                     int4 *__restrict__ rects)
 {
     const uint32_t cam_i = blockIdx.x;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -440,8 +441,14 @@ __global__ __launch_bounds__(256) void k_raygen_rect(NerfParams P, ViewParams V,
             y1 = min(y1, (int)ceilf(fminf(pymax, (float)V.H + 4.f)) + 2);
         }
     }
-    if (x0 > x1 || y0 > y1) return;                                         // the box is off screen
+    if (x0 > x1 || y0 > y1) {                                               // the box is off screen
+        if (rects && blockIdx.y == 0 && threadIdx.x == 0) rects[cam_i] = make_int4(1, 1, 0, 0);     // empty
+        return;
+    }
     const int tx0 = x0 >> 4, ty0 = y0 >> 4, ntx = (x1 >> 4) - tx0 + 1, nty = (y1 >> 4) - ty0 + 1;
+    // the pixels this candidate's rays can write: the 16x16 tiles walked below (for the CLIP preprocess's fast path)
+    if (rects && blockIdx.y == 0 && threadIdx.x == 0)
+        rects[cam_i] = make_int4(tx0 * 16, ty0 * 16, min((int)V.W, (tx0 + ntx) * 16) - 1, min((int)V.H, (ty0 + nty) * 16) - 1);
     // live rays are collected in LDS and appended to the global queue with ONE atomic per flush: the
     // queue counter is a single address, and one atomic per wave (~10^6 per pass) was what bounded
     // the full-frame generator
@@ -1067,7 +1074,7 @@ int d2r_launch_cameras_virtual(d2r_ctx *ctx, const ViewParams &V, const float *o
 
 // counters layout: [0] queue count, [1] queue head, [2..3] 64-bit sample counter
 int d2r_launch_render(d2r_ctx *ctx, const d2r_nerf *m, const ViewParams &V, const float *cams_dev, uint32_t n,
-                      bool composite, float *rgba_dev, float *depth_dev, uint8_t *frames_dev)
+                      bool composite, float *rgba_dev, float *depth_dev, uint8_t *frames_dev, void *rects_dev)
 {
     const size_t rays = (size_t)n * V.W * V.H;
     if (rays >= (1ull << 32)) return d2r_fail(ctx, D2R_ERR_INVALID, "too many rays in one pass");
@@ -1093,8 +1100,8 @@ int d2r_launch_render(d2r_ctx *ctx, const d2r_nerf *m, const ViewParams &V, cons
     size_t tr = ctx->timing_begin(D2R_T_RAYGEN);
     const bool cone = m->P.aabb_scale >= 2;          // occupancy cascades + cone stepping
     if (composite && ctx->raygen_rect) {
-        if (cone) hipLaunchKernelGGL(k_raygen_rect<true>, dim3(n, 4), dim3(256), 0, ctx->stream, m->P, V, cams_dev, (uint2 *)ctx->queue.p, cnt);
-        else hipLaunchKernelGGL(k_raygen_rect<false>, dim3(n, 4), dim3(256), 0, ctx->stream, m->P, V, cams_dev, (uint2 *)ctx->queue.p, cnt);
+        if (cone) hipLaunchKernelGGL(k_raygen_rect<true>, dim3(n, 4), dim3(256), 0, ctx->stream, m->P, V, cams_dev, (uint2 *)ctx->queue.p, cnt, (int4 *)rects_dev);
+        else hipLaunchKernelGGL(k_raygen_rect<false>, dim3(n, 4), dim3(256), 0, ctx->stream, m->P, V, cams_dev, (uint2 *)ctx->queue.p, cnt, (int4 *)rects_dev);
     } else {
         if (cone)
             hipLaunchKernelGGL(k_raygen<true>, dim3(tiles, n), dim3(256), 0, ctx->stream, m->P, V, cams_dev, (uint2 *)ctx->queue.p,

@@ -309,6 +309,9 @@ D2R_API int d2r_get_timing(d2r_ctx *ctx, d2r_timing *out);
  *     reads nothing else; same result, ~6 % less ViT work).  "attn_persistent", "attn_stagger", "gemm_stagger",
  *     "gemm_group": alternative schedules of the attention / persistent-GEMM kernels that were measured no faster
  *     and are kept switchable; results do not depend on them.
+ * "prep_reuse" (default 1): in d2r_render_score, the rows of CLIP patches of a candidate frame that its object cannot have
+ *     touched (outside the rectangle its rays are generated in) are copied from the background frame's own patches,
+ *     computed once per d2r_set_background; bit-identical to resampling them.
  * "timing" (0/1): record HIP events per kernel group for d2r_get_timing.  "march_blocks" (default 0 =
  *     one persistent workgroup per CU), "gemm_cfg" (0 default, 1 plain-K-loop 256x256 kernel, 2 force
  *     256x128): development switches. */

@@ -750,6 +750,50 @@ def test_fused_render_score_device_path(gpu):
     sc.close()
 
 
+def test_background_patch_reuse_is_bit_identical(gpu):
+    """d2r_render_score copies the background frame's patch rows for the bands of a candidate that its rays cannot have
+    touched (option prep_reuse, default on).  Logits with the fast path on and off must be the same bits — 640x360
+    frames (the bench size), a pose grid that reaches the frame edges, one pose outside the frustum, ragged chunks,
+    and a second background (the cached background patches must be refreshed)."""
+    import torch
+    engine, ctx, scene, fg, bg = gpu["engine"], gpu["ctx"], gpu["scene"], gpu["fg"], gpu["bg"]
+    cfg = CLIP_CONFIGS["vit_tiny"]
+    sd = random_clip_state_dict(cfg, seed=11, text=False)
+    sc = engine.ClipScorer(ctx, cfg, sd)
+    text = random_unit_text_embeds(cfg["proj"], 2)
+    W, H = 640, 360
+    cam_bg = host_ref.converter(np.asarray(scene.cam_poses, np.float32))[0]
+    brgba, bdepth = bg.render_batch(cam_bg[None, :3], W, H)
+    view = fg.view(W, H)
+    T1 = host_ref.converter(np.asarray(scene.obj_pose, np.float32)[None])[0]
+    poses = host_ref.sample_poses_grid(scene.scene_centre, [7, 5, 2, 1, 1, 1], scene.scene_type).reshape(-1, 4, 4)
+    far = np.array(scene.obj_pose, np.float32)
+    far[:3, 3] += (5.0, 5.0, 0.0)
+    poses = np.concatenate([poses, far[None]])
+    pn = host_ref.converter(poses).reshape(-1, 16)
+    dev = torch.device("cuda:0")
+    p_dev = torch.from_numpy(pn).to(dev)
+    out = {}
+    ctx.set_option("chunk", 16)
+    for tag, rgba in (("a", brgba[0]), ("b", np.ascontiguousarray(brgba[0][::-1]))):   # second background: flipped
+        ctx.set_background(view, rgba, bdepth[0])
+        for flag in (1, 0, 1):
+            ctx.set_option("prep_reuse", flag)
+            lg = torch.full((len(poses), 2), -7.0, dtype=torch.float32, device=dev)
+            torch.cuda.synchronize()
+            engine.render_score_device(ctx, fg, sc, view, T1, cam_bg, p_dev.data_ptr(), len(poses), text, lg.data_ptr(), None)
+            ctx.synchronize()
+            out.setdefault(tag, []).append(lg.cpu().numpy())
+    ctx.set_option("prep_reuse", 1)
+    ctx.set_option("chunk", 1024)
+    for tag in out:
+        np.testing.assert_array_equal(out[tag][0], out[tag][1])
+        np.testing.assert_array_equal(out[tag][0], out[tag][2])
+    assert np.abs(out["a"][0] - out["b"][0]).max() > 1e-3               # the backgrounds do differ
+    assert np.ptp(out["a"][0][:, 0]) > 1e-4                             # and the candidates are not all alike
+    sc.close()
+
+
 def test_full_size_properties(gpu):
     """BASELINE.json config-1 frame size (640x360): size-independent properties instead of the
     (slow) oracle — determinism, candidates only differ where the object is, a pose outside
