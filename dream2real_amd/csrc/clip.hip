@@ -266,7 +266,8 @@ enum { EPI_F32 = 0, EPI_BIAS_BF16 = 1, EPI_BIAS_GELU_BF16 = 2, EPI_BIAS_RESID_F3
        EPI_RESID_STATS_SPLIT = 8, EPI_KINDS = 9 };
 #define EPI_IS_LN(E) ((E) == EPI_LN_BIAS_BF16 || (E) == EPI_LN_BIAS_GELU_BF16)
 #define EPI_IS_STATS(E) ((E) == EPI_RESID_STATS_F32X || (E) == EPI_RESID_STATS_BF16 || (E) == EPI_RESID_STATS_SPLIT)
-#define EPI_IS_F32_LAYOUT(E) ((E) == EPI_F32 || (E) == EPI_BIAS_RESID_F32 || EPI_IS_STATS(E))
+#define EPI_IS_F32_LAYOUT(E) ((E) == EPI_F32 || (E) == EPI_BIAS_RESID_F32 || (E) == EPI_RESID_STATS_F32X)
+#define EPI_IS_RESID_BF16(E) ((E) == EPI_RESID_STATS_BF16 || (E) == EPI_RESID_STATS_SPLIT)
 
 // operands of the folded epilogues
 struct EpiAux {
@@ -342,6 +343,15 @@ __device__ __forceinline__ float row16_sum(float x)
     x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x121, 0xf, 0xf, false));   // row_ror:1
     return x;
 }
+// sum over the 8 lanes of an aligned group (lanes 8g .. 8g+7), result in every lane: xor 1, xor 2 inside the quad,
+// then the other quad of the group through row_half_mirror (lane i <-> 7 - i)
+__device__ __forceinline__ float row8_sum(float x)
+{
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xf, 0xf, false));    // quad_perm:[1,0,3,2]
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xf, 0xf, false));    // quad_perm:[2,3,0,1]
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x141, 0xf, 0xf, false));   // row_half_mirror
+    return x;
+}
 __device__ __forceinline__ float bf_lo(uint32_t u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
 
@@ -377,87 +387,130 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], float *ep, u
     // float offset of logical row R (0..7), column c (0..63) of the 8-row group in ep
     auto ep_at = [](uint32_t R, uint32_t c) -> uint32_t { return ((c >> 5) * 4u + (R & 3u)) * EP_LD + (R >> 2) * 32u + (c & 31u); };
     if (EPI_IS_F32_LAYOUT(EPI)) {
-        // fp32 outputs: a lane owns 4 columns of a row, 16 lanes (one DPP row) a 256-byte row segment.  The
-        // residual rows of TWO 32-row groups (16 loads per lane) are requested before the first transpose,
-        // so a tile pays two HBM round trips instead of eight.
+        // fp32 outputs: a lane owns 4 columns of a row, 16 lanes (one DPP row) a 256-byte row segment
         const uint32_t c4 = (lane & 15) * 4, rl0 = lane >> 4;
         const uint32_t col = col0 + c4;
         constexpr bool RESID_F32 = EPI == EPI_BIAS_RESID_F32 || EPI == EPI_RESID_STATS_F32X;
-        constexpr bool RESID_BF16 = EPI == EPI_RESID_STATS_BF16 || EPI == EPI_RESID_STATS_SPLIT;
-        constexpr bool SPLIT = EPI == EPI_RESID_STATS_SPLIT;
-        constexpr bool STATS = EPI_IS_STATS(EPI);
+        constexpr bool STATS = EPI == EPI_RESID_STATS_F32X;
         float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
         if (EPI != EPI_F32) {
             bv = *(const float4 *)(bias + col);
             asm volatile("" : "+v"(bv.x), "+v"(bv.y), "+v"(bv.z), "+v"(bv.w));      // loaded before anything else is issued
         }
-        static_assert(MT % 2 == 0, "epilogue handles m-tiles in pairs");
         if (EPI == EPI_F32) hook();
-        // element offset of this lane's 4 columns of `row` in the bf16 residual arrays (tile-major planes, or row-major)
+        // element offset of this lane's 4 columns of `row` in the bf16 operand copy (tile-major planes, or row-major)
         auto xoff = [&](uint32_t row) -> uint32_t {
             return aux.hm_rows ? ((col0 >> 6) * aux.hm_rows + row) * 64u + c4 : row * N + col;
         };
-        // m-tiles whose residual rows are requested together (the fp32-residual + statistics variant carries the
-        // most live values: one m-tile at a time keeps it out of scratch)
-        constexpr int G = (EPI == EPI_RESID_STATS_F32X || EPI == EPI_BIAS_RESID_F32) ? 1 : 2;
+        // the residual rows of one m-tile (8 loads per lane) are requested together, before its first transpose
+#pragma unroll
+        for (int ih = 0; ih < MT; ih++) {
+            float4 xr[8];
+            if (RESID_F32) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const uint32_t row = row0 + ih * 32 + rl0 + 4 * k;
+                    xr[k] = (D2R_GEMM_ABLATE & 128) ? make_float4(0.f, 0.f, 0.f, 0.f) : *(const float4 *)((const float *)Cout + row * N + col);
+                }
+                if (ih == MT - 1) hook();
+            }
+#pragma unroll
+            for (int p8 = 0; p8 < 4; p8++) {
+                transpose_in(ih, p8);
+#pragma unroll
+                for (int qq = 0; qq < 2; qq++) {
+                    const int k = 2 * p8 + qq;
+                    const uint32_t row = row0 + ih * 32 + rl0 + 4 * k;
+                    float4 v = (D2R_GEMM_ABLATE & 256) ? make_float4(acc[ih][0][k], acc[ih][0][k + 8], acc[ih][1][k], acc[ih][1][k + 8])
+                                                       : *(const float4 *)(ep + ep_at(rl0 + 4 * qq, c4));
+                    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                    if (RESID_F32) {
+                        v.x += xr[k].x; v.y += xr[k].y; v.z += xr[k].z; v.w += xr[k].w;
+                    }
+#if (D2R_GEMM_ABLATE & 128) && defined(__HIP_DEVICE_COMPILE__)
+                    asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+                    continue;
+#endif
+                    *(float4 *)((float *)Cout + row * N + col) = v;       // < 2^32 elements (checked on host)
+                    if (STATS) {
+                        // the bf16 copy the next GEMM reads as its A operand, and this 64-column group's share of
+                        // the row's LayerNorm statistics (of the fp32 values: the rounding averages out over d)
+                        *(uint2 *)(aux.xb + xoff(row)) = make_uint2(pack2(v.x, v.y), pack2(v.z, v.w));
+                        const float sm = row16_sum((v.x + v.y) + (v.z + v.w));
+                        const float sq = row16_sum(fmaf(v.x, v.x, v.y * v.y) + fmaf(v.z, v.z, v.w * v.w));
+                        if ((lane & 15) == 0) aux.part[(col0 >> 6) * aux.hm_rows + row] = make_float2(sm, sq);      // [N / 64][M_pad]: coalesced for k_rowstats
+                    }
+                }
+            }
+        }
+    } else if (EPI_IS_RESID_BF16(EPI)) {
+        // bf16 residual stream (one array, or hi + lo): same lane layout as the bf16 outputs below — a lane owns 8
+        // columns of a row, so the residual comes in and goes out in 16-byte pieces, 1 KiB per wave instruction (in
+        // the 4-column layout of the fp32 outputs a tile took 160 half-width memory instructions per wave and its
+        // epilogue 32 k cycles, against 5-8 k for the bf16 outputs).  The residual rows of two m-tiles (16 loads per
+        // lane for hi + lo) are requested before the first transpose.
+        constexpr bool SPLIT = EPI == EPI_RESID_STATS_SPLIT;
+        const uint32_t c8 = (lane & 7) * 8, rl0 = lane >> 3;
+        const uint32_t col = col0 + c8;
+        float4 b0 = *(const float4 *)(bias + col), b1 = *(const float4 *)(bias + col + 4);
+        asm volatile("" : "+v"(b0.x), "+v"(b0.y), "+v"(b0.z), "+v"(b0.w), "+v"(b1.x), "+v"(b1.y), "+v"(b1.z), "+v"(b1.w));
+        auto xoff = [&](uint32_t row) -> uint32_t {
+            return aux.hm_rows ? ((col0 >> 6) * aux.hm_rows + row) * 64u + c8 : row * N + col;
+        };
+        constexpr int G = 2;
+        static_assert(MT % G == 0, "epilogue handles m-tiles in pairs");
 #pragma unroll
         for (int ih = 0; ih < MT; ih += G) {
-            float4 xr[G][8];
-            uint2 xh[G][8], xl[G][8];
-            if (RESID_F32 || RESID_BF16) {
-#pragma unroll
-                for (int ii = 0; ii < G; ii++)
-#pragma unroll
-                    for (int k = 0; k < 8; k++) {
-                        const uint32_t row = row0 + (ih + ii) * 32 + rl0 + 4 * k;
-                        if (RESID_F32)
-                            xr[ii][k] = (D2R_GEMM_ABLATE & 128) ? make_float4(0.f, 0.f, 0.f, 0.f)
-                                                                : *(const float4 *)((const float *)Cout + row * N + col);
-                        else
-                            xh[ii][k] = *(const uint2 *)(aux.xb + xoff(row));
-                        if (SPLIT) xl[ii][k] = *(const uint2 *)(aux.xlo + xoff(row));
-                    }
-                if (ih == MT - G) hook();
-            }
+            uint4 xh[G][4], xl[G][4];
 #pragma unroll
             for (int ii = 0; ii < G; ii++)
 #pragma unroll
-                for (int p8 = 0; p8 < 4; p8++) {
-                    transpose_in(ih + ii, p8);
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t row = row0 + (ih + ii) * 32 + rl0 + 8 * k;
+                    xh[ii][k] = *(const uint4 *)(aux.xb + xoff(row));
+                    if (SPLIT) xl[ii][k] = *(const uint4 *)(aux.xlo + xoff(row));
+                }
+            if (ih == MT - G) hook();
 #pragma unroll
-                    for (int qq = 0; qq < 2; qq++) {
-                        const int k = 2 * p8 + qq;
-                        const uint32_t row = row0 + (ih + ii) * 32 + rl0 + 4 * k;
-                        float4 v = (D2R_GEMM_ABLATE & 256) ? make_float4(acc[ih + ii][0][k], acc[ih + ii][0][k + 8], acc[ih + ii][1][k], acc[ih + ii][1][k + 8])
-                                                           : *(const float4 *)(ep + ep_at(rl0 + 4 * qq, c4));
-                        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-                        if (RESID_F32) {
-                            v.x += xr[ii][k].x; v.y += xr[ii][k].y; v.z += xr[ii][k].z; v.w += xr[ii][k].w;
-                        }
-                        if (RESID_BF16) {
-                            v.x += bf_lo(xh[ii][k].x); v.y += bf_hi(xh[ii][k].x); v.z += bf_lo(xh[ii][k].y); v.w += bf_hi(xh[ii][k].y);
-                        }
-                        if (SPLIT) {
-                            v.x += bf_lo(xl[ii][k].x); v.y += bf_hi(xl[ii][k].x); v.z += bf_lo(xl[ii][k].y); v.w += bf_hi(xl[ii][k].y);
-                        }
-#if (D2R_GEMM_ABLATE & 128) && defined(__HIP_DEVICE_COMPILE__)
-                        asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
-                        continue;
-#endif
-                        if (!RESID_BF16) *(float4 *)((float *)Cout + row * N + col) = v;       // < 2^32 elements (checked on host)
-                        if (STATS) {
-                            // the bf16 copy the next GEMM reads as its A operand, and this 64-column group's share of
-                            // the row's LayerNorm statistics (of the fp32 values: the rounding averages out over d)
-                            const uint2 hv = make_uint2(pack2(v.x, v.y), pack2(v.z, v.w));
-                            *(uint2 *)(aux.xb + xoff(row)) = hv;
-                            if (SPLIT)
-                                *(uint2 *)(aux.xlo + xoff(row)) = make_uint2(pack2(v.x - bf_lo(hv.x), v.y - bf_hi(hv.x)),
-                                                                                 pack2(v.z - bf_lo(hv.y), v.w - bf_hi(hv.y)));
-                            const float sm = row16_sum((v.x + v.y) + (v.z + v.w));
-                            const float sq = row16_sum(fmaf(v.x, v.x, v.y * v.y) + fmaf(v.z, v.z, v.w * v.w));
-                            if ((lane & 15) == 0) aux.part[(col0 >> 6) * aux.hm_rows + row] = make_float2(sm, sq);      // [N / 64][M_pad]: coalesced for k_rowstats
+            for (int ii = 0; ii < G; ii++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    transpose_in(ih + ii, k);
+                    const uint32_t row = row0 + (ih + ii) * 32 + rl0 + 8 * k;
+                    const float4 u = (D2R_GEMM_ABLATE & 256) ? make_float4(acc[ih + ii][0][k], acc[ih + ii][0][k + 8], acc[ih + ii][1][k], acc[ih + ii][1][k + 8])
+                                                             : *(const float4 *)(ep + ep_at(rl0, c8));
+                    const float4 w = (D2R_GEMM_ABLATE & 256) ? make_float4(acc[ih + ii][0][k + 4], acc[ih + ii][0][k + 12], acc[ih + ii][1][k + 4], acc[ih + ii][1][k + 12])
+                                                             : *(const float4 *)(ep + ep_at(rl0, c8) + 4);
+                    float f[8] = {u.x + b0.x, u.y + b0.y, u.z + b0.z, u.w + b0.w, w.x + b1.x, w.y + b1.y, w.z + b1.z, w.w + b1.w};
+                    const uint32_t hw[4] = {xh[ii][k].x, xh[ii][k].y, xh[ii][k].z, xh[ii][k].w};
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        f[2 * e] += bf_lo(hw[e]);
+                        f[2 * e + 1] += bf_hi(hw[e]);
+                    }
+                    if (SPLIT) {
+                        const uint32_t lw[4] = {xl[ii][k].x, xl[ii][k].y, xl[ii][k].z, xl[ii][k].w};
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            f[2 * e] += bf_lo(lw[e]);
+                            f[2 * e + 1] += bf_hi(lw[e]);
                         }
                     }
+#if (D2R_GEMM_ABLATE & 128) && defined(__HIP_DEVICE_COMPILE__)
+                    asm volatile("" ::"v"(f[0]), "v"(f[1]), "v"(f[2]), "v"(f[3]), "v"(f[4]), "v"(f[5]), "v"(f[6]), "v"(f[7]));
+                    continue;
+#endif
+                    // the bf16 copy the next GEMM reads as its A operand (hi), what it leaves of the fp32 value (lo), and
+                    // this 64-column group's share of the row's LayerNorm statistics (of the fp32 values)
+                    const uint4 hv = make_uint4(pack2(f[0], f[1]), pack2(f[2], f[3]), pack2(f[4], f[5]), pack2(f[6], f[7]));
+                    *(uint4 *)(aux.xb + xoff(row)) = hv;
+                    if (SPLIT)
+                        *(uint4 *)(aux.xlo + xoff(row)) = make_uint4(pack2(f[0] - bf_lo(hv.x), f[1] - bf_hi(hv.x)), pack2(f[2] - bf_lo(hv.y), f[3] - bf_hi(hv.y)),
+                                                                     pack2(f[4] - bf_lo(hv.z), f[5] - bf_hi(hv.z)), pack2(f[6] - bf_lo(hv.w), f[7] - bf_hi(hv.w)));
+                    const float sm = row8_sum(((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7])));
+                    const float sq = row8_sum((fmaf(f[0], f[0], f[1] * f[1]) + fmaf(f[2], f[2], f[3] * f[3])) +
+                                              (fmaf(f[4], f[4], f[5] * f[5]) + fmaf(f[6], f[6], f[7] * f[7])));
+                    if ((lane & 7) == 0) aux.part[(col0 >> 6) * aux.hm_rows + row] = make_float2(sm, sq);      // [N / 64][M_pad]: coalesced for k_rowstats
                 }
         }
     } else {

@@ -15,13 +15,15 @@ sc = engine.ClipScorer(ctx, cfg, random_clip_state_dict(cfg, seed=6, text=False)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 pv = np.random.default_rng(0).standard_normal((n, 3, 224, 224), dtype=np.float32)
 lib = _lib.load()
-out = (C.c_ulonglong * 16)()
+KINDS = 9
+out = (C.c_ulonglong * (4 * KINDS))()
 sc.embed_pixels(pv)
 lib.d2r_debug_gemm_stamps(out, 1)
 sc.embed_pixels(pv)
 lib.d2r_debug_gemm_stamps(out, 0)
-names = ["patch (fp32)", "QKV (bias bf16)", "fc1 (gelu bf16)", "out-proj + fc2 (fp32 residual)"]
-for e in range(4):
+names = ["patch (fp32)", "bias bf16", "bias gelu bf16", "bias + fp32 residual", "QKV (LN-folded, bf16)", "fc1 (LN-folded, gelu, bf16)",
+         "resid + stats, fp32 + copy", "resid + stats, bf16", "out-proj + fc2 (resid + stats, split bf16)"]
+for e in range(KINDS):
     w, k, ep, t = out[4 * e:4 * e + 4]
     if t:
-        print(f"{names[e]:34s} tiles/WG-wave0 {t:7d}  drain {w / t:9.0f}  K loop {k / t:9.0f}  epilogue {ep / t:9.0f} cycles/tile")
+        print(f"{names[e]:44s} tiles/WG-wave0 {t:7d}  drain {w / t:9.0f}  K loop {k / t:9.0f}  epilogue {ep / t:9.0f} cycles/tile")
