@@ -37,16 +37,16 @@ MLP_FLOP_PER_SAMPLE = 20480
 
 def vit_gflop(cfg, executed: bool = False) -> float:
     """Forward FLOPs per image of the vision tower (35.1 GFLOP for ViT-B/16).
-    executed=True: what the library actually issues — its last block computes q/k/v for every token but
+    executed=True: what the library actually issues — its last block computes k/v for every token but q,
     attention output, out-projection and MLP for the class token only (the head reads nothing else;
-    the other rows of the last block are dead code), 2.2 GFLOP less for ViT-B/16."""
+    the other rows of the last block are dead code), 2.4 GFLOP less for ViT-B/16."""
     P, d, mlp, L = cfg["patch_size"], cfg["hidden_size"], cfg["mlp"], cfg["num_layers"]
     npatch = (cfg["image_size"] // P) ** 2
     T = npatch + 1
     per_layer = 2 * T * (4 * d * d + 2 * d * mlp) + 4 * T * T * d
     total = 2 * npatch * d * 3 * P * P + L * per_layer + 2 * d * cfg["proj"]
     if executed:
-        last = 2 * T * 3 * d * d + 4 * T * d + 2 * (d * d + 2 * d * mlp)
+        last = 2 * T * 2 * d * d + 2 * d * d + 4 * T * d + 2 * (d * d + 2 * d * mlp)
         total += last - per_layer
     return total / 1e9
 
@@ -273,7 +273,7 @@ def main():
                          "mlp_tflops": round(samples_per_launch * MLP_FLOP_PER_SAMPLE / march_avg_s / 1e12, 3) if march_avg_s > 0 else None},
             "roofline_vit": {"bound": "mfma", "gflop_per_image": round(vit_gflop(cfg, executed=cls_last), 2),
                              "gflop_per_image_architecture": round(vit_gflop(cfg), 2),
-                             "note": "last block: attention output / out-proj / MLP on the class token only (exact: the head reads nothing else)",
+                             "note": "last block: q, attention output, out-proj and MLP on the class token only (exact: the head reads nothing else)",
                              "achieved": round(clip_tflops, 2) if clip_tflops else None,
                              "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": round(clip_tflops / MFMA_BF16_PEAK_TFLOPS, 5) if clip_tflops else None},

@@ -266,16 +266,15 @@ enum { EPI_F32 = 0, EPI_BIAS_BF16 = 1, EPI_BIAS_GELU_BF16 = 2, EPI_BIAS_RESID_F3
        EPI_RESID_STATS_SPLIT = 8, EPI_KINDS = 9 };
 #define EPI_IS_LN(E) ((E) == EPI_LN_BIAS_BF16 || (E) == EPI_LN_BIAS_GELU_BF16)
 #define EPI_IS_STATS(E) ((E) == EPI_RESID_STATS_F32X || (E) == EPI_RESID_STATS_BF16 || (E) == EPI_RESID_STATS_SPLIT)
-#define EPI_IS_F32_LAYOUT(E) ((E) == EPI_F32 || (E) == EPI_BIAS_RESID_F32 || (E) == EPI_RESID_STATS_F32X)
-#define EPI_IS_RESID_BF16(E) ((E) == EPI_RESID_STATS_BF16 || (E) == EPI_RESID_STATS_SPLIT)
+#define EPI_IS_F32_LAYOUT(E) ((E) == EPI_F32 || (E) == EPI_BIAS_RESID_F32)
 
 // operands of the folded epilogues
 struct EpiAux {
     const float *cs;       // EPI_LN_*: [N] column sums of the folded (bf16-rounded) weight
     const float2 *ab;      // EPI_LN_*: [M_pad] per row (rstd, -rstd * mean) of the residual row
-    uint16_t *xb;          // EPI_RESID_STATS_*: [M_pad][N] bf16 residual (read + written by _BF16, written by _F32X)
+    uint16_t *xb;          // EPI_RESID_STATS_*: bf16 residual, tile-major [N / 64][M_pad][64] (read + written by _BF16 / _SPLIT, written by _F32X)
     float2 *part;          // EPI_RESID_STATS_*: [N / 64][M_pad] partial (sum, sum of squares) per 64-column group (needs hm_rows = M_pad)
-    uint16_t *xlo;         // EPI_RESID_STATS_SPLIT: [M_pad][N] low half of the split residual
+    uint16_t *xlo;         // EPI_RESID_STATS_SPLIT: low half of the split residual, same layout
     // Layout of bf16 activations.  "Tile-major" = [cols / 64][M_pad][64]: the 64-column group a wave tile produces
     // (one attention head; one K-tile of the GEMM that consumes it) is a contiguous plane, so an epilogue writes
     // whole 128-byte rows back to back and the consumer's LDS-DMA reads 8 KiB runs, instead of 128-byte pieces
@@ -390,18 +389,13 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], float *ep, u
         // fp32 outputs: a lane owns 4 columns of a row, 16 lanes (one DPP row) a 256-byte row segment
         const uint32_t c4 = (lane & 15) * 4, rl0 = lane >> 4;
         const uint32_t col = col0 + c4;
-        constexpr bool RESID_F32 = EPI == EPI_BIAS_RESID_F32 || EPI == EPI_RESID_STATS_F32X;
-        constexpr bool STATS = EPI == EPI_RESID_STATS_F32X;
+        constexpr bool RESID_F32 = EPI == EPI_BIAS_RESID_F32;
         float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
         if (EPI != EPI_F32) {
             bv = *(const float4 *)(bias + col);
             asm volatile("" : "+v"(bv.x), "+v"(bv.y), "+v"(bv.z), "+v"(bv.w));      // loaded before anything else is issued
         }
         if (EPI == EPI_F32) hook();
-        // element offset of this lane's 4 columns of `row` in the bf16 operand copy (tile-major planes, or row-major)
-        auto xoff = [&](uint32_t row) -> uint32_t {
-            return aux.hm_rows ? ((col0 >> 6) * aux.hm_rows + row) * 64u + c4 : row * N + col;
-        };
         // the residual rows of one m-tile (8 loads per lane) are requested together, before its first transpose
 #pragma unroll
         for (int ih = 0; ih < MT; ih++) {
@@ -432,33 +426,31 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], float *ep, u
                     continue;
 #endif
                     *(float4 *)((float *)Cout + row * N + col) = v;       // < 2^32 elements (checked on host)
-                    if (STATS) {
-                        // the bf16 copy the next GEMM reads as its A operand, and this 64-column group's share of
-                        // the row's LayerNorm statistics (of the fp32 values: the rounding averages out over d)
-                        *(uint2 *)(aux.xb + xoff(row)) = make_uint2(pack2(v.x, v.y), pack2(v.z, v.w));
-                        const float sm = row16_sum((v.x + v.y) + (v.z + v.w));
-                        const float sq = row16_sum(fmaf(v.x, v.x, v.y * v.y) + fmaf(v.z, v.z, v.w * v.w));
-                        if ((lane & 15) == 0) aux.part[(col0 >> 6) * aux.hm_rows + row] = make_float2(sm, sq);      // [N / 64][M_pad]: coalesced for k_rowstats
-                    }
                 }
             }
         }
-    } else if (EPI_IS_RESID_BF16(EPI)) {
-        // bf16 residual stream (one array, or hi + lo): same lane layout as the bf16 outputs below — a lane owns 8
-        // columns of a row, so the residual comes in and goes out in 16-byte pieces, 1 KiB per wave instruction (in
-        // the 4-column layout of the fp32 outputs a tile took 160 half-width memory instructions per wave and its
-        // epilogue 32 k cycles, against 5-8 k for the bf16 outputs).  The residual rows of two m-tiles (16 loads per
-        // lane for hi + lo) are requested before the first transpose.
+    } else if (EPI_IS_STATS(EPI)) {
+        // Residual + LayerNorm statistics (bf16 residual as one array or hi + lo; or fp32 residual + bf16 operand copy):
+        // same lane layout as the bf16 outputs below — a lane owns 8 columns of a row, so the residual comes in and
+        // goes out in 16-byte pieces, 1 KiB per wave instruction (in the 4-column layout of the plain fp32 outputs a
+        // tile took 160 half-width memory instructions per wave and its epilogue 32 k cycles, against 5-8 k for the
+        // bf16 outputs).  The residual rows of two m-tiles (16 loads per lane) are requested before the first transpose.
         constexpr bool SPLIT = EPI == EPI_RESID_STATS_SPLIT;
+        constexpr bool F32X = EPI == EPI_RESID_STATS_F32X;
         const uint32_t c8 = (lane & 7) * 8, rl0 = lane >> 3;
         const uint32_t col = col0 + c8;
         float4 b0 = *(const float4 *)(bias + col), b1 = *(const float4 *)(bias + col + 4);
         asm volatile("" : "+v"(b0.x), "+v"(b0.y), "+v"(b0.z), "+v"(b0.w), "+v"(b1.x), "+v"(b1.y), "+v"(b1.z), "+v"(b1.w));
-        auto xoff = [&](uint32_t row) -> uint32_t {
-            return aux.hm_rows ? ((col0 >> 6) * aux.hm_rows + row) * 64u + c8 : row * N + col;
-        };
-        constexpr int G = 2;
-        static_assert(MT % G == 0, "epilogue handles m-tiles in pairs");
+        // BYTE offsets in 32 bits on top of the uniform array bases (SGPR base + VGPR offset addressing, no 64-bit
+        // address per access; launch_gemm checks that the arrays are < 4 GiB and tile-major): this lane's 8 columns of
+        // the wave tile's row rl0 in plane col0 / 64; rows are 128 B apart, so the row of an access is an immediate
+        constexpr uint32_t xs = 128u;
+        const uint32_t x0 = (((col0 >> 6) * aux.hm_rows + row0 + rl0) * 64u + c8) * 2u;
+        const uint32_t p0 = ((col0 >> 6) * aux.hm_rows + row0 + rl0) * 8u;              // partial statistics [N / 64][M_pad] float2
+        const uint32_t f0 = ((row0 + rl0) * N + col) * 4u, fs = N * 4u;                 // fp32 residual, row-major
+        char *xb_b = (char *)aux.xb, *xlo_b = (char *)aux.xlo, *part_b = (char *)aux.part, *c_b = (char *)Cout;
+        constexpr int G = F32X ? 1 : 2;          // fp32 rows are twice the registers
+        static_assert(MT % G == 0, "epilogue handles m-tiles in groups");
 #pragma unroll
         for (int ih = 0; ih < MT; ih += G) {
             uint4 xh[G][4], xl[G][4];
@@ -466,9 +458,14 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], float *ep, u
             for (int ii = 0; ii < G; ii++)
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    const uint32_t row = row0 + (ih + ii) * 32 + rl0 + 8 * k;
-                    xh[ii][k] = *(const uint4 *)(aux.xb + xoff(row));
-                    if (SPLIT) xl[ii][k] = *(const uint4 *)(aux.xlo + xoff(row));
+                    const uint32_t rr = (ih + ii) * 32 + 8 * k;            // row of the wave tile, minus rl0
+                    if (F32X) {
+                        xh[ii][k] = *(const uint4 *)(c_b + f0 + rr * fs);
+                        xl[ii][k] = *(const uint4 *)(c_b + f0 + rr * fs + 16);
+                    } else {
+                        xh[ii][k] = *(const uint4 *)(xb_b + x0 + rr * xs);
+                        if (SPLIT) xl[ii][k] = *(const uint4 *)(xlo_b + x0 + rr * xs);
+                    }
                 }
             if (ih == MT - G) hook();
 #pragma unroll
@@ -476,41 +473,54 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], float *ep, u
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     transpose_in(ih + ii, k);
-                    const uint32_t row = row0 + (ih + ii) * 32 + rl0 + 8 * k;
+                    const uint32_t rr = (ih + ii) * 32 + 8 * k;
                     const float4 u = (D2R_GEMM_ABLATE & 256) ? make_float4(acc[ih + ii][0][k], acc[ih + ii][0][k + 8], acc[ih + ii][1][k], acc[ih + ii][1][k + 8])
                                                              : *(const float4 *)(ep + ep_at(rl0, c8));
                     const float4 w = (D2R_GEMM_ABLATE & 256) ? make_float4(acc[ih + ii][0][k + 4], acc[ih + ii][0][k + 12], acc[ih + ii][1][k + 4], acc[ih + ii][1][k + 12])
                                                              : *(const float4 *)(ep + ep_at(rl0, c8) + 4);
                     float f[8] = {u.x + b0.x, u.y + b0.y, u.z + b0.z, u.w + b0.w, w.x + b1.x, w.y + b1.y, w.z + b1.z, w.w + b1.w};
                     const uint32_t hw[4] = {xh[ii][k].x, xh[ii][k].y, xh[ii][k].z, xh[ii][k].w};
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        f[2 * e] += bf_lo(hw[e]);
-                        f[2 * e + 1] += bf_hi(hw[e]);
-                    }
-                    if (SPLIT) {
-                        const uint32_t lw[4] = {xl[ii][k].x, xl[ii][k].y, xl[ii][k].z, xl[ii][k].w};
+                    const uint32_t lw[4] = {xl[ii][k].x, xl[ii][k].y, xl[ii][k].z, xl[ii][k].w};
+                    if (F32X) {
 #pragma unroll
                         for (int e = 0; e < 4; e++) {
-                            f[2 * e] += bf_lo(lw[e]);
-                            f[2 * e + 1] += bf_hi(lw[e]);
+                            f[e] += __uint_as_float(hw[e]);
+                            f[4 + e] += __uint_as_float(lw[e]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            f[2 * e] += bf_lo(hw[e]);
+                            f[2 * e + 1] += bf_hi(hw[e]);
+                        }
+                        if (SPLIT) {
+#pragma unroll
+                            for (int e = 0; e < 4; e++) {
+                                f[2 * e] += bf_lo(lw[e]);
+                                f[2 * e + 1] += bf_hi(lw[e]);
+                            }
                         }
                     }
 #if (D2R_GEMM_ABLATE & 128) && defined(__HIP_DEVICE_COMPILE__)
                     asm volatile("" ::"v"(f[0]), "v"(f[1]), "v"(f[2]), "v"(f[3]), "v"(f[4]), "v"(f[5]), "v"(f[6]), "v"(f[7]));
                     continue;
 #endif
-                    // the bf16 copy the next GEMM reads as its A operand (hi), what it leaves of the fp32 value (lo), and
-                    // this 64-column group's share of the row's LayerNorm statistics (of the fp32 values)
+                    // the bf16 copy the next GEMM reads as its A operand (hi), what it leaves of the fp32 value (lo) or
+                    // the fp32 value itself, and this 64-column group's share of the row's LayerNorm statistics (of the
+                    // fp32 values)
                     const uint4 hv = make_uint4(pack2(f[0], f[1]), pack2(f[2], f[3]), pack2(f[4], f[5]), pack2(f[6], f[7]));
-                    *(uint4 *)(aux.xb + xoff(row)) = hv;
+                    *(uint4 *)(xb_b + x0 + rr * xs) = hv;
                     if (SPLIT)
-                        *(uint4 *)(aux.xlo + xoff(row)) = make_uint4(pack2(f[0] - bf_lo(hv.x), f[1] - bf_hi(hv.x)), pack2(f[2] - bf_lo(hv.y), f[3] - bf_hi(hv.y)),
-                                                                     pack2(f[4] - bf_lo(hv.z), f[5] - bf_hi(hv.z)), pack2(f[6] - bf_lo(hv.w), f[7] - bf_hi(hv.w)));
+                        *(uint4 *)(xlo_b + x0 + rr * xs) = make_uint4(pack2(f[0] - bf_lo(hv.x), f[1] - bf_hi(hv.x)), pack2(f[2] - bf_lo(hv.y), f[3] - bf_hi(hv.y)),
+                                                                      pack2(f[4] - bf_lo(hv.z), f[5] - bf_hi(hv.z)), pack2(f[6] - bf_lo(hv.w), f[7] - bf_hi(hv.w)));
+                    if (F32X) {
+                        *(float4 *)(c_b + f0 + rr * fs) = make_float4(f[0], f[1], f[2], f[3]);
+                        *(float4 *)(c_b + f0 + rr * fs + 16) = make_float4(f[4], f[5], f[6], f[7]);
+                    }
                     const float sm = row8_sum(((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7])));
                     const float sq = row8_sum((fmaf(f[0], f[0], f[1] * f[1]) + fmaf(f[2], f[2], f[3] * f[3])) +
                                               (fmaf(f[4], f[4], f[5] * f[5]) + fmaf(f[6], f[6], f[7] * f[7])));
-                    if ((lane & 7) == 0) aux.part[(col0 >> 6) * aux.hm_rows + row] = make_float2(sm, sq);      // [N / 64][M_pad]: coalesced for k_rowstats
+                    if ((lane & 7) == 0) *(float2 *)(part_b + p0 + rr * 8u) = make_float2(sm, sq);      // coalesced for k_rowstats
                 }
         }
     } else {
@@ -1573,8 +1583,9 @@ __global__ __launch_bounds__(ATTN_THREADS, 2) void k_attention_p(const uint16_t 
 // live: 1 query instead of T per (image, head), M = n rows instead of n*T for three of the four GEMMs.  The other
 // rows of the last block are dead code; the result is the same function of the inputs (K and V still come from
 // all tokens).  k_attention_cls: one wave per (image, head); fp32 softmax over the T keys.
-__global__ __launch_bounds__(256) void k_attention_cls(const uint16_t *__restrict__ QKV, uint16_t *__restrict__ AO_cls,
-                                                       uint32_t T, uint32_t d, uint32_t M_pad, uint32_t n_heads, uint32_t n_items)
+__global__ __launch_bounds__(256) void k_attention_cls(const uint16_t *__restrict__ QKV, const uint16_t *__restrict__ Q_cls,
+                                                       uint16_t *__restrict__ AO_cls, uint32_t T, uint32_t d, uint32_t M_pad,
+                                                       uint32_t n_heads, uint32_t n_items)
 {
     __shared__ float ps[4][1024];
     const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -1582,7 +1593,8 @@ __global__ __launch_bounds__(256) void k_attention_cls(const uint16_t *__restric
     if (item >= n_items) return;
     const uint32_t img = item / n_heads, head = item - img * n_heads, H = d >> 6;
     const size_t row0 = (size_t)img * T;
-    const uint16_t *Qg = QKV + ((size_t)head * M_pad + row0) * 64;                 // tile-major planes (see k_attention)
+    // q of token 0: from the compact [n][d] array when the block's q was only computed for the class tokens
+    const uint16_t *Qg = Q_cls ? Q_cls + (size_t)img * d + head * 64 : QKV + ((size_t)head * M_pad + row0) * 64;     // tile-major planes (see k_attention)
     const uint16_t *Kg = QKV + ((size_t)(H + head) * M_pad + row0) * 64;
     const uint16_t *Vg = QKV + ((size_t)(2 * H + head) * M_pad + row0) * 64;
     // q (token 0) as 64 floats, same in every lane
@@ -1646,6 +1658,19 @@ __global__ void k_gather_cls(const float *__restrict__ X, const uint16_t *__rest
         v = X[row * d + c];
     }
     X_cls[i] = v;
+}
+
+// class-token rows of the bf16 operand copy (tile-major) and their LayerNorm pairs -> compact row-major [n][d], [n]:
+// the A operand and row statistics of the last block's q projection, which only the class tokens need
+__global__ void k_gather_cls_operand(const uint16_t *__restrict__ Xhi, const float2 *__restrict__ AB, uint32_t M_pad, uint32_t T,
+                                     uint32_t d, uint32_t n, uint16_t *__restrict__ Xq, float2 *__restrict__ ABq)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, per = d / 8;
+    if (i >= n * per) return;
+    const uint32_t img = i / per, c = (i - img * per) * 8;
+    const size_t row = (size_t)img * T;
+    *(uint4 *)(Xq + (size_t)img * d + c) = *(const uint4 *)(Xhi + ((size_t)(c >> 6) * M_pad + row) * 64 + (c & 63));
+    if (c == 0) ABq[img] = AB[row];
 }
 
 // ------------------------------------------------------------------ head
@@ -1915,6 +1940,10 @@ static int launch_gemm(d2r_ctx *ctx, const uint16_t *A, const uint16_t *W, const
     if (N % 128 || K % BK) return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "GEMM N must be a multiple of 128 and K of 64");
     if ((uint64_t)round_up(M_real, BM) * N >= (1ull << 32))
         return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "GEMM output too large for 32-bit indexing");
+    if (EPI_IS_STATS(EPI) && (uint64_t)round_up(M_real, BM) * N * (EPI == EPI_RESID_STATS_F32X ? 4 : 2) >= (1ull << 32))      // its epilogue indexes the residual arrays in bytes
+        return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "residual array too large for 32-bit byte offsets");
+    if (EPI_IS_STATS(EPI) && aux.hm_rows != round_up(M_real, BM))
+        return d2r_fail(ctx, D2R_ERR_INVALID, "residual + statistics epilogues write tile-major planes of M_pad rows");
     // wide outputs: 256x256 tiles (more flops per byte staged); narrow ones keep 256x128 so the tile
     // count still covers the 256 CUs a few times
     if (ctx->gemm_cfg == 2) return launch_gemm_cfg<EPI, 4, 2, 2, 3>(ctx, A, W, bias, C, M_real, N, K, aux);   // force 256x128
@@ -1998,17 +2027,18 @@ static int attention_setup(d2r_ctx *ctx, uint32_t T_pad, size_t *lds_out)
     return D2R_OK;
 }
 
-// The last block on class-token rows only (see k_attention_cls).  QKV must already hold the block's q/k/v (tile-major);
+// The last block on class-token rows only (see k_attention_cls).  QKV must already hold the block's k/v (tile-major) and
+// its q, either there too or for the class tokens only in Qc (compact bf16 [n][d]);
 // the residual stream is X (fp32 row-major) or Xhi (+ Xlo) (bf16 tile-major).  Leaves the block's output rows in
 // Xc (compact fp32 [n][d]) for k_head with T = 1.  Workspaces: Xc, AOc (bf16 [n_pad][d]), Xnc (bf16 [n_pad][d]),
 // Hc (bf16 [n_pad][mlp]) — all row-major, padded rows hold finite leftovers.
 static int last_block_cls(d2r_ctx *ctx, const d2r_clip_desc &D, const ClipWeights::Layer &L, uint32_t n, uint32_t T, uint32_t rows_pad,
-                          const uint16_t *QKV, const float *X, const uint16_t *Xhi, const uint16_t *Xlo, float *Xc, uint16_t *AOc,
-                          uint16_t *Xnc, uint16_t *Hc)
+                          const uint16_t *QKV, const uint16_t *Qc, const float *X, const uint16_t *Xhi, const uint16_t *Xlo, float *Xc,
+                          uint16_t *AOc, uint16_t *Xnc, uint16_t *Hc)
 {
     const uint32_t d = D.hidden_size, mlp = D.mlp_size, items = n * D.num_heads;
     int rc;
-    hipLaunchKernelGGL(k_attention_cls, dim3((items + 3) / 4), dim3(256), 0, ctx->stream, QKV, AOc, T, d, rows_pad, D.num_heads, items);
+    hipLaunchKernelGGL(k_attention_cls, dim3((items + 3) / 4), dim3(256), 0, ctx->stream, QKV, Qc, AOc, T, d, rows_pad, D.num_heads, items);
     hipLaunchKernelGGL(k_gather_cls, dim3((n * d + 255) / 256), dim3(256), 0, ctx->stream, X, Xhi, Xlo, rows_pad, T, d, n, Xc);
     if ((rc = launch_gemm<EPI_BIAS_RESID_F32>(ctx, AOc, L.w_o, L.b_o, Xc, n, d, d))) return rc;
     hipLaunchKernelGGL(k_layernorm, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, Xc, L.ln2_w, L.ln2_b, Xnc, n, d);
@@ -2062,7 +2092,7 @@ int d2r_clip_forward(d2r_ctx *ctx, const d2r_clip *clip, const uint16_t *patches
                                rows, d);
             if ((rc = launch_gemm<EPI_BIAS_BF16>(ctx, Xn, L.w_qkv, L.b_qkv, QKV, rows, 3 * d, d, out_tm))) return rc;
             if (cls_last && l + 1 == D.num_layers) {
-                if ((rc = last_block_cls(ctx, D, L, n, T, rows_pad, QKV, X, nullptr, nullptr, patch_out, AO, Xn, H))) return rc;
+                if ((rc = last_block_cls(ctx, D, L, n, T, rows_pad, QKV, nullptr, X, nullptr, nullptr, patch_out, AO, Xn, H))) return rc;
                 break;
             }
             (void)launch_attention_vision(ctx, QKV, AO, T, T_pad, d, rows_pad, D.num_heads, n, attn_lds);
@@ -2101,12 +2131,26 @@ int d2r_clip_forward(d2r_ctx *ctx, const d2r_clip *clip, const uint16_t *patches
     for (uint32_t l = 0; l < D.num_layers; l++) {
         const ClipWeights::Layer &L = clip->layers[l];
         ln.cs = L.cs_qkv;
-        if ((rc = launch_gemm<EPI_LN_BIAS_BF16>(ctx, Xn, L.wf_qkv, L.bf_qkv, QKV, rows, 3 * d, d, ln))) return rc;
         if (cls_last && l + 1 == D.num_layers) {
+            // k and v of every token (planes H .. 3H-1 of QKV: weight rows d .. 3d-1), q of the class tokens only: their
+            // operand rows and LayerNorm pairs gathered into H's workspace (free until the block's fc1), a [n][d] product
+            EpiAux kv = ln;
+            kv.cs = L.cs_qkv + d;
+            if ((rc = launch_gemm<EPI_LN_BIAS_BF16>(ctx, Xn, L.wf_qkv + (size_t)d * d, L.bf_qkv + d, QKV + (size_t)d * rows_pad, rows, 2 * d, d, kv)))
+                return rc;
+            const uint32_t n_pad = round_up(n, BM);
+            uint16_t *Xq = H, *Qc = H + (size_t)n_pad * d;
+            float2 *ABq = part;                       // the partial sums are consumed: their workspace is free
+            hipLaunchKernelGGL(k_gather_cls_operand, dim3((n * (d / 8) + 255) / 256), dim3(256), 0, ctx->stream, Xn, AB, rows_pad, T, d, n, Xq, ABq);
+            EpiAux lq{};
+            lq.cs = L.cs_qkv;
+            lq.ab = ABq;
+            if ((rc = launch_gemm<EPI_LN_BIAS_BF16>(ctx, Xq, L.wf_qkv, L.bf_qkv, Qc, n, d, d, lq))) return rc;
             // (the gather reads the residual rows out of Xn / Xlo before Xn's first rows are reused for the LayerNorm output)
-            if ((rc = last_block_cls(ctx, D, L, n, T, rows_pad, QKV, X, xf32 ? nullptr : Xn, Xlo, patch_out, AO, Xn, H))) return rc;
+            if ((rc = last_block_cls(ctx, D, L, n, T, rows_pad, QKV, Qc, X, xf32 ? nullptr : Xn, Xlo, patch_out, AO, Xn, H))) return rc;
             break;
         }
+        if ((rc = launch_gemm<EPI_LN_BIAS_BF16>(ctx, Xn, L.wf_qkv, L.bf_qkv, QKV, rows, 3 * d, d, ln))) return rc;
         (void)launch_attention_vision(ctx, QKV, AO, T, T_pad, d, rows_pad, D.num_heads, n, attn_lds);
         if (xf32) rc = launch_gemm<EPI_RESID_STATS_F32X>(ctx, AO, L.w_o, L.b_o, X, rows, d, d, st);
         else if (split) rc = launch_gemm<EPI_RESID_STATS_SPLIT>(ctx, AO, L.w_o, L.b_o, Xn, rows, d, d, st);
