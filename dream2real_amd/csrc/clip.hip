@@ -917,8 +917,10 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
     STAMP(ts0);
     // everything in flight is drained ONCE per tile: the eight half-tiles staged during the previous tile's
-    // last K-tile pair and that tile's epilogue stores (stores share the vmcnt counter and may retire out of order with loads,
-    // so the counted waits below are only sound with no store outstanding)
+    // last K-tile pair and that tile's epilogue stores.  (Stores share the vmcnt counter with the loads.  The counted
+    // waits below would stay sound with stores outstanding — vmcnt(N) with N loads younger than the awaited one bounds
+    // the pending LOADS, stores only make it wait longer — but then the first of them wait for the same store
+    // acknowledgements: measured, no difference; the drain keeps the compiler's own bookkeeping trivial.)
     // (the builtin, not inline asm: hipcc's own wait-count bookkeeping must also learn that the
     // epilogue's loads and stores have retired, or it protects their registers with a vmcnt(0) of its
     // own inside the K loop)

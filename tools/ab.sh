@@ -1,5 +1,7 @@
 #!/bin/bash
-# same-box A/B of library builds: ab/run.sh lib_a.so lib_b.so ...  (alternating, ROUNDS times)
+# Same-box A/B of library builds (run on the GPU box): copy the builds to compare into ab/ (git-ignored *.so; they
+# travel with the gpurun snapshot), then  tools/ab.sh lib_a.so lib_b.so ...  — alternating, ROUNDS times each.
+# Boxes differ by +-1.5 % in the clock their power manager grants; runs on one box repeat to +-0.1 ms.
 for r in $(seq 1 ${ROUNDS:-3}); do
   for l in "$@"; do
     cp ab/$l dream2real_amd/libd2r.so
