@@ -9,7 +9,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libd2r.so")
-ABI_VERSION = 3          # D2R_ABI_VERSION of include/d2r.h this binding was written against
+ABI_VERSION = 4          # D2R_ABI_VERSION of include/d2r.h this binding was written against
 
 EXPORTS = [
     "d2r_abi_version", "d2r_ctx_create", "d2r_ctx_destroy", "d2r_ctx_set_stream", "d2r_ctx_synchronize",
@@ -19,6 +19,7 @@ EXPORTS = [
     "d2r_get_render_stats", "d2r_collect_render_stats", "d2r_ctx_set_option", "d2r_get_timing", "d2r_text_create",
     "d2r_text_destroy", "d2r_text_encode", "d2r_comm_get_unique_id", "d2r_comm_init", "d2r_comm_destroy",
     "d2r_allgather_scores", "d2r_phys_create", "d2r_phys_destroy", "d2r_phys_check", "d2r_nerf_load_ingp",
+    "d2r_rectify_background_depth",
 ]
 
 

@@ -74,7 +74,8 @@ def _centre_crop_square(img: np.ndarray) -> np.ndarray:
 def rectify_depth(depth_ori, resolution) -> np.ndarray:
     """Sensor depth of the render view -> [res_h, res_w] float32 in the CLIP-view frame: centre
     crop to a square, cubic resize (reference combined_rendering.py:166-187; the reference
-    repeats it over 4 channels and only ever reads channel 0)."""
+    repeats it over 4 channels and only ever reads channel 0).  Host mirror of the reference's
+    module-level function; renderer.render itself goes through d2r_rectify_background_depth."""
     img = _centre_crop_square(_to_numpy(depth_ori)).astype(np.float32)
     return resize_cubic(img, (resolution[0], resolution[1]))
 
@@ -130,10 +131,8 @@ class renderer:
             bg.render_ground_truth = False
             bg_rgba, bg_depth = bg.render_batch(cam_matrix[None, :3, :], W, H)
             if depths_gt is not None:
-                d = rectify_depth(depths_gt[render_idx], (W, H))
-                m = rectify_mask(movable_masks[render_idx], (W, H))
-                d[m == 0] = 100.0
-                bg_depth = d[None]
+                # rectify_depth + rectify_mask + depth[mask == 0] = 100 on the GPU (d2r_rectify_background_depth)
+                bg_depth = ctx.rectify_background_depth(_to_numpy(depths_gt[render_idx]), _to_numpy(movable_masks[render_idx]), W, H)[None]
             fg.set_camera_to_training_view(render_cam_pose_idx[render_idx])
             view = fg.view(W, H)
             ctx.set_background(view, bg_rgba[0], bg_depth[0])

@@ -145,7 +145,7 @@ void d2r_ctx_destroy(d2r_ctx *c)
     hipStreamSynchronize(c->stream);
     (void)d2r_comm_destroy(c);
     d2r_ctx::Buf *bufs[] = {&c->cams, &c->queue, &c->counters, &c->frames, &c->rgba, &c->depth, &c->poses,
-                            &c->text, &c->logits, &c->pix, &c->bg_rgba, &c->bg_depth, &c->bg_u8, &c->rects, &c->bg_patches};
+                            &c->text, &c->logits, &c->pix, &c->bg_rgba, &c->bg_depth, &c->bg_u8, &c->rects, &c->bg_patches, &c->rect_ws};
     for (auto *b : bufs)
         if (b->p) hipFree(b->p);
     for (auto &b : c->clipws)

@@ -98,6 +98,7 @@ struct d2r_ctx {
     uint32_t text_turn = 0;
     // background of the current view
     Buf bg_rgba, bg_depth, bg_u8;
+    Buf rect_ws;                 // d2r_rectify_background_depth: source images, tap tables, outputs
     Buf rects;                   // per candidate of a pass: frame rectangle (x0, y0, x1, y1) its rays were generated in
     Buf bg_patches;              // CLIP patches of the background frame itself (one image)
     const void *bg_patches_for = nullptr;   // the d2r_clip they were computed with (nullptr = stale)

@@ -95,6 +95,25 @@ class Context:
         v = _lib.view_c(view)
         self.check(self.lib.d2r_set_background(self.h, C.byref(v), _lib.ptr(a), _lib.ptr(d)))
 
+    def rectify_background_depth(self, depth, mask, width: int, height: int, return_mask: bool = False):
+        """Sensor depth [sh, sw] (fp16 or fp32 metres) and movable mask [sh, sw] (bool / uint8, or None) of a render
+        view -> background depth [height, width] float32: centre crop, cv2.INTER_CUBIC resize, 100 where the resized
+        mask is 0 (d2r_rectify_background_depth; reference combined_rendering.py:107-110, 166-209)."""
+        d = np.asarray(depth)
+        d = np.ascontiguousarray(d, np.float16 if d.dtype == np.float16 else np.float32)
+        sh, sw = d.shape
+        m = None
+        if mask is not None:
+            m = np.ascontiguousarray(np.asarray(mask).astype(np.uint8))
+            assert m.shape == (sh, sw)
+        out = np.empty((height, width), np.float32)
+        mo = np.empty((height, width), np.uint8) if (return_mask and m is not None) else None
+        self.check(self.lib.d2r_rectify_background_depth(
+            self.h, _lib.ptr(d), C.c_int(1 if d.dtype == np.float16 else 0), _lib.ptr(m) if m is not None else None,
+            C.c_uint32(sw), C.c_uint32(sh), C.c_uint32(width), C.c_uint32(height), _lib.ptr(out),
+            _lib.ptr(mo) if mo is not None else None))
+        return (out, mo) if return_mask else out
+
 
 class _Nerf:
     """`testbed.nerf` namespace (render_min_transmittance lives there in pyngp)."""

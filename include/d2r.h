@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 #define D2R_API __attribute__((visibility("default")))
-#define D2R_ABI_VERSION 3
+#define D2R_ABI_VERSION 4
 
 typedef enum {
     D2R_OK = 0,
@@ -148,6 +148,18 @@ D2R_API int d2r_nerf_eval_points(d2r_ctx *ctx, const d2r_nerf *model, const floa
  * channel 0, already rectified/masked if it came from depths_gt). */
 D2R_API int d2r_set_background(d2r_ctx *ctx, const d2r_view *view, const float *bg_rgba,
                                const float *bg_depth);
+
+/*
+ * Sensor-depth background of a render view (reference combined_rendering.py:107-110 with rectify_depth :166-187 and
+ * rectify_mask :189-209): depth (host, [src_h][src_w] metres, fp32 or fp16 as data_loader.py:43,58 stores it) and
+ * the movable-object mask (host uint8 [src_h][src_w], 0 / 1; NULL = no masking) are centre-cropped to a square and
+ * resized to w x h as cv2.resize(..., interpolation=cv2.INTER_CUBIC) does (float path for the depth, 8-bit
+ * fixed-point path for the mask); where the resized mask is 0 the depth becomes 100.  depth_out: host [h][w] fp32,
+ * what d2r_set_background takes as bg_depth; mask_out (optional): host [h][w] uint8, the resized mask.
+ */
+D2R_API int d2r_rectify_background_depth(d2r_ctx *ctx, const void *depth, int depth_is_fp16, const uint8_t *mask,
+                                         uint32_t src_w, uint32_t src_h, uint32_t w, uint32_t h, float *depth_out,
+                                         uint8_t *mask_out);
 
 /*
  * replaces the body of renderer.render's loop over valid poses

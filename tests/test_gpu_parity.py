@@ -710,6 +710,35 @@ def test_renderer_with_sensor_depth_background(gpu, tmp_path):
     assert right > 50 and left < 0.2 * right
 
 
+def test_rectify_background_depth_on_the_gpu_is_bit_exact_with_the_oracle(gpu):
+    """d2r_rectify_background_depth (reference combined_rendering.py:107-110, 166-209) against the scalar restatement of
+    cv2.resize(INTER_CUBIC) in oracle/host_ref.py: the float path and the 8-bit fixed-point path, fp16 and fp32 depth,
+    wide / tall / square sources, down- and up-scaling, non-integer ratios, and the depth[mask == 0] = 100 rule."""
+    ctx = gpu["ctx"]
+    r = np.random.default_rng(21)
+    cases = [((72, 128), (33, 33), np.float16), ((720, 1280), (336, 336), np.float16), ((90, 40), (17, 29), np.float32),
+             ((45, 45), (64, 21), np.float32), ((31, 57), (80, 80), np.float16), ((5, 9), (3, 2), np.float32)]
+    for (sh, sw), (W, H), dt in cases:
+        depth = (r.random((sh, sw), dtype=np.float32) * 3).astype(dt)
+        mask = r.random((sh, sw)) > 0.45
+        if sh >= 64:
+            mask[sh // 3: sh // 2, sw // 3: sw // 2] = False            # a solid hole as well as salt and pepper
+        want_d = host_ref.rectify_depth_ref(depth, (W, H))
+        want_m = host_ref.rectify_mask_ref(mask, (W, H))
+        plain = ctx.rectify_background_depth(depth, None, W, H)
+        assert plain.shape == (H, W) and plain.dtype == np.float32
+        np.testing.assert_array_equal(plain, want_d)                     # same products, same sums, no contraction
+        got_d, got_m = ctx.rectify_background_depth(depth, mask, W, H, return_mask=True)
+        np.testing.assert_array_equal(got_m, want_m)
+        masked = want_d.copy()
+        masked[want_m == 0] = 100.0
+        np.testing.assert_array_equal(got_d, masked)
+        assert (want_m == 0).any() and (want_m != 0).any()
+    # error behaviour: bad sizes are refused with a message, not a crash
+    with pytest.raises(Exception):
+        ctx.rectify_background_depth(np.zeros((4, 4), np.float32), None, 0, 4)
+
+
 def test_fused_render_score_device_path(gpu):
     """d2r_render_score on device pointers == render_composite + score_frames."""
     import torch
