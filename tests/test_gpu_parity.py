@@ -850,6 +850,56 @@ def test_full_size_properties(gpu):
     assert 5 < st["samples"] / max(st["rays_alive"], 1) < 60          # ~18 samples per hit ray
 
 
+def test_full_size_fused_path_is_chunk_and_permutation_invariant(gpu):
+    """BASELINE.json configs[1] at full size (4096 poses, 640x360, full-depth ViT-B/16) through d2r_render_score:
+    size-independent properties instead of the (hours-long) oracle.  Every candidate is independent through render,
+    composite and CLIP, so the logits of a pose may not depend on which pass it ran in, on
+    its neighbours in the batch, or on the run: one pass of 4096 == ragged passes of 1000 == a shuffled batch
+    un-shuffled, bit for bit.  Also: scores are finite, not all alike, and the persistent-kernel path (806 912 token
+    rows) agrees with the 6-candidate launch that goes through the small-output kernels."""
+    import torch
+    engine, ctx, scene, fg, bg = gpu["engine"], gpu["ctx"], gpu["scene"], gpu["fg"], gpu["bg"]
+    cfg = CLIP_CONFIGS["vit_b16"]
+    sd = random_clip_state_dict(cfg, seed=6, text=False)
+    sc = engine.ClipScorer(ctx, cfg, sd)
+    text = random_unit_text_embeds(cfg["proj"], 2)
+    W, H = 640, 360
+    cam_bg = host_ref.converter(np.asarray(scene.cam_poses, np.float32))[0]
+    brgba, bdepth = bg.render_batch(cam_bg[None, :3], W, H)
+    view = fg.view(W, H)
+    ctx.set_background(view, brgba[0], bdepth[0])
+    T1 = host_ref.converter(np.asarray(scene.obj_pose, np.float32)[None])[0]
+    poses = host_ref.sample_poses_grid(scene.scene_centre, [64, 64, 1, 1, 1, 1], scene.scene_type).reshape(-1, 4, 4)
+    pn = host_ref.converter(poses).reshape(-1, 16).astype(np.float32)
+    K = len(pn)
+    assert K == 4096
+    dev = torch.device("cuda:0")
+
+    def run(p, chunk):
+        ctx.set_option("chunk", chunk)
+        p_dev = torch.from_numpy(np.ascontiguousarray(p)).to(dev)
+        lg = torch.full((len(p), 2), float("nan"), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        engine.render_score_device(ctx, fg, sc, view, T1, cam_bg, p_dev.data_ptr(), len(p), text, lg.data_ptr(), None)
+        ctx.synchronize()
+        return lg.cpu().numpy()
+
+    try:
+        a = run(pn, 4096)
+        assert np.isfinite(a).all() and np.ptp(a[:, 0]) > 1e-3
+        np.testing.assert_array_equal(a, run(pn, 4096))                  # run-to-run
+        np.testing.assert_array_equal(a, run(pn, 1000))                  # 4 full passes + one of 96
+        perm = np.random.default_rng(5).permutation(K)
+        b = run(pn[perm], 4096)
+        np.testing.assert_array_equal(a[perm], b)                        # batch neighbours do not matter
+        few = np.linspace(0, K - 1, 6).astype(int)
+        c = run(pn[few], 4096)                                           # 1 182 token rows: the small-output GEMM kernels
+        assert np.abs(c - a[few]).max() / sc.logit_scale < 2e-5
+    finally:
+        ctx.set_option("chunk", 4096)
+        sc.close()
+
+
 def test_allgather_scores_c_abi(gpu):
     """d2r_allgather_scores: world 1 without an id is a device copy; with an id a
     one-rank RCCL communicator runs the real ncclAllGather on the context's stream."""
