@@ -21,6 +21,8 @@
 //   k_head         post_layernorm(CLS) -> visual_projection -> L2 normalise -> logits
 #include "d2r_internal.h"
 
+#include <type_traits>
+
 #include <math.h>
 
 #include <algorithm>
@@ -289,6 +291,9 @@ struct EpiAux {
 // rebuilds with each mask to see where the time of a tile goes.
 #ifndef D2R_GEMM_ABLATE
 #define D2R_GEMM_ABLATE 0
+#endif
+#ifndef D2R_GEMM_PRIO
+#define D2R_GEMM_PRIO 2        /* 0: s_setprio 1 around every MFMA section; 1 / 2: static priority for wave row 1 / 0; 3: none */
 #endif
 #define BM 256                 /* row padding of every GEMM operand buffer (largest tile height) */
 #define BK 64
@@ -791,17 +796,19 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
 
     f32x16 acc[4][2];
 
-    // staging: piece qq of a half-tile = 8 slot rows x 128 B per wave instruction
+    // staging: a piece of a half-tile = 8 slot rows x 128 B per wave instruction
     const uint32_t r_in = lane >> 3, pc = lane & 7;
     const uint32_t a_rs = aux.a_rs ? aux.a_rs : K;                                      // A operand layout (EpiAux)
     const size_t a_ks = aux.a_rs ? aux.a_ks : BK;
-    uint32_t voffA[2], voffB[2];
-#pragma unroll
-    for (int qq = 0; qq < 2; qq++) {
-        const uint32_t sr = (wave * 2 + qq) * 8 + r_in;                       // slot row 0..127
+    // A wave stages slot rows 8 wave + r_in (piece 0) and the same + 64 (piece 1) of every half-tile: 64 slot rows apart the
+    // swizzle term ((row >> 1) & 7) is the same and the global rows lie 128 operand rows apart for A and for W, so the
+    // two pieces share one lane-offset register per operand and differ by a wave-uniform distance on the scalar base
+    uint32_t voffA, voffB;
+    {
+        const uint32_t sr = wave * 8 + r_in;                                  // slot row of piece 0: 0..63
         const uint32_t chunk = pc ^ ((sr >> 1) & 7u);
-        voffA[qq] = (((sr >> 6) * 128 + (sr & 63)) * a_rs + chunk * 8) * 2;    // bytes from the half's first row
-        voffB[qq] = (((sr >> 5) * 64 + (sr & 31)) * K + chunk * 8) * 2;
+        voffA = (sr * a_rs + chunk * 8) * 2;                                  // bytes from the half's first row
+        voffB = (((sr >> 5) * 64 + (sr & 31)) * K + chunk * 8) * 2;
     }
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem));
     const uint32_t nk = K / BK;
@@ -815,7 +822,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
         if (D2R_GEMM_ABLATE & 1) return;
 #pragma unroll
         for (int qq = 0; qq < 2; qq++)
-            glds16s(isA ? voffA[qq] : voffB[qq], base, lds0 + kind * SLOT + (wave * 2 + qq) * 1024);
+            glds16s(isA ? voffA : voffB, base + (size_t)qq * 128 * (isA ? a_rs : K), lds0 + kind * SLOT + (wave + qq * 8) * 1024);
     };
     auto stage_pos = [&](int kind, uint32_t kt) { stage_pos_at(kind, kt, m0, n0); };
     auto tile_origin = [&](uint32_t t, uint32_t &tm, uint32_t &tn) {
@@ -830,13 +837,16 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
     // ((row >> 1) & 7 == (li >> 1) & 7), so four byte offsets per operand serve all kinds; the slot and
     // m-tile go into the instruction's immediate offset (kinds 4-7 lie beyond its 64 KiB reach and
     // add 65536 on the VALU instead of keeping eight more address registers alive)
-    uint32_t aoff[4], boff[4];
+    // (the B addresses are the A addresses plus a wave-uniform distance, added per read from an SGPR: four address
+    // registers instead of eight — the kernel sits at the 256-register limit and a spill inside the counted-vmcnt K
+    // loop is not an option)
+    uint32_t aoff[4];
 #pragma unroll
     for (int s4 = 0; s4 < 4; s4++) {
         const uint32_t sw = ((2 * s4 + hi) ^ ((li >> 1) & 7u)) << 4;
         aoff[s4] = (wm * 64 + li) * 128 + sw;
-        boff[s4] = (wn * 32 + li) * 128 + sw;
     }
+    const uint32_t d_ab = (wn * 32 - wm * 64) * 128;          // wave-uniform (modulo 2^32)
     uint4 fa[2][2][4], fb[2][4];
     auto read_pos = [&](int kind) {
         const bool isA = kind == 0 || kind == 3 || kind == 4 || kind == 7;
@@ -861,12 +871,16 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
 #pragma unroll
                 for (int s4 = 0; s4 < 4; s4++) fa[h][mt][s4] = *(const uint4 *)(sb + (aoff[s4] + far) + mt * 4096);
         } else {
+            uint32_t db = d_ab + (kind >= 4 ? 65536u : 0u);
+            asm volatile("" : "+s"(db));             // an SGPR operand of the adds below, not four loop-invariant VGPRs
 #pragma unroll
-            for (int s4 = 0; s4 < 4; s4++) fb[h][s4] = *(const uint4 *)(sb + (boff[s4] + far));
+            for (int s4 = 0; s4 < 4; s4++) fb[h][s4] = *(const uint4 *)(sb + (aoff[s4] + db));
         }
     };
     auto mfma_quadrant = [&](int mh, int nh) {
+#if D2R_GEMM_PRIO == 0
         __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int s4 = 0; s4 < 4; s4++)
 #pragma unroll
@@ -880,7 +894,9 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
                 acc[mh * 2 + mt][nh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc[mh * 2 + mt][nh], 0, 0, 0);
 #endif
             }
+#if D2R_GEMM_PRIO == 0
         __builtin_amdgcn_s_setprio(0);
+#endif
     };
     auto bar = [&]() {
         asm volatile("" ::: "memory");
@@ -937,6 +953,11 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
     // DMA that the NEXT phase reads at the end of its section that precedes the barrier in front of
     // group 0's next read section: after the MFMAs for wm = 0, after the DMA issue for wm = 1.
     if (wm == 1) bar();
+#if D2R_GEMM_PRIO == 1
+    if (wm == 1) __builtin_amdgcn_s_setprio(1);      // static priority for the second-dispatched half
+#elif D2R_GEMM_PRIO == 2
+    if (wm == 0) __builtin_amdgcn_s_setprio(1);
+#endif
 
     // The ring runs on across tile boundaries: the last K-tile pair of a tile stages the first pair of the
     // workgroup's NEXT tile, so the memory pipe (the resource this kernel is bound by) is not left idle
@@ -946,22 +967,13 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
     uint32_t m0n = 0, n0n = 0;
     if (has_next) tile_origin(t_next, m0n, n0n);
     const uint32_t n_iter = nk / 2;
+    // Every K-tile pair stages eight positions, the last pair of a workgroup's last tile too (it re-requests the first
+    // pair of the launch's first tile: valid addresses, never read), so the waits are the same vmcnt(10) everywhere and
+    // the loop carries no end-of-work special case; the queue is drained before the workgroup exits.
     for (uint32_t u = 0; u < n_iter; u++) {
         const bool last = u + 1 == n_iter;            // block-uniform
-        const bool tail = last && !has_next;          // nothing left to stage: the queue drains
 #pragma unroll
         for (int P = 0; P < 8; P++) {
-            auto wait_next = [&]() {                  // position 8u+P+3 must have landed; younger ones stay in flight
-                if (!tail) {
-                    wait_vmcnt<10>();
-                } else {
-                    if (P == 0) wait_vmcnt<8>();
-                    if (P == 1) wait_vmcnt<6>();
-                    if (P == 2) wait_vmcnt<4>();
-                    if (P == 3) wait_vmcnt<2>();
-                    if (P == 4) wait_vmcnt<0>();
-                }
-            };
             // read section: position 8u+P+2 (kind (P+2) mod 8) for the next phase's MFMAs; stage position
             // 8u+P+8 (kind P): K-tile 2(u+1) + (P >= 4) of this tile, or K-tile (P >= 4) of the next one
             if (EPI_IS_LN(EPI) && last && P == 0) {     // older than every request that follows: landed by the last counted wait
@@ -969,8 +981,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
                 glds16s(l16, aux.ab + m0 + wm * 128, lds0 + 8 * SLOT + 8 * EP_WAVE_FLOATS * 4 + wave * 1024);
             }
             if (!(last && P >= 6)) read_pos((P + 2) & 7);
-            if (!tail) stage_pos_at(P, (last ? 0u : 2 * (u + 1)) + (P >= 4 ? 1u : 0u), last ? m0n : m0, last ? n0n : n0);
-            if (wm == 1) wait_next();
+            stage_pos_at(P, (last ? 0u : 2 * (u + 1)) + (P >= 4 ? 1u : 0u), last ? m0n : m0, last ? n0n : n0);
+            if (wm == 1) wait_vmcnt<10>();            // position 8u+P+3 must have landed; younger ones stay in flight
             __builtin_amdgcn_sched_barrier(0);
             bar();
             // MFMA section
@@ -978,7 +990,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
             const int nh = (P == 1 || P == 2 || P == 4 || P == 7) ? 1 : 0;
             mfma_quadrant(mh, nh);
             __builtin_amdgcn_sched_barrier(0);
-            if (wm == 0) wait_next();
+            if (wm == 0) wait_vmcnt<10>();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             bar();
         }
@@ -1017,6 +1029,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
     m0 = m0n;
     n0 = n0n;
     }
+    wait_vmcnt<0>();          // the last pair's (unused) requests must have landed before the LDS is given back
 }
 
 // -------------------------------------------------------- embeddings + LN
