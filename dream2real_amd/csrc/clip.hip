@@ -814,17 +814,24 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
     const uint32_t nk = K / BK;
     // kind -> operand / half
     uint32_t m0 = 0, n0 = 0;                           // tile whose K loop runs
-    auto stage_pos_at = [&](int kind, uint32_t kt, uint32_t m0, uint32_t n0) {
-        const bool isA = kind == 0 || kind == 3 || kind == 4 || kind == 7;
+    // Running source pointers, one per kind (scalar registers): where the kind's next request reads.  A request
+    // advances its pointer by two K-tiles; the last K-tile pair of a tile re-seats the pointers on the next tile first.
+    const uint16_t *src[8];
+    auto kind_is_a = [](int kind) { return kind == 0 || kind == 3 || kind == 4 || kind == 7; };
+    auto seat = [&](int kind, uint32_t tm, uint32_t tn) -> const uint16_t * {       // K-tile (kind >= 4) of tile (tm, tn)
         const uint32_t h = (kind == 2 || kind == 3 || kind == 5 || kind == 7) ? 1u : 0u;
-        const uint16_t *base = isA ? A + (size_t)(m0 + h * 64) * a_rs + (size_t)kt * a_ks
-                                   : W + (size_t)(n0 + h * 32) * K + (size_t)kt * BK;
+        return kind_is_a(kind) ? A + (size_t)(tm + h * 64) * a_rs + (kind >= 4 ? a_ks : (size_t)0)
+                               : W + (size_t)(tn + h * 32) * K + (kind >= 4 ? (size_t)BK : (size_t)0);
+    };
+    auto stage = [&](int kind) {
+        const bool isA = kind_is_a(kind);
+        const uint16_t *base = src[kind];
+        src[kind] = base + 2 * (isA ? a_ks : (size_t)BK);
         if (D2R_GEMM_ABLATE & 1) return;
 #pragma unroll
         for (int qq = 0; qq < 2; qq++)
             glds16s(isA ? voffA : voffB, base + (size_t)qq * 128 * (isA ? a_rs : K), lds0 + kind * SLOT + (wave + qq * 8) * 1024);
     };
-    auto stage_pos = [&](int kind, uint32_t kt) { stage_pos_at(kind, kt, m0, n0); };
     auto tile_origin = [&](uint32_t t, uint32_t &tm, uint32_t &tn) {
         const uint32_t per_group = mp_cnt * gn;                    // tiles of a full column group
         const uint32_t g = t / per_group, r = t - g * per_group;
@@ -910,7 +917,10 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
     if (t >= t_end) return;
     tile_origin(t, m0, n0);
 #pragma unroll
-    for (int kind = 0; kind < 8; kind++) stage_pos(kind, kind >= 4 ? 1u : 0u);
+    for (int kind = 0; kind < 8; kind++) {
+        src[kind] = seat(kind, m0, n0);
+        stage(kind);
+    }
     // Every tile of a launch costs the same, so workgroups that start together stay together: the whole chip runs K
     // loops (HBM nearly idle), then the whole chip runs epilogues (HBM saturated: the epilogues' loads and stores
     // took 30 of a step's 145 GEMM ms at exactly the HBM rate).  Workgroup `loc` of each XCD starts (loc mod 8) / 8
@@ -981,8 +991,13 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
                 glds16s(l16, aux.ab + m0 + wm * 128, lds0 + 8 * SLOT + 8 * EP_WAVE_FLOATS * 4 + wave * 1024);
             }
             if (!(last && P >= 6)) read_pos((P + 2) & 7);
-            stage_pos_at(P, (last ? 0u : 2 * (u + 1)) + (P >= 4 ? 1u : 0u), last ? m0n : m0, last ? n0n : n0);
-            if (wm == 1) wait_vmcnt<10>();            // position 8u+P+3 must have landed; younger ones stay in flight
+            if (last) src[P] = seat(P, m0n, n0n);
+            stage(P);
+            // position 8u+P+3 must have landed before the barrier in front of the read section that takes it; younger
+            // requests stay in flight.  That barrier is this one for wave row 1 and the one behind the MFMAs for wave row
+            // 0 (half a phase apart); both rows wait at both — the second wait of a row finds its count already met, and
+            // two unconditional waits are cheaper than a wave-uniform branch around each
+            wait_vmcnt<10>();
             __builtin_amdgcn_sched_barrier(0);
             bar();
             // MFMA section
@@ -990,7 +1005,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
             const int nh = (P == 1 || P == 2 || P == 4 || P == 7) ? 1 : 0;
             mfma_quadrant(mh, nh);
             __builtin_amdgcn_sched_barrier(0);
-            if (wm == 0) wait_vmcnt<10>();
+            wait_vmcnt<10>();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             bar();
         }
