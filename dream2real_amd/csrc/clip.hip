@@ -543,40 +543,75 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], float *ep, u
         }
         asm volatile("" : "+v"(b0.x), "+v"(b0.y), "+v"(b0.z), "+v"(b0.w), "+v"(b1.x), "+v"(b1.y), "+v"(b1.z), "+v"(b1.w));
         hook();
-#pragma unroll
-        for (int i = 0; i < MT; i++) {
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                transpose_in(i, k);
-                const uint32_t row = row0 + i * 32 + rl0 + 8 * k;
-                float4 u = (D2R_GEMM_ABLATE & 256) ? make_float4(acc[i][0][k], acc[i][0][k + 8], acc[i][1][k], acc[i][1][k + 8])
-                                                   : *(const float4 *)(ep + ep_at(rl0, c8));
-                float4 w = (D2R_GEMM_ABLATE & 256) ? make_float4(acc[i][0][k + 4], acc[i][0][k + 12], acc[i][1][k + 4], acc[i][1][k + 12])
-                                                   : *(const float4 *)(ep + ep_at(rl0, c8) + 4);
-                float f[8];
-                if (LN) {
-                    const float2 ab = ab_lds[i * 32 + rl0 + 8 * k];          // (rstd, -rstd * mean) of this row
-                    f[0] = fmaf(ab.x, u.x, fmaf(ab.y, s0.x, b0.x)); f[1] = fmaf(ab.x, u.y, fmaf(ab.y, s0.y, b0.y));
-                    f[2] = fmaf(ab.x, u.z, fmaf(ab.y, s0.z, b0.z)); f[3] = fmaf(ab.x, u.w, fmaf(ab.y, s0.w, b0.w));
-                    f[4] = fmaf(ab.x, w.x, fmaf(ab.y, s1.x, b1.x)); f[5] = fmaf(ab.x, w.y, fmaf(ab.y, s1.y, b1.y));
-                    f[6] = fmaf(ab.x, w.z, fmaf(ab.y, s1.z, b1.z)); f[7] = fmaf(ab.x, w.w, fmaf(ab.y, s1.w, b1.w));
-                } else {
-                    f[0] = u.x + b0.x; f[1] = u.y + b0.y; f[2] = u.z + b0.z; f[3] = u.w + b0.w;
-                    f[4] = w.x + b1.x; f[5] = w.y + b1.y; f[6] = w.z + b1.z; f[7] = w.w + b1.w;
-                }
-                if (GELU) {
-                    // quick_gelu: x * sigmoid(1.702 x) = x / (1 + exp2(-1.702 log2(e) x))
-#pragma unroll
-                    for (int e = 0; e < 8; e++)
-                        f[e] *= __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930156f * f[e]));
-                }
-                const uint4 pk = make_uint4(pack2(f[0], f[1]), pack2(f[2], f[3]), pack2(f[4], f[5]), pack2(f[6], f[7]));
-#if (D2R_GEMM_ABLATE & 128) && defined(__HIP_DEVICE_COMPILE__)
-                asm volatile("" ::"v"(pk.x), "v"(pk.y), "v"(pk.z), "v"(pk.w));
-                continue;
-#endif
-                *(uint4 *)((uint16_t *)Cout + (aux.hm_rows ? ((col0 >> 6) * aux.hm_rows + row) * 64u + c8 : row * N + col)) = pk;
+        // output addressing: a wave-uniform 64-bit base (the wave tile's first row in its plane, or in the row-major
+        // array) + a 32-bit lane offset + a wave-uniform row distance: no per-store 64-bit arithmetic, no layout branch
+        const uint32_t rs = aux.hm_rows ? 128u : N * 2u;                                   // bytes between rows
+        char *const cb = (char *)Cout + (aux.hm_rows ? ((size_t)(col0 >> 6) * aux.hm_rows + row0) * 128u : ((size_t)row0 * N + col0) * 2u);
+        const uint32_t loff = rl0 * rs + c8 * 2u;
+        // The transposes are software-pipelined: group g + 1 is written to the wave's buffer and read back into a second
+        // register set BEFORE group g's values are consumed.  One buffer suffices — a wave's LDS instructions execute in
+        // order, so the reads of group g (issued earlier) see group g's data and the writes of group g + 1 land behind
+        // them; only the arithmetic waits (lgkmcnt) for its own reads.  Unpipelined, every group paid two LDS round trips
+        // back to back (write -> read -> use): 16 groups, ~4 k of a tile's 5 k epilogue cycles.
+        constexpr int NG = MT * 4;
+        // The buffer reads are issued from inline asm like the writes: hipcc cannot count the LDS operations inside an asm
+        // statement, so with compiler-visible reads its own lgkmcnt waits came out too strict (a group's values were
+        // waited for together with the NEXT group's eight writes).  Here the compiler sees no LDS traffic at all and the
+        // waits are counted by hand: when group g is consumed, exactly the operations of fetch(g + 1) may be outstanding.
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        constexpr int FETCH_OPS = 8 + 2 + (LN ? 1 : 0);
+        f32x4 ub[2], wb[2];
+        f32x2 abv[2];
+        const uint32_t rd_addr = lds_addr(ep) + ep_at(rl0, c8) * 4u;
+        const uint32_t ab_addr = LN ? lds_addr(ab_lds) + rl0 * 8u : 0u;
+        auto fetch = [&](int g, int slot) {
+            const int i = g >> 2, k = g & 3;
+            transpose_in(i, k);
+            if (D2R_GEMM_ABLATE & 256) {
+                ub[slot] = f32x4{acc[i][0][k], acc[i][0][k + 8], acc[i][1][k], acc[i][1][k + 8]};
+                wb[slot] = f32x4{acc[i][0][k + 4], acc[i][0][k + 12], acc[i][1][k + 4], acc[i][1][k + 12]};
+                abv[slot] = f32x2{1.f, 0.f};
+                return;
             }
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16" : "=&v"(ub[slot]), "=&v"(wb[slot]) : "v"(rd_addr) : "memory");
+            if (LN) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(abv[slot]) : "v"(ab_addr), "n"((i * 32 + 8 * k) * 8) : "memory");   // (rstd, -rstd * mean) of this row
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int g = 0; g < NG; g++) {
+            const int cur = g & 1;
+            if (g + 1 < NG) fetch(g + 1, cur ^ 1);
+            // group g's values have landed once at most fetch(g + 1)'s operations are outstanding (LDS operations of a
+            // wave complete in order); the operands are tied to the wait so that no use is scheduled above it
+            if (!(D2R_GEMM_ABLATE & 256)) {
+                if (g + 1 < NG) asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(ub[cur]), "+v"(wb[cur]), "+v"(abv[cur]) : "n"(FETCH_OPS) : "memory");
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ub[cur]), "+v"(wb[cur]), "+v"(abv[cur]) : : "memory");
+            }
+            const float4 u = make_float4(ub[cur][0], ub[cur][1], ub[cur][2], ub[cur][3]), w = make_float4(wb[cur][0], wb[cur][1], wb[cur][2], wb[cur][3]);
+            float f[8];
+            if (LN) {
+                const float2 ab = make_float2(abv[cur][0], abv[cur][1]);
+                f[0] = fmaf(ab.x, u.x, fmaf(ab.y, s0.x, b0.x)); f[1] = fmaf(ab.x, u.y, fmaf(ab.y, s0.y, b0.y));
+                f[2] = fmaf(ab.x, u.z, fmaf(ab.y, s0.z, b0.z)); f[3] = fmaf(ab.x, u.w, fmaf(ab.y, s0.w, b0.w));
+                f[4] = fmaf(ab.x, w.x, fmaf(ab.y, s1.x, b1.x)); f[5] = fmaf(ab.x, w.y, fmaf(ab.y, s1.y, b1.y));
+                f[6] = fmaf(ab.x, w.z, fmaf(ab.y, s1.z, b1.z)); f[7] = fmaf(ab.x, w.w, fmaf(ab.y, s1.w, b1.w));
+            } else {
+                f[0] = u.x + b0.x; f[1] = u.y + b0.y; f[2] = u.z + b0.z; f[3] = u.w + b0.w;
+                f[4] = w.x + b1.x; f[5] = w.y + b1.y; f[6] = w.z + b1.z; f[7] = w.w + b1.w;
+            }
+            if (GELU) {
+                // quick_gelu: x * sigmoid(1.702 x) = x / (1 + exp2(-1.702 log2(e) x))
+#pragma unroll
+                for (int e = 0; e < 8; e++)
+                    f[e] *= __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930156f * f[e]));
+            }
+            const uint4 pk = make_uint4(pack2(f[0], f[1]), pack2(f[2], f[3]), pack2(f[4], f[5]), pack2(f[6], f[7]));
+#if (D2R_GEMM_ABLATE & 128) && defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" ::"v"(pk.x), "v"(pk.y), "v"(pk.z), "v"(pk.w));
+            continue;
+#endif
+            *(uint4 *)(cb + (loff + (uint32_t)((g >> 2) * 32 + (g & 3) * 8) * rs)) = pk;
         }
     }
 }
@@ -774,7 +809,7 @@ template <int EPI>
 __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A, const uint16_t *__restrict__ W,
                                                  const float *__restrict__ bias, void *__restrict__ Cout,
                                                  uint32_t M_pad, uint32_t N, uint32_t K, uint32_t n_xcd, EpiAux aux,
-                                                 uint32_t stagger_sleeps, uint32_t gn)
+                                                 uint32_t stagger_sleeps, uint32_t gn_split)
 {
     constexpr uint32_t SLOT = 128 * BK * 2;          // 16 KiB
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -785,9 +820,15 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
     // column tiles: the group's W panels (gn x K x 512 B = 1.5 MB at K = 768) are touched every round and stay in
     // the 4 MiB L2 while the A panels stream past — with the plain column-fastest order every round cycled ALL of W
     // (3.5-4.7 MB for the QKV / fc1 products) through the L2 and a quarter of the operand reads missed it.
-    const uint32_t tiles_n = N / 256, mp_all = M_pad / 256;
+    // Column sections (`gn_split` >> 16 = n_split, 1 = none): the XCDs form n_split sets; set c owns the column tiles
+    // [c, c + 1) * tiles / n_split of EVERY row panel, its XCDs share the row panels among them.  A set's W panels
+    // (half or a quarter of W) stay in its XCDs' L2s across rounds; the A panels are then read by n_split XCDs, at about
+    // the same time (the sets walk the row panels in step), i.e. once from HBM and otherwise from the Infinity Cache.
+    const uint32_t n_split = max(1u, gn_split >> 16), gn = gn_split & 0xffffu;
+    const uint32_t tiles_n = N / 256 / n_split, mp_all = M_pad / 256;          // column tiles of this XCD's section
     const uint32_t xcd = blockIdx.x % n_xcd, loc = blockIdx.x / n_xcd, per_xcd = gridDim.x / n_xcd;
-    const uint32_t mp_lo = (uint32_t)((uint64_t)mp_all * xcd / n_xcd), mp_cnt = (uint32_t)((uint64_t)mp_all * (xcd + 1) / n_xcd) - mp_lo;
+    const uint32_t csec = xcd % n_split, xr = xcd / n_split, n_xr = n_xcd / n_split;
+    const uint32_t mp_lo = (uint32_t)((uint64_t)mp_all * xr / n_xr), mp_cnt = (uint32_t)((uint64_t)mp_all * (xr + 1) / n_xr) - mp_lo;
     const uint32_t t_begin = 0, t_end = mp_cnt * tiles_n;          // local tile ids of this XCD
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -838,7 +879,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
         const uint32_t gw = min(gn, tiles_n - g * gn);             // the last group may be narrower
         const uint32_t mi = r / gw;
         tm = (mp_lo + mi) * 256;
-        tn = (g * gn + (r - mi * gw)) * 256;
+        tn = (csec * tiles_n + g * gn + (r - mi * gw)) * 256;
     };
     // fragment read addresses: the swizzle term is the same for every row this lane reads
     // ((row >> 1) & 7 == (li >> 1) & 7), so four byte offsets per operand serve all kinds; the slot and
@@ -2008,8 +2049,12 @@ static int launch_gemm(d2r_ctx *ctx, const uint16_t *A, const uint16_t *W, const
                 }
             }
             gn = std::max(1u, std::min(gn, N / 256));
+            // column sections: only when they divide the XCDs and the column tiles evenly
+            uint32_t ns = (uint32_t)ctx->gemm_nsplit;
+            if (ns == 0) ns = 2;            // default: two sections where they fit (fc1: -0.2 ms per launch; four measure the same)
+            if (ns < 1 || (uint32_t)ctx->n_xcd % ns || (N / 256) % ns) ns = 1;
             hipLaunchKernelGGL((k_gemm8<EPI>), dim3(nwg8), dim3(512), LDS8, ctx->stream, A, W, bias, C, M_pad, N, K,
-                               (uint32_t)ctx->n_xcd, aux, sleeps, gn);
+                               (uint32_t)ctx->n_xcd, aux, sleeps, (ns << 16) | std::min(gn, 0xffffu));
             D2R_HIP(ctx, hipGetLastError());
             return D2R_OK;
         }

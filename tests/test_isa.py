@@ -35,12 +35,29 @@ def kernels(isa, prefix):
         yield m.group(1), m.group(2).split("\n")
 
 
+def mfma_blocks(lines):
+    """The basic blocks that contain MFMA instructions = the K loop (the code layout may put the epilogue between
+    them in text order, so "between the first and the last MFMA" is not the loop).  Ends of blocks: labels and
+    branches."""
+    blocks, cur = [], []
+    for l in lines:
+        t = l.strip()
+        if re.match(r"^\.LBB\w+:", t):
+            blocks.append(cur)
+            cur = []
+        cur.append(l)
+        if t.startswith("s_cbranch") or t.startswith("s_branch"):
+            blocks.append(cur)
+            cur = []
+    blocks.append(cur)
+    return [b for b in blocks if any("v_mfma" in l for l in b)]
+
+
 def test_no_spill_stores_inside_the_counted_vmcnt_k_loop(clip_isa):
     seen = 0
     for name, lines in kernels(clip_isa, "k_gemm8"):
-        mf = [i for i, l in enumerate(lines) if "v_mfma" in l]
-        assert len(mf) >= 64, name
-        body = lines[mf[0]:mf[-1] + 1]
+        assert sum("v_mfma" in l for l in lines) >= 64, name
+        body = [l for b in mfma_blocks(lines) for l in b]
         spills = [l for l in body if "scratch_store" in l or "scratch_load" in l]
         assert not spills, f"{name}: scratch traffic inside the K loop: {spills[:3]}"
         seen += 1
@@ -48,12 +65,11 @@ def test_no_spill_stores_inside_the_counted_vmcnt_k_loop(clip_isa):
 
 
 def test_k_loop_waits_are_counted_not_drained(clip_isa):
-    """between the MFMAs of the K loop every vmcnt wait is one of the hand-placed ones (inline asm: counted,
-    10 outstanding, plus the 8/6/4/2/0 of a workgroup's final tile); a compiler-placed vmcnt wait there
-    would mean a load it knows about (a spill reload, an address it re-fetches) inside the counted ring."""
+    """inside the K loop every vmcnt wait is one of the hand-placed ones (inline asm: counted, 10 outstanding);
+    a compiler-placed vmcnt wait there would mean a load it knows about (a spill reload, an address it re-fetches)
+    inside the counted ring."""
     for name, lines in kernels(clip_isa, "k_gemm8"):
-        mf = [i for i, l in enumerate(lines) if "v_mfma" in l]
-        body = lines[mf[0]:mf[-1] + 1]
+        body = [l for b in mfma_blocks(lines) for l in b]
         assert sum("vmcnt(10)" in l for l in body) >= 8, name
         in_asm, compiler_waits = False, []
         for l in body:

@@ -1,0 +1,9 @@
+#!/bin/bash
+# Same-box A/B of library OPTIONS (run on the GPU box): tools/opt_ab.sh "gemm_group=0" "gemm_group=4" ... ("" = defaults)
+for r in $(seq 1 ${ROUNDS:-2}); do
+  for o in "$@"; do
+    python bench.py --steps ${STEPS:-6} --warmup 2 --cpu-sample 0 ${o:+--opt $o} 2>/dev/null | python -c "
+import sys,json
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('[$o]', d['value'], d['device_ms_per_step'])"
+  done
+done
