@@ -976,13 +976,13 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
     const float2 *ab_lds = (const float2 *)(smem + 8 * SLOT + 8 * EP_WAVE_FLOATS * 4) + wave * 128;
 
     for (;;) {
+    STAMP(ts0);               // (the first bucket of the cycle stamps: accumulator reset + drain + first fragment reads)
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-    STAMP(ts0);
     // everything in flight is drained ONCE per tile: the eight half-tiles staged during the previous tile's
     // last K-tile pair and that tile's epilogue stores.  (Stores share the vmcnt counter with the loads.  The counted
     // waits below would stay sound with stores outstanding — vmcnt(N) with N loads younger than the awaited one bounds
