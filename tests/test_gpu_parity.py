@@ -1151,3 +1151,34 @@ def test_vit_layernorm_fold_modes_match_oracle(gpu, name, n):
         bar = 1e-3 if (name == "vit_b16" and mode != 2) else 2.5e-3
         assert cos_err < 1e-4 and logit_err <= bar, (mode, cos_err, logit_err)
     sc.close()
+
+
+@pytest.mark.gpu
+def test_gemm_tile_orders_and_last_block_schedules_do_not_change_results(gpu):
+    """The persistent GEMM's tile order (column sections over XCD sets, column groups) and its start stagger decide
+    WHICH workgroup computes a tile and when, never how: embeddings must be bit-identical under every setting.
+    cls_last (the last block on the class-token rows only) changes which kernels run the last block, so it is held to
+    the rounding of one block instead: 1 - cos < 2e-6 against the full last block.  300 images: every product runs on
+    the persistent 256x256 kernel (345 row panels, several tiles per workgroup)."""
+    engine, ctx = gpu["engine"], gpu["ctx"]
+    cfg = CLIP_CONFIGS["vit_b16"]
+    sd = random_clip_state_dict(cfg, seed=6, text=False)
+    sc = engine.ClipScorer(ctx, cfg, sd)
+    r = np.random.Generator(np.random.PCG64(17))
+    pv = r.standard_normal((300, 3, 224, 224), dtype=np.float32)
+    defaults = {"gemm_nsplit": 0, "gemm_group": 65535, "gemm_stagger": 0, "cls_last": 1}
+    try:
+        base = sc.embed_pixels(pv)
+        for key, values in (("gemm_nsplit", (1, 2, 4)), ("gemm_group", (0, 1, 2, 4)), ("gemm_stagger", (1,))):
+            for v in values:
+                ctx.set_option(key, v)
+                np.testing.assert_array_equal(sc.embed_pixels(pv), base, err_msg=f"{key}={v}")
+            ctx.set_option(key, defaults[key])
+        ctx.set_option("cls_last", 0)
+        full = sc.embed_pixels(pv)
+        assert (1.0 - cosine(full, base)).max() < 2e-6
+        assert np.abs(full - base).max() > 0            # it IS a different schedule (guards against the option being ignored)
+    finally:
+        for k, v in defaults.items():
+            ctx.set_option(k, v)
+        sc.close()
