@@ -1390,6 +1390,127 @@ __device__ __forceinline__ void attn_qtile(const uint8_t *__restrict__ Ks, const
     }
 }
 
+// TWO 32-query tiles of one (image, head) per wave (vision tower): the K and V^T fragments are read once for both
+// tiles and the loop / address arithmetic is shared, and the two tiles' chains — S MFMAs, softmax, PV MFMAs — are
+// independent, so one tile's exp2 section can sit beside the other's MFMAs inside ONE wave; the workgroup then needs
+// four waves instead of eight (two waves per SIMD with ~200 registers each instead of four with 128).
+__device__ __forceinline__ void attn_qtile2(const uint8_t *__restrict__ Ks, const uint16_t *__restrict__ Vt, uint32_t vstride,
+                                            const uint4 (&qf)[2][4], uint32_t qt0, uint32_t T, uint32_t n_kt, uint32_t li,
+                                            uint32_t hi, uint16_t *__restrict__ AO, size_t row_base, uint32_t M_pad, uint32_t head)
+{
+    const float sm_c = 0.125f * 1.4426950408889634f;   // head_dim^-0.5 * log2(e), head_dim = 64
+    f32x16 o0[2], o1[2];
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) o0[q][r] = o1[q][r] = 0.f;
+    const uint8_t *kp[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) kp[s] = Ks + lds_off(li, 2 * s + hi);
+    const uint16_t *vp0 = Vt + (size_t)li * vstride + 4 * hi, *vp1 = Vt + (size_t)(32 + li) * vstride + 4 * hi;
+    uint4 ka[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) ka[s] = *(const uint4 *)(kp[s]);
+    for (uint32_t kt = 0; kt < n_kt; kt++) {
+        f32x16 sacc[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) sacc[q][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                union { uint4 u; bf16x8 v; } a, b;
+                a.u = ka[s];
+                b.u = qf[q][s];
+                sacc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, sacc[q], 0, 0, 0);
+            }
+        if (kt + 1 < n_kt) {
+#pragma unroll
+            for (int s = 0; s < 4; s++) ka[s] = *(const uint4 *)(kp[s] + (kt + 1) * 4096u);
+        }
+        if ((kt + 1) * 32 > T) {                                       // wave-uniform: the tile that holds keys >= T
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const uint32_t key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    sacc[q][r] = key < T ? sacc[q][r] : -INFINITY;
+                }
+        }
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            float tmax = sacc[q][0];
+#pragma unroll
+            for (int r = 1; r < 16; r++) tmax = fmaxf(tmax, sacc[q][r]);
+            tmax = half_max(tmax) * sm_c;
+            const float m_new = fmaxf(m_run[q], tmax);
+            if (__builtin_amdgcn_ballot_w64(m_new != m_run[q]) != 0) {
+                const float alpha = __builtin_amdgcn_exp2f(m_run[q] - m_new);
+                l_run[q] *= alpha;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    o0[q][r] *= alpha;
+                    o1[q][r] *= alpha;
+                }
+                m_run[q] = m_new;
+            }
+            typedef float f32x8 __attribute__((ext_vector_type(8)));
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            const f32x16 cv = sm_c, mv = -m_new;
+            const f32x16 t = __builtin_elementwise_fma(sacc[q], cv, mv);
+#pragma unroll
+            for (int r = 0; r < 16; r++) sacc[q][r] = __builtin_amdgcn_exp2f(t[r]);
+            const f32x8 s8 = sacc[q].lo + sacc[q].hi;
+            const f32x4 s4 = s8.lo + s8.hi;
+            const f32x2 s2 = s4.lo + s4.hi;
+            l_run[q] += s2.x + s2.y;
+        }
+        const uint16_t *vq0 = vp0 + kt * 32, *vq1 = vp1 + kt * 32;
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            union { uint4 u; bf16x8 v; } va0, va1;
+            const uint2 a00 = *(const uint2 *)(vq0 + 16 * s);
+            const uint2 a01 = *(const uint2 *)(vq0 + 16 * s + 8);
+            const uint2 a10 = *(const uint2 *)(vq1 + 16 * s);
+            const uint2 a11 = *(const uint2 *)(vq1 + 16 * s + 8);
+            va0.u = make_uint4(a00.x, a00.y, a01.x, a01.y);
+            va1.u = make_uint4(a10.x, a10.y, a11.x, a11.y);
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                union { uint4 u; bf16x8 v; } pb;
+                pb.u.x = pack2(sacc[q][8 * s + 0], sacc[q][8 * s + 1]);
+                pb.u.y = pack2(sacc[q][8 * s + 2], sacc[q][8 * s + 3]);
+                pb.u.z = pack2(sacc[q][8 * s + 4], sacc[q][8 * s + 5]);
+                pb.u.w = pack2(sacc[q][8 * s + 6], sacc[q][8 * s + 7]);
+                o0[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va0.v, pb.v, o0[q], 0, 0, 0);
+                o1[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va1.v, pb.v, o1[q], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const uint32_t qrow = (qt0 + q) * 32 + li;
+        const float inv_l = 1.0f / half_sum(l_run[q]);
+        if (qrow < T) {
+            uint16_t *dst = AO + ((size_t)head * M_pad + row_base + qrow) * 64;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; g4++) {
+                uint2 w0, w1;
+                w0.x = pack2(o0[q][4 * g4 + 0] * inv_l, o0[q][4 * g4 + 1] * inv_l);
+                w0.y = pack2(o0[q][4 * g4 + 2] * inv_l, o0[q][4 * g4 + 3] * inv_l);
+                w1.x = pack2(o1[q][4 * g4 + 0] * inv_l, o1[q][4 * g4 + 1] * inv_l);
+                w1.y = pack2(o1[q][4 * g4 + 2] * inv_l, o1[q][4 * g4 + 3] * inv_l);
+                *(uint2 *)(dst + 8 * g4 + 4 * hi) = w0;
+                *(uint2 *)(dst + 32 + 8 * g4 + 4 * hi) = w1;
+            }
+        }
+    }
+}
+
 #ifdef D2R_ATTN_STAMPS
 // development only: shader-clock cycles per workgroup section seen by wave 0:
 // [0] issue of all loads + V transposes, [1] wait for the K copies, [2] barrier, [3] compute + store, [4] workgroups
@@ -1404,11 +1525,13 @@ extern "C" __attribute__((visibility("default"))) int d2r_debug_attn_stamps(unsi
     return 0;
 }
 #endif
-template <bool CAUSAL>
-__global__ __launch_bounds__(ATTN_THREADS, 4) void k_attention(const uint16_t *__restrict__ QKV,
+template <bool CAUSAL, int NQ = 1>
+__global__ __launch_bounds__(ATTN_THREADS / NQ, NQ == 2 ? 2 : 4) void k_attention(const uint16_t *__restrict__ QKV,
                                                                uint16_t *__restrict__ AO, uint32_t T, uint32_t T_pad,
                                                                uint32_t d, uint32_t M_pad, uint32_t stagger_lo, uint32_t stagger_hi)
 {
+    constexpr uint32_t TH = ATTN_THREADS / NQ;          // NQ = 2: four waves, two query tiles each (attn_qtile2)
+    static_assert(NQ == 1 || !CAUSAL, "the two-tile variant serves the vision tower");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     // Every workgroup does the same work — load Q/K/V, barrier, arithmetic — so a launch whose workgroups all start
     // together stays in lockstep: the whole chip loads (each CU at its HBM share), then the whole chip computes with
@@ -1439,26 +1562,27 @@ __global__ __launch_bounds__(ATTN_THREADS, 4) void k_attention(const uint16_t *_
     // this wave's first query tile is requested before the staging so that its latency hides under it
     // (B operand of S^T = K Q^T: lane (q, hi) holds Q[q][16s + 8hi .. +8))
     const uint32_t n_qt = (T + 31) / 32, n_kt = T_pad / 32;
-    uint4 qf[4];
-    {
-        const uint32_t qrow0 = wave * 32 + li;
+    uint4 qf[NQ][4];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        const uint32_t qrow0 = (wave * NQ + q) * 32 + li;
 #pragma unroll
         for (int s = 0; s < 4; s++)
-            qf[s] = (!(D2R_ATTN_ABLATE & 8) && wave < n_qt && qrow0 < T) ? *(const uint4 *)(Qg + (size_t)qrow0 * ld + 16 * s + 8 * hi) : make_uint4(lane, s, 0, 0);
+            qf[q][s] = (!(D2R_ATTN_ABLATE & 8) && qrow0 < T) ? *(const uint4 *)(Qg + (size_t)qrow0 * ld + 16 * s + 8 * hi) : make_uint4(0, 0, 0, 0);
     }
     // K (row-major, swizzled 16-byte chunks) goes straight to LDS by LDS-DMA, 8 key rows per wave
     // instruction, issued before anything else so it overlaps the V transposes.  Rows >= T repeat row
     // T-1: their scores are masked by a select below, so any finite value does.
     {
         const uint32_t ks0 = __builtin_amdgcn_readfirstlane(lds_addr(Ks));
-        for (uint32_t b = __builtin_amdgcn_readfirstlane(wave); b < ((D2R_ATTN_ABLATE & 1) ? 0u : T_pad / 8); b += ATTN_THREADS / 64) {
+        for (uint32_t b = __builtin_amdgcn_readfirstlane(wave); b < ((D2R_ATTN_ABLATE & 1) ? 0u : T_pad / 8); b += TH / 64) {
             const uint32_t row = b * 8 + (lane >> 3), src_row = row < T ? row : T - 1;
             glds16(Kg + (size_t)src_row * ld + ((lane & 7) ^ ((row >> 1) & 7u)) * 8, ks0 + b * 1024);
         }
     }
     // stage V^T: a task takes 4 keys x 8 dims (four 16-byte loads), transposes the 4x8 block in
     // registers (v_perm_b32) and writes one 8-byte word of 4 consecutive keys per dim
-    for (uint32_t i = tid; i < ((D2R_ATTN_ABLATE & 2) ? 0u : (T_pad / 4) * 8); i += ATTN_THREADS) {
+    for (uint32_t i = tid; i < ((D2R_ATTN_ABLATE & 2) ? 0u : (T_pad / 4) * 8); i += TH) {
         const uint32_t kb = (i >> 3) * 4, c = i & 7;
         uint4 v[4];
 #pragma unroll
@@ -1490,16 +1614,20 @@ __global__ __launch_bounds__(ATTN_THREADS, 4) void k_attention(const uint16_t *_
 #endif
 
     if (D2R_ATTN_ABLATE & 4) {       // keep the loaded values alive
-        if (qf[0].x == 0x12345678u && Ks[tid] == 0x7f && Vt[tid] == 0x1234) AO[tid] = 1;
+        if (qf[0][0].x == 0x12345678u && Ks[tid] == 0x7f && Vt[tid] == 0x1234) AO[tid] = 1;
     }
-    for (uint32_t qt = wave; qt < ((D2R_ATTN_ABLATE & 4) ? 0u : n_qt); qt += ATTN_THREADS / 64) {
-        if (qt != wave) {
-            const uint32_t qrow = qt * 32 + li;
+    for (uint32_t qt = wave * NQ; qt < ((D2R_ATTN_ABLATE & 4) ? 0u : n_qt); qt += TH / 64 * NQ) {
+        if (qt != wave * NQ) {
 #pragma unroll
-            for (int s = 0; s < 4; s++)
-                qf[s] = qrow < T ? *(const uint4 *)(Qg + (size_t)qrow * ld + 16 * s + 8 * hi) : make_uint4(0, 0, 0, 0);
+            for (int q = 0; q < NQ; q++) {
+                const uint32_t qrow = (qt + q) * 32 + li;
+#pragma unroll
+                for (int s = 0; s < 4; s++)
+                    qf[q][s] = qrow < T ? *(const uint4 *)(Qg + (size_t)qrow * ld + 16 * s + 8 * hi) : make_uint4(0, 0, 0, 0);
+            }
         }
-        attn_qtile<CAUSAL>(Ks, Vt, vstride, qf, qt, T, n_kt, li, hi, AO, row_base, M_pad, head);
+        if constexpr (NQ == 2) attn_qtile2(Ks, Vt, vstride, qf, qt, T, n_kt, li, hi, AO, row_base, M_pad, head);
+        else attn_qtile<CAUSAL>(Ks, Vt, vstride, qf[0], qt, T, n_kt, li, hi, AO, row_base, M_pad, head);
     }
 #ifdef D2R_ATTN_STAMPS
     {
@@ -2083,6 +2211,10 @@ static int launch_attention_vision(d2r_ctx *ctx, const uint16_t *QKV, uint16_t *
     } else {
         // (two workgroups per CU when 2 * attn_lds fits: stagger the second one of the first generation)
         const uint32_t lo = ctx->attn_stagger && 2 * attn_lds <= 160 * 1024 ? (uint32_t)ctx->n_cu : 0u;
+        if (ctx->attn_q2)
+            hipLaunchKernelGGL((k_attention<false, 2>), dim3(n_heads, n), dim3(ATTN_THREADS / 2), attn_lds, ctx->stream, QKV, AO, T, T_pad, d,
+                               M_pad, 0u, 0u);
+        else
         hipLaunchKernelGGL(k_attention<false>, dim3(n_heads, n), dim3(ATTN_THREADS), attn_lds, ctx->stream, QKV, AO, T, T_pad, d,
                            M_pad, lo, lo ? 2u * (uint32_t)ctx->n_cu : 0u);
     }
@@ -2097,6 +2229,7 @@ static int attention_setup(d2r_ctx *ctx, uint32_t T_pad, size_t *lds_out)
     attn_attr.run(ctx->device, [] {
         (void)hipFuncSetAttribute((const void *)k_attention<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void *)k_attention<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_attention<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     *lds_out = attn_lds;
     return D2R_OK;

@@ -319,7 +319,7 @@ D2R_API int d2r_get_timing(d2r_ctx *ctx, d2r_timing *out);
  *     scale in the tail, so it is not the default), 3: fp32 next to the bf16 copy.
  * "cls_last" (default 1): the last transformer block of the vision tower runs on the class-token rows only (the head
  *     reads nothing else; same result, ~6 % less ViT work).  "gemm_nsplit" (default 0 = 2 where the column tiles and XCDs divide evenly; 1 = off): XCD sets own column
- *     sections of the persistent GEMM's outputs so that a section's weight panels stay in their L2s.  "attn_persistent", "attn_stagger", "gemm_stagger",
+ *     sections of the persistent GEMM's outputs so that a section's weight panels stay in their L2s.  "attn_q2" (two query tiles per wave), "attn_persistent", "attn_stagger", "gemm_stagger",
  *     "gemm_group": alternative schedules of the attention / persistent-GEMM kernels that were measured no faster
  *     and are kept switchable; results do not depend on them.
  * "prep_reuse" (default 1): in d2r_render_score, the rows of CLIP patches of a candidate frame that its object cannot have

@@ -1166,10 +1166,11 @@ def test_gemm_tile_orders_and_last_block_schedules_do_not_change_results(gpu):
     sc = engine.ClipScorer(ctx, cfg, sd)
     r = np.random.Generator(np.random.PCG64(17))
     pv = r.standard_normal((300, 3, 224, 224), dtype=np.float32)
-    defaults = {"gemm_nsplit": 0, "gemm_group": 65535, "gemm_stagger": 0, "cls_last": 1}
+    defaults = {"gemm_nsplit": 0, "gemm_group": 65535, "gemm_stagger": 0, "cls_last": 1, "attn_q2": 0}
     try:
         base = sc.embed_pixels(pv)
-        for key, values in (("gemm_nsplit", (1, 2, 4)), ("gemm_group", (0, 1, 2, 4)), ("gemm_stagger", (1,))):
+        # attn_q2: two query tiles per wave in the attention kernel — the same arithmetic in the same order per query
+        for key, values in (("gemm_nsplit", (1, 2, 4)), ("gemm_group", (0, 1, 2, 4)), ("gemm_stagger", (1,)), ("attn_q2", (1,))):
             for v in values:
                 ctx.set_option(key, v)
                 np.testing.assert_array_equal(sc.embed_pixels(pv), base, err_msg=f"{key}={v}")
