@@ -51,6 +51,52 @@ def vit_gflop(cfg, executed: bool = False) -> float:
     return total / 1e9
 
 
+def power_probe(step_fn, device_index: int, seconds: float):
+    """Socket power and shader clock (rocm-smi) sampled over EXTRA, untimed steps after the timed region: the step
+    runs against the package power limit, which is what prices the ViT's MFMA fraction.
+    Returns None when rocm-smi is not there."""
+    import re
+    import shutil
+    import subprocess
+    import threading
+    smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(smi) or seconds <= 0:
+        return None
+    samples, stop = [], threading.Event()
+
+    def work():
+        while not stop.is_set():
+            try:
+                txt = subprocess.run([smi, "-d", str(device_index), "--showpower", "--showclocks"], capture_output=True,
+                                     text=True, timeout=5).stdout
+            except Exception:
+                return
+            w = re.search(r"Power \(W\):\s*([\d.]+)", txt)
+            c = re.search(r"sclk clock level:\s*\S+\s*\((\d+)Mhz\)", txt)
+            if w and c:
+                samples.append((float(w.group(1)), int(c.group(1))))
+
+    th = threading.Thread(target=work, daemon=True)
+    th.start()
+    t_end = time.perf_counter() + seconds
+    while time.perf_counter() < t_end:
+        step_fn()
+    stop.set()
+    th.join(timeout=6)
+    cap = None
+    try:
+        m = re.search(r"Max Graphics Package Power \(W\):\s*([\d.]+)", subprocess.run([smi, "-d", str(device_index), "--showmaxpower"],
+                                                                                  capture_output=True, text=True, timeout=5).stdout)
+        cap = float(m.group(1)) if m else None
+    except Exception:
+        pass
+    if not samples:
+        return None
+    return {"avg_w": round(sum(s[0] for s in samples) / len(samples), 1), "max_w": max(s[0] for s in samples), "cap_w": cap,
+            "sclk_mhz_avg": round(sum(s[1] for s in samples) / len(samples)), "samples": len(samples),
+            "note": "rocm-smi over extra untimed steps after the timed region"}
+
+
 def cpu_baseline(scene, W, H, cfg, sd, text, poses_world, n_sample):
     """The oracle (CPU restatement) timed on the host cores on a bounded sample of the same
     workload.  Checker code used here ONLY as the reported CPU baseline."""
@@ -109,6 +155,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=4096, help="candidates per pass (the library caps it per model/view)")
     ap.add_argument("--opt", action="append", default=[], help="library tunable key=value (repeatable)")
     ap.add_argument("--cpu-sample", type=int, default=6, help="candidates in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--power-seconds", type=float, default=2.5, help="extra untimed seconds sampled with rocm-smi for the power line (0 = skip)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args.gpus)
@@ -281,6 +328,8 @@ def main():
             "render_stats_per_step": stats,
             "argmax_pose": best,
         }
+        if world == 1:
+            out["power"] = power_probe(step, dev.index or 0, args.power_seconds)
         if world == 1 and args.cpu_sample > 0:
             cb, frames_o, lg_o, idx = cpu_baseline(scene, W, H, cfg, sd, text, pose_batch, args.cpu_sample)
             out["cpu_baseline"] = cb
