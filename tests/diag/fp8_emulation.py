@@ -1,5 +1,11 @@
-import sys, numpy as np
-sys.path.insert(0,'/root/repo')
+"""Numpy emulation of an e4m3 ViT-B/16 (MX block-32 or per-row scales on activations and weights) against the fp32
+oracle: the measurement behind "no fp8 tower" in DESIGN.md section 7.  Test-side diagnostic (uses oracle/)."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import clip_ref
 from dream2real_amd.clip_model import CLIP_CONFIGS, random_clip_state_dict
 cfg = CLIP_CONFIGS["vit_b16"]; sd = random_clip_state_dict(cfg, seed=6, text=False)

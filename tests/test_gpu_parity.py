@@ -1,7 +1,7 @@
 """Parity tests proper: the HIP path (through the C ABI, via dream2real_amd.engine) against
 the oracle on the same seeded inputs.  Run on the MI355X box:  pytest -m gpu.
 
-Tolerances (measured headroom in tools/gpu_diag.py, gpurun_out/diag1.log):
+Tolerances (measured headroom in tests/diag/gpu_diag.py, gpurun_out/diag1.log):
   field      sigma within 1e-2 relative, rgb within 1e-2 absolute   (bf16 MLP vs fp32 oracle)
   frames     fp32 RGBA within 5e-3, identical hit-pixel sets, uint8 frames within 1 LSB with
              at most 2% of pixels off by that 1 LSB
