@@ -9,7 +9,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libd2r.so")
-ABI_VERSION = 4          # D2R_ABI_VERSION of include/d2r.h this binding was written against
+ABI_VERSION = 5          # D2R_ABI_VERSION of include/d2r.h this binding was written against
 
 EXPORTS = [
     "d2r_abi_version", "d2r_ctx_create", "d2r_ctx_destroy", "d2r_ctx_set_stream", "d2r_ctx_synchronize",
@@ -19,7 +19,7 @@ EXPORTS = [
     "d2r_get_render_stats", "d2r_collect_render_stats", "d2r_ctx_set_option", "d2r_get_timing", "d2r_text_create",
     "d2r_text_destroy", "d2r_text_encode", "d2r_comm_get_unique_id", "d2r_comm_init", "d2r_comm_destroy",
     "d2r_allgather_scores", "d2r_phys_create", "d2r_phys_destroy", "d2r_phys_check", "d2r_nerf_load_ingp",
-    "d2r_rectify_background_depth",
+    "d2r_rectify_background_depth", "d2r_ingp_inspect",
 ]
 
 
@@ -117,6 +117,18 @@ def load() -> C.CDLL:
         raise D2RError("libd2r.so ABI version mismatch")
     _lib = lib
     return lib
+
+
+def ingp_inspect(data: bytes) -> str:
+    """d2r_ingp_inspect: the msgpack tree of a snapshot as text, each leaf marked as read / ignored by the loader,
+    plus the sizes the loader derives (host only: works without a GPU)."""
+    lib = load()
+    lib.d2r_ingp_inspect.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    need = C.c_size_t(0)
+    check(lib.d2r_ingp_inspect(data, len(data), None, 0, C.byref(need)))
+    buf = C.create_string_buffer(need.value)
+    check(lib.d2r_ingp_inspect(data, len(data), buf, need.value, None))
+    return buf.value.decode("utf-8", "replace")
 
 
 def check(rc: int, ctx=None):

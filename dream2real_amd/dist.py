@@ -9,6 +9,7 @@ hence gather first, smooth after."""
 from __future__ import annotations
 
 import os
+import socket
 
 import numpy as np
 
@@ -63,6 +64,20 @@ def allgather_logits(local_logits, n_total: int, rank: int, world: int):
     return torch.cat(parts, 0)
 
 
+def _device_identity(index: int) -> str:
+    """Something that names the physical GPU behind torch device `index` whatever HIP_VISIBLE_DEVICES maps it to:
+    its UUID, else its PCI bus id, else (no way to tell) the visible-devices string + index."""
+    import torch
+    props = torch.cuda.get_device_properties(index)
+    for attr in ("uuid", "pci_bus_id"):
+        v = getattr(props, attr, None)
+        if v not in (None, ""):
+            dom, dev = getattr(props, "pci_domain_id", ""), getattr(props, "pci_device_id", "")
+            return f"{attr}:{v}:{dom}:{dev}" if attr == "pci_bus_id" else f"uuid:{v}"
+    vis = os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES", os.environ.get("CUDA_VISIBLE_DEVICES", "all")))
+    return f"visible:{vis}:{index}"
+
+
 def init_comm(ctx, rank: int, world: int) -> bool:
     """Bring up the C-ABI communicator of `ctx` (d2r_comm_init: RCCL over xGMI): rank 0 draws the id
     blob, torch.distributed (whatever backend the process group has) hands it to the other ranks.
@@ -75,8 +90,14 @@ def init_comm(ctx, rank: int, world: int) -> bool:
     if world == 1:
         ctx.comm_init(None, 0, 1)
         return True
-    # all ranks must agree before anyone enters ncclCommInitRank (it blocks on the others)
-    shared = torch.cuda.device_count() < world
+    # all ranks must agree before anyone enters ncclCommInitRank (it blocks on the others).  RCCL refuses two ranks
+    # on one physical GPU; whether that is the case is decided from what the ranks actually hold — (host, device
+    # identity) pairs gathered over the process group — not from device_count(), which is 1 on every rank when a
+    # launcher gives each rank its own HIP_VISIBLE_DEVICES and says nothing about other nodes
+    mine = (socket.gethostname(), _device_identity(ctx.device))
+    held = [None] * world
+    dist.all_gather_object(held, mine)
+    shared = len(set(held)) < world
     blob = [None]
     if rank == 0 and not shared:
         try:
@@ -117,13 +138,19 @@ class ShardGather:
         self._rows = np.concatenate([r * self.n_max + np.arange(b - a) for r, (a, b) in enumerate(sizes)]) if world > 1 else None
 
     def gather(self) -> np.ndarray:
+        """Blocking.  The producer of `local` (d2r_render_score) and the all-gather run on the CONTEXT's stream, the
+        device -> host copies below on torch's current stream: the context is synchronised first, so the result
+        does not depend on the caller having made the two streams the same one."""
         import torch.distributed as dist
         if self.world == 1:
+            self.ctx.synchronize()
             return self.local[: self.n_total].cpu().numpy()
         if self.use_c_abi:
             self.ctx.allgather_scores(self.local.data_ptr(), self.n_max * self.C, self.full.data_ptr())
+            self.ctx.synchronize()
             out = self.full.cpu().numpy()
         else:
+            self.ctx.synchronize()
             loc = self.local.cpu() if dist.get_backend() == "gloo" else self.local
             full = self.full.cpu() if dist.get_backend() == "gloo" else self.full
             dist.all_gather_into_tensor(full.view(-1, self.C), loc)

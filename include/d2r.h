@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 #define D2R_API __attribute__((visibility("default")))
-#define D2R_ABI_VERSION 4
+#define D2R_ABI_VERSION 5
 
 typedef enum {
     D2R_OK = 0,
@@ -108,6 +108,16 @@ typedef struct {
 } d2r_ingp_info;
 D2R_API int d2r_nerf_load_ingp(d2r_ctx *ctx, const void *bytes, size_t len, d2r_nerf **out, d2r_ingp_info *info,
                                d2r_ingp_view *views, uint32_t views_cap);
+/*
+ * What a snapshot holds next to what d2r_nerf_load_ingp reads of it — the first check to run on a real
+ * `method_out/<scene>/{fg,bg}_base.ingp` (reference install.sh:38-50), since the loader is written against the believed
+ * layout.  HOST ONLY: needs no device and no context (errors go to d2r_last_error(NULL)).  Writes NUL-terminated text
+ * into out[cap] (truncated if short; *needed = bytes for all of it): one line per leaf of the msgpack tree,
+ * "<R|-> <kind> <elements or bytes> <path> [= value]" with R = read by the loader, then "# derived:" lines with the
+ * parameter / density-grid counts and the level table the loader computes from the config, beside the sizes of
+ * params_binary / density_grid_binary.  Malformed or truncated input returns D2R_ERR_INVALID.
+ */
+D2R_API int d2r_ingp_inspect(const void *bytes, size_t len, char *out, size_t cap, size_t *needed);
 
 /* Camera state set on a Testbed before render(): set_camera_to_training_view (intrinsics),
  * background_color, nerf.render_min_transmittance, dataset scale/offset used by

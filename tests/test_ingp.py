@@ -109,3 +109,71 @@ def test_l8f4_layout_background_and_render_aabb_round_trip(tmp_path):
     open(path, "wb").write(zlib.compress(msgpack.packb(cfg, use_bin_type=True)))
     with pytest.raises(ValueError):
         ingp.load_ingp(path)
+
+
+# ---- the C reader (libd2r.so): host-only entry d2r_ingp_inspect shares the msgpack / zlib code of d2r_nerf_load_ingp
+
+def test_c_inspect_lists_the_tree_and_what_the_loader_reads(tmp_path):
+    """d2r_ingp_inspect on a synthetic snapshot: every leaf is listed, the ones the loader reads are marked, extra keys
+    (what a real instant-ngp file will carry beyond the believed layout) show up as ignored, and the derived parameter
+    counts agree with the file."""
+    import msgpack, zlib
+    from dream2real_amd import _lib
+    scene = make_scene("pool_triangle")
+    path = str(tmp_path / "fg_base.ingp")
+    save_ingp(path, scene.fg, training_views=[dict(fx=900.0, fy=910.0, cx=640.0, cy=350.0, w=1280, h=720)] * 3)
+    cfg = msgpack.unpackb(zlib.decompress(open(path, "rb").read()), raw=False)
+    cfg["snapshot"]["nerf"]["cone_angle_constant"] = 0.00390625          # keys the loader does not know
+    cfg["dir_encoding"] = {"otype": "SphericalHarmonics", "degree": 4}
+    blob = zlib.compress(msgpack.packb(cfg, use_bin_type=True), 1)
+    text = _lib.ingp_inspect(blob)
+    lines = [ln for ln in text.splitlines() if not ln.startswith("#")]
+    by_path = {ln.split(" ")[3]: ln for ln in lines}
+    assert by_path["snapshot.params_binary"].startswith("R bin ")
+    assert by_path["snapshot.density_grid_binary"].startswith("R bin ")
+    assert by_path["encoding.n_levels"].startswith("R int 1 ") and by_path["encoding.n_levels"].endswith("= 16")
+    assert by_path["snapshot.nerf.cone_angle_constant"].startswith("- float ")
+    assert by_path["dir_encoding.degree"].startswith("- int ") and by_path["dir_encoding.otype"].endswith('= "SphericalHarmonics"')
+    assert by_path["snapshot.nerf.dataset.metadata[]"] == "- array 3 snapshot.nerf.dataset.metadata[]"
+    assert by_path["snapshot.nerf.dataset.metadata[].focal_length"].startswith("R array 2 ")
+    derived = [ln for ln in text.splitlines() if ln.startswith("# derived: grid_entries")][0].split()
+    vals = dict(zip(derived[2::2], derived[3::2]))
+    assert int(vals["n_params_expected"]) == int(vals["params_binary_halves"]) == len(cfg["snapshot"]["params_binary"]) // 2
+    assert int(vals["grid_entries"]) == scene.fg.levels.n_entries
+    assert sum(ln.startswith("# level ") for ln in text.splitlines()) == 16
+    # the same bytes uncompressed (.msgpack) read the same
+    assert _lib.ingp_inspect(msgpack.packb(cfg, use_bin_type=True)).splitlines()[2:] == text.splitlines()[2:]
+
+
+def test_c_reader_returns_errors_on_truncated_and_malformed_input(tmp_path):
+    """Nothing a file can contain may take the process down (no exception crosses the C ABI, include/d2r.h): truncated
+    msgpack (also inside a map key, the case that used to build a std::string from a null pointer), truncated and
+    corrupted zlib streams, garbage, absurd lengths."""
+    import msgpack, zlib
+    from dream2real_amd import _lib
+    scene = make_scene("pool_triangle")
+    path = str(tmp_path / "fg_base.ingp")
+    save_ingp(path, scene.fg)
+    blob = open(path, "rb").read()
+    raw = zlib.decompress(blob)
+    bad = [
+        bytes([0x81, 0xd9, 0xc8]) + b"abc",                    # map of 1, str8 key of 200 bytes, 3 present
+        bytes([0x81, 0xa3]) + b"ab",                           # fixstr key cut short
+        bytes([0x82, 0xa1]) + b"a" + bytes([0x01, 0xa1]),      # second key missing its payload
+        bytes([0xdf, 0xff, 0xff, 0xff, 0xff]),                 # map32 of 4 G entries, nothing behind it
+        bytes([0xdd, 0xff, 0xff, 0xff, 0xff, 0x01]),           # array32 of 4 G entries
+        bytes([0xc6, 0xff, 0xff, 0xff, 0xff]) + b"x" * 8,      # bin32 of 4 GiB
+        bytes([0x93, 0x01, 0x02, 0x03]) + b"\x00" * 4,         # valid msgpack, not a map
+        raw[: len(raw) // 2], raw[:100], raw[:5],              # truncated uncompressed snapshots
+        blob[: len(blob) // 2], blob[:20],                     # truncated zlib streams
+        blob[:200] + bytes(200) + blob[400:],                  # corrupted zlib stream
+        zlib.compress(bytes([0x81, 0xd9, 0xc8]) + b"abc"),     # the map-key case behind a valid zlib stream
+        zlib.compress(bytes(range(256)) * 64),                 # garbage behind a valid zlib stream
+        bytes([0x1f, 0x8b, 0x08, 0x00]) + b"\x00" * 32,        # gzip magic, nonsense body
+        bytes([0x91] * 100),                                   # nesting deeper than the reader allows
+    ]
+    for k, data in enumerate(bad):
+        with pytest.raises(_lib.D2RError):
+            _lib.ingp_inspect(data)
+    # sanity: the intact file still reads
+    assert "snapshot.params_binary" in _lib.ingp_inspect(blob)
