@@ -6,15 +6,29 @@ A "step" is one pass of the hot path over one batch of candidate poses: pose bat
 background -> rot90 + CLIP preprocess -> ViT forward -> logits against the cached text
 embeddings, then (N>1) ONE all-gather of logits, ratio, smoothing, argmax.
 
-Workload (config.workload): BASELINE.json configs[1] — synthetic "shopping" scene (seeded,
-SURVEY.md §8(d)), 4 096 candidate poses per GPU, 640x360 renders, ViT-B/16, bf16 MFMA with
-fp32 accumulation.  N>1: one process per GPU; every rank renders+scores its own contiguous block of
-the pose grid, no data-path collective except ONE all-gather of the logits (d2r_allgather_scores:
-RCCL over xGMI behind the C ABI).
-  --scaling weak   (default) 4 096 poses per GPU, grid [64,64,N]
-  --scaling strong --poses-total 131072: BASELINE.json configs[3], grid [128,128,8] split over N GPUs
+python bench.py [--gpus N] [--steps K] [--warmup W] [--config C]
 
-python bench.py [--gpus N] [--steps K] [--warmup W]
+Default workload (no --config): BASELINE.json configs[1] — synthetic "shopping" scene (seeded,
+SURVEY.md §8(d)), 4 096 candidate poses per GPU, 640x360 renders, ViT-B/16, bf16 MFMA with fp32
+accumulation; N>1 = weak scaling, pose grid [64,64,N], every rank renders+scores its own contiguous
+block, no data-path collective except ONE all-gather of the logits (d2r_allgather_scores: RCCL over
+xGMI behind the C ABI).  This is the line a 1/2/4/8-GPU scaling sweep reads (`--gpus N`, nothing else).
+
+--config C runs BASELINE.json configs[C] as a named workload (pose grids of SURVEY.md §8(d),
+reference vision_3d/obj_pose_opt.py:16-36):
+  0  shopping, grid [8,4,1,1,1,1] = 32 (type 3), 160x90, ViT-B/16 — the reference's CPU-runnable case; the CPU
+     baseline covers all 32 candidates
+  1  shopping, [64,64,1,1,1,1] = 4 096 per GPU (type 3), 640x360, ViT-B/16 (the default; weak over N)
+  2  pool_triangle, [128,128,1,1,1,1] = 16 384 per GPU (type 0), 640x360, ViT-B/16 (weak over N)
+  3  shopping, [128,128,8,1,1,1] = 131 072 in total (type 3), 640x360, ViT-B/16: STRONG scaling, the grid is
+     split over the N GPUs (on one GPU the whole grid runs)
+  4  shelf (aabb_scale 2), 6-DoF grid [16,16,16,4,4,4] = 262 144 in total (type 1, eulers linspace(-pi, pi/2, 4)),
+     640x360, ViT-L/14: STRONG scaling; with fewer than 8 GPUs each rank takes shard `rank` of the 8-GPU partition
+     (one GPU: a 1/8 slice, 32 768 candidates; --slice-of 1 runs the whole grid).  BASELINE.json words this
+     config "fp16 render + fp8 MFMA ViT"; this build computes it in bf16 (an MX-fp8 tower
+     misses the 1e-3 parity bar) and says so in the line.
+Individual flags (--scene, --sample-res, --clip, --width, --height, --scaling, ...) override the table.
+
 With --gpus N > 1 and no launcher environment (WORLD_SIZE unset) the script re-executes itself under
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`.
 """
@@ -104,7 +118,8 @@ def cpu_baseline(scene, W, H, cfg, sd, text, poses_world, n_sample):
     from tests.parity_utils import OraclePipeline, oracle_logits
     pipe = OraclePipeline(scene, W, H)
     bg = pipe.background()                       # setup, not timed (once per view)
-    idx = np.linspace(0, len(poses_world) - 1, n_sample).astype(int)
+    n_sample = min(n_sample, len(poses_world))
+    idx = np.unique(np.linspace(0, len(poses_world) - 1, n_sample).astype(int))
     t0 = time.time()
     frames = pipe.frames(poses_world[idx].reshape(-1, 4, 4), bg=bg)
     t_render = time.time() - t0
@@ -112,11 +127,18 @@ def cpu_baseline(scene, W, H, cfg, sd, text, poses_world, n_sample):
     lg, _ = oracle_logits(frames, cfg, sd, text)
     t_clip = time.time() - t1
     dt = time.time() - t0
-    return {"value": round(n_sample / dt, 4), "unit": "candidates/s", "cores": os.cpu_count(),
+    blas = None
+    try:
+        from threadpoolctl import threadpool_info
+        blas = max([int(i.get("num_threads", 0)) for i in threadpool_info() if i.get("user_api") == "blas"] or [0]) or None
+    except Exception:
+        pass
+    return {"value": round(len(idx) / dt, 4), "unit": "candidates/s", "cores": os.cpu_count(),
+            "threads": {"render_openmp": render_ref.num_threads(), "vit_blas": blas},
             "kind": "port",
-            "sample": f"{n_sample} of the {len(poses_world)} candidates at {W}x{H}: oracle C render+composite "
+            "sample": f"{len(idx)} of the {len(poses_world)} candidates at {W}x{H}: oracle C render+composite "
                       f"(OpenMP, {render_ref.num_threads()} threads, {t_render:.1f}s) + numpy fp32 ViT "
-                      f"(BLAS threads, {t_clip:.1f}s)"}, frames, lg, idx
+                      f"(BLAS, {blas} threads, {t_clip:.1f}s); `cores` = os.cpu_count() of the box, `threads` = what the two legs used"}, frames, lg, idx
 
 
 def self_launch(n: int):
@@ -127,6 +149,9 @@ def self_launch(n: int):
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     env = dict(os.environ)
+    # dmabuf IPC: the host driver of these boxes has no legacy IPC mode; without it RCCL's (and torch's) cross-process
+    # buffer registration fails with `hipIpcGetMemHandle: invalid argument`.  The image exports it already — this only
+    # fills it in for an environment that was built without it, and never overrides a value the caller set.
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "8")
     if torch.cuda.device_count() < n:
@@ -139,22 +164,67 @@ def self_launch(n: int):
     os.execve(sys.executable, cmd, env)
 
 
+# BASELINE.json configs[0..4] as named workloads (pose-grid bounds per scene type:
+# reference vision_3d/obj_pose_opt.py:16-36).  "per_gpu": weak scaling, the grid's z axis grows with the GPU count;
+# "total": strong scaling, the grid is fixed and split over the GPUs.
+BASELINE_CONFIGS = {
+    0: dict(scene="shopping", sample_res=[8, 4, 1, 1, 1, 1], width=160, height=90, clip="vit_b16", scaling="strong",
+            name="shopping_demo.json, 32 candidate poses, 160x90 render (the reference's CPU-runnable case)"),
+    1: dict(scene="shopping", sample_res=[64, 64, 1, 1, 1, 1], width=640, height=360, clip="vit_b16", scaling="weak",
+            name="shopping scene, 4096 candidate poses per GPU, 640x360, bf16 MLP + ViT-B/16"),
+    2: dict(scene="pool_triangle", sample_res=[128, 128, 1, 1, 1, 1], width=640, height=360, clip="vit_b16", scaling="weak",
+            name="pool_triangle scene, 16384 candidate poses per GPU, 640x360 (hash-grid HBM-bound stress)"),
+    3: dict(scene="shopping", sample_res=[128, 128, 8, 1, 1, 1], width=640, height=360, clip="vit_b16", scaling="strong",
+            name="shopping scene, pose-shard over the GPUs, 131072 candidates, all-gather of scores"),
+    4: dict(scene="shelf", sample_res=[16, 16, 16, 4, 4, 4], width=640, height=360, clip="vit_l14", scaling="strong", partition=8,
+            name="shelf_demo 6-DoF, 262144 candidates, ViT-L/14 encoder (BASELINE words it fp16 render + fp8 ViT: computed in bf16 here)"),
+}
+
+
+def shard_plan(sample_res, world: int, partition: int) -> dict:
+    """Which candidates each rank renders and in which order the gathered logits come back.
+    `order`: the pose-batch indices in sharding order — 3-DoF grids (orientations 1, nz > 1) are walked z-major so
+    that a rank owns whole (x, y) sheets (pose order has z fastest); 6-DoF grids keep the pose order (orientations
+    fastest: contiguous blocks are x slabs with every orientation).  The order is cut into `partition` contiguous
+    shards (dist.shard_range); rank r takes shard r.  partition == world except for a strong-scaling grid run on
+    fewer GPUs than the partition its config names: then only shards 0..world-1 run (`n_run` candidates per step) and
+    the rest of the grid keeps score 0.  `run_idx`: pose indices of the gathered rows, rank-major."""
+    from dream2real_amd.dist import shard_range
+    N = int(np.prod(sample_res))
+    nx, ny, nz = sample_res[:3]
+    n_ori = sample_res[3] * sample_res[4] * sample_res[5]
+    if n_ori == 1 and nz > 1:
+        order = np.arange(N).reshape(nx, ny, nz).transpose(2, 0, 1).reshape(-1)
+    else:
+        order = np.arange(N)
+    shards = [order[slice(*shard_range(N, r, partition))] for r in range(world)]
+    run_idx = np.concatenate(shards)
+    return {"order": order, "shards": shards, "run_idx": run_idx, "n_run": int(len(run_idx))}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--width", type=int, default=640)
-    ap.add_argument("--height", type=int, default=360)
-    ap.add_argument("--poses-per-gpu", type=int, default=4096, help="weak scaling: candidates per GPU (a square)")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
-    ap.add_argument("--poses-total", type=int, default=131072,
+    ap.add_argument("--config", type=int, choices=sorted(BASELINE_CONFIGS), default=None,
+                    help="run BASELINE.json configs[C] (default: configs[1], weak over --gpus)")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--poses-per-gpu", type=int, default=None, help="weak scaling: candidates per GPU (a square) -> grid [s,s,N,1,1,1]")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=None)
+    ap.add_argument("--poses-total", type=int, default=None,
                     help="strong scaling: total candidates = x*x*8 (131072 = BASELINE.json configs[3])")
-    ap.add_argument("--clip", default="vit_b16")
-    ap.add_argument("--scene", default="shopping")
+    ap.add_argument("--sample-res", default=None, help="six comma-separated grid resolutions x,y,z,rx,ry,rz (overrides the config's)")
+    ap.add_argument("--slice-of", type=int, default=None,
+                    help="strong scaling on fewer GPUs than the partition: every rank takes shard `rank` of this many (config 4 "
+                         "defaults to 8: one GPU = a 1/8 slice; 1 = the whole grid)")
+    ap.add_argument("--clip", default=None)
+    ap.add_argument("--scene", default=None)
     ap.add_argument("--chunk", type=int, default=4096, help="candidates per pass (the library caps it per model/view)")
     ap.add_argument("--opt", action="append", default=[], help="library tunable key=value (repeatable)")
-    ap.add_argument("--cpu-sample", type=int, default=6, help="candidates in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=32, help="candidates in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--dump", default=None, help="rank 0: write the last step's gathered logits, scores, pose order and grid to this .npz (tests)")
     ap.add_argument("--power-seconds", type=float, default=2.5, help="extra untimed seconds sampled with rocm-smi for the power line (0 = skip)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -175,10 +245,34 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
+    # ---------------- which workload
+    base = dict(BASELINE_CONFIGS[1 if args.config is None else args.config])
+    scene_name = args.scene or base["scene"]
+    clip_name = args.clip or base["clip"]
+    W, H = args.width or base["width"], args.height or base["height"]
+    scaling = args.scaling or base["scaling"]
+    sample_res = list(base["sample_res"])
+    if args.sample_res:
+        sample_res = [int(x) for x in args.sample_res.split(",")]
+        assert len(sample_res) == 6, "--sample-res takes six numbers"
+    elif args.poses_total is not None or (args.scaling == "strong" and args.config is None):
+        total = args.poses_total or 131072
+        side = int(round(np.sqrt(total / 8)))
+        assert side * side * 8 == total, "--poses-total must be x*x*8"
+        sample_res, scaling = [side, side, 8, 1, 1, 1], "strong"
+    elif args.poses_per_gpu is not None:
+        side = int(round(np.sqrt(args.poses_per_gpu)))
+        assert side * side == args.poses_per_gpu, "--poses-per-gpu must be a square"
+        sample_res = [side, side, 1, 1, 1, 1]
+    if scaling == "weak":
+        assert sample_res[2] == 1, "weak scaling stacks one [x,y] sheet per GPU along z"
+        sample_res[2] = world
+    partition = max(world, args.slice_of if args.slice_of is not None else base.get("partition", 1)) if scaling == "strong" else world
+    assert partition % world == 0 or partition == world, "--slice-of must be a multiple of --gpus"
+
     # ---------------- setup (untimed): scene, models, background, poses in HBM
-    W, H = args.width, args.height
-    scene = make_scene(args.scene)
-    cfg = CLIP_CONFIGS[args.clip]
+    scene = make_scene(scene_name)
+    cfg = CLIP_CONFIGS[clip_name]
     sd = random_clip_state_dict(cfg, seed=6)
     ctx = engine.Context(local)
     ctx.set_option("chunk", args.chunk)
@@ -188,22 +282,12 @@ def main():
     fg, bg = engine.Testbed(ctx, scene.fg), engine.Testbed(ctx, scene.bg)
     fg.background_color = list(scene.fg_background)
     scorer = engine.ClipScorer(ctx, cfg, sd)
-    if args.scaling == "weak":
-        side, nz = int(round(np.sqrt(args.poses_per_gpu))), world
-        assert side * side == args.poses_per_gpu, "--poses-per-gpu must be a square"
-    else:
-        nz = 8
-        side = int(round(np.sqrt(args.poses_total / nz)))
-        assert side * side * nz == args.poses_total, "--poses-total must be x*x*8"
-    sample_res = [side, side, nz, 1, 1, 1]
     task = make_task(scene)
     pose_batch = obj_pose_opt.sample_poses_grid(task, sample_res, scene.scene_type)       # [N,16] world
     N = pose_batch.shape[0]
-    lo, hi = d2r_dist.shard_range(N, rank, world)
-    # contiguous in (x, y, z) order means z interleaves: shard in z-major order so a rank gets whole
-    # (x, y) sheets -> permute for sharding, remember the inverse for the gather
-    order = np.arange(N).reshape(side, side, nz).transpose(2, 0, 1).reshape(-1)
-    my_idx = order[lo:hi]
+    plan = shard_plan(sample_res, world, partition)
+    order, run_idx, N_run = plan["order"], plan["run_idx"], plan["n_run"]
+    my_idx = plan["shards"][rank]
     poses_ngp = converter(pose_batch[my_idx].reshape(-1, 4, 4)).reshape(-1, 16).astype(np.float32)
     poses_dev = torch.from_numpy(poses_ngp).to(dev)
     K_local = poses_dev.shape[0]
@@ -224,15 +308,18 @@ def main():
     # the one collective: the C-ABI communicator (RCCL over xGMI); torch.distributed only bootstraps it
     # (id blob) and provides the timing barrier
     c_abi_comm = d2r_dist.init_comm(ctx, rank, world)
-    gather = d2r_dist.ShardGather(ctx, N, text.shape[0], rank, world, dev, c_abi_comm)
+    # gathered layout: `world` shards of the partition in rank order (padded to the largest inside the exchange)
+    N_gather = N_run
+    gather = d2r_dist.ShardGather(ctx, N_gather, text.shape[0], rank, world, dev, c_abi_comm)
     logits_dev = gather.local
 
     def step():
         engine.render_score_device(ctx, fg, scorer, view, T1, cam_ngp, poses_dev.data_ptr(), K_local, text,
                                    logits_dev.data_ptr())
-        lg = gather.gather()                                               # [N, C], z-major order (ONE all-gather at N>1)
+        lg = gather.gather()                                               # [N_gather, C], shard order (ONE all-gather at N>1)
+        step.logits = lg
         scores = np.zeros(N, np.float32)
-        scores[order] = reduce_logits(lg, 1, True)
+        scores[run_idx] = reduce_logits(lg, 1, True)                       # poses outside a slice stay 0 = "invalid" (clip_scoring.py:205-209)
         scores = spatially_smooth_heatmap(scores, sample_res)
         return int(np.argmax(scores)), scores
 
@@ -271,17 +358,19 @@ def main():
     def recorded_traffic():
         """HBM-side bytes per k_march launch from the committed PMC passes (bench.py cannot run
         under --pmc itself); only reported when it was measured on this exact workload."""
-        try:
-            t = json.load(open(os.path.join(REPO, "profiles", "r01_march_traffic.json")))
-        except OSError:
-            return None, None
-        wl = t["workload"]
-        if (wl["scene"], wl["width"], wl["height"], wl["chunk"], wl["clip"]) != (args.scene, W, H, per_launch, args.clip):
-            return None, None
-        return t["traffic_bytes_per_launch"], "profiles/r01_march_traffic.json (FETCH_SIZE+WRITE_SIZE, uncorrected: narrow gathers)"
+        for name in ("r03_march_traffic.json", "r01_march_traffic.json"):
+            try:
+                t = json.load(open(os.path.join(REPO, "profiles", name)))
+            except OSError:
+                continue
+            wl = t["workload"]
+            if (wl["scene"], wl["width"], wl["height"], wl["chunk"], wl["clip"]) != (scene_name, W, H, per_launch, clip_name):
+                return None, None
+            return t["traffic_bytes_per_launch"], f"profiles/{name} ({t.get('how', 'FETCH_SIZE+WRITE_SIZE')})"
+        return None, None
 
     if rank == 0:
-        total = N * args.steps
+        total = N_run * args.steps
         traffic, traffic_src = recorded_traffic()
         value = total / elapsed
         samples_per_launch = stats["samples"] / launches_per_step
@@ -292,20 +381,34 @@ def main():
         # textbook count of the architecture
         cls_last = "cls_last=0" not in args.opt
         clip_tflops = vit_gflop(cfg, executed=cls_last) * 1e9 * n_img / (timing["clip_ms"] * 1e-3) / 1e12 if timing["clip_ms"] > 0 else None
+        # name the workload from what actually ran: the BASELINE.json config whose scene / grid / size / encoder it is
+        per_gpu_res = sample_res[:2] + [1] + sample_res[3:] if scaling == "weak" else sample_res
+        match = [k for k, c in BASELINE_CONFIGS.items()
+                 if (c["scene"], c["sample_res"], c["width"], c["height"], c["clip"], c["scaling"]) == (scene_name, per_gpu_res, W, H, clip_name, scaling)]
+        label = f"BASELINE.json configs[{match[0]}]: {BASELINE_CONFIGS[match[0]]['name']}" if match else "custom (not a BASELINE.json config)"
+        what = (f"{scene_name} scene, pose grid {sample_res} = {N} candidates (scene type {scene.scene_type}), {W}x{H}, bf16 MLP + {clip_name}, "
+                + (f"{scaling} scaling over {world} GPU(s)" if world > 1 else "one GPU"))
+        if N_run != N:
+            what += f"; SLICE: shards 0..{world - 1} of a {partition}-way partition = {N_run} of the {N} candidates per step (the rest of the grid scores 0)"
+        rccl = None
+        try:
+            rccl = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception:
+            pass
         out = {
-            "metric": "candidate renders scored/sec (640x360)", "value": round(value, 2), "unit": "candidates/s",
+            "metric": f"candidate renders scored/sec ({W}x{H})", "value": round(value, 2), "unit": "candidates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic", "ranks_seen": ranks_seen,
-            "config": {"workload": (f"BASELINE.json configs[1]: {args.scene} scene, {args.poses_per_gpu} candidate poses per GPU, "
-                                    f"{W}x{H}, bf16 MLP + {args.clip}") if args.scaling == "weak" else
-                                   (f"BASELINE.json configs[3]: {args.scene} scene, {N} candidates over {world} GPU(s), "
-                                    f"{W}x{H}, bf16 MLP + {args.clip}"),
-                       "poses_total": N, "sample_res": sample_res, "chunk": per_launch,
+            "config": {"workload": f"{label} — ran: {what}",
+                       "baseline_config": match[0] if match else None,
+                       "scene": scene_name, "clip": clip_name, "width": W, "height": H,
+                       "poses_total": N, "poses_per_step": N_run, "sample_res": sample_res, "chunk": per_launch,
                        "parallelism": f"pose-shard x{world}" if world > 1 else "single GPU",
                        "collective": ("none (single GPU)" if world == 1 else
                                       "d2r_allgather_scores: one ncclAllGather (RCCL) of fp32 logits per step" if c_abi_comm else
                                       f"torch.distributed all_gather ({torch.distributed.get_backend()}): ranks share a GPU, RCCL unavailable"),
+                       "rccl_version": rccl,
                        "text_embeds": "2 seeded unit vectors correlated with the scene's image embedding (random-weight "
                                       "towers give uncorrelated text: the goal/norm ratio needs positive logits); "
                                       "throughput does not depend on their values"},
@@ -331,17 +434,20 @@ def main():
         if world == 1:
             out["power"] = power_probe(step, dev.index or 0, args.power_seconds)
         if world == 1 and args.cpu_sample > 0:
-            cb, frames_o, lg_o, idx = cpu_baseline(scene, W, H, cfg, sd, text, pose_batch, args.cpu_sample)
+            cb, frames_o, lg_o, idx = cpu_baseline(scene, W, H, cfg, sd, text, pose_batch[my_idx], args.cpu_sample)
             out["cpu_baseline"] = cb
             # same candidates through the GPU path: parity of the benchmark itself
-            pos = np.empty(N, np.int64)
-            pos[my_idx] = np.arange(K_local)
-            lg_gpu = logits_dev[:K_local].cpu().numpy()[pos[idx]] if world == 1 else None
-            if lg_gpu is not None:
-                out["parity_vs_oracle"] = {"max_cosine_err": float(np.abs(lg_gpu - lg_o).max() / scorer.logit_scale),
-                                           "n": int(len(idx))}
+            lg_gpu = logits_dev[:K_local].cpu().numpy()[idx]
+            out["parity_vs_oracle"] = {"max_cosine_err": float(np.abs(lg_gpu - lg_o).max() / scorer.logit_scale),
+                                       "n": int(len(idx))}
+        elif world > 1:
+            out["cpu_baseline"] = {"value": None, "unit": "candidates/s", "cores": os.cpu_count(), "kind": "port",
+                                   "sample": "timed on rank 0 at n_gpus = 1 only: see the n_gpus = 1 line of the same --config"}
         else:
             out["cpu_baseline"] = None
+        if args.dump:
+            np.savez(args.dump, logits=step.logits, scores=scores, run_idx=run_idx, sample_res=np.asarray(sample_res), best=best,
+                     pose_batch=pose_batch)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()

@@ -191,6 +191,8 @@ int d2r_ctx_set_option(d2r_ctx *ctx, const char *key, int64_t value)
     } else if (!strcmp(key, "ln_fold")) {
         if (value < 0 || value > 3) return d2r_fail(ctx, D2R_ERR_INVALID, "ln_fold must be 0..3");
         ctx->ln_fold = value;
+    } else if (!strcmp(key, "attn_stream")) {
+        ctx->attn_stream = value != 0;
     } else if (!strcmp(key, "attn_q2")) {
         ctx->attn_q2 = value != 0;
     } else if (!strcmp(key, "gemm_nsplit")) {

@@ -1643,6 +1643,251 @@ __global__ __launch_bounds__(ATTN_THREADS / NQ, NQ == 2 ? 2 : 4) void k_attentio
 #endif
 }
 
+// ---- streamed attention (vision tower) ----
+//
+// One workgroup = up to eight 32-query tiles (one per wave) of one (image, head).  K and V are NOT held whole: they
+// stream through a ring of ATS_STAGES slots of 32 keys (K 4 KiB + V 4 KiB each), filled by LDS-DMA three key tiles
+// ahead of the arithmetic — every wave issues ONE 1-KiB request per key tile (waves 0-3 the K rows, 4-7 the V rows),
+// waits for its own request of the tile about to be used with a counted vmcnt, and one barrier per key tile both
+// publishes the tile and retires the slot read in the previous iteration.  40 KiB of LDS whatever the sequence length
+// (the resident kernel above needs 57 KiB at 197 tokens and 156 KiB at 577, i.e. one workgroup per CU there), the
+// first MFMA starts when the first 8 KiB have landed instead of after the whole head, and loads and arithmetic of one
+// workgroup overlap instead of alternating.
+//   K slot: rows of 128 B, 16-byte chunks XOR-swizzled with (row >> 1) & 7 (lds_off) for conflict-free ds_read_b128.
+//   V slot: ROW-major as it lies in HBM (no register transposes, no V^T image); the A operand of O^T = V^T P^T is read
+//           with ds_read_b64_tr_b16 (a 16-lane group reads a [4 keys][16 dims] block, lane i receives dim i of the four
+//           keys).  Chunk c of key row r sits at chunk c ^ (((r >> 1) & 1) << 2), so the four rows a group reads cover
+//           all 64 banks once.
+// Softmax: exp2 domain, running maximum with a deferred rescale — the accumulators are rescaled only when some
+// query's tile maximum exceeds its running maximum by more than ATS_DEFER (p <= 2^ATS_DEFER in between; bf16 keeps
+// fp32's exponent, so the relative rounding of P is unchanged).  The last key tile of a CLIP sequence holds T mod 32
+// = 5 (197 tokens) or 1 (257, 577) valid keys: when that is <= 8 only accumulator registers 0..3 (keys 0..7 of the
+// tile) go through the softmax and only the first of the two PV k-steps runs.
+#define ATS_THREADS 512
+#define ATS_STAGES 5
+#define ATS_SLOT 8192u
+#define ATS_DEFER 8.0f
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 lds_read_tr16(uint32_t byte_addr)
+{
+    union { s16x4 s; uint2 u; } c;
+    c.s = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(size_t)byte_addr);
+    return c.u;
+}
+
+// softmax + PV of one key tile.  NR = 16: all of the tile's keys; NR = 4: the tile's first 8 keys only (registers 0..3).
+template <int NR>
+__device__ __forceinline__ void ats_softmax_pv(f32x16 &sacc, f32x16 &o0, f32x16 &o1, float &m_run, float &l_run, uint32_t vaddr0,
+                                               uint32_t vaddr1)
+{
+    const float sm_c = 0.125f * 1.4426950408889634f;   // head_dim^-0.5 * log2(e), head_dim = 64
+    float tmax = sacc[0];
+#pragma unroll
+    for (int r = 1; r < NR; r++) tmax = fmaxf(tmax, sacc[r]);
+    tmax = half_max(tmax) * sm_c;
+    if (__builtin_amdgcn_ballot_w64(tmax > m_run + ATS_DEFER) != 0) {       // first tile: m_run = -inf
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);          // -inf - finite -> 0; equal -> 1
+        l_run *= alpha;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            o0[r] *= alpha;
+            o1[r] *= alpha;
+        }
+        m_run = m_new;
+    }
+    if constexpr (NR == 16) {
+        typedef float f32x8 __attribute__((ext_vector_type(8)));
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x16 cv = sm_c, mv = -m_run;
+        const f32x16 t = __builtin_elementwise_fma(sacc, cv, mv);
+#pragma unroll
+        for (int r = 0; r < 16; r++) sacc[r] = __builtin_amdgcn_exp2f(t[r]);
+        const f32x8 s8 = sacc.lo + sacc.hi;
+        const f32x4 s4 = s8.lo + s8.hi;
+        const f32x2 s2 = s4.lo + s4.hi;
+        l_run += s2.x + s2.y;
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; r++) sacc[r] = __builtin_amdgcn_exp2f(fmaf(sacc[r], sm_c, -m_run));
+        l_run += (sacc[0] + sacc[1]) + (sacc[2] + sacc[3]);
+    }
+    // O^T[d][q] += V^T[d][key] P^T[key][q]; P regs 8s..8s+7 are the B fragment of k-step s;
+    // A slot (hi, j) <-> key 16s + 8(j>>2) + 4hi + (j&3): two transposing reads of 4 keys each per O tile
+#pragma unroll
+    for (int s = 0; s < (NR == 16 ? 2 : 1); s++) {
+        union { uint4 u; bf16x8 v; } pb, va0, va1;
+        pb.u.x = pack2(sacc[8 * s + 0], sacc[8 * s + 1]);
+        pb.u.y = pack2(sacc[8 * s + 2], sacc[8 * s + 3]);
+        if constexpr (NR == 16) {
+            pb.u.z = pack2(sacc[8 * s + 4], sacc[8 * s + 5]);
+            pb.u.w = pack2(sacc[8 * s + 6], sacc[8 * s + 7]);
+        } else {
+            pb.u.z = pb.u.w = 0u;                       // keys 8.. of the tile: P = 0
+        }
+        const uint2 a00 = lds_read_tr16(vaddr0 + 2048u * s), a01 = lds_read_tr16(vaddr0 + 2048u * s + 1024u);
+        const uint2 a10 = lds_read_tr16(vaddr1 + 2048u * s), a11 = lds_read_tr16(vaddr1 + 2048u * s + 1024u);
+        va0.u = make_uint4(a00.x, a00.y, a01.x, a01.y);
+        va1.u = make_uint4(a10.x, a10.y, a11.x, a11.y);
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va0.v, pb.v, o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va1.v, pb.v, o1, 0, 0, 0);
+    }
+}
+
+// grid (heads, images, ceil(n_qt / 8)); block 512; dynamic LDS ATS_STAGES * ATS_SLOT
+__global__ __launch_bounds__(ATS_THREADS, 4) void k_attention_s(const uint16_t *__restrict__ QKV, uint16_t *__restrict__ AO, uint32_t T,
+                                                               uint32_t d, uint32_t M_pad)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const uint32_t head = blockIdx.x, img = blockIdx.y;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 31, hi = lane >> 5;
+    const size_t row_base = (size_t)img * T;
+    const uint32_t H = d >> 6;
+    const uint32_t n_kt = (T + 31) / 32;
+    const uint32_t qt = blockIdx.z * 8 + wave;
+    const bool active = qt < n_kt;                        // query tiles = key tiles = ceil(T / 32)
+    const uint32_t qrow = qt * 32 + li;
+    const uint16_t *Qg = QKV + ((size_t)head * M_pad + row_base) * 64;
+    // this wave's slice of every key tile: waves 0-3 eight K rows each, waves 4-7 eight V rows each; a lane fetches the
+    // 16-byte chunk whose swizzled position in the slot is (its row, lane & 7)
+    const uint32_t r_loc = (wave & 3) * 8 + (lane >> 3);
+    const bool is_v = wave >= 4;
+    const uint32_t src_chunk = (lane & 7) ^ (is_v ? ((r_loc >> 1) & 1u) << 2 : (r_loc >> 1) & 7u);
+    const uint16_t *src_plane = QKV + ((size_t)((is_v ? 2 * H : H) + head) * M_pad + row_base) * 64 + src_chunk * 8;
+    const uint32_t smem0 = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+    const uint32_t dst_off = (is_v ? 4096u : 0u) + (wave & 3) * 1024u;
+    auto request = [&](uint32_t kt) {                    // key tile kt -> slot kt % ATS_STAGES (rows >= T repeat row T-1: masked / P = 0)
+        const uint32_t row = kt * 32 + r_loc;
+        glds16(src_plane + (size_t)(row < T ? row : T - 1) * 64, smem0 + (kt % ATS_STAGES) * ATS_SLOT + dst_off);
+    };
+    // Q fragments (B operand of S^T = K Q^T: lane (q, hi) holds Q[q][16s + 8hi .. +8)) first: oldest in the vmcnt order.
+    // Loaded from inline asm and awaited by hand: a load hipcc can see makes it put `s_waitcnt vmcnt(0)` in front of the
+    // first use INSIDE the tile loop, which would drain the request ring every iteration.  Query rows >= T read row
+    // T-1 (finite; they are never stored).
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 qv[4] = {0u, 0u, 0u, 0u};
+    if (active) {
+        const uint16_t *qp = Qg + (size_t)(qrow < T ? qrow : T - 1) * 64 + 8 * hi;
+        asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:32\n\t"
+                     "global_load_dwordx4 %2, %4, off offset:64\n\tglobal_load_dwordx4 %3, %4, off offset:96"
+                     : "=&v"(qv[0]), "=&v"(qv[1]), "=&v"(qv[2]), "=&v"(qv[3]) : "v"(qp) : "memory");
+    }
+    const uint32_t n_req = min((uint32_t)ATS_STAGES - 1, n_kt);
+#pragma unroll
+    for (uint32_t c = 0; c < ATS_STAGES - 1; c++)
+        if (c < n_kt) request(c);
+    // the Q loads are older than every request: done when only the requests remain outstanding; then tile 0 (the oldest
+    // request), published by the first barrier
+    static_assert(ATS_STAGES == 5, "the waits below are written for a five-slot ring");
+#define ATS_WAIT_Q(N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(qv[0]), "+v"(qv[1]), "+v"(qv[2]), "+v"(qv[3]) : : "memory")
+    if (n_req == 4) { ATS_WAIT_Q(4); wait_vmcnt<3>(); }
+    else if (n_req == 3) { ATS_WAIT_Q(3); wait_vmcnt<2>(); }
+    else if (n_req == 2) { ATS_WAIT_Q(2); wait_vmcnt<1>(); }
+    else { ATS_WAIT_Q(1); wait_vmcnt<0>(); }
+#undef ATS_WAIT_Q
+    __syncthreads();
+    uint4 qf[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) qf[s] = make_uint4(qv[s][0], qv[s][1], qv[s][2], qv[s][3]);
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; r++) o0[r] = o1[r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    // per-lane LDS offsets inside a slot.  K: row li, chunks 2s + hi.  V (transposing read): a 16-lane group g = li >> 4
+    // with lane-in-group i reads key row 4hi + (i >> 2) (+ 16s + 8j per read), dims 32t + 16g + 4(i & 3)
+    uint32_t koff[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) koff[s] = lds_off(li, 2 * s + hi);
+    const uint32_t vi = li & 15, vg = li >> 4, vrow = 4 * hi + (vi >> 2), vsw = (vrow >> 1) & 1u;
+    const uint32_t vlc = 2 * vg + ((vi & 3) >> 1);                               // logical 16-byte chunk of O tile 0 (tile 1: + 4)
+    const uint32_t voff0 = 4096u + vrow * 128u + ((vlc ^ (vsw << 2)) << 4) + (vi & 1) * 8u;
+    const uint32_t voff1 = 4096u + vrow * 128u + (((vlc + 4) ^ (vsw << 2)) << 4) + (vi & 1) * 8u;
+    const uint32_t n_last = T - (n_kt - 1) * 32;                                 // valid keys of the last tile (1..32)
+
+    // K fragments of the tile about to be used: read one tile ahead, under the previous tile's softmax
+    uint4 ka[4];
+    auto read_k = [&](uint32_t kt) {
+        const uint32_t slot = smem0 + (kt % ATS_STAGES) * ATS_SLOT;
+#pragma unroll
+        for (int s = 0; s < 4; s++) ka[s] = *(const uint4 *)(__attribute__((address_space(3))) const uint8_t *)(size_t)(slot + koff[s]);
+    };
+    if (active) read_k(0);
+    // One key tile.  S^T = K Q^T from the fragments read an iteration ago; then (unless LAST) the hand-over to the next
+    // tile: wait for this wave's request of tile kt+1 (WAIT younger requests may stay in flight), barrier — tile kt+1 is
+    // complete and every wave has finished tile kt-1, whose slot takes the request for tile kt + ATS_STAGES - 1 (REQ) —
+    // and the K fragments of tile kt+1 are read while this tile's softmax and PV run.
+    auto tile = [&](uint32_t kt, auto wait_tag, auto req_tag, auto last_tag) {
+        constexpr int WAIT = decltype(wait_tag)::value;
+        constexpr bool LAST = decltype(last_tag)::value, REQ = decltype(req_tag)::value;
+        f32x16 sacc;
+        if (active) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) sacc[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                union { uint4 u; bf16x8 v; } a, b;
+                a.u = ka[s];
+                b.u = qf[s];
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, sacc, 0, 0, 0);
+            }
+        }
+        if constexpr (!LAST) {
+            wait_vmcnt<WAIT>();
+            __syncthreads();
+            if constexpr (REQ) request(kt + ATS_STAGES - 1);
+            if (active) read_k(kt + 1);
+        }
+        if (!active) return;
+        const uint32_t slot = smem0 + (kt % ATS_STAGES) * ATS_SLOT;
+        // lane (q, hi), reg r  <->  key kt*32 + (r&3) + 8*(r>>2) + 4*hi
+        if (LAST && n_last <= 8) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) sacc[r] = (uint32_t)r + 4 * hi < n_last ? sacc[r] : -INFINITY;
+            ats_softmax_pv<4>(sacc, o0, o1, m_run, l_run, slot + voff0, slot + voff1);
+        } else {
+            if (LAST && n_last < 32) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) sacc[r] = (uint32_t)((r & 3) + 8 * (r >> 2)) + 4 * hi < n_last ? sacc[r] : -INFINITY;
+            }
+            ats_softmax_pv<16>(sacc, o0, o1, m_run, l_run, slot + voff0, slot + voff1);
+        }
+    };
+    using std::integral_constant;
+    const integral_constant<bool, false> no{};
+    const integral_constant<bool, true> yes{};
+    uint32_t kt = 0;
+    for (; kt + ATS_STAGES - 1 < n_kt; kt++) tile(kt, integral_constant<int, ATS_STAGES - 3>{}, yes, no);
+    // the last ATS_STAGES - 1 tiles request nothing; r tiles left -> r - 2 requests younger than tile kt+1's
+    if (n_kt - kt == 4) { tile(kt, integral_constant<int, 2>{}, no, no); kt++; }
+    if (n_kt - kt == 3) { tile(kt, integral_constant<int, 1>{}, no, no); kt++; }
+    if (n_kt - kt == 2) { tile(kt, integral_constant<int, 0>{}, no, no); kt++; }
+    tile(kt, integral_constant<int, 0>{}, no, yes);
+    if (!active) return;
+    const float inv_l = 1.0f / half_sum(l_run);
+    // lane (q, hi), reg r of o{0,1} <-> dim 32*{0,1} + (r&3) + 8*(r>>2) + 4*hi: after bf16 packing a lane owns 4 dims of
+    // every 8-dim group; v_permlane32_swap pairs the groups (2g, 2g+1) so that lanes 0-31 hold dims 16g .. 16g+7 and
+    // lanes 32-63 dims 16g+8 .. 16g+15 of their query: 16-byte stores, 4 per O tile instead of 8 of 8 bytes.
+    // (the lane id is taken afresh so that the output address is not kept in registers across the tile loop)
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const uint32_t lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const uint32_t qrow_e = qt * 32 + (lane_e & 31);
+    uint16_t *dst = AO + ((size_t)head * M_pad + row_base + qrow_e) * 64 + 8 * (lane_e >> 5);   // tile-major: head h is plane h of [d/64][M_pad][64]
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const f32x16 &o = t ? o1 : o0;
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+            uint32_t a0 = pack2(o[8 * g + 0] * inv_l, o[8 * g + 1] * inv_l), a1 = pack2(o[8 * g + 2] * inv_l, o[8 * g + 3] * inv_l);
+            uint32_t b0 = pack2(o[8 * g + 4] * inv_l, o[8 * g + 5] * inv_l), b1 = pack2(o[8 * g + 6] * inv_l, o[8 * g + 7] * inv_l);
+            const u32x2 x = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+            const u32x2 y = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+            if (qrow_e < T) *(uint4 *)(dst + 32 * t + 16 * g) = make_uint4(x[0], y[0], x[1], y[1]);
+        }
+    }
+}
+
 // ---- persistent, double-buffered attention (vision tower) ----
 //
 // k_attention above gives each (image, head) its own workgroup: load Q/K/V, barrier, compute.  Every workgroup
@@ -2201,6 +2446,11 @@ static int launch_attention_vision(d2r_ctx *ctx, const uint16_t *QKV, uint16_t *
 {
     const size_t two = 2 * attn_lds;
     const uint32_t n_items = n * n_heads;
+    if (ctx->attn_stream) {
+        const uint32_t n_qt = (T + 31) / 32;
+        hipLaunchKernelGGL(k_attention_s, dim3(n_heads, n, (n_qt + 7) / 8), dim3(ATS_THREADS), ATS_STAGES * ATS_SLOT, ctx->stream, QKV, AO, T, d, M_pad);
+        return D2R_OK;
+    }
     if (ctx->attn_persistent && two <= 160 * 1024 && (T_pad / 4) * 8 <= ATTN_MAX_VTASKS * ATTN_THREADS && n_items >= (uint32_t)ctx->n_cu) {
         static PerDeviceOnce attr;
         attr.run(ctx->device, [] {

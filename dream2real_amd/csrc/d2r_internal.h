@@ -118,6 +118,7 @@ struct d2r_ctx {
     int64_t refill_min = 64;   // measured on MI355X: a refill (queue + camera loads, ray setup, SH) costs several iterations,
                                // so a wave runs its 64 rays to the end (lane utilisation 0.79) rather than topping up at 16 free lanes (0.90)
     int64_t ln_fold = 1;       // vision tower: 0 LayerNorm kernels + fp32 residual; LayerNorm folded into the GEMMs with 1 a split (hi + lo) bf16 residual, 2 a bf16 residual, 3 an fp32 residual + bf16 copy
+    int64_t attn_stream = 1;       // vision tower: streamed attention (k_attention_s: K / V through a ring of 32-key slots) instead of the resident-K/V kernel
     int64_t attn_stagger = 1;      // one-workgroup-per-item attention: delay the second workgroup per CU of the first generation
     int64_t attn_persistent = 0;   // vision tower: persistent double-buffered attention when two K / V^T buffers fit in LDS
     int64_t gemm_stagger = 0;      // persistent GEMM: stagger the workgroups' first tile over a tile period (epilogues spread in time)

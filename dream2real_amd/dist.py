@@ -94,7 +94,7 @@ def init_comm(ctx, rank: int, world: int) -> bool:
     # on one physical GPU; whether that is the case is decided from what the ranks actually hold — (host, device
     # identity) pairs gathered over the process group — not from device_count(), which is 1 on every rank when a
     # launcher gives each rank its own HIP_VISIBLE_DEVICES and says nothing about other nodes
-    mine = (socket.gethostname(), _device_identity(ctx.device))
+    mine = (socket.gethostname(), _device_identity(ctx.device) if ctx is not None and torch.cuda.is_available() else "no-gpu")
     held = [None] * world
     dist.all_gather_object(held, mine)
     shared = len(set(held)) < world
@@ -137,20 +137,24 @@ class ShardGather:
         sizes = [shard_range(n_total, r, world) for r in range(world)]
         self._rows = np.concatenate([r * self.n_max + np.arange(b - a) for r, (a, b) in enumerate(sizes)]) if world > 1 else None
 
+    def _sync(self):
+        if self.ctx is not None:          # CPU tests drive the torch fallback without a context
+            self.ctx.synchronize()
+
     def gather(self) -> np.ndarray:
         """Blocking.  The producer of `local` (d2r_render_score) and the all-gather run on the CONTEXT's stream, the
         device -> host copies below on torch's current stream: the context is synchronised first, so the result
         does not depend on the caller having made the two streams the same one."""
         import torch.distributed as dist
         if self.world == 1:
-            self.ctx.synchronize()
+            self._sync()
             return self.local[: self.n_total].cpu().numpy()
         if self.use_c_abi:
             self.ctx.allgather_scores(self.local.data_ptr(), self.n_max * self.C, self.full.data_ptr())
-            self.ctx.synchronize()
+            self._sync()
             out = self.full.cpu().numpy()
         else:
-            self.ctx.synchronize()
+            self._sync()
             loc = self.local.cpu() if dist.get_backend() == "gloo" else self.local
             full = self.full.cpu() if dist.get_backend() == "gloo" else self.full
             dist.all_gather_into_tensor(full.view(-1, self.C), loc)
