@@ -58,7 +58,7 @@ class TextDesc(C.Structure):
 class PhysParams(C.Structure):
     _fields_ = [("sample_res", C.c_uint32 * 6), ("init_pose", C.c_float * 16), ("table_z", C.c_float),
                 ("unsup_thresh", C.c_float), ("gravity", C.c_float * 3), ("perturb", C.c_float),
-                ("stability_check", C.c_int32), ("disallow_regrasp", C.c_int32)]
+                ("stability_check", C.c_int32), ("disallow_regrasp", C.c_int32), ("margin", C.c_float)]
 
 
 class IngpView(C.Structure):

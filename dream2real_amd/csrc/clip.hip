@@ -1681,6 +1681,10 @@ __device__ __forceinline__ void ats_softmax_pv(f32x16 &sacc, f32x16 &o0, f32x16 
                                                uint32_t vaddr1)
 {
     const float sm_c = 0.125f * 1.4426950408889634f;   // head_dim^-0.5 * log2(e), head_dim = 64
+#if D2R_ATTN_ABLATE & 32
+    l_run += sacc[0];
+    o0[0] += sacc[1];
+#else
     float tmax = sacc[0];
 #pragma unroll
     for (int r = 1; r < NR; r++) tmax = fmaxf(tmax, sacc[r]);
@@ -1713,10 +1717,11 @@ __device__ __forceinline__ void ats_softmax_pv(f32x16 &sacc, f32x16 &o0, f32x16 
         for (int r = 0; r < 4; r++) sacc[r] = __builtin_amdgcn_exp2f(fmaf(sacc[r], sm_c, -m_run));
         l_run += (sacc[0] + sacc[1]) + (sacc[2] + sacc[3]);
     }
+#endif
     // O^T[d][q] += V^T[d][key] P^T[key][q]; P regs 8s..8s+7 are the B fragment of k-step s;
     // A slot (hi, j) <-> key 16s + 8(j>>2) + 4hi + (j&3): two transposing reads of 4 keys each per O tile
 #pragma unroll
-    for (int s = 0; s < (NR == 16 ? 2 : 1); s++) {
+    for (int s = 0; s < ((D2R_ATTN_ABLATE & 64) ? 0 : NR == 16 ? 2 : 1); s++) {
         union { uint4 u; bf16x8 v; } pb, va0, va1;
         pb.u.x = pack2(sacc[8 * s + 0], sacc[8 * s + 1]);
         pb.u.y = pack2(sacc[8 * s + 2], sacc[8 * s + 3]);
@@ -1758,6 +1763,7 @@ __global__ __launch_bounds__(ATS_THREADS, 4) void k_attention_s(const uint16_t *
     const uint32_t smem0 = __builtin_amdgcn_readfirstlane(lds_addr(smem));
     const uint32_t dst_off = (is_v ? 4096u : 0u) + (wave & 3) * 1024u;
     auto request = [&](uint32_t kt) {                    // key tile kt -> slot kt % ATS_STAGES (rows >= T repeat row T-1: masked / P = 0)
+        if (D2R_ATTN_ABLATE & 16) return;
         const uint32_t row = kt * 32 + r_loc;
         glds16(src_plane + (size_t)(row < T ? row : T - 1) * 64, smem0 + (kt % ATS_STAGES) * ATS_SLOT + dst_off);
     };
@@ -1766,26 +1772,25 @@ __global__ __launch_bounds__(ATS_THREADS, 4) void k_attention_s(const uint16_t *
     // first use INSIDE the tile loop, which would drain the request ring every iteration.  Query rows >= T read row
     // T-1 (finite; they are never stored).
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 qv[4] = {0u, 0u, 0u, 0u};
-    if (active) {
-        const uint16_t *qp = Qg + (size_t)(qrow < T ? qrow : T - 1) * 64 + 8 * hi;
+    u32x4 qv[4];
+    {
+        // every wave loads (waves without a query tile read row T-1 too) and nothing branches between the loads and
+        // their wait: a conditional here makes hipcc merge the destination registers with copies placed BEFORE the wait
+        const uint32_t qr = active && qrow < T ? qrow : T - 1;
+        const uint16_t *qp = Qg + (size_t)qr * 64 + 8 * hi;
         asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:32\n\t"
                      "global_load_dwordx4 %2, %4, off offset:64\n\tglobal_load_dwordx4 %3, %4, off offset:96"
                      : "=&v"(qv[0]), "=&v"(qv[1]), "=&v"(qv[2]), "=&v"(qv[3]) : "v"(qp) : "memory");
     }
-    const uint32_t n_req = min((uint32_t)ATS_STAGES - 1, n_kt);
-#pragma unroll
-    for (uint32_t c = 0; c < ATS_STAGES - 1; c++)
-        if (c < n_kt) request(c);
-    // the Q loads are older than every request: done when only the requests remain outstanding; then tile 0 (the oldest
-    // request), published by the first barrier
+    // ATS_STAGES - 1 requests whatever the sequence length (tiles >= n_kt re-read row T-1 into slots nobody reads), so
+    // that the waits below are the same straight-line code for every launch
     static_assert(ATS_STAGES == 5, "the waits below are written for a five-slot ring");
-#define ATS_WAIT_Q(N) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(qv[0]), "+v"(qv[1]), "+v"(qv[2]), "+v"(qv[3]) : : "memory")
-    if (n_req == 4) { ATS_WAIT_Q(4); wait_vmcnt<3>(); }
-    else if (n_req == 3) { ATS_WAIT_Q(3); wait_vmcnt<2>(); }
-    else if (n_req == 2) { ATS_WAIT_Q(2); wait_vmcnt<1>(); }
-    else { ATS_WAIT_Q(1); wait_vmcnt<0>(); }
-#undef ATS_WAIT_Q
+#pragma unroll
+    for (uint32_t c = 0; c < ATS_STAGES - 1; c++) request(c);
+    // the Q loads are older than the four requests: done when only those remain outstanding; then tile 0 (the oldest
+    // request), published by the first barrier
+    asm volatile("s_waitcnt vmcnt(4)" : "+v"(qv[0]), "+v"(qv[1]), "+v"(qv[2]), "+v"(qv[3]) : : "memory");
+    wait_vmcnt<3>();
     __syncthreads();
     uint4 qf[4];
 #pragma unroll
@@ -1824,9 +1829,9 @@ __global__ __launch_bounds__(ATS_THREADS, 4) void k_attention_s(const uint16_t *
         f32x16 sacc;
         if (active) {
 #pragma unroll
-            for (int r = 0; r < 16; r++) sacc[r] = 0.f;
+            for (int r = 0; r < 16; r++) sacc[r] = (D2R_ATTN_ABLATE & 128) ? __uint_as_float(ka[r & 3].x) : 0.f;
 #pragma unroll
-            for (int s = 0; s < 4; s++) {
+            for (int s = 0; s < ((D2R_ATTN_ABLATE & 128) ? 0 : 4); s++) {
                 union { uint4 u; bf16x8 v; } a, b;
                 a.u = ka[s];
                 b.u = qf[s];
@@ -1835,7 +1840,7 @@ __global__ __launch_bounds__(ATS_THREADS, 4) void k_attention_s(const uint16_t *
         }
         if constexpr (!LAST) {
             wait_vmcnt<WAIT>();
-            __syncthreads();
+            if (!(D2R_ATTN_ABLATE & 256)) __syncthreads();
             if constexpr (REQ) request(kt + ATS_STAGES - 1);
             if (active) read_k(kt + 1);
         }
@@ -1864,6 +1869,7 @@ __global__ __launch_bounds__(ATS_THREADS, 4) void k_attention_s(const uint16_t *
     if (n_kt - kt == 3) { tile(kt, integral_constant<int, 1>{}, no, no); kt++; }
     if (n_kt - kt == 2) { tile(kt, integral_constant<int, 0>{}, no, no); kt++; }
     tile(kt, integral_constant<int, 0>{}, no, yes);
+    wait_vmcnt<0>();          // sequences shorter than the prologue's four tiles leave filler requests in flight: nothing may land after the exit
     if (!active) return;
     const float inv_l = 1.0f / half_sum(l_run);
     // lane (q, hi), reg r of o{0,1} <-> dim 32*{0,1} + (r&3) + 8*(r>>2) + 4*hi: after bf16 packing a lane owns 4 dims of

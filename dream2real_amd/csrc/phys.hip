@@ -16,13 +16,15 @@
 #include <string.h>
 
 #include <algorithm>
+#include <new>
 
 #include "d2r_internal.h"
 
 struct d2r_phys {
     d2r_ctx *ctx;
-    float *d_mov = nullptr;        // [n_mov][3] movable hull vertices, world frame at the object's initial pose
-    uint32_t n_mov = 0;
+    float *d_mov = nullptr;        // movable object's hull vertices (one or several convex parts, concatenated), world frame at the object's initial pose
+    uint32_t *d_moff = nullptr;    // [n_mov + 1] first vertex of each movable hull
+    uint32_t n_mov = 0, n_mov_verts = 0;
     float *d_stat = nullptr;       // static hull vertices, concatenated
     uint32_t *d_off = nullptr;     // [n_stat + 1] first vertex of each static hull
     uint32_t n_stat = 0, n_stat_verts = 0;
@@ -34,6 +36,7 @@ struct PhysKernelParams {
     float gravity[3];
     int stability_check;
     uint32_t oris_per_pos;
+    float margin2;                 // sum of the two shapes' collision margins: hulls closer than this "touch"
 };
 
 struct V3 { float x, y, z; };
@@ -61,9 +64,12 @@ __device__ __forceinline__ V3 hull_support(const float *__restrict__ verts, uint
     return {verts[3 * bi], verts[3 * bi + 1], verts[3 * bi + 2]};
 }
 
-// Do hull A (vertices a, moved by x -> R x + t) and hull B intersect?  GJK on the Minkowski difference.
+// Do hull A (vertices a, moved by x -> R x + t) and hull B come within `margin2` of each other (margin2 = 0: do they
+// intersect)?  Boolean GJK on the Minkowski difference A - B, inflated by a sphere of radius margin2 through its support
+// function (Bullet gives every convex shape a collision margin; two shapes are in contact when their cores are closer
+// than the sum of the margins).
 __device__ bool gjk_intersect(const float *__restrict__ a, uint32_t na, const float R[9], V3 t,
-                              const float *__restrict__ b, uint32_t nb, uint32_t lane)
+                              const float *__restrict__ b, uint32_t nb, uint32_t lane, float margin2)
 {
     auto support = [&](V3 d) -> V3 {
         // arg max over A of (R v + t) . d = arg max of v . (R^T d)
@@ -74,7 +80,12 @@ __device__ bool gjk_intersect(const float *__restrict__ a, uint32_t na, const fl
                        fmaf(R[3], va.x, fmaf(R[4], va.y, fmaf(R[5], va.z, t.y))),
                        fmaf(R[6], va.x, fmaf(R[7], va.y, fmaf(R[8], va.z, t.z)))};
         const V3 vb = hull_support(b, nb, neg(d), lane);
-        return wa - vb;
+        V3 p = wa - vb;
+        if (margin2 > 0.f) {
+            const float k = margin2 * rsqrtf(dot(d, d));
+            p = {fmaf(k, d.x, p.x), fmaf(k, d.y, p.y), fmaf(k, d.z, p.z)};
+        }
+        return p;
     };
     V3 s[4];
     int n = 1;
@@ -82,9 +93,19 @@ __device__ bool gjk_intersect(const float *__restrict__ a, uint32_t na, const fl
     s[0] = support(d);
     d = neg(s[0]);
     for (int it = 0; it < 64; it++) {
-        if (dot(d, d) < 1e-20f) return true;                 // the origin lies on the simplex
+        const float dd = dot(d, d);
+        if (dd < 1e-20f) return true;                         // the origin lies on the simplex
         const V3 p = support(d);
-        if (dot(p, d) < 0.f) return false;                    // a separating direction
+        const float pd = dot(p, d);
+        if (pd < 0.f) return false;                           // a separating direction
+        // Progress test: d points from the simplex's closest feature towards the origin.  Were the origin strictly
+        // inside, the support point along d would lie beyond the origin, hence strictly beyond every simplex point;
+        // a support point that is no further along d than the simplex already reaches (to 1e-7 m) means the simplex
+        // holds the closest feature and the origin is outside, or on the boundary to within rounding: no contact.
+        // Without this test near-touching pairs cycle until the iteration cap.
+        float reach = dot(s[0], d);
+        for (int i = 1; i < n; i++) reach = fmaxf(reach, dot(s[i], d));
+        if (pd - reach <= 1e-7f * sqrtf(dd)) return false;
         s[n++] = p;
         const V3 A = s[n - 1], AO = neg(A);
         if (n == 4) {
@@ -136,13 +157,15 @@ __device__ bool gjk_intersect(const float *__restrict__ a, uint32_t na, const fl
             }
         }
     }
-    return true;            // no separating direction found within the iteration cap: report contact
+    // the cap is only reached by an inflated (curved) difference whose boundary passes within rounding of the origin:
+    // a touch at exactly the margin distance, reported like the stalled case above
+    return false;
 }
 
 // block = 256 threads = 4 waves, one pose per wave
 __global__ __launch_bounds__(256) void k_phys_check(PhysKernelParams P, const float *__restrict__ poses, uint32_t n_poses,
                                                     const uint8_t *__restrict__ ori_mask,
-                                                    const float *__restrict__ mov, uint32_t n_mov,
+                                                    const float *__restrict__ mov, const uint32_t *__restrict__ moff, uint32_t n_mov,
                                                     const float *__restrict__ stat, const uint32_t *__restrict__ off,
                                                     uint32_t n_stat, uint8_t *__restrict__ valid)
 {
@@ -166,9 +189,13 @@ __global__ __launch_bounds__(256) void k_phys_check(PhysKernelParams P, const fl
                                      fmaf(M[i * 4 + 2], P.inv_init[2 * 4 + j], M[i * 4 + 3] * P.inv_init[3 * 4 + j])));
     const float R[9] = {T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10]};
     const V3 pos = {T[3], T[7], T[11]};
+    // PyBullet's pairwise test between two bodies is true when ANY pair of their convex parts is in contact
     auto touches_any = [&](V3 t) -> bool {
-        for (uint32_t h = 0; h < n_stat; h++)
-            if (gjk_intersect(mov, n_mov, R, t, stat + 3 * (size_t)off[h], off[h + 1] - off[h], lane)) return true;
+        for (uint32_t m = 0; m < n_mov; m++)
+            for (uint32_t h = 0; h < n_stat; h++)
+                if (gjk_intersect(mov + 3 * (size_t)moff[m], moff[m + 1] - moff[m], R, t, stat + 3 * (size_t)off[h], off[h + 1] - off[h],
+                                  lane, P.margin2))
+                    return true;
         return false;
     };
     bool ok = !touches_any(pos);                              // in collision -> invalid
@@ -189,24 +216,31 @@ __global__ __launch_bounds__(256) void k_phys_check(PhysKernelParams P, const fl
 
 extern "C" {
 
-int d2r_phys_create(d2r_ctx *ctx, const float *movable_verts, uint32_t n_movable, const float *static_verts,
-                    const uint32_t *static_offsets, uint32_t n_static, d2r_phys **out)
+int d2r_phys_create(d2r_ctx *ctx, const float *movable_verts, const uint32_t *movable_offsets, uint32_t n_movable,
+                    const float *static_verts, const uint32_t *static_offsets, uint32_t n_static, d2r_phys **out)
 {
-    if (!ctx || !movable_verts || !out || n_movable == 0 || (n_static && (!static_verts || !static_offsets)))
+    if (!ctx || !movable_verts || !movable_offsets || !out || n_movable == 0 || (n_static && (!static_verts || !static_offsets)))
         return d2r_fail(ctx, D2R_ERR_INVALID, "null argument");
+    if (movable_offsets[0] != 0 || (n_static && static_offsets[0] != 0)) return d2r_fail(ctx, D2R_ERR_INVALID, "hull offsets must start at 0");
+    for (uint32_t h = 0; h < n_movable; h++)
+        if (movable_offsets[h + 1] <= movable_offsets[h]) return d2r_fail(ctx, D2R_ERR_INVALID, "movable hull offsets must increase");
     for (uint32_t h = 0; h < n_static; h++)
         if (static_offsets[h + 1] <= static_offsets[h]) return d2r_fail(ctx, D2R_ERR_INVALID, "static hull offsets must increase");
     (void)hipSetDevice(ctx->device);
-    d2r_phys *p = new d2r_phys();
+    d2r_phys *p = new (std::nothrow) d2r_phys();
+    if (!p) return d2r_fail(ctx, D2R_ERR_MEMORY, "out of host memory");
     p->ctx = ctx;
     p->n_mov = n_movable;
+    p->n_mov_verts = movable_offsets[n_movable];
     p->n_stat = n_static;
     p->n_stat_verts = n_static ? static_offsets[n_static] : 0;
     const uint32_t zero = 0;
-    bool ok = hipMalloc(&p->d_mov, (size_t)n_movable * 12) == hipSuccess &&
+    bool ok = hipMalloc(&p->d_mov, (size_t)p->n_mov_verts * 12) == hipSuccess &&
+              hipMalloc(&p->d_moff, ((size_t)n_movable + 1) * 4) == hipSuccess &&
               hipMalloc(&p->d_stat, std::max<size_t>(1, (size_t)p->n_stat_verts * 12)) == hipSuccess &&
               hipMalloc(&p->d_off, ((size_t)n_static + 1) * 4) == hipSuccess;
-    ok = ok && hipMemcpy(p->d_mov, movable_verts, (size_t)n_movable * 12, hipMemcpyHostToDevice) == hipSuccess &&
+    ok = ok && hipMemcpy(p->d_mov, movable_verts, (size_t)p->n_mov_verts * 12, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(p->d_moff, movable_offsets, ((size_t)n_movable + 1) * 4, hipMemcpyHostToDevice) == hipSuccess &&
          (p->n_stat_verts == 0 || hipMemcpy(p->d_stat, static_verts, (size_t)p->n_stat_verts * 12, hipMemcpyHostToDevice) == hipSuccess) &&
          hipMemcpy(p->d_off, n_static ? static_offsets : &zero, ((size_t)n_static + 1) * 4, hipMemcpyHostToDevice) == hipSuccess;
     if (!ok) {
@@ -221,6 +255,7 @@ void d2r_phys_destroy(d2r_phys *p)
 {
     if (!p) return;
     if (p->d_mov) (void)hipFree(p->d_mov);
+    if (p->d_moff) (void)hipFree(p->d_moff);
     if (p->d_stat) (void)hipFree(p->d_stat);
     if (p->d_off) (void)hipFree(p->d_off);
     delete p;
@@ -274,6 +309,8 @@ int d2r_phys_check(d2r_ctx *ctx, const d2r_phys *phys, const d2r_phys_params *pr
     for (int i = 0; i < 3; i++) P.gravity[i] = prm->gravity[i];
     P.stability_check = prm->stability_check;
     P.oris_per_pos = (uint32_t)oris;
+    if (!(prm->margin >= 0.f) || !(prm->margin < 1.f)) return d2r_fail(ctx, D2R_ERR_INVALID, "collision margin must be in [0, 1) metres");
+    P.margin2 = 2.f * prm->margin;
     // orientation uniqueness (reference :260-278: greedy over the orientations of the FIRST position, then tiled)
     // and the regrasp rule (:281-301) are a few thousand 3x3 compares at most: host side, uploaded as one mask
     std::vector<uint8_t> mask(oris, 1);
@@ -314,7 +351,7 @@ int d2r_phys_check(d2r_ctx *ctx, const d2r_phys *phys, const d2r_phys_params *pr
     D2R_HIP(ctx, hipMemcpyAsync(d_valid, valid_io, N, hipMemcpyHostToDevice, ctx->stream));
     D2R_HIP(ctx, hipMemcpyAsync(d_mask, mask.data(), oris, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_phys_check, dim3((N + 3) / 4), dim3(256), 0, ctx->stream, P, (const float *)ctx->poses.p, N,
-                       (const uint8_t *)d_mask, (const float *)phys->d_mov, phys->n_mov, (const float *)phys->d_stat,
+                       (const uint8_t *)d_mask, (const float *)phys->d_mov, (const uint32_t *)phys->d_moff, phys->n_mov, (const float *)phys->d_stat,
                        (const uint32_t *)phys->d_off, phys->n_stat, d_valid);
     D2R_HIP(ctx, hipGetLastError());
     D2R_HIP(ctx, hipMemcpyAsync(valid_io, d_valid, N, hipMemcpyDeviceToHost, ctx->stream));

@@ -373,15 +373,19 @@ D2R_API int d2r_allgather_scores(d2r_ctx *ctx, const float *local_dev, size_t n_
  * phys_check the path calls before rendering (clip_scoring.py:108-113, dream2real.py:304-326): duplicate
  * orientations (:260-278), optional regrasp rule (:281-301), then per pose collision (:314-321), support
  * (:329-340) and stability (:349-365).  Shapes are convex hulls given as vertex sets — PyBullet's GEOM_MESH
- * without the concave flag (:239) is the convex hull of the mesh; "collides / touches" is hull intersection
- * (GJK, one wavefront per pose).  PyBullet's collision margins are not modelled.
- *   movable_verts   host [n_movable][3]  movable object's hull, world frame, at the object's initial pose
- *   static_verts    host [static_offsets[n_static]][3]  hulls of the static objects, concatenated
- *   static_offsets  host [n_static + 1]  first vertex of each static hull
+ * without the concave flag (:239) turns every shape (`o` / `g` group) of the mesh file into the convex hull of its
+ * vertices, so a VHACD-decomposed object is a compound of convex parts; two bodies "collide / touch" when any pair
+ * of their parts is in contact (GJK, one wavefront per pose), contact meaning the hulls come closer than the sum of
+ * the two shapes' collision margins (d2r_phys_params.margin; 0 = plain hull intersection).
+ *   movable_verts    host [movable_offsets[n_movable]][3]  the movable object's convex parts, concatenated, world
+ *                    frame, at the object's initial pose (the reference's mesh files are written in world coordinates)
+ *   movable_offsets  host [n_movable + 1]  first vertex of each movable part (movable_offsets[0] = 0)
+ *   static_verts     host [static_offsets[n_static]][3]  convex parts of all static objects, concatenated
+ *   static_offsets   host [n_static + 1]  first vertex of each static part
  */
 typedef struct d2r_phys d2r_phys;
-D2R_API int d2r_phys_create(d2r_ctx *ctx, const float *movable_verts, uint32_t n_movable, const float *static_verts,
-                            const uint32_t *static_offsets, uint32_t n_static, d2r_phys **out);
+D2R_API int d2r_phys_create(d2r_ctx *ctx, const float *movable_verts, const uint32_t *movable_offsets, uint32_t n_movable,
+                            const float *static_verts, const uint32_t *static_offsets, uint32_t n_static, d2r_phys **out);
 D2R_API void d2r_phys_destroy(d2r_phys *phys);
 typedef struct {
     uint32_t sample_res[6];   /* the pose grid's resolution: orientations per position = res[3] * res[4] * res[5] */
@@ -392,6 +396,10 @@ typedef struct {
     float perturb;            /* 0.04: sideways offset of the four stability probes */
     int32_t stability_check;  /* non-zero: run the stability probes */
     int32_t disallow_regrasp; /* non-zero: keep only orientations whose object z axis faces +z or -y (:281-301) */
+    float margin;             /* collision margin of every convex part, metres: two parts are in contact when their hulls
+                               * are closer than 2 * margin.  PyBullet loads GEOM_MESH convex hulls with a margin of 0.001
+                               * (believed: its default collision margin for file-loaded convex shapes; PyBullet is not
+                               * available offline, so this is unpinned); 0 = exact hull intersection */
 } d2r_phys_params;
 /*
  *   pose_batch  host [N][16] sampled poses (world, sample_poses_grid order: orientations fastest)

@@ -2,12 +2,14 @@
 (vision_3d/physics_utils.py:248-375), with convex-hull intersection as the collision predicate.
 
 TEST INFRASTRUCTURE ONLY — see oracle/d2r_oracle.c.  The reference asks PyBullet
-(`pyb_planner.pairwise_collision`, :318,:338,:357) whether two GEOM_MESH bodies — convex hulls of their mesh
-files (:239, no GEOM_FORCE_CONCAVE_TRIMESH) — are in contact.  PyBullet is not installed here and its
-collision margins are not restated: PARITY UNPINNED against PyBullet; the predicate is pinned by
-hand-built hull pairs with known answers (tests/test_physics.py).  Deliberately independent of the GPU
-kernel's GJK: intersection is decided as a linear-programming feasibility problem (is there a point that is
-a convex combination of both vertex sets?).
+(`pyb_planner.pairwise_collision`, :318,:338,:357) whether two GEOM_MESH bodies — compounds of the convex hulls
+of their mesh files' shapes (:239, no GEOM_FORCE_CONCAVE_TRIMESH) — are in contact.  PyBullet is not installed
+here: PARITY UNPINNED against PyBullet; its collision margin is a parameter (`margin`, per convex part: contact
+when two hulls are closer than 2 * margin; what value PyBullet uses for file-loaded hulls is a belief, see
+dream2real_amd/physics_utils.PYBULLET_MESH_MARGIN).  The predicates are pinned by hand-built hull pairs with known
+answers (tests/test_physics.py).  Deliberately independent of the GPU kernel's GJK: intersection is decided as a
+linear-programming feasibility problem (is there a point that is a convex combination of both vertex sets?),
+distance as a small quadratic program.
 """
 from __future__ import annotations
 
@@ -17,10 +19,40 @@ from scipy.optimize import linprog
 GRAVITY_DIRECTION = np.array([0, 0, -1])        # vision_3d/physics_utils.py:18
 
 
-def hulls_intersect(a: np.ndarray, b: np.ndarray) -> bool:
-    """conv(a) and conv(b) share a point  <=>  exist l, m >= 0, sum l = sum m = 1, a^T l = b^T m."""
+def hull_distance(a: np.ndarray, b: np.ndarray) -> float:
+    """Euclidean distance between conv(a) and conv(b): min |a^T l - b^T m| over the two simplices, as a small QP
+    (SLSQP from several starts; the problem is convex, the starts guard against a stalled line search)."""
+    from scipy.optimize import minimize
     a = np.asarray(a, np.float64).reshape(-1, 3)
     b = np.asarray(b, np.float64).reshape(-1, 3)
+    na, nb = len(a), len(b)
+    M = np.concatenate([a, -b]).T                                  # 3 x (na + nb)
+    cons = [{"type": "eq", "fun": lambda x: x[:na].sum() - 1.0, "jac": lambda x: np.r_[np.ones(na), np.zeros(nb)]},
+            {"type": "eq", "fun": lambda x: x[na:].sum() - 1.0, "jac": lambda x: np.r_[np.zeros(na), np.ones(nb)]}]
+    best = np.inf
+    ca, cb = a.mean(0), b.mean(0)
+    starts = [np.r_[np.full(na, 1.0 / na), np.full(nb, 1.0 / nb)]]
+    x0 = np.zeros(na + nb)
+    x0[np.argmax(a @ (cb - ca))] = 1.0                             # the vertices facing the other hull
+    x0[na + np.argmax(b @ (ca - cb))] = 1.0
+    starts.append(x0)
+    for x0 in starts:
+        r = minimize(lambda x: 0.5 * float((M @ x) @ (M @ x)), x0, jac=lambda x: M.T @ (M @ x), bounds=[(0, 1)] * (na + nb),
+                     constraints=cons, method="SLSQP", options={"maxiter": 500, "ftol": 1e-16})
+        best = min(best, float(np.linalg.norm(M @ np.clip(r.x, 0, 1))))
+    return best
+
+
+def hulls_intersect(a: np.ndarray, b: np.ndarray, margin: float = 0.0) -> bool:
+    """conv(a) and conv(b) share a point  <=>  exist l, m >= 0, sum l = sum m = 1, a^T l = b^T m (an LP).
+    margin > 0 (each shape's collision margin): in contact when the hulls are closer than 2 * margin."""
+    a = np.asarray(a, np.float64).reshape(-1, 3)
+    b = np.asarray(b, np.float64).reshape(-1, 3)
+    if margin > 0.0:
+        lo_a, hi_a, lo_b, hi_b = a.min(0), a.max(0), b.min(0), b.max(0)
+        if (lo_a > hi_b + 2 * margin).any() or (lo_b > hi_a + 2 * margin).any():
+            return False
+        return hull_distance(a, b) <= 2.0 * margin
     lo_a, hi_a, lo_b, hi_b = a.min(0), a.max(0), b.min(0), b.max(0)
     if (lo_a > hi_b).any() or (lo_b > hi_a).any():
         return False
@@ -53,8 +85,9 @@ def unique_orientation_mask(first_pos_oris: np.ndarray) -> np.ndarray:
 
 
 def unsupcol_check(pose_batch, init_pose, movable_hull, static_hulls, sample_res, valid_so_far, table_z,
-                   disallow_regrasp=False, unsup_thresh=0.02, stability_check=True):
-    """vision_3d/physics_utils.py:248-375, line by line; returns the bool mask [N]."""
+                   disallow_regrasp=False, unsup_thresh=0.02, stability_check=True, margin=0.0):
+    """vision_3d/physics_utils.py:248-375, line by line; returns the bool mask [N].  movable_hull: one vertex array, or
+    a list of them (a compound of convex parts: two bodies touch when any pair of parts does)."""
     valid = np.array(valid_so_far, bool, copy=True)
     poses = np.asarray(pose_batch, np.float32).reshape(-1, 4, 4)
     transforms = poses.astype(np.float64) @ np.linalg.inv(np.asarray(init_pose, np.float64).reshape(4, 4))   # :253
@@ -74,11 +107,11 @@ def unsupcol_check(pose_batch, init_pose, movable_hull, static_hulls, sample_res
             if not facing:
                 m2[i] = False
     valid &= np.tile(m2, n_pos)                                          # :300-301
-    mov = np.asarray(movable_hull, np.float64).reshape(-1, 3)
+    movs = [np.asarray(m, np.float64).reshape(-1, 3) for m in movable_hull] if isinstance(movable_hull, (list, tuple)) else \
+        [np.asarray(movable_hull, np.float64).reshape(-1, 3)]
 
     def touches_any(R, t):
-        w = mov @ R.T + t
-        return any(hulls_intersect(w, h) for h in static_hulls)
+        return any(hulls_intersect(m @ R.T + t, h, margin) for m in movs for h in static_hulls)
 
     for i in range(len(poses)):                                          # :308
         if not valid[i]:

@@ -42,6 +42,75 @@ def test_hull_intersection_known_answers():
     assert phys_ref.hulls_intersect(unit, tet) and not phys_ref.hulls_intersect(unit, tet + 2.0)
 
 
+def test_hull_distance_and_margins_known_answers():
+    """Contact with collision margins: two parts touch when their hulls are closer than the sum of the margins."""
+    unit = box([0, 0, 0], [1, 1, 1])
+    assert abs(phys_ref.hull_distance(unit, unit + [1.25, 0, 0]) - 0.25) < 1e-7            # face to face
+    assert abs(phys_ref.hull_distance(unit, unit + [1.3, 1.4, 0]) - 0.5) < 1e-7             # edge to edge: (0.3, 0.4)
+    assert abs(phys_ref.hull_distance(unit, unit + [1.1, 1.2, 1.2]) - 0.3) < 1e-7           # corner to corner: (0.1, 0.2, 0.2)
+    assert phys_ref.hull_distance(unit, unit + [0.5, 0.5, 0.5]) < 1e-9                      # overlapping
+    tet = np.array([[2.0, 0.5, 0.5], [3.0, 0.0, 0.0], [3.0, 1.0, 0.0], [3.0, 0.5, 1.0]])
+    assert abs(phys_ref.hull_distance(unit, tet) - 1.0) < 1e-7                              # vertex to face
+    # margin 1 mm per shape: contact below a 2 mm gap
+    assert phys_ref.hulls_intersect(unit, unit + [1.0015, 0, 0], margin=0.001)
+    assert not phys_ref.hulls_intersect(unit, unit + [1.0025, 0, 0], margin=0.001)
+    assert not phys_ref.hulls_intersect(unit, unit + [1.0015, 0, 0])                       # plain intersection: apart
+    c = (box([-0.5, -0.5, -0.5], [0.5, 0.5, 0.5]) @ rot_z(np.pi / 4).T)                     # edge at x = 0.70711
+    assert phys_ref.hulls_intersect(c, unit + [0.7085, -0.5, -0.5], margin=0.001)
+    assert not phys_ref.hulls_intersect(c, unit + [0.7095, -0.5, -0.5], margin=0.001)
+
+
+def _write_obj(path, parts, header="", group="o"):
+    """parts: list of (vertices [V,3], faces as 0-based local index triples)"""
+    lines, base = [header] if header else [], 0
+    for k, (v, faces) in enumerate(parts):
+        lines.append(f"{group} part_{k}")
+        lines += [f"v {x:.9g} {y:.9g} {z:.9g}" for x, y, z in v]
+        lines += ["f " + " ".join(str(base + i + 1) for i in f) for f in faces]
+        base += len(v)
+    open(path, "w").write("\n".join(lines) + "\n")
+
+
+BOX_FACES = [(0, 1, 3), (0, 3, 2), (4, 6, 7), (4, 7, 5), (0, 4, 5), (0, 5, 1), (2, 3, 7), (2, 7, 6), (0, 2, 6), (0, 6, 4), (1, 5, 7), (1, 7, 3)]
+
+
+def test_hulls_from_obj_splits_shapes_like_the_mesh_loader(tmp_path):
+    """PyBullet's GEOM_MESH loader makes one convex hull per shape of the .obj (reference vision_3d/physics_utils.py:238
+    loads obj.phys_model that way; VHACD writes one `o` group per convex part)."""
+    from dream2real_amd import physics_utils
+    a, b = box([0, 0, 0], [1, 1, 1]), box([2, 0, 0], [3, 1, 0.5])
+    p = str(tmp_path / "two.obj")
+    _write_obj(p, [(a, BOX_FACES), (b, BOX_FACES)], header="# VHACD-style output")
+    hulls = physics_utils.hulls_from_obj(p)
+    assert len(hulls) == 2
+    np.testing.assert_allclose(hulls[0], a) and np.testing.assert_allclose(hulls[1], b)
+    _write_obj(p, [(a, BOX_FACES), (b, BOX_FACES)], group="g")
+    assert len(physics_utils.hulls_from_obj(p)) == 2
+    # no groups: one shape; vertices no face references are not part of it; v/vt/vn and negative indices
+    lines = [f"v {x} {y} {z}" for x, y, z in a] + ["v 9 9 9", "vt 0 0", "vn 0 0 1"]
+    lines += ["f " + " ".join(f"{i + 1}/1/1" for i in f) for f in BOX_FACES[:6]] + ["f -3/1/1 -2/1/1 -4/1/1"]
+    open(p, "w").write("\n".join(lines) + "\n")
+    (h,) = physics_utils.hulls_from_obj(p)
+    assert len(h) == 8 and not (h == 9).any()
+    # a group without faces is skipped; a file with vertices only is one hull of all of them
+    open(p, "w").write("o empty\nv 5 5 5\no real\n" + "\n".join(f"v {x} {y} {z}" for x, y, z in a) + "\nf 2 3 4\n")
+    (h,) = physics_utils.hulls_from_obj(p)
+    assert len(h) == 3
+    open(p, "w").write("\n".join(f"v {x} {y} {z}" for x, y, z in b) + "\n")
+    (h,) = physics_utils.hulls_from_obj(p)
+    np.testing.assert_allclose(h, b)
+    open(p, "w").write("v 0 0 0\nf 1 2 3\n")
+    with pytest.raises(ValueError):
+        physics_utils.hulls_from_obj(p)
+    # object_hulls: vertex arrays take precedence over the mesh path
+    import types
+    _write_obj(p, [(a, BOX_FACES)])
+    assert len(physics_utils.object_hulls(types.SimpleNamespace(phys_model=p))) == 1
+    assert len(physics_utils.object_hulls(types.SimpleNamespace(phys_model=p, phys_hulls=[a, b, a]))) == 3
+    with pytest.raises(ValueError):
+        physics_utils.object_hulls(types.SimpleNamespace(phys_model=None))
+
+
 def test_unique_orientations_follow_the_reference_rule():
     # shelf-type grid: eulers linspace(-pi, pi/2, 3) per axis (obj_pose_opt.py:27-29): (-pi,-pi,-pi) equals the
     # identity (-pi, ..) duplicates show up as equal rotation matrices
@@ -140,7 +209,70 @@ def test_gpu_prefilter_matches_oracle_on_hulls_and_grids():
     task = types.SimpleNamespace(movable_obj=types.SimpleNamespace(pose=torch.tensor(init), phys_hull=mov),
                                  task_bground_obj=types.SimpleNamespace(phys_hulls=[shelf, blob]),
                                  scene_model=types.SimpleNamespace(scene_centre=torch.tensor([0.45, 0.85, 0.20])))
-    check, shapes = physics_utils.create_unsupcol_check(ctx, task, res, embodied=False)
+    check, static_handles, movable_handles = physics_utils.create_unsupcol_check(ctx, task, res, embodied=False, margin=0.0)
     out = check(torch.from_numpy(poses), task, torch.from_numpy(v0))
     assert out.dtype == torch.bool and (out.numpy() == sh.check(poses, v0, res, init, 0.2)).all()
-    shapes.close(); sh.close(); ctx.close()
+    assert len(static_handles) == 1 and len(static_handles[0]) == 2 and len(movable_handles) == 1      # the reference's triple (:377)
+    check.shapes.close(); sh.close(); ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_prefilter_with_margins_compound_parts_and_mesh_files(tmp_path):
+    """The drop-in form: shapes from .obj files (one hull per `o` group, the movable object itself a compound of two
+    convex parts), lazy_phys_mods on and off (reference vision_3d/physics_utils.py:235), and contact with PyBullet's
+    collision margin (believed 1 mm per convex part) against the oracle's distance test, margin 0 and > 0."""
+    import types
+    import torch
+    from dream2real_amd import engine, physics_utils
+    ctx = engine.Context(0)
+    table = box([-1, -1, -0.1], [1, 1, 0.0])
+    block = box([0.30, -0.10, 0.0], [0.50, 0.10, 0.20])
+    post = box([0.70, -0.03, 0.0], [0.74, 0.03, 0.05])                      # a pebble low enough to fit under the plate
+    # a movable object of two convex parts, a plate on one leg (its convex hull would fill the space under the plate)
+    part_a = box([-0.05, -0.05, 0.08], [0.05, 0.05, 0.12]) + [0, 0, 0.005]
+    part_b = box([-0.05, -0.05, 0.0], [-0.01, 0.05, 0.08]) + [0, 0, 0.005]
+    init = np.eye(4, dtype=np.float32)
+    xs, ys, zs = np.linspace(-0.6, 1.15, 36), [0.0, 0.07], [0.0, 0.0115, 0.0135, 0.1, 0.2055, 0.2175, 0.2195, -0.5]
+    poses = _grid(xs, ys, zs)
+    res = [len(xs), len(ys), len(zs), 1, 1, 1]
+    v0 = np.ones(len(poses), bool)
+    # (1) margins on explicit hulls: 5 mm initial gap + lowering by 2 cm; z offsets 0.0115 / 0.0135 put the lowered part
+    # 1.5 mm / 3.5 mm... above the table: inside / outside the 2 mm contact distance
+    sh = physics_utils.PhysicsShapes(ctx, [part_a, part_b], [table, block, post])
+    results = {}
+    for m in (0.0, 0.001, 0.004):
+        got = sh.check(poses, v0, res, init, -0.3, margin=m)
+        want = phys_ref.unsupcol_check(poses, init, [part_a, part_b], [table, block, post], res, v0, -0.3, margin=m)
+        assert (got != want).mean() < 0.005, (m, np.nonzero(got != want)[0][:10])
+        results[m] = want
+    assert (results[0.0] != results[0.001]).any() and (results[0.001] != results[0.004]).any()     # the margin matters on this grid
+    # the compound is not its hull: with the pebble under the plate beside the leg a pose is valid only as two parts
+    hull_only = phys_ref.unsupcol_check(poses, init, np.concatenate([part_a, part_b]), [table, block, post], res, v0, -0.3)
+    assert (hull_only != results[0.0]).any()
+    sh.close()
+    # (2) the same shapes through mesh files and the reference's call: lazy_phys_mods=True -> merged background + movable
+    bg_path, mov_path = str(tmp_path / "bground.obj"), str(tmp_path / "movable.obj")
+    _write_obj(bg_path, [(table, BOX_FACES), (block, BOX_FACES), (post, BOX_FACES)])
+    _write_obj(mov_path, [(part_a, BOX_FACES), (part_b, BOX_FACES)])
+    movable = types.SimpleNamespace(pose=torch.tensor(init), phys_model=mov_path)
+    bground = types.SimpleNamespace(phys_model=bg_path)
+    scene_model = types.SimpleNamespace(scene_centre=torch.tensor([0.0, 0.0, -0.3]), objs=None)
+    task = types.SimpleNamespace(movable_obj=movable, task_bground_obj=bground, scene_model=scene_model)
+    check, static_handles, movable_handles = physics_utils.create_unsupcol_check(ctx, task, res, embodied=False, lazy_phys_mods=True)
+    out = check(torch.from_numpy(poses), task, torch.from_numpy(v0)).numpy()
+    assert (out != results[physics_utils.PYBULLET_MESH_MARGIN]).mean() < 0.005
+    assert [len(p) for p in static_handles] == [3] and [len(p) for p in movable_handles] == [2]
+    check.shapes.close()
+    # lazy_phys_mods=False: every scene object is its own body, all but the movable one static (:235-245)
+    paths = []
+    for k, h in enumerate((table, block, post)):
+        paths.append(str(tmp_path / f"obj{k}.obj"))
+        _write_obj(paths[-1], [(h, BOX_FACES)])
+    scene_model.objs = [types.SimpleNamespace(phys_model=paths[0]), movable, types.SimpleNamespace(phys_model=paths[1]),
+                        types.SimpleNamespace(phys_model=paths[2])]
+    check2, static2, movable2 = physics_utils.create_unsupcol_check(ctx, task, res, embodied=False, lazy_phys_mods=False)
+    out2 = check2(torch.from_numpy(poses), task, torch.from_numpy(v0)).numpy()
+    np.testing.assert_array_equal(out2, out)
+    assert len(static2) == 3 and len(movable2) == 1
+    check2.shapes.close()
+    ctx.close()

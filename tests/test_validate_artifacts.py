@@ -1,0 +1,114 @@
+"""tools/validate_artifacts.py — the harness that measures parity against the reference's real artefacts (snapshots,
+CLIP checkpoint, method_out/<scene>/ of a reference run) — exercised on this repo's synthetic stand-ins: snapshots
+written in the believed layout, a random-weight checkpoint directory, and the outputs of the library's own run standing
+in for the reference's cb_render / pose_scores / pose_batch / goal_pose."""
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests.ingp_writer import save_ingp
+from tests.scenes import make_scene, make_task
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOOL = os.path.join(REPO, "tools", "validate_artifacts.py")
+VIEWS = [dict(fx=924.66912, fy=926.49735, cx=654.51953, cy=355.18523, w=1280, h=720)]
+
+
+def run_tool(*flags):
+    r = subprocess.run([sys.executable, TOOL, *flags], capture_output=True, text=True, timeout=900, cwd=REPO)
+    assert r.stdout.strip().startswith("{"), (r.stdout[-1500:], r.stderr[-3000:])
+    return r.returncode, json.loads(r.stdout)
+
+
+def test_snapshot_section_runs_without_a_gpu(tmp_path):
+    scene = make_scene("pool_triangle")
+    d = str(tmp_path)
+    save_ingp(os.path.join(d, "fg_base.ingp"), scene.fg, training_views=VIEWS)
+    rc, rep = run_tool("--method-out", d, "--no-gpu")
+    a = rep["sections"]["a_snapshots"]
+    assert rc == 0 and rep["ok"] and a["fg"]["problems"] == [] and "skipped" in a["bg"]
+    assert a["fg"]["derived"]["n_params_expected"] == a["fg"]["derived"]["params_binary_halves"]
+    assert len(a["fg"]["derived"]["levels"]) == 16 and any("params_binary" in k for k in a["fg"]["keys_read"])
+    for s in ("b_clip", "c_render", "d_argmax"):
+        assert "skipped" in rep["sections"][s]
+    # a snapshot whose parameter blob does not have the size the config implies is reported, not loaded
+    import msgpack, zlib
+    p = os.path.join(d, "bg_base.ingp")
+    save_ingp(p, scene.bg)
+    cfg = msgpack.unpackb(zlib.decompress(open(p, "rb").read()), raw=False)
+    cfg["snapshot"]["params_binary"] = cfg["snapshot"]["params_binary"][:-4]
+    cfg["snapshot"]["some_new_field"] = [1, 2, 3]
+    open(p, "wb").write(zlib.compress(msgpack.packb(cfg, use_bin_type=True), 1))
+    rc, rep = run_tool("--method-out", d, "--no-gpu")
+    bg = rep["sections"]["a_snapshots"]["bg"]
+    assert rc == 1 and not rep["ok"] and "params_binary holds" in bg["problems"][0]
+    assert any("snapshot.some_new_field" in k for k in bg["keys_ignored"])
+    # an empty directory: nothing to do
+    rc, rep = run_tool("--method-out", str(tmp_path / "nothing"), "--no-gpu")
+    assert rc == 2
+
+
+@pytest.mark.gpu
+def test_full_harness_on_synthetic_stand_ins(tmp_path):
+    """writer -> GPU run (snapshots through the C loader, renders, scores, PNGs, txt files) -> harness: every section
+    runs and is exact, because both sides are this library — what the test pins is that the harness reads the
+    reference's file formats and conventions (sorted PNG order, zero = invalid, smoothed scores, pose conventions)."""
+    import torch
+    from safetensors.torch import save_file
+    from dream2real_amd import clip_scoring, combined_rendering, engine
+    from dream2real_amd.clip_model import CLIP_CONFIGS, random_clip_state_dict
+    from dream2real_amd.tokenizer import ClipBpeTokenizer
+    g = os.path.join(REPO, "tests", "golden")
+    scene = make_scene("shopping")
+    d = str(tmp_path / "method_out" / "shopping")
+    os.makedirs(d)
+    save_ingp(os.path.join(d, "fg_base.ingp"), scene.fg, training_views=VIEWS, background_color=scene.fg_background)
+    save_ingp(os.path.join(d, "bg_base.ingp"), scene.bg, training_views=VIEWS)
+    # a checkpoint directory as the Hugging Face hub lays it out
+    ck = str(tmp_path / "clip")
+    os.makedirs(ck)
+    shutil.copy(os.path.join(g, "bpe_vocab.json"), os.path.join(ck, "vocab.json"))
+    shutil.copy(os.path.join(g, "bpe_merges.txt"), os.path.join(ck, "merges.txt"))
+    tok = ClipBpeTokenizer.from_files(os.path.join(ck, "vocab.json"), os.path.join(ck, "merges.txt"), context_length=32)
+    cfg = dict(CLIP_CONFIGS["vit_tiny"], vocab=len(tok.vocab), ctx=32)
+    sd = random_clip_state_dict(cfg, seed=6)
+    # random text towers give logits of either sign; a positive projection bias keeps the goal / norm ratio well conditioned
+    save_file({k: torch.from_numpy(np.asarray(v, np.float32).reshape(np.shape(v) or (1,)).copy()) for k, v in sd.items()},
+              os.path.join(ck, "model.safetensors"))
+    # the "reference run": this library, writing what the reference writes
+    ctx = engine.Context(0)
+    fg, bg = engine.Testbed.from_snapshot(ctx, os.path.join(d, "fg_base.ingp")), engine.Testbed.from_snapshot(ctx, os.path.join(d, "bg_base.ingp"))
+    sc, enc = engine.ClipScorer(ctx, cfg, sd), engine.TextEncoder(ctx, cfg, sd)
+    task = make_task(scene, fg, bg)
+    W, H = 96, 54
+    sample_res = [5, 4, 2, 1, 1, 1]
+    rend = combined_rendering.renderer(d, task, resolution=(W, H))
+    invalid = {3, 17}
+    phys = lambda p, t, v: v & torch.tensor([i not in invalid for i in range(len(v))])
+    best, pose_batch, scores = clip_scoring.optimise_pose_grid(rend, None, [0], task, d, sample_res=sample_res, phys_check=phys,
+                                                               scene_type=scene.scene_type, smoothing=True, scorer=sc, text_encoder=enc, tokenizer=tok)
+    clip_scoring.save_pose_outputs(d, best, pose_batch, scores)
+    assert len(os.listdir(os.path.join(d, "cb_render"))) == 38 and scores[3] == 0
+    np.savetxt(str(tmp_path / "obj_pose.txt"), scene.obj_pose)
+    np.savetxt(str(tmp_path / "cam_pose.txt"), scene.cam_poses[0])
+    sc.close(); enc.close(); fg.close(); bg.close(); ctx.close()
+    rc, rep = run_tool("--method-out", d, "--clip", ck, "--goal-caption", task.goal_caption, "--norm-caption", task.norm_captions[0],
+                       "--sample-res", ",".join(map(str, sample_res)), "--obj-pose", str(tmp_path / "obj_pose.txt"),
+                       "--cam-pose", str(tmp_path / "cam_pose.txt"), "--resolution", f"{W},{H}", "--out", str(tmp_path / "report.json"))
+    s = rep["sections"]
+    assert rc == 0 and rep["ok"], rep
+    assert s["a_snapshots"]["fg"]["gpu_loader"]["ok"] and s["a_snapshots"]["bg"]["gpu_loader"]["ok"]
+    assert s["b_clip"]["matches"] == "smoothed" and s["b_clip"]["smoothed"]["max_rel_err"] < 1e-5 and s["b_clip"]["valid_poses"] == 38
+    assert s["b_clip"]["raw"]["max_rel_err"] > s["b_clip"]["smoothed"]["max_rel_err"]
+    assert s["c_render"]["frames_compared"] == 38 and s["c_render"]["max_abs_diff"] == 0 and s["c_render"]["psnr_db_min"] == 99.0
+    assert s["d_argmax"]["identical"] and s["d_argmax"]["goal_pose_is_a_grid_pose"]
+    assert json.load(open(str(tmp_path / "report.json")))["ok"]
+    # wrong captions: the harness notices (scores move, exit code 1)
+    rc, rep = run_tool("--method-out", d, "--clip", ck, "--goal-caption", "a completely different sentence about shelves",
+                       "--norm-caption", task.norm_captions[0], "--sample-res", ",".join(map(str, sample_res)))
+    assert rc == 1 and not rep["sections"]["b_clip"]["within_bar"]

@@ -1,8 +1,9 @@
 #!/bin/bash
-# Run on the GPU box: rebuild libd2r with each k_attention ablation mask (1 no K copies, 2 no V staging, 4 no
+# Run on the GPU box: rebuild libd2r with each attention ablation mask (k_attention_s: 16 no DMA requests, 32 no softmax,
+# 64 no PV, 128 no S MFMAs, 256 no per-tile barriers; resident k_attention: 1 no K copies, 2 no V staging, 4 no
 # arithmetic, 8 no Q loads) and report the kernel's average duration (2048 images x 12 heads per launch).
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-for A in ${MASKS:-0 1 2 3 4 8 11 15}; do
+for A in ${MASKS:-0 16 32 64 128 256 224 272 96 480}; do
   touch $ROOT/dream2real_amd/csrc/clip.hip
   make -C $ROOT/dream2real_amd/csrc -j3 ATTN_ABLATE=$A 2>&1 | grep -E " error"
   rm -rf /tmp/attn_abl; mkdir -p /tmp/attn_abl
