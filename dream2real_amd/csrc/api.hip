@@ -180,36 +180,32 @@ int d2r_ctx_set_option(d2r_ctx *ctx, const char *key, int64_t value)
     if (!strcmp(key, "chunk")) {
         if (value < 1 || value > 16384) return d2r_fail(ctx, D2R_ERR_INVALID, "chunk must be in [1, 16384]");
         ctx->chunk = value;
-    } else if (!strcmp(key, "march_blocks")) {
-        if (value < 0 || value > 65535) return d2r_fail(ctx, D2R_ERR_INVALID, "march_blocks out of range");
-        ctx->march_blocks = value;
     } else if (!strcmp(key, "refill_min")) {
         if (value < 1 || value > 64) return d2r_fail(ctx, D2R_ERR_INVALID, "refill_min must be in [1, 64]");
         ctx->refill_min = value;
-    } else if (!strcmp(key, "gemm_cfg")) {
-        ctx->gemm_cfg = value;
     } else if (!strcmp(key, "ln_fold")) {
         if (value < 0 || value > 3) return d2r_fail(ctx, D2R_ERR_INVALID, "ln_fold must be 0..3");
         ctx->ln_fold = value;
-    } else if (!strcmp(key, "attn_stream")) {
-        ctx->attn_stream = value != 0;
-    } else if (!strcmp(key, "attn_q2")) {
-        ctx->attn_q2 = value != 0;
     } else if (!strcmp(key, "gemm_nsplit")) {
         ctx->gemm_nsplit = value;
     } else if (!strcmp(key, "prep_reuse")) {
         ctx->prep_reuse = value != 0;
     } else if (!strcmp(key, "cls_last")) {
         ctx->cls_last = value != 0;
+#ifdef D2R_DEV
+    // experiment switches of development builds (make DEV=1): schedules that were measured no faster and tile
+    // configurations kept for comparison; a product build does not know these keys
+    } else if (!strcmp(key, "march_blocks")) {
+        if (value < 0 || value > 65535) return d2r_fail(ctx, D2R_ERR_INVALID, "march_blocks out of range");
+        ctx->march_blocks = value;
+    } else if (!strcmp(key, "gemm_cfg")) {
+        ctx->gemm_cfg = value;
     } else if (!strcmp(key, "gemm_group")) {
         if (value < 0 || value > 65535) return d2r_fail(ctx, D2R_ERR_INVALID, "gemm_group out of range");
         ctx->gemm_group = value;
     } else if (!strcmp(key, "gemm_stagger")) {
         ctx->gemm_stagger = value != 0;
-    } else if (!strcmp(key, "attn_stagger")) {
-        ctx->attn_stagger = value != 0;
-    } else if (!strcmp(key, "attn_persistent")) {
-        ctx->attn_persistent = value != 0;
+#endif
     } else if (!strcmp(key, "gbrick_slots")) {
         if (value < 0 || value > 3) return d2r_fail(ctx, D2R_ERR_INVALID, "gbrick_slots must be in [0, 3]");
         ctx->gbrick_slots = value;

@@ -285,12 +285,14 @@ struct EpiAux {
     uint32_t a_rs, a_ks;   // A operand: elements between rows, and between K-tiles (row-major: K, 64; tile-major: 64, 64 M_pad); 0,0 = row-major
 };
 
-// Development-only ablation switches of k_gemm8 and the shared epilogue (bitmask, default 0 = the real
-// kernel): 1 no LDS-DMA, 2 no fragment ds_reads, 4 no epilogue, 8 no MFMA, 128 no global loads/stores in
-// the epilogue, 256 no LDS transposes in the epilogue.  Results are garbage when set; tools/gemm_ablate.sh
-// rebuilds with each mask to see where the time of a tile goes.
-#ifndef D2R_GEMM_ABLATE
+// Measurement switches (ablation masks, cycle stamps) live in clip_dev.h, which only development builds (make DEV=1,
+// or any ablation mask) include; a product build sees the masks as the constant 0 and no stamp code at all.
+#ifdef D2R_DEV
+#include "clip_dev.h"
+#else
 #define D2R_GEMM_ABLATE 0
+#define D2R_ATTN_ABLATE 0
+#define STAMP(var)
 #endif
 #ifndef D2R_GEMM_PRIO
 #define D2R_GEMM_PRIO 2        /* 0: s_setprio 1 around every MFMA section; 1 / 2: static priority for wave row 1 / 0; 3: none */
@@ -787,24 +789,6 @@ __device__ __forceinline__ void glds16s(uint32_t voff, const void *sbase, uint32
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
 }
 
-#ifdef D2R_GEMM_STAMPS
-// development only: shader-clock cycles wave 0 of every workgroup spends per tile section,
-// [EPI][0 drain wait, 1 K loop, 2 epilogue, 3 tiles]
-__device__ unsigned long long d2r_gemm_stamps[EPI_KINDS][4];
-extern "C" __attribute__((visibility("default"))) int d2r_debug_gemm_stamps(unsigned long long *out, int reset)
-{
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(d2r_gemm_stamps), sizeof(unsigned long long) * 4 * EPI_KINDS) != hipSuccess) return -1;
-    if (reset) {
-        unsigned long long z[4 * EPI_KINDS] = {0};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(d2r_gemm_stamps), z, sizeof(z)) != hipSuccess) return -1;
-    }
-    return 0;
-}
-#define STAMP(var) const unsigned long long var = __builtin_readcyclecounter()
-#else
-#define STAMP(var)
-#endif
-
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A, const uint16_t *__restrict__ W,
                                                  const float *__restrict__ bias, void *__restrict__ Cout,
@@ -1259,11 +1243,6 @@ __device__ __forceinline__ float half_sum(float x)
 // reads and writes contiguous T x 128-byte blocks.
 // grid (heads, images); block 256; dynamic LDS: K [T_pad][64] swizzled + Vt [64][T_pad+4].
 #define ATTN_THREADS 512
-// development only (bitmask, default 0): 1 skip the K copies, 2 skip the V staging, 4 skip the arithmetic, 8 skip the
-// Q loads — results are garbage; tools/attn_ablate.sh rebuilds with each mask to see what a workgroup's time is made of
-#ifndef D2R_ATTN_ABLATE
-#define D2R_ATTN_ABLATE 0
-#endif
 // One 32-query tile of one (image, head) against all keys staged in LDS (Ks: K rows, swizzled 16-byte chunks;
 // Vt: V^T, [64][vstride]): S^T = K Q^T so that a query's scores are lane-local, online softmax in the exp2
 // domain, P fed back as the MFMA B operand, O^T accumulated; writes the tile's rows of AO.
@@ -1390,164 +1369,15 @@ __device__ __forceinline__ void attn_qtile(const uint8_t *__restrict__ Ks, const
     }
 }
 
-// TWO 32-query tiles of one (image, head) per wave (vision tower): the K and V^T fragments are read once for both
-// tiles and the loop / address arithmetic is shared, and the two tiles' chains — S MFMAs, softmax, PV MFMAs — are
-// independent, so one tile's exp2 section can sit beside the other's MFMAs inside ONE wave; the workgroup then needs
-// four waves instead of eight (two waves per SIMD with ~200 registers each instead of four with 128).
-__device__ __forceinline__ void attn_qtile2(const uint8_t *__restrict__ Ks, const uint16_t *__restrict__ Vt, uint32_t vstride,
-                                            const uint4 (&qf)[2][4], uint32_t qt0, uint32_t T, uint32_t n_kt, uint32_t li,
-                                            uint32_t hi, uint16_t *__restrict__ AO, size_t row_base, uint32_t M_pad, uint32_t head)
+// The resident form: one workgroup per (sequence, head) stages the whole K (swizzled rows) and V^T of the head in LDS,
+// then its waves take the 32-query tiles.  Serves the text tower (causal, <= 77 tokens, a handful of sequences per
+// task); the vision tower streams K / V instead (k_attention_s below).
+template <bool CAUSAL>
+__global__ __launch_bounds__(ATTN_THREADS, 4) void k_attention(const uint16_t *__restrict__ QKV, uint16_t *__restrict__ AO, uint32_t T,
+                                                              uint32_t T_pad, uint32_t d, uint32_t M_pad)
 {
-    const float sm_c = 0.125f * 1.4426950408889634f;   // head_dim^-0.5 * log2(e), head_dim = 64
-    f32x16 o0[2], o1[2];
-    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
-#pragma unroll
-    for (int q = 0; q < 2; q++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) o0[q][r] = o1[q][r] = 0.f;
-    const uint8_t *kp[4];
-#pragma unroll
-    for (int s = 0; s < 4; s++) kp[s] = Ks + lds_off(li, 2 * s + hi);
-    const uint16_t *vp0 = Vt + (size_t)li * vstride + 4 * hi, *vp1 = Vt + (size_t)(32 + li) * vstride + 4 * hi;
-    uint4 ka[4];
-#pragma unroll
-    for (int s = 0; s < 4; s++) ka[s] = *(const uint4 *)(kp[s]);
-    for (uint32_t kt = 0; kt < n_kt; kt++) {
-        f32x16 sacc[2];
-#pragma unroll
-        for (int q = 0; q < 2; q++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) sacc[q][r] = 0.f;
-#pragma unroll
-        for (int s = 0; s < 4; s++)
-#pragma unroll
-            for (int q = 0; q < 2; q++) {
-                union { uint4 u; bf16x8 v; } a, b;
-                a.u = ka[s];
-                b.u = qf[q][s];
-                sacc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, sacc[q], 0, 0, 0);
-            }
-        if (kt + 1 < n_kt) {
-#pragma unroll
-            for (int s = 0; s < 4; s++) ka[s] = *(const uint4 *)(kp[s] + (kt + 1) * 4096u);
-        }
-        if ((kt + 1) * 32 > T) {                                       // wave-uniform: the tile that holds keys >= T
-#pragma unroll
-            for (int q = 0; q < 2; q++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const uint32_t key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    sacc[q][r] = key < T ? sacc[q][r] : -INFINITY;
-                }
-        }
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-            float tmax = sacc[q][0];
-#pragma unroll
-            for (int r = 1; r < 16; r++) tmax = fmaxf(tmax, sacc[q][r]);
-            tmax = half_max(tmax) * sm_c;
-            const float m_new = fmaxf(m_run[q], tmax);
-            if (__builtin_amdgcn_ballot_w64(m_new != m_run[q]) != 0) {
-                const float alpha = __builtin_amdgcn_exp2f(m_run[q] - m_new);
-                l_run[q] *= alpha;
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    o0[q][r] *= alpha;
-                    o1[q][r] *= alpha;
-                }
-                m_run[q] = m_new;
-            }
-            typedef float f32x8 __attribute__((ext_vector_type(8)));
-            typedef float f32x4 __attribute__((ext_vector_type(4)));
-            typedef float f32x2 __attribute__((ext_vector_type(2)));
-            const f32x16 cv = sm_c, mv = -m_new;
-            const f32x16 t = __builtin_elementwise_fma(sacc[q], cv, mv);
-#pragma unroll
-            for (int r = 0; r < 16; r++) sacc[q][r] = __builtin_amdgcn_exp2f(t[r]);
-            const f32x8 s8 = sacc[q].lo + sacc[q].hi;
-            const f32x4 s4 = s8.lo + s8.hi;
-            const f32x2 s2 = s4.lo + s4.hi;
-            l_run[q] += s2.x + s2.y;
-        }
-        const uint16_t *vq0 = vp0 + kt * 32, *vq1 = vp1 + kt * 32;
-#pragma unroll
-        for (int s = 0; s < 2; s++) {
-            union { uint4 u; bf16x8 v; } va0, va1;
-            const uint2 a00 = *(const uint2 *)(vq0 + 16 * s);
-            const uint2 a01 = *(const uint2 *)(vq0 + 16 * s + 8);
-            const uint2 a10 = *(const uint2 *)(vq1 + 16 * s);
-            const uint2 a11 = *(const uint2 *)(vq1 + 16 * s + 8);
-            va0.u = make_uint4(a00.x, a00.y, a01.x, a01.y);
-            va1.u = make_uint4(a10.x, a10.y, a11.x, a11.y);
-#pragma unroll
-            for (int q = 0; q < 2; q++) {
-                union { uint4 u; bf16x8 v; } pb;
-                pb.u.x = pack2(sacc[q][8 * s + 0], sacc[q][8 * s + 1]);
-                pb.u.y = pack2(sacc[q][8 * s + 2], sacc[q][8 * s + 3]);
-                pb.u.z = pack2(sacc[q][8 * s + 4], sacc[q][8 * s + 5]);
-                pb.u.w = pack2(sacc[q][8 * s + 6], sacc[q][8 * s + 7]);
-                o0[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va0.v, pb.v, o0[q], 0, 0, 0);
-                o1[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va1.v, pb.v, o1[q], 0, 0, 0);
-            }
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < 2; q++) {
-        const uint32_t qrow = (qt0 + q) * 32 + li;
-        const float inv_l = 1.0f / half_sum(l_run[q]);
-        if (qrow < T) {
-            uint16_t *dst = AO + ((size_t)head * M_pad + row_base + qrow) * 64;
-#pragma unroll
-            for (int g4 = 0; g4 < 4; g4++) {
-                uint2 w0, w1;
-                w0.x = pack2(o0[q][4 * g4 + 0] * inv_l, o0[q][4 * g4 + 1] * inv_l);
-                w0.y = pack2(o0[q][4 * g4 + 2] * inv_l, o0[q][4 * g4 + 3] * inv_l);
-                w1.x = pack2(o1[q][4 * g4 + 0] * inv_l, o1[q][4 * g4 + 1] * inv_l);
-                w1.y = pack2(o1[q][4 * g4 + 2] * inv_l, o1[q][4 * g4 + 3] * inv_l);
-                *(uint2 *)(dst + 8 * g4 + 4 * hi) = w0;
-                *(uint2 *)(dst + 32 + 8 * g4 + 4 * hi) = w1;
-            }
-        }
-    }
-}
-
-#ifdef D2R_ATTN_STAMPS
-// development only: shader-clock cycles per workgroup section seen by wave 0:
-// [0] issue of all loads + V transposes, [1] wait for the K copies, [2] barrier, [3] compute + store, [4] workgroups
-__device__ unsigned long long d2r_attn_stamps[8];
-extern "C" __attribute__((visibility("default"))) int d2r_debug_attn_stamps(unsigned long long *out, int reset)
-{
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(d2r_attn_stamps), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
-    if (reset) {
-        unsigned long long z[8] = {0};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(d2r_attn_stamps), z, sizeof(z)) != hipSuccess) return -1;
-    }
-    return 0;
-}
-#endif
-template <bool CAUSAL, int NQ = 1>
-__global__ __launch_bounds__(ATTN_THREADS / NQ, NQ == 2 ? 2 : 4) void k_attention(const uint16_t *__restrict__ QKV,
-                                                               uint16_t *__restrict__ AO, uint32_t T, uint32_t T_pad,
-                                                               uint32_t d, uint32_t M_pad, uint32_t stagger_lo, uint32_t stagger_hi)
-{
-    constexpr uint32_t TH = ATTN_THREADS / NQ;          // NQ = 2: four waves, two query tiles each (attn_qtile2)
-    static_assert(NQ == 1 || !CAUSAL, "the two-tile variant serves the vision tower");
+    constexpr uint32_t TH = ATTN_THREADS;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    // Every workgroup does the same work — load Q/K/V, barrier, arithmetic — so a launch whose workgroups all start
-    // together stays in lockstep: the whole chip loads (each CU at its HBM share), then the whole chip computes with
-    // the memory system idle (cycle stamps: 18 k + 13 k cycles per workgroup).  The first generation's second
-    // workgroup per CU starts half a period late; equal durations keep later generations half a period apart, so one
-    // workgroup's loads overlap the other's arithmetic on every CU.
-    {
-        const uint32_t lin = blockIdx.y * gridDim.x + blockIdx.x;
-        if (lin >= stagger_lo && lin < stagger_hi) {
-#pragma unroll 1
-            for (int i = 0; i < 2; i++) __builtin_amdgcn_s_sleep(127);
-        }
-    }
-#ifdef D2R_ATTN_STAMPS
-    const unsigned long long at0 = __builtin_readcyclecounter();
-#endif
     uint8_t *Ks = smem;                                  // T_pad * 128 B
     uint16_t *Vt = (uint16_t *)(smem + (size_t)T_pad * 128);
     const uint32_t vstride = T_pad + 4;
@@ -1562,27 +1392,26 @@ __global__ __launch_bounds__(ATTN_THREADS / NQ, NQ == 2 ? 2 : 4) void k_attentio
     // this wave's first query tile is requested before the staging so that its latency hides under it
     // (B operand of S^T = K Q^T: lane (q, hi) holds Q[q][16s + 8hi .. +8))
     const uint32_t n_qt = (T + 31) / 32, n_kt = T_pad / 32;
-    uint4 qf[NQ][4];
-#pragma unroll
-    for (int q = 0; q < NQ; q++) {
-        const uint32_t qrow0 = (wave * NQ + q) * 32 + li;
+    uint4 qf[4];
+    {
+        const uint32_t qrow0 = wave * 32 + li;
 #pragma unroll
         for (int s = 0; s < 4; s++)
-            qf[q][s] = (!(D2R_ATTN_ABLATE & 8) && qrow0 < T) ? *(const uint4 *)(Qg + (size_t)qrow0 * ld + 16 * s + 8 * hi) : make_uint4(0, 0, 0, 0);
+            qf[s] = qrow0 < T ? *(const uint4 *)(Qg + (size_t)qrow0 * ld + 16 * s + 8 * hi) : make_uint4(0, 0, 0, 0);
     }
     // K (row-major, swizzled 16-byte chunks) goes straight to LDS by LDS-DMA, 8 key rows per wave
     // instruction, issued before anything else so it overlaps the V transposes.  Rows >= T repeat row
     // T-1: their scores are masked by a select below, so any finite value does.
     {
         const uint32_t ks0 = __builtin_amdgcn_readfirstlane(lds_addr(Ks));
-        for (uint32_t b = __builtin_amdgcn_readfirstlane(wave); b < ((D2R_ATTN_ABLATE & 1) ? 0u : T_pad / 8); b += TH / 64) {
+        for (uint32_t b = __builtin_amdgcn_readfirstlane(wave); b < T_pad / 8; b += TH / 64) {
             const uint32_t row = b * 8 + (lane >> 3), src_row = row < T ? row : T - 1;
             glds16(Kg + (size_t)src_row * ld + ((lane & 7) ^ ((row >> 1) & 7u)) * 8, ks0 + b * 1024);
         }
     }
     // stage V^T: a task takes 4 keys x 8 dims (four 16-byte loads), transposes the 4x8 block in
     // registers (v_perm_b32) and writes one 8-byte word of 4 consecutive keys per dim
-    for (uint32_t i = tid; i < ((D2R_ATTN_ABLATE & 2) ? 0u : (T_pad / 4) * 8); i += TH) {
+    for (uint32_t i = tid; i < (T_pad / 4) * 8; i += TH) {
         const uint32_t kb = (i >> 3) * 4, c = i & 7;
         uint4 v[4];
 #pragma unroll
@@ -1601,46 +1430,17 @@ __global__ __launch_bounds__(ATTN_THREADS / NQ, NQ == 2 ? 2 : 4) void k_attentio
             *(uint2 *)(Vt + (size_t)(c * 8 + 2 * p + 1) * vstride + kb) = hi2;
         }
     }
-#ifdef D2R_ATTN_STAMPS
-    const unsigned long long at1 = __builtin_readcyclecounter();
-#endif
     wait_vmcnt<0>();              // this wave's K copies have landed
-#ifdef D2R_ATTN_STAMPS
-    const unsigned long long at2 = __builtin_readcyclecounter();
-#endif
     __syncthreads();
-#ifdef D2R_ATTN_STAMPS
-    const unsigned long long at3 = __builtin_readcyclecounter();
-#endif
-
-    if (D2R_ATTN_ABLATE & 4) {       // keep the loaded values alive
-        if (qf[0][0].x == 0x12345678u && Ks[tid] == 0x7f && Vt[tid] == 0x1234) AO[tid] = 1;
-    }
-    for (uint32_t qt = wave * NQ; qt < ((D2R_ATTN_ABLATE & 4) ? 0u : n_qt); qt += TH / 64 * NQ) {
-        if (qt != wave * NQ) {
+    for (uint32_t qt = wave; qt < n_qt; qt += TH / 64) {
+        if (qt != wave) {
+            const uint32_t qrow = qt * 32 + li;
 #pragma unroll
-            for (int q = 0; q < NQ; q++) {
-                const uint32_t qrow = (qt + q) * 32 + li;
-#pragma unroll
-                for (int s = 0; s < 4; s++)
-                    qf[q][s] = qrow < T ? *(const uint4 *)(Qg + (size_t)qrow * ld + 16 * s + 8 * hi) : make_uint4(0, 0, 0, 0);
-            }
+            for (int s = 0; s < 4; s++)
+                qf[s] = qrow < T ? *(const uint4 *)(Qg + (size_t)qrow * ld + 16 * s + 8 * hi) : make_uint4(0, 0, 0, 0);
         }
-        if constexpr (NQ == 2) attn_qtile2(Ks, Vt, vstride, qf, qt, T, n_kt, li, hi, AO, row_base, M_pad, head);
-        else attn_qtile<CAUSAL>(Ks, Vt, vstride, qf[0], qt, T, n_kt, li, hi, AO, row_base, M_pad, head);
+        attn_qtile<CAUSAL>(Ks, Vt, vstride, qf, qt, T, n_kt, li, hi, AO, row_base, M_pad, head);
     }
-#ifdef D2R_ATTN_STAMPS
-    {
-        const unsigned long long at4 = __builtin_readcyclecounter();
-        if (threadIdx.x == 0) {
-            atomicAdd(&d2r_attn_stamps[0], at1 - at0);
-            atomicAdd(&d2r_attn_stamps[1], at2 - at1);
-            atomicAdd(&d2r_attn_stamps[2], at3 - at2);
-            atomicAdd(&d2r_attn_stamps[3], at4 - at3);
-            atomicAdd(&d2r_attn_stamps[4], 1ull);
-        }
-    }
-#endif
 }
 
 // ---- streamed attention (vision tower) ----
@@ -1668,17 +1468,19 @@ __global__ __launch_bounds__(ATTN_THREADS / NQ, NQ == 2 ? 2 : 4) void k_attentio
 #define ATS_SLOT 8192u
 #define ATS_DEFER 8.0f
 typedef short s16x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ uint2 lds_read_tr16(uint32_t byte_addr)
+typedef __attribute__((address_space(3))) const uint8_t *lds_cptr;       // pointer arithmetic on it folds constants into the DS offset field
+__device__ __forceinline__ uint2 lds_read_tr16(lds_cptr p)
 {
     union { s16x4 s; uint2 u; } c;
-    c.s = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(size_t)byte_addr);
+    c.s = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)p);
     return c.u;
 }
 
-// softmax + PV of one key tile.  NR = 16: all of the tile's keys; NR = 4: the tile's first 8 keys only (registers 0..3).
+// softmax of one key tile's scores: running maximum with deferred rescale, P = exp2(s c - m) packed to bf16 as the B
+// fragments of the two PV k-steps (P regs 8s..8s+7 -> pb[s]).  NR = 16: all of the tile's keys; NR = 4: the tile's first
+// 8 keys only (registers 0..3; the other keys' P is 0).
 template <int NR>
-__device__ __forceinline__ void ats_softmax_pv(f32x16 &sacc, f32x16 &o0, f32x16 &o1, float &m_run, float &l_run, uint32_t vaddr0,
-                                               uint32_t vaddr1)
+__device__ __forceinline__ void ats_softmax(f32x16 &sacc, f32x16 &o0, f32x16 &o1, float &m_run, float &l_run, uint4 (&pb)[2])
 {
     const float sm_c = 0.125f * 1.4426950408889634f;   // head_dim^-0.5 * log2(e), head_dim = 64
 #if D2R_ATTN_ABLATE & 32
@@ -1718,25 +1520,15 @@ __device__ __forceinline__ void ats_softmax_pv(f32x16 &sacc, f32x16 &o0, f32x16 
         l_run += (sacc[0] + sacc[1]) + (sacc[2] + sacc[3]);
     }
 #endif
-    // O^T[d][q] += V^T[d][key] P^T[key][q]; P regs 8s..8s+7 are the B fragment of k-step s;
-    // A slot (hi, j) <-> key 16s + 8(j>>2) + 4hi + (j&3): two transposing reads of 4 keys each per O tile
-#pragma unroll
-    for (int s = 0; s < ((D2R_ATTN_ABLATE & 64) ? 0 : NR == 16 ? 2 : 1); s++) {
-        union { uint4 u; bf16x8 v; } pb, va0, va1;
-        pb.u.x = pack2(sacc[8 * s + 0], sacc[8 * s + 1]);
-        pb.u.y = pack2(sacc[8 * s + 2], sacc[8 * s + 3]);
-        if constexpr (NR == 16) {
-            pb.u.z = pack2(sacc[8 * s + 4], sacc[8 * s + 5]);
-            pb.u.w = pack2(sacc[8 * s + 6], sacc[8 * s + 7]);
-        } else {
-            pb.u.z = pb.u.w = 0u;                       // keys 8.. of the tile: P = 0
-        }
-        const uint2 a00 = lds_read_tr16(vaddr0 + 2048u * s), a01 = lds_read_tr16(vaddr0 + 2048u * s + 1024u);
-        const uint2 a10 = lds_read_tr16(vaddr1 + 2048u * s), a11 = lds_read_tr16(vaddr1 + 2048u * s + 1024u);
-        va0.u = make_uint4(a00.x, a00.y, a01.x, a01.y);
-        va1.u = make_uint4(a10.x, a10.y, a11.x, a11.y);
-        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va0.v, pb.v, o0, 0, 0, 0);
-        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va1.v, pb.v, o1, 0, 0, 0);
+    pb[0].x = pack2(sacc[0], sacc[1]);
+    pb[0].y = pack2(sacc[2], sacc[3]);
+    if constexpr (NR == 16) {
+        pb[0].z = pack2(sacc[4], sacc[5]);
+        pb[0].w = pack2(sacc[6], sacc[7]);
+        pb[1] = make_uint4(pack2(sacc[8], sacc[9]), pack2(sacc[10], sacc[11]), pack2(sacc[12], sacc[13]), pack2(sacc[14], sacc[15]));
+    } else {
+        pb[0].z = pb[0].w = 0u;
+        pb[1] = make_uint4(0u, 0u, 0u, 0u);
     }
 }
 
@@ -1762,10 +1554,15 @@ __global__ __launch_bounds__(ATS_THREADS, 4) void k_attention_s(const uint16_t *
     const uint16_t *src_plane = QKV + ((size_t)((is_v ? 2 * H : H) + head) * M_pad + row_base) * 64 + src_chunk * 8;
     const uint32_t smem0 = __builtin_amdgcn_readfirstlane(lds_addr(smem));
     const uint32_t dst_off = (is_v ? 4096u : 0u) + (wave & 3) * 1024u;
-    auto request = [&](uint32_t kt) {                    // key tile kt -> slot kt % ATS_STAGES (rows >= T repeat row T-1: masked / P = 0)
-        if (D2R_ATTN_ABLATE & 16) return;
+    // ring positions as running byte offsets (scalar add + wrap; a modulo by five per use costs a multiply-high and a
+    // vector add per LDS address): slot_req = where the next request lands, slot_k / slot_v = the slots the K
+    // fragments are read from next and this tile's V is read from
+    uint32_t slot_req = 0, slot_k = 0, slot_v = 0;
+    auto advance = [](uint32_t &slot) { slot = slot + ATS_SLOT == ATS_STAGES * ATS_SLOT ? 0u : slot + ATS_SLOT; };
+    auto request = [&](uint32_t kt) {                    // key tile kt -> the next ring slot (rows >= T repeat row T-1: masked / P = 0)
         const uint32_t row = kt * 32 + r_loc;
-        glds16(src_plane + (size_t)(row < T ? row : T - 1) * 64, smem0 + (kt % ATS_STAGES) * ATS_SLOT + dst_off);
+        if (!(D2R_ATTN_ABLATE & 16)) glds16(src_plane + (size_t)(row < T ? row : T - 1) * 64, smem0 + slot_req + dst_off);
+        advance(slot_req);
     };
     // Q fragments (B operand of S^T = K Q^T: lane (q, hi) holds Q[q][16s + 8hi .. +8)) first: oldest in the vmcnt order.
     // Loaded from inline asm and awaited by hand: a load hipcc can see makes it put `s_waitcnt vmcnt(0)` in front of the
@@ -1813,50 +1610,79 @@ __global__ __launch_bounds__(ATS_THREADS, 4) void k_attention_s(const uint16_t *
 
     // K fragments of the tile about to be used: read one tile ahead, under the previous tile's softmax
     uint4 ka[4];
-    auto read_k = [&](uint32_t kt) {
-        const uint32_t slot = smem0 + (kt % ATS_STAGES) * ATS_SLOT;
+    auto read_k = [&]() {                                 // the tile in slot_k, then on to the next slot
+        if (active) {
 #pragma unroll
-        for (int s = 0; s < 4; s++) ka[s] = *(const uint4 *)(__attribute__((address_space(3))) const uint8_t *)(size_t)(slot + koff[s]);
+            for (int s = 0; s < 4; s++) ka[s] = *(const uint4 *)(lds_cptr)(size_t)(smem0 + slot_k + koff[s]);
+        }
+        advance(slot_k);
     };
-    if (active) read_k(0);
-    // One key tile.  S^T = K Q^T from the fragments read an iteration ago; then (unless LAST) the hand-over to the next
-    // tile: wait for this wave's request of tile kt+1 (WAIT younger requests may stay in flight), barrier — tile kt+1 is
-    // complete and every wave has finished tile kt-1, whose slot takes the request for tile kt + ATS_STAGES - 1 (REQ) —
-    // and the K fragments of tile kt+1 are read while this tile's softmax and PV run.
+    read_k();
+    // S^T = K Q^T of the tile whose K fragments are in ka (4 dependent MFMAs)
+    f32x16 sacc;
+    auto s_mfma = [&](f32x16 &acc, int s) {
+        union { uint4 u; bf16x8 v; } a, b;
+        a.u = ka[s];
+        b.u = qf[s];
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc, 0, 0, 0);
+    };
+    if (active) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) sacc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < ((D2R_ATTN_ABLATE & 128) ? 0 : 4); s++) s_mfma(sacc, s);
+    }
+    // One key tile, whose scores are already in sacc.  Unless LAST, first the hand-over to the next tile: wait for
+    // this wave's request of tile kt+1 (WAIT younger requests may stay in flight), barrier — tile kt+1 is complete and
+    // every wave has finished tile kt-1, whose slot takes the request for tile kt + ATS_STAGES - 1 (REQ) — and the K
+    // fragments of tile kt+1 are read, their latency under this tile's softmax.  Then O^T += V^T P^T (two accumulators,
+    // two k-steps) and the NEXT tile's S^T = K Q^T.
     auto tile = [&](uint32_t kt, auto wait_tag, auto req_tag, auto last_tag) {
         constexpr int WAIT = decltype(wait_tag)::value;
         constexpr bool LAST = decltype(last_tag)::value, REQ = decltype(req_tag)::value;
-        f32x16 sacc;
-        if (active) {
-#pragma unroll
-            for (int r = 0; r < 16; r++) sacc[r] = (D2R_ATTN_ABLATE & 128) ? __uint_as_float(ka[r & 3].x) : 0.f;
-#pragma unroll
-            for (int s = 0; s < ((D2R_ATTN_ABLATE & 128) ? 0 : 4); s++) {
-                union { uint4 u; bf16x8 v; } a, b;
-                a.u = ka[s];
-                b.u = qf[s];
-                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, sacc, 0, 0, 0);
-            }
-        }
         if constexpr (!LAST) {
             wait_vmcnt<WAIT>();
             if (!(D2R_ATTN_ABLATE & 256)) __syncthreads();
             if constexpr (REQ) request(kt + ATS_STAGES - 1);
-            if (active) read_k(kt + 1);
+            read_k();
         }
+        const lds_cptr v0 = (lds_cptr)(size_t)(smem0 + slot_v + voff0), v1 = (lds_cptr)(size_t)(smem0 + slot_v + voff1);
+        advance(slot_v);
         if (!active) return;
-        const uint32_t slot = smem0 + (kt % ATS_STAGES) * ATS_SLOT;
         // lane (q, hi), reg r  <->  key kt*32 + (r&3) + 8*(r>>2) + 4*hi
-        if (LAST && n_last <= 8) {
+        uint4 pb[2];
+        const bool short_tile = LAST && n_last <= 8;          // wave-uniform
+        if (short_tile) {
 #pragma unroll
             for (int r = 0; r < 4; r++) sacc[r] = (uint32_t)r + 4 * hi < n_last ? sacc[r] : -INFINITY;
-            ats_softmax_pv<4>(sacc, o0, o1, m_run, l_run, slot + voff0, slot + voff1);
+            ats_softmax<4>(sacc, o0, o1, m_run, l_run, pb);
         } else {
             if (LAST && n_last < 32) {
 #pragma unroll
                 for (int r = 0; r < 16; r++) sacc[r] = (uint32_t)((r & 3) + 8 * (r >> 2)) + 4 * hi < n_last ? sacc[r] : -INFINITY;
             }
-            ats_softmax_pv<16>(sacc, o0, o1, m_run, l_run, slot + voff0, slot + voff1);
+            ats_softmax<16>(sacc, o0, o1, m_run, l_run, pb);
+        }
+        // A slot (hi, j) <-> key 16s + 8(j>>2) + 4hi + (j&3): two transposing reads of 4 keys each per O tile and k-step
+#pragma unroll
+        for (int s = 0; s < ((D2R_ATTN_ABLATE & 64) ? 0 : 2); s++) {
+            if (s == 1 && short_tile) break;                  // keys 16.. of a short last tile: P = 0
+            union { uint4 u; bf16x8 v; } p, va0, va1;
+            p.u = pb[s];
+            const uint2 a00 = lds_read_tr16(v0 + 2048u * s), a01 = lds_read_tr16(v0 + 2048u * s + 1024u);
+            const uint2 a10 = lds_read_tr16(v1 + 2048u * s), a11 = lds_read_tr16(v1 + 2048u * s + 1024u);
+            va0.u = make_uint4(a00.x, a00.y, a01.x, a01.y);
+            va1.u = make_uint4(a10.x, a10.y, a11.x, a11.y);
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va0.v, p.v, o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va1.v, p.v, o1, 0, 0, 0);
+        }
+        // the next tile's scores (interleaving these four with the four above, three independent chains, measured
+        // no faster and costs ten registers)
+        if constexpr (!LAST) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) sacc[r] = (D2R_ATTN_ABLATE & 128) ? __uint_as_float(ka[r & 3].x) : 0.f;
+#pragma unroll
+            for (int s = 0; s < ((D2R_ATTN_ABLATE & 128) ? 0 : 4); s++) s_mfma(sacc, s);
         }
     };
     using std::integral_constant;
@@ -1891,138 +1717,6 @@ __global__ __launch_bounds__(ATS_THREADS, 4) void k_attention_s(const uint16_t *
             const u32x2 y = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
             if (qrow_e < T) *(uint4 *)(dst + 32 * t + 16 * g) = make_uint4(x[0], y[0], x[1], y[1]);
         }
-    }
-}
-
-// ---- persistent, double-buffered attention (vision tower) ----
-//
-// k_attention above gives each (image, head) its own workgroup: load Q/K/V, barrier, compute.  Every workgroup
-// of the launch is in the same phase at the same time (cycle stamps: 18 k cycles of loads at the per-CU HBM share,
-// then 13 k cycles of arithmetic with the memory system idle), so the kernel runs at ~55 % of the HBM rate.  Here one
-// workgroup per CU walks its share of the items with TWO K / V^T buffers in LDS: while item i is computed from
-// one buffer, item i+1's K streams into the other by LDS-DMA and its V and Q rows wait in registers; V is
-// transposed into LDS after the arithmetic.  Loads and arithmetic of different items overlap on every CU.
-// Items are (image, head) pairs, consecutive items = consecutive heads of one image (the same QKV rows).
-#define ATTN_MAX_VTASKS 2          /* V staging tasks per thread: (T_pad / 4) * 8 <= 2 * ATTN_THREADS */
-__global__ __launch_bounds__(ATTN_THREADS, 2) void k_attention_p(const uint16_t *__restrict__ QKV, uint16_t *__restrict__ AO,
-                                                                 uint32_t T, uint32_t T_pad, uint32_t d, uint32_t M_pad,
-                                                                 uint32_t n_heads, uint32_t n_items)
-{
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const uint32_t vstride = T_pad + 4;
-    const uint32_t buf_bytes = T_pad * 128u + 64u * vstride * 2u;       // K rows + V^T of one item (a multiple of 16)
-    const uint32_t tid = threadIdx.x, lane = tid & 63, li = lane & 31, hi = lane >> 5;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t ld = 64, H = d >> 6, n_qt = (T + 31) / 32, n_kt = T_pad / 32;
-    const uint32_t n_vtasks = (T_pad / 4) * 8;
-    const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem));
-
-    auto item_base = [&](uint32_t item, size_t &row_base, uint32_t &head) {
-        const uint32_t img = item / n_heads;
-        head = item - img * n_heads;
-        row_base = (size_t)img * T;
-    };
-    // K rows of `item` -> buffer b by LDS-DMA (rows >= T repeat row T-1: masked by a select, any finite value does)
-    auto issue_k = [&](uint32_t item, uint32_t b) {
-        size_t rb; uint32_t head;
-        item_base(item, rb, head);
-        const uint16_t *Kg = QKV + ((size_t)(H + head) * M_pad + rb) * 64;
-        for (uint32_t blk = wave; blk < T_pad / 8; blk += ATTN_THREADS / 64) {
-            const uint32_t row = blk * 8 + (lane >> 3), src_row = row < T ? row : T - 1;
-            glds16(Kg + (size_t)src_row * ld + ((lane & 7) ^ ((row >> 1) & 7u)) * 8, lds0 + b * buf_bytes + blk * 1024);
-        }
-    };
-    // V rows of `item` -> registers: a task takes 4 keys x 8 dims (four 16-byte loads)
-    auto load_v = [&](uint32_t item, uint4 (&v)[ATTN_MAX_VTASKS][4]) {
-        size_t rb; uint32_t head;
-        item_base(item, rb, head);
-        const uint16_t *Vg = QKV + ((size_t)(2 * H + head) * M_pad + rb) * 64;
-#pragma unroll
-        for (int t = 0; t < ATTN_MAX_VTASKS; t++) {
-            const uint32_t i = tid + t * ATTN_THREADS;
-            if (i < n_vtasks) {
-                const uint32_t kb = (i >> 3) * 4, c = i & 7;
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    v[t][k] = *(const uint4 *)(Vg + (size_t)(kb + k < T ? kb + k : T - 1) * ld + c * 8);   // keys >= T: finite filler, their P is 0
-            }
-        }
-    };
-    // ... transposed 4x8 blocks in registers (v_perm_b32) -> V^T of buffer b, 8-byte words of 4 consecutive keys per dim
-    auto store_vt = [&](const uint4 (&v)[ATTN_MAX_VTASKS][4], uint32_t b) {
-        uint16_t *Vt = (uint16_t *)(smem + b * buf_bytes + T_pad * 128u);
-#pragma unroll
-        for (int t = 0; t < ATTN_MAX_VTASKS; t++) {
-            const uint32_t i = tid + t * ATTN_THREADS;
-            if (i < n_vtasks) {
-                const uint32_t kb = (i >> 3) * 4, c = i & 7;
-                const uint32_t *w0 = (const uint32_t *)&v[t][0], *w1 = (const uint32_t *)&v[t][1];
-                const uint32_t *w2 = (const uint32_t *)&v[t][2], *w3 = (const uint32_t *)&v[t][3];
-#pragma unroll
-                for (int p = 0; p < 4; p++) {      // dims 2p, 2p+1 live in word p of every key's chunk
-                    uint2 lo, hi2;
-                    lo.x = __builtin_amdgcn_perm(w1[p], w0[p], 0x05040100);
-                    lo.y = __builtin_amdgcn_perm(w3[p], w2[p], 0x05040100);
-                    hi2.x = __builtin_amdgcn_perm(w1[p], w0[p], 0x07060302);
-                    hi2.y = __builtin_amdgcn_perm(w3[p], w2[p], 0x07060302);
-                    *(uint2 *)(Vt + (size_t)(c * 8 + 2 * p) * vstride + kb) = lo;
-                    *(uint2 *)(Vt + (size_t)(c * 8 + 2 * p + 1) * vstride + kb) = hi2;
-                }
-            }
-        }
-    };
-    // this wave's query tile of `item` (B operand of S^T = K Q^T: lane (q, hi) holds Q[q][16s + 8hi .. +8))
-    auto load_q = [&](uint32_t item, uint4 (&q)[4]) {
-        size_t rb; uint32_t head;
-        item_base(item, rb, head);
-        const uint16_t *Qg = QKV + ((size_t)head * M_pad + rb) * 64;
-        const uint32_t qrow = wave * 32 + li;
-#pragma unroll
-        for (int s = 0; s < 4; s++)
-            q[s] = (wave < n_qt && qrow < T) ? *(const uint4 *)(Qg + (size_t)qrow * ld + 16 * s + 8 * hi) : make_uint4(0, 0, 0, 0);
-    };
-
-    uint32_t item = blockIdx.x;
-    if (item >= n_items) return;
-    uint4 qf[4], vreg[ATTN_MAX_VTASKS][4];
-    issue_k(item, 0);
-    load_v(item, vreg);
-    load_q(item, qf);
-    store_vt(vreg, 0);
-    wait_vmcnt<0>();
-    __syncthreads();
-    for (uint32_t b = 0;; b ^= 1u) {
-        const uint32_t next = item + gridDim.x;
-        const bool has_next = next < n_items;                      // block-uniform
-        uint4 qn[4];
-        if (has_next) {
-            // buffer b^1 was last read while the PREVIOUS item was computed; every wave has passed the barrier since
-            issue_k(next, b ^ 1u);
-            load_v(next, vreg);
-            load_q(next, qn);
-        }
-        size_t rb; uint32_t head;
-        item_base(item, rb, head);
-        const uint8_t *Ks = smem + b * buf_bytes;
-        const uint16_t *Vt = (const uint16_t *)(Ks + T_pad * 128u);
-        // one query tile per wave (n_qt <= 8); longer sequences take several rounds (their Q rows are loaded here)
-        for (uint32_t qt = wave; qt < n_qt; qt += ATTN_THREADS / 64) {
-            if (qt != wave) {
-                const uint16_t *Qg = QKV + ((size_t)head * M_pad + rb) * 64;
-                const uint32_t qrow = qt * 32 + li;
-#pragma unroll
-                for (int s = 0; s < 4; s++)
-                    qf[s] = qrow < T ? *(const uint4 *)(Qg + (size_t)qrow * ld + 16 * s + 8 * hi) : make_uint4(0, 0, 0, 0);
-            }
-            attn_qtile<false>(Ks, Vt, vstride, qf, qt, T, n_kt, li, hi, AO, rb, M_pad, head);
-        }
-        if (!has_next) break;
-        store_vt(vreg, b ^ 1u);
-#pragma unroll
-        for (int s = 0; s < 4; s++) qf[s] = qn[s];
-        wait_vmcnt<0>();              // this wave's K copies (and its AO stores) are complete
-        __syncthreads();              // buffer b^1 is complete; buffer b is free for the item after next
-        item = next;
     }
 }
 
@@ -2442,50 +2136,23 @@ static int launch_gemm(d2r_ctx *ctx, const uint16_t *A, const uint16_t *W, const
     return launch_gemm_cfg<EPI, 4, 2, 2, 3>(ctx, A, W, bias, C, M_real, N, K, aux);
 }
 
-// LDS footprint of k_attention for a padded sequence length, and the one-time opt-in to more than 64 KiB
-// of dynamic LDS (both the vision and the text tower go through here)
-// vision tower: the persistent double-buffered kernel when two K / V^T buffers fit in LDS (T <= ~270), else one
-// workgroup per (image, head)
-static int attention_setup(d2r_ctx *ctx, uint32_t T_pad, size_t *lds_out);
-static int launch_attention_vision(d2r_ctx *ctx, const uint16_t *QKV, uint16_t *AO, uint32_t T, uint32_t T_pad, uint32_t d,
-                                   uint32_t M_pad, uint32_t n_heads, uint32_t n, size_t attn_lds)
+// vision tower: streamed attention, one workgroup per (image, head, group of eight query tiles)
+static void launch_attention_vision(d2r_ctx *ctx, const uint16_t *QKV, uint16_t *AO, uint32_t T, uint32_t d, uint32_t M_pad,
+                                    uint32_t n_heads, uint32_t n)
 {
-    const size_t two = 2 * attn_lds;
-    const uint32_t n_items = n * n_heads;
-    if (ctx->attn_stream) {
-        const uint32_t n_qt = (T + 31) / 32;
-        hipLaunchKernelGGL(k_attention_s, dim3(n_heads, n, (n_qt + 7) / 8), dim3(ATS_THREADS), ATS_STAGES * ATS_SLOT, ctx->stream, QKV, AO, T, d, M_pad);
-        return D2R_OK;
-    }
-    if (ctx->attn_persistent && two <= 160 * 1024 && (T_pad / 4) * 8 <= ATTN_MAX_VTASKS * ATTN_THREADS && n_items >= (uint32_t)ctx->n_cu) {
-        static PerDeviceOnce attr;
-        attr.run(ctx->device, [] {
-            (void)hipFuncSetAttribute((const void *)k_attention_p, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        });
-        hipLaunchKernelGGL(k_attention_p, dim3((uint32_t)ctx->n_cu), dim3(ATTN_THREADS), two, ctx->stream, QKV, AO, T, T_pad, d,
-                           M_pad, n_heads, n_items);
-    } else {
-        // (two workgroups per CU when 2 * attn_lds fits: stagger the second one of the first generation)
-        const uint32_t lo = ctx->attn_stagger && 2 * attn_lds <= 160 * 1024 ? (uint32_t)ctx->n_cu : 0u;
-        if (ctx->attn_q2)
-            hipLaunchKernelGGL((k_attention<false, 2>), dim3(n_heads, n), dim3(ATTN_THREADS / 2), attn_lds, ctx->stream, QKV, AO, T, T_pad, d,
-                               M_pad, 0u, 0u);
-        else
-        hipLaunchKernelGGL(k_attention<false>, dim3(n_heads, n), dim3(ATTN_THREADS), attn_lds, ctx->stream, QKV, AO, T, T_pad, d,
-                           M_pad, lo, lo ? 2u * (uint32_t)ctx->n_cu : 0u);
-    }
-    return D2R_OK;
+    const uint32_t n_qt = (T + 31) / 32;
+    hipLaunchKernelGGL(k_attention_s, dim3(n_heads, n, (n_qt + 7) / 8), dim3(ATS_THREADS), ATS_STAGES * ATS_SLOT, ctx->stream, QKV, AO, T, d, M_pad);
 }
 
+// LDS footprint of the resident k_attention (text tower) for a padded sequence length, and the one-time opt-in to
+// more than 64 KiB of dynamic LDS
 static int attention_setup(d2r_ctx *ctx, uint32_t T_pad, size_t *lds_out)
 {
     const size_t attn_lds = (size_t)T_pad * 128 + (size_t)64 * (T_pad + 4) * 2;
-    if (attn_lds > 160 * 1024) return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "sequence too long for the attention LDS layout");
+    if (attn_lds > 160 * 1024) return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "sequence too long for the resident attention LDS layout");
     static PerDeviceOnce attn_attr;
     attn_attr.run(ctx->device, [] {
-        (void)hipFuncSetAttribute((const void *)k_attention<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void *)k_attention<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void *)k_attention<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     *lds_out = attn_lds;
     return D2R_OK;
@@ -2533,9 +2200,6 @@ int d2r_clip_forward(d2r_ctx *ctx, const d2r_clip *clip, const uint16_t *patches
 
     if ((rc = launch_gemm<EPI_F32>(ctx, patches_dev, clip->w.w_patch, nullptr, patch_out, prow, d, clip->Kp_pad)))
         return rc;
-    const uint32_t T_pad = round_up(T, 32);
-    size_t attn_lds = 0;
-    if ((rc = attention_setup(ctx, T_pad, &attn_lds))) return rc;
     const int fold = (int)ctx->ln_fold;
     // the last block runs on the class-token rows only (last_block_cls); needs its small workspaces to fit what exists
     const bool cls_last = ctx->cls_last && D.num_layers >= 1 && T <= 1024 && round_up(n, BM) <= round_up(prow, BM);
@@ -2559,7 +2223,7 @@ int d2r_clip_forward(d2r_ctx *ctx, const d2r_clip *clip, const uint16_t *patches
                 if ((rc = last_block_cls(ctx, D, L, n, T, rows_pad, QKV, nullptr, X, nullptr, nullptr, patch_out, AO, Xn, H))) return rc;
                 break;
             }
-            (void)launch_attention_vision(ctx, QKV, AO, T, T_pad, d, rows_pad, D.num_heads, n, attn_lds);
+            launch_attention_vision(ctx, QKV, AO, T, d, rows_pad, D.num_heads, n);
             if ((rc = launch_gemm<EPI_BIAS_RESID_F32>(ctx, AO, L.w_o, L.b_o, X, rows, d, d, a_tm))) return rc;
             hipLaunchKernelGGL(k_layernorm, dim3((rows + 3) / 4), dim3(256), 0, ctx->stream, X, L.ln2_w, L.ln2_b, Xn,
                                rows, d);
@@ -2615,7 +2279,7 @@ int d2r_clip_forward(d2r_ctx *ctx, const d2r_clip *clip, const uint16_t *patches
             break;
         }
         if ((rc = launch_gemm<EPI_LN_BIAS_BF16>(ctx, Xn, L.wf_qkv, L.bf_qkv, QKV, rows, 3 * d, d, ln))) return rc;
-        (void)launch_attention_vision(ctx, QKV, AO, T, T_pad, d, rows_pad, D.num_heads, n, attn_lds);
+        launch_attention_vision(ctx, QKV, AO, T, d, rows_pad, D.num_heads, n);
         if (xf32) rc = launch_gemm<EPI_RESID_STATS_F32X>(ctx, AO, L.w_o, L.b_o, X, rows, d, d, st);
         else if (split) rc = launch_gemm<EPI_RESID_STATS_SPLIT>(ctx, AO, L.w_o, L.b_o, Xn, rows, d, d, st);
         else rc = launch_gemm<EPI_RESID_STATS_BF16>(ctx, AO, L.w_o, L.b_o, Xn, rows, d, d, st);
@@ -2908,7 +2572,7 @@ extern "C" int d2r_text_encode(d2r_ctx *ctx, const d2r_text *tt, const int32_t *
         const ClipWeights::Layer &L = tt->layers[l];
         hipLaunchKernelGGL(k_layernorm, dim3((rows + 3) / 4), dim3(256), 0, ctx->stream, X, L.ln1_w, L.ln1_b, Xn, rows, d);
         if ((rc = launch_gemm<EPI_BIAS_BF16>(ctx, Xn, L.w_qkv, L.b_qkv, QKV, rows, 3 * d, d, out_tm))) return rc;
-        hipLaunchKernelGGL(k_attention<true>, dim3(D.num_heads, Cn), dim3(ATTN_THREADS), attn_lds, ctx->stream, QKV, AO, T, T_pad, d, rows_pad, 0u, 0u);
+        hipLaunchKernelGGL(k_attention<true>, dim3(D.num_heads, Cn), dim3(ATTN_THREADS), attn_lds, ctx->stream, QKV, AO, T, T_pad, d, rows_pad);
         if ((rc = launch_gemm<EPI_BIAS_RESID_F32>(ctx, AO, L.w_o, L.b_o, X, rows, d, d, a_tm))) return rc;
         hipLaunchKernelGGL(k_layernorm, dim3((rows + 3) / 4), dim3(256), 0, ctx->stream, X, L.ln2_w, L.ln2_b, Xn, rows, d);
         if ((rc = launch_gemm<EPI_BIAS_GELU_BF16>(ctx, Xn, L.w_fc1, L.b_fc1, H, rows, mlp, d, out_tm))) return rc;

@@ -1,0 +1,34 @@
+// clip_dev.h — measurement switches of clip.hip.  DEVELOPMENT BUILDS ONLY (make DEV=1, or GEMM_ABLATE= / ATTN_ABLATE= /
+// EXTRA=-DD2R_GEMM_STAMPS): the product library is built without this file.
+//
+// D2R_GEMM_ABLATE (bitmask) — k_gemm8 and the shared epilogue: 1 no LDS-DMA, 2 no fragment ds_reads, 4 no epilogue,
+//   8 no MFMA, 128 no global loads/stores in the epilogue, 256 no LDS transposes in the epilogue.
+// D2R_ATTN_ABLATE (bitmask) — k_attention_s: 16 no DMA requests, 32 no softmax, 64 no PV (V reads + MFMAs), 128 no
+//   S MFMAs, 256 no per-tile barriers.
+// Results are garbage when a mask is set; tools/gemm_ablate.sh / tools/attn_ablate.sh rebuild with each mask to see
+// what a tile's time is made of.
+// D2R_GEMM_STAMPS — shader-clock cycles wave 0 of every workgroup spends per tile section of k_gemm8, read back with
+//   d2r_debug_gemm_stamps (tools/gemm_stamps.py): [EPI][0 drain wait, 1 K loop, 2 epilogue, 3 tiles].
+#pragma once
+#ifndef D2R_GEMM_ABLATE
+#define D2R_GEMM_ABLATE 0
+#endif
+#ifndef D2R_ATTN_ABLATE
+#define D2R_ATTN_ABLATE 0
+#endif
+#ifdef D2R_GEMM_STAMPS
+#define D2R_GEMM_STAMP_KINDS 9          /* EPI_KINDS of clip.hip */
+__device__ unsigned long long d2r_gemm_stamps[D2R_GEMM_STAMP_KINDS][4];
+extern "C" __attribute__((visibility("default"))) int d2r_debug_gemm_stamps(unsigned long long *out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(d2r_gemm_stamps), sizeof(unsigned long long) * 4 * D2R_GEMM_STAMP_KINDS) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[4 * D2R_GEMM_STAMP_KINDS] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(d2r_gemm_stamps), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#define STAMP(var) const unsigned long long var = __builtin_readcyclecounter()
+#else
+#define STAMP(var)
+#endif

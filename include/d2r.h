@@ -328,16 +328,15 @@ D2R_API int d2r_get_timing(d2r_ctx *ctx, d2r_timing *out);
  *     bits), 2: one bf16 array (fastest; its accumulated rounding puts the logit error past 1e-3 of the logit
  *     scale in the tail, so it is not the default), 3: fp32 next to the bf16 copy.
  * "cls_last" (default 1): the last transformer block of the vision tower runs on the class-token rows only (the head
- *     reads nothing else; same result, ~6 % less ViT work).  "gemm_nsplit" (default 0 = 2 where the column tiles and XCDs divide evenly; 1 = off): XCD sets own column
- *     sections of the persistent GEMM's outputs so that a section's weight panels stay in their L2s.  "attn_q2" (two query tiles per wave), "attn_persistent", "attn_stagger", "gemm_stagger",
- *     "gemm_group": alternative schedules of the attention / persistent-GEMM kernels that were measured no faster
- *     and are kept switchable; results do not depend on them.
+ *     reads nothing else; same result, ~6 % less ViT work).  "gemm_nsplit" (default 0 = 2 where the column tiles and
+ *     XCDs divide evenly; 1 = off): XCD sets own column sections of the persistent GEMM's outputs so that a section's
+ *     weight panels stay in their L2s; results do not depend on it.
  * "prep_reuse" (default 1): in d2r_render_score, the rows of CLIP patches of a candidate frame that its object cannot have
  *     touched (outside the rectangle its rays are generated in) are copied from the background frame's own patches,
  *     computed once per d2r_set_background; bit-identical to resampling them.
- * "timing" (0/1): record HIP events per kernel group for d2r_get_timing.  "march_blocks" (default 0 =
- *     one persistent workgroup per CU), "gemm_cfg" (0 default, 1 plain-K-loop 256x256 kernel, 2 force
- *     256x128): development switches. */
+ * "timing" (0/1): record HIP events per kernel group for d2r_get_timing.
+ * Development builds of the library (make DEV=1) also know experiment switches — schedules that were measured no faster
+ * and tile configurations kept for comparison; they are not part of this interface. */
 D2R_API int d2r_ctx_set_option(d2r_ctx *ctx, const char *key, int64_t value);
 
 /* ------------------------------------------------------ multi-GPU (one process per GPU) */

@@ -118,10 +118,11 @@ def test_aabb_scale_4_model_renders_like_the_oracle(tmp_path):
     rgba, depth = bg.render_batch(cam[None, :3], W, H)
     orgba, odepth = pipe.background()
     assert (odepth > 0).sum() > 1000 and odepth.max() > 2.0          # the far wall is seen
-    assert ((depth[0] > 0) != (odepth > 0)).mean() < 2e-3
-    ok = (depth[0] > 0) == (odepth > 0)
-    assert np.abs(rgba[0] - orgba)[ok].max() < 2e-2 and np.abs(depth[0] - odepth)[ok].max() < 1.5e-2
-    assert np.abs(rgba[0] - orgba)[ok].mean() < 5e-4
+    # held to the bar of the unit-cube models: identical hit masks (the cone-step lattice and the cascade choice are the
+    # same fp32 expressions on both sides: measured 0 differing pixels, max |drgba| 1.8e-3, max |ddepth| 9e-4)
+    assert ((depth[0] > 0) == (odepth > 0)).all()
+    np.testing.assert_allclose(rgba[0], orgba, rtol=0, atol=5e-3)
+    np.testing.assert_allclose(depth[0], odepth, rtol=0, atol=2e-3)
     poses = host_ref.sample_poses_grid(scene.scene_centre, [2, 2, 2, 1, 1, 1], scene.scene_type).reshape(-1, 4, 4)
     view = fg.view(W, H)
     ctx.set_background(view, orgba, odepth)
@@ -129,7 +130,7 @@ def test_aabb_scale_4_model_renders_like_the_oracle(tmp_path):
     frames = fg.render_composite(view, T1, cam, host_ref.converter(poses.astype(np.float32)))
     want = pipe.frames(poses, bg=(orgba, odepth))
     diff = np.abs(frames.astype(int) - want.astype(int)).max(-1)
-    assert (diff > 1).mean() < 5e-4 and (diff > 0).mean() < 0.02
+    assert diff.max() <= 1 and (diff > 0).mean() < 0.02                 # uint8 frames within 1 LSB (measured: 0.1 % of pixels off by one)
     assert ctx.render_stats()["samples"] > 1000
     # snapshot round trip with three Morton-ordered cascades (C loader)
     path = str(tmp_path / "room.ingp")
@@ -162,10 +163,9 @@ def test_aabb_scale_2_model_renders_like_the_oracle():
     rgba, depth = bg.render_batch(cam[None, :3], W, H)
     orgba, odepth = pipe.background()
     assert (odepth > 0).sum() > 1000
-    assert ((depth[0] > 0) != (odepth > 0)).mean() < 2e-3        # lattice points within an ulp of a cell face
-    ok = (depth[0] > 0) == (odepth > 0)
-    assert np.abs(rgba[0] - orgba)[ok].max() < 2e-2 and np.abs(depth[0] - odepth)[ok].max() < 1e-2
-    assert np.abs(rgba[0] - orgba)[ok].mean() < 5e-4
+    assert ((depth[0] > 0) == (odepth > 0)).all()                # identical hit masks, as for the unit-cube models
+    np.testing.assert_allclose(rgba[0], orgba, rtol=0, atol=5e-3)
+    np.testing.assert_allclose(depth[0], odepth, rtol=0, atol=2e-3)
     assert bg.last_samples > 10000
     # foreground candidates, composited
     poses = host_ref.sample_poses_grid(scene.scene_centre, [3, 2, 1, 1, 1, 1], scene.scene_type).reshape(-1, 4, 4)
@@ -180,7 +180,7 @@ def test_aabb_scale_2_model_renders_like_the_oracle():
     np.testing.assert_array_equal(out[0], out[1])
     want = pipe.frames(poses, bg=(orgba, odepth))
     diff = np.abs(out[1].astype(int) - want.astype(int)).max(-1)
-    assert (want != want[:1]).any() and (diff > 1).mean() < 1e-3 and (diff > 0).mean() < 0.02
+    assert (want != want[:1]).any() and diff.max() <= 1 and (diff > 0).mean() < 0.02
     # field queries take positions in the unit cube of the box
     r = np.random.Generator(np.random.PCG64(4))
     xyz = r.random((777, 3)).astype(np.float32)
@@ -1136,9 +1136,8 @@ def test_six_dof_pose_grid_on_the_shelf_scene_matches_oracle():
     st = ctx.render_stats()
     want = pipe.frames(poses.reshape(-1, 4, 4), bg=obg)
     diff = np.abs(frames.astype(int) - want.astype(int)).max(-1)
-    # cone-stepped lattice points within an ulp of a cell face may fall either side (see the aabb_scale-2
-    # test above): a handful of pixels may differ by more than 1 LSB
-    assert (diff > 1).mean() < 5e-4 and (diff > 0).mean() < 0.02
+    # within 1 LSB everywhere, like the unit-cube scenes (measured: 0.15 % of the pixels off by one, none by more)
+    assert diff.max() <= 1 and (diff > 0).mean() < 0.02
     base = render_ref.composite(np.zeros((H, W, 4), np.float32), np.zeros((H, W), np.float32), obg[0], obg[1])
     n_visible = sum(bool((f != base).any()) for f in want)
     assert 10 < n_visible <= len(want) and st["samples"] > 10000
@@ -1213,11 +1212,12 @@ def test_argmax_pose_identical_with_vit_b16_on_a_16x16_grid(gpu, tmp_path):
     got2 = scores2.numpy()
     np.testing.assert_allclose(got2, want, rtol=0, atol=tol)
     np.testing.assert_allclose(got2, host_ref.spatially_smooth_heatmap(got.copy(), sample_res), rtol=0, atol=1e-5)   # same frames, same logits
+    # the smoothed landscape of this fixture keeps a distinct peak too (oracle-side property: 2.3 x the propagated
+    # tolerance above the runner-up), so the argmax after smoothing must be identical as well — unconditionally
     stop = np.sort(want)[::-1]
-    if stop[0] - stop[1] > 2 * tol:
-        assert int(np.argmax(got2)) == int(np.argmax(want))
-    else:
-        assert want[int(np.argmax(got2))] >= stop[0] - 2 * tol
+    assert stop[0] - stop[1] > 2 * tol, "fixture must keep a distinct peak after smoothing"
+    assert int(np.argmax(got2)) == int(np.argmax(want)) == target
+    np.testing.assert_array_equal(best2.numpy().reshape(16), poses[target])
     assert np.loadtxt(tmp_path / "goal_pose.txt").shape == (4, 4)
     sc.close()
 
@@ -1262,8 +1262,8 @@ def test_vit_layernorm_fold_modes_match_oracle(gpu, name, n):
 
 @pytest.mark.gpu
 def test_gemm_tile_orders_and_last_block_schedules_do_not_change_results(gpu):
-    """The persistent GEMM's tile order (column sections over XCD sets, column groups) and its start stagger decide
-    WHICH workgroup computes a tile and when, never how: embeddings must be bit-identical under every setting.
+    """The persistent GEMM's tile order (column sections over XCD sets) decides WHICH workgroup computes a tile and
+    when, never how: embeddings must be bit-identical under every setting.
     cls_last (the last block on the class-token rows only) changes which kernels run the last block, so it is held to
     the rounding of one block instead: 1 - cos < 2e-6 against the full last block.  300 images: every product runs on
     the persistent 256x256 kernel (345 row panels, several tiles per workgroup)."""
@@ -1273,11 +1273,10 @@ def test_gemm_tile_orders_and_last_block_schedules_do_not_change_results(gpu):
     sc = engine.ClipScorer(ctx, cfg, sd)
     r = np.random.Generator(np.random.PCG64(17))
     pv = r.standard_normal((300, 3, 224, 224), dtype=np.float32)
-    defaults = {"gemm_nsplit": 0, "gemm_group": 65535, "gemm_stagger": 0, "cls_last": 1, "attn_q2": 0}
+    defaults = {"gemm_nsplit": 0, "cls_last": 1}
     try:
         base = sc.embed_pixels(pv)
-        # attn_q2: two query tiles per wave in the attention kernel — the same arithmetic in the same order per query
-        for key, values in (("gemm_nsplit", (1, 2, 4)), ("gemm_group", (0, 1, 2, 4)), ("gemm_stagger", (1,)), ("attn_q2", (1,))):
+        for key, values in (("gemm_nsplit", (1, 2, 4)),):
             for v in values:
                 ctx.set_option(key, v)
                 np.testing.assert_array_equal(sc.embed_pixels(pv), base, err_msg=f"{key}={v}")
@@ -1290,3 +1289,8 @@ def test_gemm_tile_orders_and_last_block_schedules_do_not_change_results(gpu):
         for k, v in defaults.items():
             ctx.set_option(k, v)
         sc.close()
+    # the experiment switches of development builds are not part of the product's option surface
+    from dream2real_amd import _lib
+    for key in ("gemm_group", "gemm_stagger", "gemm_cfg", "attn_q2", "attn_persistent", "attn_stagger", "attn_stream"):
+        with pytest.raises(_lib.D2RError):
+            ctx.set_option(key, 1)

@@ -232,7 +232,9 @@ def test_gpu_prefilter_with_margins_compound_parts_and_mesh_files(tmp_path):
     part_a = box([-0.05, -0.05, 0.08], [0.05, 0.05, 0.12]) + [0, 0, 0.005]
     part_b = box([-0.05, -0.05, 0.0], [-0.01, 0.05, 0.08]) + [0, 0, 0.005]
     init = np.eye(4, dtype=np.float32)
-    xs, ys, zs = np.linspace(-0.6, 1.15, 36), [0.0, 0.07], [0.0, 0.0115, 0.0135, 0.1, 0.2055, 0.2175, 0.2195, -0.5]
+    # (the grid is offset by a millimetre so that no face lies exactly in the plane of another: at distance exactly 0 an
+    # LP says "they share a point" while GJK's progress test says "no closer than touching" — either is right)
+    xs, ys, zs = np.linspace(-0.6, 1.15, 36) + 0.0013, [0.0007, 0.0707], [0.0, 0.0115, 0.0135, 0.1, 0.2055, 0.2175, 0.2195, -0.5]
     poses = _grid(xs, ys, zs)
     res = [len(xs), len(ys), len(zs), 1, 1, 1]
     v0 = np.ones(len(poses), bool)
