@@ -87,27 +87,24 @@ int d2r_comm_init(d2r_ctx *ctx, const void *id_blob, int rank, int world)
     if (!ctx) return d2r_fail(nullptr, D2R_ERR_INVALID, "null ctx");
     if (world < 1 || rank < 0 || rank >= world) return d2r_fail(ctx, D2R_ERR_INVALID, "bad rank / world size");
     if (ctx->comm) return d2r_fail(ctx, D2R_ERR_INVALID, "context already has a communicator");
-    ctx->comm_rank = rank;
-    ctx->comm_world = world;
-    if (world == 1 && !id_blob) return D2R_OK;       // single GPU: the gather is a device copy, no RCCL needed
+    // (the context's rank / world change only when the call succeeds)
+    if (world == 1 && !id_blob) {                    // single GPU: the gather is a device copy, no RCCL needed
+        ctx->comm_rank = 0;
+        ctx->comm_world = 1;
+        return D2R_OK;
+    }
     if (!id_blob) return d2r_fail(ctx, D2R_ERR_INVALID, "null id blob");
     RcclApi &R = rccl();
-    if (!R.error.empty()) {
-        ctx->comm_world = 1;
-        ctx->comm_rank = 0;
-        return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, R.error);
-    }
+    if (!R.error.empty()) return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, R.error);
     D2R_HIP(ctx, hipSetDevice(ctx->device));
     ncclUniqueId id;
     memcpy(id.internal, id_blob, NCCL_UNIQUE_ID_BYTES);
     ncclComm_t comm = nullptr;
     ncclResult_t r = R.CommInitRank(&comm, world, id, rank);
-    if (r != ncclSuccess) {
-        ctx->comm_world = 1;
-        ctx->comm_rank = 0;
-        return rccl_fail(ctx, "ncclCommInitRank", r);
-    }
+    if (r != ncclSuccess) return rccl_fail(ctx, "ncclCommInitRank", r);
     ctx->comm = comm;
+    ctx->comm_rank = rank;
+    ctx->comm_world = world;
     return D2R_OK;
 }
 

@@ -53,3 +53,108 @@ def test_product_does_not_use_oracle():
                 assert not re.search(r'#include\s*[<"].*oracle', src), f
     deps = subprocess.run(["ldd", _lib.LIB_PATH], capture_output=True, text=True).stdout
     assert "oracle" not in deps
+
+
+@pytest.mark.gpu
+def test_bad_arguments_return_error_codes():
+    """include/d2r.h: every function returns a negative d2r_status on bad input, with a message in d2r_last_error — no
+    exception crosses the ABI, nothing aborts.  Null handles, null buffers, zero sizes, mismatched sizes, unknown options,
+    handles of one context used with another's entry points."""
+    import numpy as np
+    C = ctypes
+    lib = _lib.load()
+    from dream2real_amd import engine
+    from dream2real_amd.clip_model import CLIP_CONFIGS, pack_vision_weights, random_clip_state_dict
+    from tests.scenes import make_scene
+    ctx = engine.Context(0)
+    h = ctx.h
+    null = C.c_void_p(0)
+    INVALID, DEVICE, UNSUPPORTED = -1, -2, -4
+
+    def msg():
+        return lib.d2r_last_error(h).decode()
+
+    out = C.c_void_p()
+    assert lib.d2r_ctx_create(12345, C.byref(out)) == INVALID and not out.value      # device index out of range
+    assert lib.d2r_ctx_create(0, None) == INVALID
+    assert lib.d2r_ctx_set_option(h, b"no_such_option", C.c_int64(1)) == INVALID and "no_such_option" in msg()
+    assert lib.d2r_ctx_set_option(h, b"chunk", C.c_int64(0)) == INVALID
+    assert lib.d2r_ctx_set_option(h, None, C.c_int64(0)) == INVALID
+    assert lib.d2r_ctx_set_option(null, b"chunk", C.c_int64(1)) == INVALID
+    assert lib.d2r_ctx_synchronize(null) == INVALID
+    # model creation: null descriptor, unsupported layout, bad aabb_scale
+    assert lib.d2r_nerf_create(h, None, C.byref(out)) < 0
+    scene = make_scene("pool_triangle")
+    tb = engine.Testbed(ctx, scene.fg)
+    k, lv = tb._keep, scene.fg.levels
+    def desc(**over):
+        d = _lib.NerfDesc(lv.n_levels, lv.n_features, _lib.ptr(k["scale"]), _lib.ptr(k["res"]), _lib.ptr(k["size"]), _lib.ptr(k["offset"]),
+                          lv.n_entries, _lib.ptr(k["grid"]), _lib.ptr(k["dw1"]), _lib.ptr(k["dw2"]), _lib.ptr(k["cw1"]), _lib.ptr(k["cw2"]),
+                          _lib.ptr(k["cw3"]), _lib.ptr(k["occ"]), 1, (C.c_float * 6)(*([0.0] * 6)))
+        for name, v in over.items():
+            setattr(d, name, v)
+        return d
+    for over in (dict(n_levels=12), dict(n_features=3), dict(aabb_scale=3), dict(aabb_scale=256), dict(grid_fp16=None), dict(occupancy_bits=None)):
+        d = desc(**over)
+        rc = lib.d2r_nerf_create(h, C.byref(d), C.byref(out))
+        assert rc in (INVALID, UNSUPPORTED), (over, rc)
+        assert msg()
+    # rendering: null model / view / cameras, zero-sized view
+    view = _lib.view_c(tb.view(32, 18))
+    cams = np.zeros((1, 12), np.float32)
+    rgba = np.zeros((1, 18, 32, 4), np.float32)
+    assert lib.d2r_render(h, null, C.byref(view), _lib.ptr(cams), 1, _lib.ptr(rgba), None, None) == INVALID
+    assert lib.d2r_render(h, tb.h, None, _lib.ptr(cams), 1, _lib.ptr(rgba), None, None) == INVALID
+    assert lib.d2r_render(h, tb.h, C.byref(view), None, 1, _lib.ptr(rgba), None, None) == INVALID
+    bad_view = _lib.view_c(tb.view(32, 18))
+    bad_view.width = 0
+    assert lib.d2r_render(h, tb.h, C.byref(bad_view), _lib.ptr(cams), 1, _lib.ptr(rgba), None, None) == INVALID
+    # composite / render_score before any background was set
+    poses = np.tile(np.eye(4, dtype=np.float32).reshape(1, 16), (2, 1))
+    frames = np.zeros((2, 18, 32, 3), np.uint8)
+    eye = np.eye(4, dtype=np.float32).reshape(16)
+    ctx2 = engine.Context(0)                                             # a context that never saw d2r_set_background
+    tb2 = engine.Testbed(ctx2, scene.fg)
+    assert lib.d2r_render_composite(ctx2.h, tb2.h, C.byref(view), _lib.ptr(eye), _lib.ptr(eye), _lib.ptr(poses), 2, _lib.ptr(frames)) == INVALID
+    assert "background" in lib.d2r_last_error(ctx2.h).decode()
+    assert lib.d2r_set_background(h, C.byref(view), None, None) == INVALID
+    # CLIP: wrong blob size, head dim != 64, null frames, zero captions
+    cfg = CLIP_CONFIGS["vit_tiny"]
+    sd = random_clip_state_dict(cfg, seed=6, text=False)
+    blob = pack_vision_weights(sd, cfg)
+    cd = _lib.ClipDesc(cfg["image_size"], cfg["patch_size"], cfg["hidden_size"], cfg["num_layers"], cfg["num_heads"], cfg["mlp"], cfg["proj"])
+    assert lib.d2r_clip_create(h, C.byref(cd), _lib.ptr(blob), C.c_size_t(blob.size - 1), C.byref(out)) == INVALID and "blob size" in msg()
+    cd_bad = _lib.ClipDesc(cfg["image_size"], cfg["patch_size"], cfg["hidden_size"], cfg["num_layers"], cfg["num_heads"] + 1, cfg["mlp"], cfg["proj"])
+    assert lib.d2r_clip_create(h, C.byref(cd_bad), _lib.ptr(blob), C.c_size_t(blob.size), C.byref(out)) in (INVALID, UNSUPPORTED)
+    sc = engine.ClipScorer(ctx, cfg, sd)
+    text = np.zeros((2, cfg["proj"]), np.float32)
+    lg = np.zeros((2, 2), np.float32)
+    assert lib.d2r_clip_score_frames(h, sc.h, None, 2, 32, 18, 1, _lib.ptr(text), 2, C.c_float(100.0), _lib.ptr(lg), None) == INVALID
+    assert lib.d2r_clip_score_frames(h, sc.h, _lib.ptr(frames), 2, 32, 18, 1, _lib.ptr(text), 0, C.c_float(100.0), _lib.ptr(lg), None) == INVALID
+    assert lib.d2r_clip_score_frames(h, null, _lib.ptr(frames), 2, 32, 18, 1, _lib.ptr(text), 2, C.c_float(100.0), _lib.ptr(lg), None) == INVALID
+    # collective: gather without a communicator on a context told it is one of several ranks; double init
+    assert lib.d2r_comm_init(h, None, 0, 2) == INVALID                   # world 2 needs an id blob
+    assert lib.d2r_comm_init(h, None, 3, 2) == INVALID                   # rank outside the world
+    assert lib.d2r_allgather_scores(h, None, C.c_size_t(4), None) == INVALID
+    # physics: offsets that do not increase, pose count that does not match the grid
+    v = np.zeros((4, 3), np.float32)
+    off_bad = np.array([0, 0], np.uint32)
+    assert lib.d2r_phys_create(h, _lib.ptr(v), _lib.ptr(off_bad), 1, None, None, 0, C.byref(out)) == INVALID
+    off = np.array([0, 4], np.uint32)
+    ph = C.c_void_p()
+    assert lib.d2r_phys_create(h, _lib.ptr(v), _lib.ptr(off), 1, None, _lib.ptr(np.zeros(1, np.uint32)), 0, C.byref(ph)) == 0
+    prm = _lib.PhysParams((C.c_uint32 * 6)(2, 2, 1, 1, 1, 1), (C.c_float * 16)(*eye), 0.0, 0.02, (C.c_float * 3)(0, 0, -1), 0.04, 1, 0, 0.0)
+    valid = np.ones(3, np.uint8)
+    assert lib.d2r_phys_check(h, ph, C.byref(prm), _lib.ptr(np.zeros((3, 16), np.float32)), 3, _lib.ptr(valid)) == INVALID and "sample_res" in msg()
+    prm.margin = -1.0
+    assert lib.d2r_phys_check(h, ph, C.byref(prm), _lib.ptr(np.zeros((4, 16), np.float32)), 4, _lib.ptr(np.ones(4, np.uint8))) == INVALID
+    lib.d2r_phys_destroy(ph)
+    # snapshot loader through the device entry: garbage and truncated bytes come back as error codes too
+    info, views = _lib.IngpInfo(), (_lib.IngpView * 4)()
+    for data in (b"\x81\xd9\xc8abc", b"\x78\x9c" + b"\x00" * 40, bytes(range(256)) * 8):
+        buf = np.frombuffer(data, np.uint8)
+        assert lib.d2r_nerf_load_ingp(h, _lib.ptr(buf), C.c_size_t(buf.size), C.byref(out), C.byref(info), views, 4) == INVALID
+    # the context still works after all of that
+    r2, d2 = tb.render_batch(cams.reshape(1, 3, 4), 32, 18)
+    assert np.isfinite(r2).all()
+    sc.close(); tb.close(); tb2.close(); ctx2.close(); ctx.close()

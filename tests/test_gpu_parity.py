@@ -474,6 +474,52 @@ def test_vit_embeddings_match_oracle(gpu, name, n):
     sc.close()
 
 
+@pytest.mark.parametrize("image_size", [32, 112, 128, 160, 192, 256])
+def test_streamed_attention_at_every_ring_tail_length(gpu, image_size):
+    """The streamed attention kernel walks ceil(T / 32) key tiles through a five-slot ring with a steady loop for tiles
+    that still request a later one and a hand-written tail (2, then 1, then 0 younger requests in flight) for the last
+    four, a short path for a last tile of <= 8 keys and a masked one otherwise.  The CLIP geometries only exercise
+    7, 9 and 19 tiles; these two-layer models cover 1 ... 5 and 9 tiles (the steady loop entered 0, 1 and 5 times) with
+    last tiles of 5, 18, 1, 5, 17 and 1 keys: tokens = (image_size / 16)^2 + 1 = 5, 50, 65, 101, 145, 257.  Three runs
+    bitwise equal (the ring is ordered by counted waits and barriers only)."""
+    engine, ctx = gpu["engine"], gpu["ctx"]
+    cfg = dict(CLIP_CONFIGS["vit_tiny"], image_size=image_size)
+    T = (image_size // 16) ** 2 + 1
+    assert T in (5, 50, 65, 101, 145, 257)
+    sd = random_clip_state_dict(cfg, seed=6, text=False)
+    sc = engine.ClipScorer(ctx, cfg, sd)
+    try:
+        r = np.random.Generator(np.random.PCG64(image_size))
+        pv = r.standard_normal((37, 3, image_size, image_size), dtype=np.float32)
+        ctx.set_option("cls_last", 0)                       # both layers through the full attention kernel
+        got = sc.embed_pixels(pv)
+        for _ in range(2):
+            np.testing.assert_array_equal(sc.embed_pixels(pv), got)
+        want = clip_ref.vision_embeds(pv[:6], sd, cfg)
+        assert (1.0 - cosine(got[:6], want)).max() < 1e-4
+    finally:
+        ctx.set_option("cls_last", 1)
+        sc.close()
+    # With these weights a score row spans ~1.4 (log2 units), so after the first tile no tile maximum ever exceeds the
+    # running one by the deferral threshold of 8 and the rescale never fires again.  Triple the q / k projections:
+    # rows span ~13, and (oracle-side count) the rescale fires mid-sequence for more than half of the query rows.  The
+    # bf16 rounding of q and k is amplified nine-fold in the scores, so the bar is the catastrophic-error one: a
+    # rescale applied to the wrong operands is an O(1) error, not 1e-2.
+    sd3 = {k: (v * np.float32(3.0) if ("q_proj.weight" in k or "k_proj.weight" in k) else v) for k, v in sd.items()}
+    sc = engine.ClipScorer(ctx, cfg, sd3)
+    try:
+        ctx.set_option("cls_last", 0)
+        g3 = sc.embed_pixels(pv[:8])
+        np.testing.assert_array_equal(sc.embed_pixels(pv[:8]), g3)
+        w3 = clip_ref.vision_embeds(pv[:8], sd3, cfg)
+        err = float((1.0 - cosine(g3, w3)).max())
+        print(f"streamed attention, T = {T}, q/k x3: 1 - cos = {err:.2e}")
+        assert np.isfinite(g3).all() and err < 1e-2
+    finally:
+        ctx.set_option("cls_last", 1)
+        sc.close()
+
+
 def test_vit_large_batch_is_deterministic_and_matches_oracle_at_both_ends(gpu):
     """448 images: every GEMM of the tower runs the persistent 256x256 kernel with several tiles per
     workgroup (rows = 88 256 -> 345 row panels).  Its staging ring is ordered by counted waits and
