@@ -113,3 +113,21 @@ def test_config4_six_dof_shelf_vit_l14(tmp_path):
     assert (np.abs(R - np.eye(3)).reshape(len(R), -1).max(1) > 0.5).mean() > 0.9
     lg = d["logits"]
     assert np.ptp(lg[:, 0]) > 1e-3                                        # candidates differ
+
+
+def test_eight_ranks_give_the_single_rank_scores(tmp_path):
+    """The N = 8 code path end to end (rendezvous, shard plan, ragged gather, scatter, smoothing) on whatever GPUs the
+    box has — eight ranks time-sharing one GPU here, so the gather goes through torch.distributed (gloo) instead of
+    RCCL — against the same grid on one rank: bit-identical logits and scores, the same argmax.  Grid [6,5,8]: 240
+    poses = 30 per rank."""
+    flags = ["--sample-res", "6,5,8,1,1,1", "--scaling", "strong", "--scene", "shopping", "--width", "160", "--height", "90", "--clip", "vit_tiny",
+             "--steps", "1", "--warmup", "0", "--cpu-sample", "0", "--chunk", "64"]
+    one, d1 = run_bench(tmp_path, *flags)
+    d1 = {k: d1[k] for k in d1.files}
+    eight, d8 = run_bench(tmp_path, "--gpus", "8", *flags)
+    assert eight["n_gpus"] == eight["ranks_seen"] == 8 and eight["config"]["poses_per_step"] == 240 and eight["cpu_baseline"]["value"] is None
+    assert one["config"]["baseline_config"] is None and "custom" in one["config"]["workload"]
+    np.testing.assert_array_equal(d8["run_idx"], d1["run_idx"])            # z-major shard order, whatever the rank count
+    np.testing.assert_array_equal(d8["logits"], d1["logits"])
+    np.testing.assert_array_equal(d8["scores"], d1["scores"])
+    assert eight["argmax_pose"] == one["argmax_pose"]
