@@ -1,6 +1,7 @@
 """Control flow of optimise_pose_grid (reference clip_scoring.py:71-234) with a fake renderer and
 scorer: validity scatter, score ratio, smoothing, argmax/best pose, best_render.png, cached
 renders, physics-only and template branches.  CPU only."""
+import dataclasses
 import os
 import types
 
@@ -175,3 +176,82 @@ def test_text_encoder_hook(tmp_path):
                                     phys_check=lambda p, t, v: v, scene_type=3, scorer=sc, text_encoder=Enc(), tokenizer=tok)
     assert len(calls) == 1 and calls[0].shape == (2, 3) and calls[0][0, 0] == 1       # "g", "n"
     np.testing.assert_array_equal(sc.seen[1], np.eye(2, 8, dtype=np.float32))
+
+
+@pytest.mark.gpu
+def test_dream_best_pose_flow_with_mesh_file_physics(tmp_path):
+    """The caller of the path (reference dream2real.py:286-358) end to end on the GPU: physics pre-filter from the
+    objects' .obj files -> renderer -> optimise_pose_grid -> goal_pose / pose_batch / pose_scores.txt, then the cached
+    goal pose read back.  Invalid poses per the oracle's restatement of unsupcol_check score exactly 0, the valid ones
+    match the oracle pipeline, one PNG per valid pose."""
+    import torch
+    from dream2real_amd import dream2real, engine, physics_utils
+    from dream2real_amd.clip_model import CLIP_CONFIGS, random_clip_state_dict
+    from oracle import host_ref, phys_ref
+    from tests.parity_utils import OraclePipeline, oracle_logits, scene_text_embeds
+    from tests.scenes import make_scene, make_task
+    from tests.test_physics import box, icosphere
+    scene = make_scene("shopping")
+    c = np.asarray(scene.scene_centre, np.float64)
+    # physics shapes in world coordinates, as get_phys_models would have written them: the table slab and the three
+    # blobs of the synthetic background in ONE file (lazy_phys_mods: the merged background object), the apple in another
+    table = box([c[0] - 0.6, c[1] - 0.6, -0.06], [c[0] + 0.6, c[1] + 0.6, 0.0])
+    blobs = [icosphere(c + np.array([dx, dy, r - 0.035]), r, 40, k) for k, (dx, dy, r) in enumerate(((0.12, -0.10, 0.05), (-0.15, 0.08, 0.04), (0.05, 0.15, 0.045)))]
+    apple = icosphere(np.asarray(scene.obj_pose)[:3, 3], 0.03, 40, 9)
+    bg_path, mov_path = str(tmp_path / "bground.obj"), str(tmp_path / "movable.obj")
+    with open(bg_path, "w") as f:
+        for k, h in enumerate([table] + blobs):
+            f.write(f"o part_{k}\n" + "".join(f"v {x:.9g} {y:.9g} {z:.9g}\n" for x, y, z in h))
+            base = sum(len(q) for q in ([table] + blobs)[:k])
+            f.write("".join(f"f {base + i + 1} {base + i + 2} {base + i + 3}\n" for i in range(len(h) - 2)))      # any faces that reference every vertex
+    open(mov_path, "w").write("".join(f"v {x:.9g} {y:.9g} {z:.9g}\n" for x, y, z in apple))
+    assert [len(h) for h in physics_utils.hulls_from_obj(bg_path)] == [8, 40, 40, 40] and len(physics_utils.hulls_from_obj(mov_path)[0]) == 40
+
+    ctx = engine.Context(0)
+    fg, bg = engine.Testbed(ctx, scene.fg), engine.Testbed(ctx, scene.bg)
+    fg.background_color = list(scene.fg_background)
+    cfg_clip = CLIP_CONFIGS["vit_tiny"]
+    sd = random_clip_state_dict(cfg_clip, seed=6)
+    sc = engine.ClipScorer(ctx, cfg_clip, sd)
+    W, H = 96, 54
+    pipe = OraclePipeline(scene, W, H)
+    _, e0 = oracle_logits(pipe.frames(np.asarray(scene.obj_pose, np.float32)[None]), cfg_clip, sd, np.zeros((1, cfg_clip["proj"])))
+    task = make_task(scene, fg, bg)
+    task.text_embeds = scene_text_embeds(e0[0])
+    task.movable_obj.phys_model, task.task_bground_obj.phys_model = mov_path, bg_path
+    sample_res = [7, 6, 2, 1, 1, 1]
+    d = str(tmp_path / "run")
+    os.makedirs(d)
+    cfg = dream2real.PathConfig(data_dir=d, sample_res=sample_res, scene_type=scene.scene_type, resolution=(W, H), spatial_smoothing=False)
+    eng = dream2real.ImaginationEngine(cfg, ctx, sc)
+    best, pose_batch, scores = eng.dream_best_pose(task)
+    assert len(eng.static_phys_handles) == 1 and len(eng.static_phys_handles[0]) == 4 and len(eng.movable_phys_handle) == 1
+    # oracle: physics mask, then render + score the valid poses
+    valid = phys_ref.unsupcol_check(pose_batch.numpy(), np.asarray(scene.obj_pose, np.float32), [apple], [table] + blobs, sample_res,
+                                    np.ones(84, bool), float(c[2]), margin=physics_utils.PYBULLET_MESH_MARGIN)
+    got = scores.numpy()
+    assert 5 < valid.sum() < 80, valid.sum()
+    assert ((got != 0) == valid).mean() > 0.97                       # hulls within rounding of the contact distance may fall either way
+    both = valid & (got != 0)
+    frames = pipe.frames(pose_batch.numpy()[both])
+    lg, _ = oracle_logits(frames, cfg_clip, sd, task.text_embeds)
+    want = host_ref.score_logits(lg, True)
+    tol = float((0.25 * (1.0 + np.abs(want)) / np.abs(lg[:, 1])).max())        # vit_tiny: 2.5e-3 cosine per logit, propagated
+    np.testing.assert_allclose(got[both], want, rtol=0, atol=tol)
+    assert len(os.listdir(os.path.join(d, "cb_render"))) == int((got != 0).sum())
+    for name in ("goal_pose.txt", "pose_batch.txt", "pose_scores.txt", "best_render.png"):
+        assert os.path.exists(os.path.join(d, name)), name
+    np.testing.assert_allclose(np.loadtxt(os.path.join(d, "pose_scores.txt")), got, rtol=1e-6)
+    assert got[int(np.argmax(got))] > 0 and np.allclose(best.numpy().reshape(16), pose_batch.numpy()[int(np.argmax(got))])
+    # the cached goal pose (use_cache_goal_pose, reference :335-341)
+    eng2 = dream2real.ImaginationEngine(dataclasses.replace(cfg, use_cache_goal_pose=True), ctx, sc)
+    b2, p2, s2 = eng2.dream_best_pose(task)
+    np.testing.assert_allclose(b2.numpy(), best.numpy(), rtol=1e-6)
+    np.testing.assert_allclose(s2.numpy(), got, rtol=1e-6)
+    # physics off: every pose is rendered (reference :324-326)
+    d3 = str(tmp_path / "run3")
+    os.makedirs(d3)
+    eng3 = dream2real.ImaginationEngine(dataclasses.replace(cfg, data_dir=d3, use_phys=False, sample_res=[3, 2, 1, 1, 1, 1]), ctx, sc)
+    _, _, s3 = eng3.dream_best_pose(task)
+    assert (s3.numpy() != 0).all() and len(os.listdir(os.path.join(d3, "cb_render"))) == 6
+    sc.close(); fg.close(); bg.close(); ctx.close()
