@@ -66,16 +66,20 @@ def allgather_logits(local_logits, n_total: int, rank: int, world: int):
 
 def _device_identity(index: int) -> str:
     """Something that names the physical GPU behind torch device `index` whatever HIP_VISIBLE_DEVICES maps it to:
-    its UUID, else its PCI bus id, else (no way to tell) the visible-devices string + index."""
+    every identifying property the runtime reports (UUID, PCI domain / bus / device), concatenated — a runtime that
+    leaves one of them empty or equal on all devices is still told apart by the others; with none of them, the
+    visible-devices string + index."""
     import torch
     props = torch.cuda.get_device_properties(index)
-    for attr in ("uuid", "pci_bus_id"):
+    parts = []
+    for attr in ("uuid", "pci_domain_id", "pci_bus_id", "pci_device_id"):
         v = getattr(props, attr, None)
         if v not in (None, ""):
-            dom, dev = getattr(props, "pci_domain_id", ""), getattr(props, "pci_device_id", "")
-            return f"{attr}:{v}:{dom}:{dev}" if attr == "pci_bus_id" else f"uuid:{v}"
-    vis = os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES", os.environ.get("CUDA_VISIBLE_DEVICES", "all")))
-    return f"visible:{vis}:{index}"
+            parts.append(f"{attr}={v}")
+    if not parts:
+        vis = os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES", os.environ.get("CUDA_VISIBLE_DEVICES", "all")))
+        parts.append(f"visible={vis}:{index}")
+    return ";".join(parts)
 
 
 def init_comm(ctx, rank: int, world: int) -> bool:
