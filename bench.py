@@ -115,7 +115,7 @@ def cpu_baseline(scene, W, H, cfg, sd, text, poses_world, n_sample):
     """The oracle (CPU restatement) timed on the host cores on a bounded sample of the same
     workload.  Checker code used here ONLY as the reported CPU baseline."""
     from oracle import render_ref
-    from tests.parity_utils import OraclePipeline, oracle_logits
+    from oracle.pipeline import OraclePipeline, oracle_logits
     pipe = OraclePipeline(scene, W, H)
     bg = pipe.background()                       # setup, not timed (once per view)
     n_sample = min(n_sample, len(poses_world))
@@ -202,6 +202,135 @@ def shard_plan(sample_res, world: int, partition: int) -> dict:
     return {"order": order, "shards": shards, "run_idx": run_idx, "n_run": int(len(run_idx))}
 
 
+# The reference's own workload (configs/shopping_demo.json:28, combined_rendering.py:86, clip_scoring.py:150-151): pose grid
+# [100,100,7,1,1,1] = 70 000 poses, 336x336 renders, openai/clip-vit-large-patch14-336, physics pre-filter on.
+REFERENCE_WORKLOAD = dict(scene="shopping", sample_res=[100, 100, 7, 1, 1, 1], width=336, height=336, clip="vit_l14_336",
+                          name="the reference's own configuration: shopping_demo.json grid [100,100,7,1,1,1] = 70000 poses, "
+                               "336x336, ViT-L/14-336, physics pre-filter on")
+
+
+def run_api(args):
+    """--api: the number a caller of the drop-in API gets.  One step = one `ImaginationEngine.dream_best_pose` call
+    (reference dream2real.py:286-358): physics pre-filter on the objects' mesh files -> renderer -> optimise_pose_grid (the
+    fused, chunked d2r_render_score_host call; pose-sharded with ONE all-gather under a launcher) -> smoothing -> argmax ->
+    goal_pose / pose_batch / pose_scores.txt (+ cb_render/*.png with --api-save 1, as the reference does).  Host arrays in,
+    host arrays out: pose upload, logits download, text files and PNG encoding are all inside the timed region."""
+    import resource
+    import shutil
+    import tempfile
+
+    import torch
+    from dream2real_amd import dist as d2r_dist
+    from dream2real_amd import dream2real, engine
+    from dream2real_amd.accio2ngp import converter
+    from dream2real_amd.clip_model import CLIP_CONFIGS, random_clip_state_dict
+    from synthetic_scenes import make_scene, make_task, scene_text_embeds, write_phys_meshes
+
+    rank, world, local = d2r_dist.init_from_env()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    local = local % torch.cuda.device_count()
+    torch.cuda.set_device(local)
+    base = dict(REFERENCE_WORKLOAD if args.config is None else BASELINE_CONFIGS[args.config])
+    scene_name, clip_name = args.scene or base["scene"], args.clip or base["clip"]
+    W, H = args.width or base["width"], args.height or base["height"]
+    sample_res = [int(x) for x in args.sample_res.split(",")] if args.sample_res else list(base["sample_res"])
+    scene = make_scene(scene_name)
+    cfg = CLIP_CONFIGS[clip_name]
+    sd = random_clip_state_dict(cfg, seed=6)
+    ctx = engine.Context(local)
+    ctx.set_option("chunk", args.chunk)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        ctx.set_option(k, int(v))
+    fg, bg = engine.Testbed(ctx, scene.fg), engine.Testbed(ctx, scene.bg)
+    fg.background_color = list(scene.fg_background)
+    scorer = engine.ClipScorer(ctx, cfg, sd)
+    task = make_task(scene, fg, bg)
+    cam_ngp = converter(np.asarray(scene.cam_poses, np.float32))[0]
+    T1 = converter(np.asarray(scene.obj_pose, np.float32)[None])[0]
+    bg_rgba, bg_depth = bg.render_batch(cam_ngp[None, :3], W, H)
+    view = fg.view(W, H)
+    ctx.set_background(view, bg_rgba[0], bg_depth[0])
+    _, e0 = scorer.score_frames(fg.render_composite(view, T1, cam_ngp, T1[None]), np.zeros((1, cfg["proj"]), np.float32), return_embeds=True)
+    task.text_embeds = scene_text_embeds(e0[0])
+    root = args.api_dir or tempfile.mkdtemp(prefix="d2r_api_")
+    data_dir = os.path.join(root, "run")
+    if rank == 0:
+        os.makedirs(data_dir, exist_ok=True)
+    use_phys = bool(args.api_phys) and scene_name in ("shopping", "pool_triangle")
+    if use_phys:
+        if rank == 0:
+            write_phys_meshes(scene, root)
+        task.movable_obj.phys_model, task.task_bground_obj.phys_model = os.path.join(root, "movable.obj"), os.path.join(root, "bground.obj")
+    if world > 1:
+        torch.distributed.barrier()
+    pcfg = dream2real.PathConfig(data_dir=data_dir, sample_res=sample_res, scene_type=scene.scene_type, resolution=(W, H),
+                                 use_phys=use_phys, save_renders=bool(args.api_save))
+    eng = dream2real.ImaginationEngine(pcfg, ctx, scorer)
+    stages = {}
+
+    def one():
+        t0 = time.perf_counter()
+        best, pose_batch, scores = eng.dream_best_pose(task)
+        stages["last_s"] = time.perf_counter() - t0
+        return best, pose_batch, scores
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one()
+    ctx.set_option("timing", 1)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        best, pose_batch, scores = one()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if torch.distributed.get_backend() == "nccl" else "cpu")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    timing = ctx.timing()
+    ctx.set_option("timing", 0)
+    if rank == 0:
+        sc = scores.numpy()
+        n_valid, N = int((sc != 0).sum()), int(sc.shape[0])
+        n_png = len(os.listdir(os.path.join(data_dir, "cb_render"))) if args.api_save else 0
+        label = (f"BASELINE.json configs[{args.config}]: {base['name']}" if args.config is not None else base["name"])
+        out = {
+            "metric": f"candidate renders scored/sec ({W}x{H}) through the drop-in API (ImaginationEngine.dream_best_pose)",
+            "value": round(n_valid * args.steps / elapsed, 2), "unit": "candidates/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{label} — ran: {scene_name} scene, pose grid {sample_res} = {N} poses sampled, {n_valid} valid after the "
+                                   f"physics pre-filter ({'GPU GJK on the mesh files' if use_phys else 'off: every pose valid'}), {W}x{H}, bf16 MLP + {clip_name}, "
+                                   f"{'pose-shard x' + str(world) if world > 1 else 'one GPU'}; host arrays in / out, "
+                                   f"save_renders={bool(args.api_save)} ({n_png} PNG files written per step)",
+                       "api": "dream2real_amd.dream2real.ImaginationEngine.dream_best_pose", "scene": scene_name, "clip": clip_name,
+                       "width": W, "height": H, "poses_sampled": N, "poses_valid": n_valid, "sample_res": sample_res,
+                       "save_renders": bool(args.api_save), "physics": use_phys,
+                       "parallelism": f"pose-shard x{world}" if world > 1 else "single GPU"},
+            "poses_sampled_per_s": round(N * args.steps / elapsed, 2),
+            "device_ms_per_step": {k.replace("_ms", ""): round(v / args.steps, 3) for k, v in timing.items() if k.endswith("_ms")},
+            "note_device_ms": "with the two-stream pipeline the render half (march / raygen / prep) overlaps the ViT of the previous chunk: the parts do not add up to the step",
+            "peak_host_rss_gb": round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1048576, 2),
+            "argmax_pose": int(np.argmax(sc)),
+            "roofline": None, "cpu_baseline": None,
+            "note": "API-level line (bench.py --api): the kernel-level line with roofline and cpu_baseline is the default `python bench.py`",
+        }
+        print(json.dumps(out), flush=True)
+        if not args.api_dir:
+            shutil.rmtree(root, ignore_errors=True)
+    if world > 1:
+        torch.distributed.barrier()
+        ctx.comm_destroy()
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -226,9 +355,17 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=32, help="candidates in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--dump", default=None, help="rank 0: write the last step's gathered logits, scores, pose order and grid to this .npz (tests)")
     ap.add_argument("--power-seconds", type=float, default=2.5, help="extra untimed seconds sampled with rocm-smi for the power line (0 = skip)")
+    ap.add_argument("--api", action="store_true",
+                    help="time the drop-in API (ImaginationEngine.dream_best_pose) instead of the kernel-level step; without --config: "
+                         "the reference's own workload (70 000 poses, 336x336, ViT-L/14-336, physics on)")
+    ap.add_argument("--api-save", type=int, default=0, help="--api: 1 = write cb_render/*.png for every valid pose, as the reference does")
+    ap.add_argument("--api-phys", type=int, default=1, help="--api: 0 = skip the physics pre-filter (every pose valid)")
+    ap.add_argument("--api-dir", default=None, help="--api: data_dir root (default: a temporary directory, removed afterwards)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args.gpus)
+    if args.api:
+        return run_api(args)
 
     import torch
     from dream2real_amd import dist as d2r_dist
@@ -237,7 +374,7 @@ def main():
     from dream2real_amd.clip_model import CLIP_CONFIGS, random_clip_state_dict
     from dream2real_amd.clip_scoring import reduce_logits
     from dream2real_amd.geometry_utils import spatially_smooth_heatmap
-    from tests.scenes import make_scene, make_task, scene_text_embeds
+    from synthetic_scenes import make_scene, make_task, scene_text_embeds
 
     rank, world, local = d2r_dist.init_from_env()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"

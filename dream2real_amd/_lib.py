@@ -9,7 +9,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libd2r.so")
-ABI_VERSION = 5          # D2R_ABI_VERSION of include/d2r.h this binding was written against
+ABI_VERSION = 6          # D2R_ABI_VERSION of include/d2r.h this binding was written against
 
 EXPORTS = [
     "d2r_abi_version", "d2r_ctx_create", "d2r_ctx_destroy", "d2r_ctx_set_stream", "d2r_ctx_synchronize",
@@ -19,7 +19,8 @@ EXPORTS = [
     "d2r_get_render_stats", "d2r_collect_render_stats", "d2r_ctx_set_option", "d2r_get_timing", "d2r_text_create",
     "d2r_text_destroy", "d2r_text_encode", "d2r_comm_get_unique_id", "d2r_comm_init", "d2r_comm_destroy",
     "d2r_allgather_scores", "d2r_phys_create", "d2r_phys_destroy", "d2r_phys_check", "d2r_nerf_load_ingp",
-    "d2r_rectify_background_depth", "d2r_ingp_inspect",
+    "d2r_rectify_background_depth", "d2r_ingp_inspect", "d2r_render_score_host", "d2r_png_write", "d2r_png_write_batch",
+    "d2r_png_read_batch", "d2r_png_size", "d2r_savetxt",
 ]
 
 
@@ -69,6 +70,10 @@ class IngpInfo(C.Structure):
     _fields_ = [("n_levels", C.c_uint32), ("n_features", C.c_uint32), ("aabb_scale", C.c_uint32),
                 ("has_background", C.c_int32), ("dataset_scale", C.c_double), ("dataset_offset", C.c_double * 3),
                 ("background_color", C.c_float * 4), ("n_views", C.c_uint32), ("n_views_written", C.c_uint32)]
+
+
+class FrameSink(C.Structure):
+    _fields_ = [("png_dir", C.c_char_p), ("png_first_index", C.c_uint32), ("png_threads", C.c_int32), ("png_level", C.c_int32)]
 
 
 class RenderStats(C.Structure):
@@ -129,6 +134,54 @@ def ingp_inspect(data: bytes) -> str:
     buf = C.create_string_buffer(need.value)
     check(lib.d2r_ingp_inspect(data, len(data), buf, need.value, None))
     return buf.value.decode("utf-8", "replace")
+
+
+def png_write(rgb, path: str, level: int = 1):
+    """d2r_png_write: one uint8 [h,w,3] image -> an RGB PNG file (host only)."""
+    a = np.ascontiguousarray(rgb, np.uint8)
+    assert a.ndim == 3 and a.shape[2] == 3
+    check(load().d2r_png_write(ptr(a), C.c_uint32(a.shape[1]), C.c_uint32(a.shape[0]), os.fsencode(path), C.c_int(level)))
+
+
+def png_write_batch(frames, out_dir: str, first_index: int = 0, threads: int = 0, level: int = 1):
+    """d2r_png_write_batch: uint8 [n,h,w,3] -> <out_dir>/cb_rgb_%04d.png on a pool of host threads (the GIL is released
+    for the duration of the call)."""
+    a = np.ascontiguousarray(frames, np.uint8)
+    assert a.ndim == 4 and a.shape[3] == 3
+    check(load().d2r_png_write_batch(ptr(a), C.c_uint32(a.shape[0]), C.c_uint32(a.shape[2]), C.c_uint32(a.shape[1]),
+                                     os.fsencode(out_dir), C.c_uint32(first_index), C.c_int(threads), C.c_int(level)))
+
+
+def png_size(path: str):
+    w, h = C.c_uint32(0), C.c_uint32(0)
+    check(load().d2r_png_size(os.fsencode(path), C.byref(w), C.byref(h)))
+    return int(w.value), int(h.value)
+
+
+def png_read_batch(in_dir: str, n: int = 0, first_index: int = 0, threads: int = 0, indices=None, size=None) -> np.ndarray:
+    """d2r_png_read_batch: <in_dir>/cb_rgb_%04d.png for n consecutive indices from first_index (or for the given
+    `indices`) -> uint8 [n,h,w,3].  `size` = (w, h), default the first file's; a file of another size is an error."""
+    idx = None if indices is None else np.ascontiguousarray(indices, np.uint32)
+    if idx is not None:
+        n = idx.shape[0]
+    if n == 0:
+        return np.empty((0, 0, 0, 3), np.uint8)
+    w, h = size or png_size(os.path.join(in_dir, f"cb_rgb_{int(idx[0]) if idx is not None else first_index:04d}.png"))
+    out = np.empty((n, h, w, 3), np.uint8)
+    check(load().d2r_png_read_batch(os.fsencode(in_dir), ptr(idx), C.c_uint32(first_index), C.c_uint32(n), C.c_uint32(w),
+                                    C.c_uint32(h), ptr(out), C.c_int(threads)))
+    return out
+
+
+def savetxt(path: str, array):
+    """d2r_savetxt: np.savetxt(path, array) with numpy's defaults, byte for byte, formatted on the library's worker
+    threads (1-D: one number per line; 2-D: one row per line; 0-D is refused like np.savetxt does)."""
+    a = np.asarray(array)
+    if a.ndim == 0 or a.ndim > 2:
+        raise ValueError(f"Expected 1D or 2D array, got {a.ndim}D array instead")
+    a = np.ascontiguousarray(a, np.float64)
+    rows, cols = (a.shape[0], 1) if a.ndim == 1 else a.shape
+    check(load().d2r_savetxt(os.fsencode(path), ptr(a), C.c_uint64(rows), C.c_uint64(cols), C.c_int(0)))
 
 
 def check(rc: int, ctx=None):

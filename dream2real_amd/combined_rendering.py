@@ -91,20 +91,105 @@ def _to_numpy(x):
     return x.detach().cpu().numpy() if hasattr(x, "detach") else np.asarray(x)
 
 
+# vision_3d/camera_info.py: INTRINSICS_CLIP_VIEW — the 336 x 336 CLIP-view camera convert_poses writes into the render
+# transforms (reference combined_rendering.py:211-247)
+INTRINSICS_CLIP_VIEW = np.array([[436.01158022, 0.0, 168.0], [0.0, 435.90814372, 168.0], [0.0, 0.0, 1.0]])
+
+
+class obj_nerf:
+    """`obj_nerf` of the reference's snapshot-file mode (combined_rendering.py:36-51): a Testbed loaded from an `.ingp`
+    file with the unit-test render settings.  The reference keeps it under `.testbed`; `renderer.render` reads
+    `.vis_model` (and `.pose` of the foreground), so both names are set here and `pose` defaults to the identity."""
+
+    def __init__(self, ctx, nerf_file, pose=None):
+        from .engine import Testbed
+        self.testbed = Testbed.from_snapshot(ctx, nerf_file)
+        self.testbed.background_color = [1.0, 1.0, 1.0, 0.0]
+        self.testbed.snap_to_pixel_centers = True
+        self.spp = 1
+        self.testbed.nerf.render_min_transmittance = 1e-4
+        self.testbed.shall_train = False
+        self.vis_model = self.testbed
+        self.pose = np.eye(4, dtype=np.float32) if pose is None else pose
+
+
 class renderer:
     resolution = (336, 336)     # (width, height); the reference hard-wires 336x336 (:86,:121)
 
-    def __init__(self, data_dir, task_model=None, resolution=None):
+    def __init__(self, data_dir, task_model=None, resolution=None, ctx=None):
+        """task_model given: the background / movable objects of the task (reference :58-60).  task_model None: the
+        reference's snapshot-file mode (:61-67) — `bg_base.ingp` / `fg_base.ingp` of data_dir are loaded through the
+        library's snapshot reader (needs `ctx`, an engine.Context) and `convert_poses` writes the render transforms."""
         self.root = data_dir
-        if task_model is None:
-            raise ValueError("renderer needs a task_model (the snapshot-file unit-test mode of the "
-                             "reference is not part of the path)")
-        self.bg_obj = task_model.task_bground_obj
-        self.fg_obj = task_model.movable_obj
+        if task_model is not None:
+            self.bg_obj = task_model.task_bground_obj
+            self.fg_obj = task_model.movable_obj
+        else:
+            if ctx is None:
+                raise ValueError("renderer(data_dir, task_model=None) loads bg_base.ingp / fg_base.ingp itself and needs ctx=engine.Context(...)")
+            self.bg_obj = obj_nerf(ctx, os.path.join(self.root, "bg_base.ingp"))
+            self.fg_obj = obj_nerf(ctx, os.path.join(self.root, "fg_base.ingp"))
+            self.bg_render_file = os.path.join(self.root, "bg_render_transforms.json")
+            self.fg_render_file = os.path.join(self.root, "fg_render_transforms.json")
+            self.convert_poses()
         if resolution is not None:
             self.resolution = tuple(resolution)
         self.out_render_path = os.path.join(self.root, "cb_render")
         os.makedirs(self.out_render_path, exist_ok=True)
+
+    def convert_poses(self):
+        """reference :211-247: bg/fg_transforms.json -> bg/fg_render_transforms.json with the CLIP-view intrinsics at
+        336 x 336; the background keeps its first frame, the foreground frames become the first one shifted by 2 cm per
+        index along -z and -y."""
+        import json
+        for name, fg in (("bg", False), ("fg", True)):
+            with open(os.path.join(self.root, f"{name}_transforms.json")) as f:
+                out = json.load(f)
+            out["fl_x"], out["fl_y"] = float(INTRINSICS_CLIP_VIEW[0, 0]), float(INTRINSICS_CLIP_VIEW[1, 1])
+            out["cx"], out["cy"] = float(INTRINSICS_CLIP_VIEW[0, 2]), float(INTRINSICS_CLIP_VIEW[1, 2])
+            out["w"] = out["h"] = 336
+            if not fg:
+                out["frames"] = [out["frames"][0]]
+            else:
+                m0 = np.array(out["frames"][0]["transform_matrix"])
+                for i in range(len(out["frames"])):
+                    m = m0.copy()
+                    m[2, 3] -= 0.02 * i
+                    m[1, 3] -= 0.02 * i
+                    out["frames"][i]["transform_matrix"] = m.tolist()
+            with open(os.path.join(self.root, f"{name}_render_transforms.json"), "w") as f:
+                json.dump(out, f, indent=2)
+
+    def _clear_renders(self):
+        # reference :88-92: old renders are deleted first
+        if os.path.exists(self.out_render_path):
+            shutil.rmtree(self.out_render_path)
+        os.makedirs(self.out_render_path)
+
+    def _setup_view(self, render_idx, render_poses, render_cam_pose_idx, depths_gt, movable_masks):
+        """Background of one render view (reference :95-116): Shade (+ Depth) render of the background model, or the
+        rectified sensor depth, handed to the library as the fixed frame the candidates are composited over.
+        -> (view, cam_matrix [4,4])."""
+        W, H = self.resolution
+        fg, bg = self.fg_obj.vis_model, self.bg_obj.vis_model
+        ctx = fg.ctx
+        cam_matrix = np.asarray(render_poses[render_idx])
+        bg.set_camera_to_training_view(render_cam_pose_idx[render_idx])
+        bg.background_color = [0.0, 0.0, 0.0, 1.0]
+        bg.set_nerf_camera_matrix(cam_matrix[:-1, :])
+        bg.render_ground_truth = False
+        bg_rgba, bg_depth = bg.render_batch(cam_matrix[None, :3, :], W, H)
+        if depths_gt is not None:
+            # rectify_depth + rectify_mask + depth[mask == 0] = 100 on the GPU (d2r_rectify_background_depth)
+            bg_depth = ctx.rectify_background_depth(_to_numpy(depths_gt[render_idx]), _to_numpy(movable_masks[render_idx]), W, H)[None]
+        fg.set_camera_to_training_view(render_cam_pose_idx[render_idx])
+        view = fg.view(W, H)
+        ctx.set_background(view, bg_rgba[0], bg_depth[0])
+        self._last = (view, cam_matrix)
+        return view, cam_matrix
+
+    def _T_WO_1(self):
+        return accio2ngp.converter(_to_numpy(self.fg_obj.pose)[None])[0]
 
     def render(self, valid_poses, render_poses, render_cam_pose_idx, depths_gt=None, movable_masks=None, save=True):
         """valid_poses [K,4,4] and render_poses [L,4,4] in NGP convention -> list of K*L uint8 [H,W,3].
@@ -112,47 +197,59 @@ class renderer:
         where the rectified movable mask is 0 (reference :107-110; note the reference indexes
         depths_gt and movable_masks by the loop counter, reproduced here); otherwise the
         background NeRF's own depth render is used (:111-113)."""
-        W, H = self.resolution
-        fg, bg = self.fg_obj.vis_model, self.bg_obj.vis_model
-        ctx = fg.ctx
-        T_WO_1 = accio2ngp.converter(_to_numpy(self.fg_obj.pose)[None])[0]
+        fg = self.fg_obj.vis_model
+        T_WO_1 = self._T_WO_1()
         valid_poses = np.asarray(valid_poses)
         render_imgs = []
         if save:
-            if os.path.exists(self.out_render_path):
-                shutil.rmtree(self.out_render_path)
-            os.makedirs(self.out_render_path)
+            self._clear_renders()
         for render_idx in range(len(render_cam_pose_idx)):
-            cam_matrix = np.asarray(render_poses[render_idx])
-            # background: one Shade + Depth render per view (:98-113)
-            bg.set_camera_to_training_view(render_cam_pose_idx[render_idx])
-            bg.background_color = [0.0, 0.0, 0.0, 1.0]
-            bg.set_nerf_camera_matrix(cam_matrix[:-1, :])
-            bg.render_ground_truth = False
-            bg_rgba, bg_depth = bg.render_batch(cam_matrix[None, :3, :], W, H)
-            if depths_gt is not None:
-                # rectify_depth + rectify_mask + depth[mask == 0] = 100 on the GPU (d2r_rectify_background_depth)
-                bg_depth = ctx.rectify_background_depth(_to_numpy(depths_gt[render_idx]), _to_numpy(movable_masks[render_idx]), W, H)[None]
-            fg.set_camera_to_training_view(render_cam_pose_idx[render_idx])
-            view = fg.view(W, H)
-            ctx.set_background(view, bg_rgba[0], bg_depth[0])
+            view, cam_matrix = self._setup_view(render_idx, render_poses, render_cam_pose_idx, depths_gt, movable_masks)
             frames = fg.render_composite(view, T_WO_1, cam_matrix, valid_poses)
             render_imgs.extend(list(frames))
         if save and render_idx == 0:
-            # the reference writes cb_rgb_%04d.png inline (:157-159); here PNG encoding runs on a worker
-            # thread so that scoring starts at once — wait_saved() joins it (optimise_pose_grid does)
-            self._start_writer(list(render_imgs))
+            # the reference writes cb_rgb_%04d.png inline (:157-159); here PNG encoding runs on the library's worker
+            # threads (d2r_png_write_batch, GIL released) behind a Python thread so that scoring starts at once —
+            # wait_saved() joins it (optimise_pose_grid does)
+            self._start_writer(np.stack(render_imgs) if render_imgs else np.empty((0, 1, 1, 3), np.uint8))
         return render_imgs
 
-    def _start_writer(self, imgs):
+    def render_score(self, valid_poses, render_poses, render_cam_pose_idx, scorer, text_embeds, depths_gt=None,
+                     movable_masks=None, save=True, first_index=0, clear=True, return_frames=False):
+        """The fused form of `render` + the CLIP batches of optimise_pose_grid (reference :73-163 and
+        clip_scoring.py:142-185) for one render view: K candidate poses -> logits_per_image [K,C], frames staying on the
+        GPU (d2r_render_score_host).  save: cb_rgb_%04d.png for every candidate, numbered from `first_index`, written by the
+        library while it renders the next chunk (complete on return); `clear`: delete old renders first, as `render` does
+        (a pose shard other than the first passes False).  return_frames: also the uint8 frames [K,H,W,3]."""
+        from .engine import render_score_host
+        if len(render_cam_pose_idx) != 1:
+            raise ValueError("render_score scores one render view (the reference's score scatter assumes one frame per valid pose)")
+        fg = self.fg_obj.vis_model
+        if save and clear:
+            self._clear_renders()
+        view, cam_matrix = self._setup_view(0, render_poses, render_cam_pose_idx, depths_gt, movable_masks)
+        return render_score_host(fg.ctx, fg, scorer, view, self._T_WO_1(), cam_matrix, np.asarray(valid_poses), text_embeds,
+                                 return_frames=return_frames, png_dir=self.out_render_path if save else None,
+                                 png_first_index=first_index)
+
+    def render_one(self, pose_ngp):
+        """One candidate's frame in the view `render` / `render_score` set up last (uint8 [H,W,3])."""
+        view, cam_matrix = self._last
+        return self.fg_obj.vis_model.render_composite(view, self._T_WO_1(), cam_matrix, np.asarray(pose_ngp)[None])[0]
+
+    def _start_writer(self, frames):
         import threading
+        from . import _lib
         out_dir = self.out_render_path
+        err = []
 
         def work():
-            from PIL import Image
-            for i, img in enumerate(imgs):
-                Image.fromarray(img).save(os.path.join(out_dir, f"cb_rgb_{i:04d}.png"), compress_level=1)
+            try:
+                _lib.png_write_batch(frames, out_dir)
+            except Exception as e:       # surfaced by wait_saved
+                err.append(e)
         self.wait_saved()
+        self._writer_err = err
         self._writer = threading.Thread(target=work, name="d2r-png-writer", daemon=False)
         self._writer.start()
 
@@ -162,3 +259,5 @@ class renderer:
         if t is not None:
             t.join()
             self._writer = None
+            if self._writer_err:
+                raise self._writer_err[0]

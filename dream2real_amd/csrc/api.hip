@@ -6,6 +6,7 @@
 #include <algorithm>
 
 #include "d2r_internal.h"
+#include "pngio.h"
 
 // implemented in clip.hip / nerf.hip
 struct d2r_clip;
@@ -144,8 +145,12 @@ void d2r_ctx_destroy(d2r_ctx *c)
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     (void)d2r_comm_destroy(c);
+    if (c->render_stream) hipStreamSynchronize(c->render_stream);
+    if (c->copy_stream) hipStreamSynchronize(c->copy_stream);
+    delete c->pool;
     d2r_ctx::Buf *bufs[] = {&c->cams, &c->queue, &c->counters, &c->frames, &c->rgba, &c->depth, &c->poses,
-                            &c->text, &c->logits, &c->pix, &c->bg_rgba, &c->bg_depth, &c->bg_u8, &c->rects, &c->bg_patches, &c->rect_ws};
+                            &c->text, &c->logits, &c->pix, &c->bg_rgba, &c->bg_depth, &c->bg_u8, &c->rects, &c->bg_patches, &c->rect_ws,
+                            &c->patches2, &c->frames2};
     for (auto *b : bufs)
         if (b->p) hipFree(b->p);
     for (auto &b : c->clipws)
@@ -155,6 +160,14 @@ void d2r_ctx_destroy(d2r_ctx *c)
         if (c->text_ev[k]) (void)hipEventDestroy(c->text_ev[k]);
         if (c->text_host[k]) (void)hipHostFree(c->text_host[k]);
     }
+    hipEvent_t evs[] = {c->ev_fork, c->ev_prep[0], c->ev_prep[1], c->ev_clip[0], c->ev_clip[1], c->ev_march[0], c->ev_march[1],
+                        c->ev_copy[0], c->ev_copy[1]};
+    for (hipEvent_t e : evs)
+        if (e) (void)hipEventDestroy(e);
+    for (int k = 0; k < 2; k++)
+        if (c->frame_host[k]) (void)hipHostFree(c->frame_host[k]);
+    if (c->render_stream) (void)hipStreamDestroy(c->render_stream);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -192,12 +205,14 @@ int d2r_ctx_set_option(d2r_ctx *ctx, const char *key, int64_t value)
         ctx->prep_reuse = value != 0;
     } else if (!strcmp(key, "cls_last")) {
         ctx->cls_last = value != 0;
-#ifdef D2R_DEV
-    // experiment switches of development builds (make DEV=1): schedules that were measured no faster and tile
-    // configurations kept for comparison (DESIGN.md section 4); a product build does not know these keys
+    } else if (!strcmp(key, "overlap")) {
+        ctx->overlap = value != 0;
     } else if (!strcmp(key, "march_blocks")) {
         if (value < 0 || value > 65535) return d2r_fail(ctx, D2R_ERR_INVALID, "march_blocks out of range");
         ctx->march_blocks = value;
+#ifdef D2R_DEV
+    // experiment switches of development builds (make DEV=1): schedules that were measured no faster and tile
+    // configurations kept for comparison (DESIGN.md section 4); a product build does not know these keys
     } else if (!strcmp(key, "gemm_cfg")) {
         ctx->gemm_cfg = value;
     } else if (!strcmp(key, "gemm_group")) {
@@ -751,27 +766,108 @@ int d2r_clip_embed_pixels(d2r_ctx *ctx, const d2r_clip *clip, const float *pixel
 
 // ------------------------------------------------------------ fused hot path
 
-int d2r_render_score(d2r_ctx *ctx, const d2r_nerf *fg, const d2r_clip *clip, const d2r_view *view,
-                     const float *obj_pose_now, const float *cam_pose, const float *obj_poses_dev, uint32_t K,
-                     const float *text_embeds, uint32_t C, float logit_scale, float *logits_dev, uint8_t *frames_out)
+// Runs launches on another stream of the context for the lifetime of the guard (the launchers of nerf.hip / clip.hip
+// and the timing events all go to ctx->stream).
+struct StreamSwap {
+    d2r_ctx *c;
+    hipStream_t saved;
+    StreamSwap(d2r_ctx *ctx, hipStream_t s) : c(ctx), saved(ctx->stream) { ctx->stream = s; }
+    ~StreamSwap() { c->stream = saved; }
+};
+
+static int ensure_pipeline(d2r_ctx *ctx, bool need_copy)
 {
-    if (!ctx || !fg || !clip || !obj_pose_now || !cam_pose || !obj_poses_dev || !logits_dev)
-        return d2r_fail(ctx, D2R_ERR_INVALID, "null argument");
-    int rc = check_view(ctx, view);
-    if (rc) return rc;
-    hipSetDevice(ctx->device);
-    if ((rc = upload_text(ctx, clip, text_embeds, C))) return rc;
+    if (!ctx->render_stream) D2R_HIP(ctx, hipStreamCreateWithFlags(&ctx->render_stream, hipStreamNonBlocking));
+    if (need_copy && !ctx->copy_stream) D2R_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    hipEvent_t *all[] = {&ctx->ev_fork, &ctx->ev_prep[0], &ctx->ev_prep[1], &ctx->ev_clip[0], &ctx->ev_clip[1],
+                         &ctx->ev_march[0], &ctx->ev_march[1], &ctx->ev_copy[0], &ctx->ev_copy[1]};
+    for (hipEvent_t *e : all)
+        if (!*e) D2R_HIP(ctx, hipEventCreateWithFlags(e, hipEventDisableTiming));
+    return D2R_OK;
+}
+
+// Candidates per pass when frames leave the GPU: two pinned staging buffers of at most 1 GiB each.
+static uint32_t frame_pass_size(uint32_t per, size_t px)
+{
+    const uint64_t fit = std::max<uint64_t>(64, (1ull << 30) / (px * 3));
+    uint64_t p = std::min<uint64_t>(per, fit);
+    if (p >= 256) p -= p % 256;
+    return (uint32_t)std::max<uint64_t>(1, p);
+}
+
+// Hands the frames of one finished chunk (in pinned buffer b) to the worker pool: PNG files and / or the copy into
+// the caller's array.  The buffer is free again when the pool has finished group b.
+static void dispatch_frames(d2r_ctx *ctx, int b, uint32_t c0, uint32_t nc, uint32_t W, uint32_t H, uint8_t *frames_out,
+                            const d2r_frame_sink *sink)
+{
+    const uint8_t *src = (const uint8_t *)ctx->frame_host[b];
+    const size_t fb = (size_t)W * H * 3;
+    if (sink && sink->png_dir) {
+        const std::string dir(sink->png_dir);
+        const uint32_t first = sink->png_first_index + c0;
+        const int level = sink->png_level;
+        for (uint32_t i = 0; i < nc; i++)
+            ctx->pool->submit(b, [=](std::string &err) { return d2r_png_write_file(src + fb * i, W, H, level, d2r_png_name(dir, first + i), err); });
+    }
+    if (frames_out) {
+        const uint32_t step = std::max<uint32_t>(1, (uint32_t)((32u << 20) / fb));
+        for (uint32_t i = 0; i < nc; i += step) {
+            const uint32_t m = std::min(step, nc - i);
+            uint8_t *dst = frames_out + ((size_t)c0 + i) * fb;
+            ctx->pool->submit(b, [=](std::string &) { memcpy(dst, src + fb * i, fb * m); return 0; });
+        }
+    }
+}
+
+// The pass over K candidates: per chunk  cameras -> ray generation -> march + composite -> (frames to the host) ->
+// rot90 + CLIP preprocess  on the RENDER stream, ViT forward + logits on the context's stream; the patch buffer is
+// double-buffered between the two, so chunk i+1 renders while chunk i is scored ("overlap" option; with 0 both
+// halves run on the context's stream in program order, as before round 4).  poses_dev / logits_dev are device
+// pointers ordered on the context's stream.  With frames_out / sink the frames of every chunk are copied to one of two
+// pinned host buffers on a copy stream and handed to the worker pool; the call then returns after the last file is
+// written, otherwise it is asynchronous.
+static int render_score_core(d2r_ctx *ctx, const d2r_nerf *fg, const d2r_clip *clip, const d2r_view *view,
+                             const float *obj_pose_now, const float *cam_pose, const float *poses_dev, uint32_t K,
+                             uint32_t C, float logit_scale, float *logits_dev, uint8_t *frames_out, const d2r_frame_sink *sink)
+{
+    int rc;
     const ViewParams V = d2r_view_params(view);
     const size_t px = (size_t)V.W * V.H;
-    const uint32_t per = pass_size(ctx, clip, px);
+    const bool to_host = frames_out || (sink && sink->png_dir);
+    uint32_t per = pass_size(ctx, clip, px);
+    if (to_host) per = frame_pass_size(per, px);
+    const uint32_t nchunks = (K + per - 1) / per;
     ctx->last_pass = per;
-    ctx->last_chunks = (K + per - 1) / per;
-    // workspaces are sized once for a full chunk so that no allocation happens inside the loop
+    ctx->last_chunks = nchunks;
     const uint32_t cap = std::min(per, K);
+    const bool two = ctx->overlap != 0 && nchunks > 1;
+    if ((rc = ensure_pipeline(ctx, to_host))) return rc;
+    // workspaces are sized once for a full chunk so that no allocation happens inside the loop
+    const size_t patch_bytes = d2r_clip_patch_bytes(clip, cap);
     if ((rc = d2r_reserve(ctx, ctx->cams, (size_t)cap * 48))) return rc;
+    if ((rc = d2r_reserve(ctx, ctx->queue, (size_t)cap * px * sizeof(uint2)))) return rc;
     if ((rc = d2r_reserve(ctx, ctx->frames, (size_t)cap * px * 3))) return rc;
-    if ((rc = d2r_reserve(ctx, ctx->clipws[6], d2r_clip_patch_bytes(clip, cap)))) return rc;
-    if ((rc = d2r_reserve(ctx, ctx->counters, 64 + 32 * (size_t)((K + per - 1) / per)))) return rc;
+    if ((rc = d2r_reserve(ctx, ctx->clipws[6], patch_bytes))) return rc;
+    if (two && (rc = d2r_reserve(ctx, ctx->patches2, patch_bytes))) return rc;
+    if (to_host && nchunks > 1 && (rc = d2r_reserve(ctx, ctx->frames2, (size_t)cap * px * 3))) return rc;
+    if ((rc = d2r_reserve(ctx, ctx->counters, 64 + 32 * (size_t)nchunks))) return rc;
+    if (to_host) {
+        const size_t hb = (size_t)cap * px * 3;
+        for (int b = 0; b < (nchunks > 1 ? 2 : 1); b++)
+            if (ctx->frame_host_cap[b] < hb) {
+                if (ctx->frame_host[b]) (void)hipHostFree(ctx->frame_host[b]);
+                ctx->frame_host[b] = nullptr;
+                ctx->frame_host_cap[b] = 0;
+                if (hipHostMalloc(&ctx->frame_host[b], hb, hipHostMallocDefault) != hipSuccess)
+                    return d2r_fail(ctx, D2R_ERR_MEMORY, "hipHostMalloc(" + std::to_string(hb) + ") failed for the frame staging buffer");
+                ctx->frame_host_cap[b] = hb;
+            }
+        const int want = sink && sink->png_threads > 0 ? sink->png_threads : d2r_default_io_threads();
+        if (!ctx->pool || ctx->pool->size() != want) {
+            delete ctx->pool;
+            ctx->pool = new D2rJobPool(want);
+        }
+    }
     // the background frame's own patches, once per (background, CLIP model): bands of a candidate that its rays cannot
     // have touched are copies of these (k_preprocess)
     const bool reuse_bg = ctx->prep_reuse && ctx->raygen_rect && ctx->bg_w == V.W && ctx->bg_h == V.H && ctx->bg_u8.p;
@@ -786,32 +882,117 @@ int d2r_render_score(d2r_ctx *ctx, const d2r_nerf *fg, const d2r_clip *clip, con
         }
     }
     ctx->stats = d2r_render_stats{0, 0, 0, 0};
-    for (uint32_t c0 = 0; c0 < K; c0 += per) {
-        uint32_t nc = std::min(per, K - c0);
-        if ((rc = d2r_launch_cameras_virtual(ctx, V, obj_pose_now, cam_pose, obj_poses_dev + (size_t)c0 * 16, nc, (float *)ctx->cams.p)))
-            return rc;
-        if ((rc = d2r_launch_render(ctx, fg, V, (const float *)ctx->cams.p, nc, true, nullptr, nullptr, (uint8_t *)ctx->frames.p,
-                                    reuse_bg ? ctx->rects.p : nullptr)))
-            return rc;
-        // keep this chunk's counters for the stats read-back at the end
-        D2R_HIP(ctx, hipMemcpyAsync((uint8_t *)ctx->counters.p + 64 + 32 * (size_t)(c0 / per), ctx->counters.p, 32,
-                                    hipMemcpyDeviceToDevice, ctx->stream));
-        if (frames_out)
-            D2R_HIP(ctx, hipMemcpyAsync(frames_out + (size_t)c0 * px * 3, ctx->frames.p, (size_t)nc * px * 3, hipMemcpyDeviceToHost, ctx->stream));
-        size_t tp = ctx->timing_begin(D2R_T_PREP);
-        if ((rc = d2r_launch_preprocess(ctx, (d2r_clip *)clip, (const uint8_t *)ctx->frames.p, nc, V.W, V.H, 1,
-                                        (uint16_t *)ctx->clipws[6].p, nullptr, reuse_bg ? ctx->rects.p : nullptr,
-                                        reuse_bg ? (const uint16_t *)ctx->bg_patches.p : nullptr)))
-            return rc;
-        ctx->timing_end(tp);
+    hipStream_t main = ctx->stream, rs = two ? ctx->render_stream : main, xs = ctx->copy_stream;
+    if (rs != main) {       // the render stream starts after whatever the caller queued before this call (pose upload, text)
+        D2R_HIP(ctx, hipEventRecord(ctx->ev_fork, main));
+        D2R_HIP(ctx, hipStreamWaitEvent(rs, ctx->ev_fork, 0));
+    }
+    uint32_t prev_c0 = 0, prev_nc = 0;
+    int prev_b = -1;
+    for (uint32_t c0 = 0, ci = 0; c0 < K; c0 += per, ci++) {
+        const uint32_t nc = std::min(per, K - c0);
+        const int b = (int)(ci & 1u), pb = two ? b : 0, fbuf = (to_host && nchunks > 1) ? b : 0;
+        uint8_t *frames_dev = (uint8_t *)(fbuf ? ctx->frames2.p : ctx->frames.p);
+        uint16_t *patches = (uint16_t *)(pb ? ctx->patches2.p : ctx->clipws[6].p);
+        if (to_host && ci >= 2) ctx->pool->wait(b);                 // pinned buffer b: chunk ci-2's files are written
+        {
+            StreamSwap sw(ctx, rs);
+            if (to_host && ci >= 2) D2R_HIP(ctx, hipStreamWaitEvent(rs, ctx->ev_copy[b], 0));   // frames buffer b has left the GPU
+            if ((rc = d2r_launch_cameras_virtual(ctx, V, obj_pose_now, cam_pose, poses_dev + (size_t)c0 * 16, nc, (float *)ctx->cams.p)))
+                return rc;
+            if ((rc = d2r_launch_render(ctx, fg, V, (const float *)ctx->cams.p, nc, true, nullptr, nullptr, frames_dev,
+                                        reuse_bg ? ctx->rects.p : nullptr)))
+                return rc;
+            // keep this chunk's counters for the stats read-back at the end
+            D2R_HIP(ctx, hipMemcpyAsync((uint8_t *)ctx->counters.p + 64 + 32 * (size_t)ci, ctx->counters.p, 32,
+                                        hipMemcpyDeviceToDevice, rs));
+            if (to_host) {
+                D2R_HIP(ctx, hipEventRecord(ctx->ev_march[b], rs));
+                D2R_HIP(ctx, hipStreamWaitEvent(xs, ctx->ev_march[b], 0));
+                D2R_HIP(ctx, hipMemcpyAsync(ctx->frame_host[b], frames_dev, (size_t)nc * px * 3, hipMemcpyDeviceToHost, xs));
+                D2R_HIP(ctx, hipEventRecord(ctx->ev_copy[b], xs));
+            }
+            if (two && ci >= 2) D2R_HIP(ctx, hipStreamWaitEvent(rs, ctx->ev_clip[pb], 0));      // patch buffer pb: chunk ci-2 is scored
+            size_t tp = ctx->timing_begin(D2R_T_PREP);
+            if ((rc = d2r_launch_preprocess(ctx, (d2r_clip *)clip, frames_dev, nc, V.W, V.H, 1, patches, nullptr,
+                                            reuse_bg ? ctx->rects.p : nullptr, reuse_bg ? (const uint16_t *)ctx->bg_patches.p : nullptr)))
+                return rc;
+            ctx->timing_end(tp);
+            if (two) D2R_HIP(ctx, hipEventRecord(ctx->ev_prep[pb], rs));
+        }
+        if (two) D2R_HIP(ctx, hipStreamWaitEvent(main, ctx->ev_prep[pb], 0));
         size_t tc = ctx->timing_begin(D2R_T_CLIP);
-        if ((rc = d2r_clip_forward(ctx, clip, (const uint16_t *)ctx->clipws[6].p, nc, (const float *)ctx->text.p, C,
-                                   logit_scale, logits_dev + (size_t)c0 * C, nullptr)))
+        if ((rc = d2r_clip_forward(ctx, clip, patches, nc, (const float *)ctx->text.p, C, logit_scale,
+                                   logits_dev + (size_t)c0 * C, nullptr)))
             return rc;
         ctx->timing_end(tc);
+        if (two) D2R_HIP(ctx, hipEventRecord(ctx->ev_clip[pb], main));
+        if (to_host) {
+            if (prev_b >= 0) {                 // the previous chunk's frames: on the host by now, or soon
+                D2R_HIP(ctx, hipEventSynchronize(ctx->ev_copy[prev_b]));
+                dispatch_frames(ctx, prev_b, prev_c0, prev_nc, V.W, V.H, frames_out, sink);
+            }
+            prev_b = b;
+            prev_c0 = c0;
+            prev_nc = nc;
+        }
     }
-    if (frames_out) D2R_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (to_host) {
+        if (prev_b >= 0) {
+            D2R_HIP(ctx, hipEventSynchronize(ctx->ev_copy[prev_b]));
+            dispatch_frames(ctx, prev_b, prev_c0, prev_nc, V.W, V.H, frames_out, sink);
+        }
+        ctx->pool->wait(-1);
+        std::string err;
+        int prc = ctx->pool->take_error(err);
+        D2R_HIP(ctx, hipStreamSynchronize(main));
+        if (prc) return d2r_fail(ctx, prc, err);
+    }
     ctx->stats.rays_total = (uint64_t)K * px;
+    return D2R_OK;
+}
+
+static int check_render_score_args(d2r_ctx *ctx, const d2r_nerf *fg, const d2r_clip *clip, const d2r_view *view,
+                                   const float *obj_pose_now, const float *cam_pose, const void *poses, const void *logits,
+                                   const d2r_frame_sink *sink)
+{
+    if (!ctx || !fg || !clip || !obj_pose_now || !cam_pose || !poses || !logits)
+        return d2r_fail(ctx, D2R_ERR_INVALID, "null argument");
+    if (sink && sink->png_dir && (sink->png_level > 9 || sink->png_threads > 1024))
+        return d2r_fail(ctx, D2R_ERR_INVALID, "bad d2r_frame_sink (png_level 0..9 or negative for the default, png_threads <= 1024)");
+    return check_view(ctx, view);
+}
+
+int d2r_render_score(d2r_ctx *ctx, const d2r_nerf *fg, const d2r_clip *clip, const d2r_view *view,
+                     const float *obj_pose_now, const float *cam_pose, const float *obj_poses_dev, uint32_t K,
+                     const float *text_embeds, uint32_t C, float logit_scale, float *logits_dev, uint8_t *frames_out)
+{
+    int rc = check_render_score_args(ctx, fg, clip, view, obj_pose_now, cam_pose, obj_poses_dev, logits_dev, nullptr);
+    if (rc) return rc;
+    hipSetDevice(ctx->device);
+    if ((rc = upload_text(ctx, clip, text_embeds, C))) return rc;
+    return render_score_core(ctx, fg, clip, view, obj_pose_now, cam_pose, obj_poses_dev, K, C, logit_scale, logits_dev,
+                             frames_out, nullptr);
+}
+
+int d2r_render_score_host(d2r_ctx *ctx, const d2r_nerf *fg, const d2r_clip *clip, const d2r_view *view,
+                          const float *obj_pose_now, const float *cam_pose, const float *obj_poses, uint32_t K,
+                          const float *text_embeds, uint32_t C, float logit_scale, float *logits_out,
+                          uint8_t *frames_out, const d2r_frame_sink *sink)
+{
+    int rc = check_render_score_args(ctx, fg, clip, view, obj_pose_now, cam_pose, obj_poses, logits_out, sink);
+    if (rc) return rc;
+    if (K == 0) return D2R_OK;
+    hipSetDevice(ctx->device);
+    if ((rc = upload_text(ctx, clip, text_embeds, C))) return rc;
+    if ((rc = d2r_reserve(ctx, ctx->poses, (size_t)K * 64))) return rc;
+    if ((rc = d2r_reserve(ctx, ctx->logits, (size_t)K * C * 4))) return rc;
+    D2R_HIP(ctx, hipMemcpyAsync(ctx->poses.p, obj_poses, (size_t)K * 64, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = render_score_core(ctx, fg, clip, view, obj_pose_now, cam_pose, (const float *)ctx->poses.p, K, C, logit_scale,
+                                (float *)ctx->logits.p, frames_out, sink)))
+        return rc;
+    D2R_HIP(ctx, hipMemcpyAsync(logits_out, ctx->logits.p, (size_t)K * C * 4, hipMemcpyDeviceToHost, ctx->stream));
+    D2R_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return D2R_OK;
 }
 

@@ -10,6 +10,8 @@
 
 #include "../../include/d2r.h"
 
+class D2rJobPool;   // pngio.h
+
 #define D2R_MAX_LEVELS 16
 #define D2R_MAX_DEVICES 64              // per-device "kernel attribute already set" flags
 #define D2R_GRID 128
@@ -111,6 +113,17 @@ struct d2r_ctx {
     // pose-shard communicator (comm.hip): an ncclComm_t, or null at world size 1
     void *comm = nullptr;
     int comm_rank = 0, comm_world = 1;
+    // the render-and-score pipeline (api.hip render_score_core): the render half of chunk i+1 runs on render_stream while
+    // the ViT scores chunk i on `stream`; frames that leave the GPU go through copy_stream into two pinned buffers and
+    // from there to the worker pool (PNG files, the caller's array)
+    hipStream_t render_stream = nullptr, copy_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_prep[2] = {nullptr, nullptr}, ev_clip[2] = {nullptr, nullptr},
+               ev_march[2] = {nullptr, nullptr}, ev_copy[2] = {nullptr, nullptr};
+    Buf patches2, frames2;
+    void *frame_host[2] = {nullptr, nullptr};
+    size_t frame_host_cap[2] = {0, 0};
+    D2rJobPool *pool = nullptr;
+    int64_t overlap = 0;        // 1: render half of chunk i+1 on render_stream under the ViT of chunk i (measured neutral: both sides fill whole CUs); 0: program order on `stream`
     uint32_t last_chunks = 0;   // chunks of the last d2r_render_score (its per-chunk counters are behind counters+64)
     int64_t chunk = 4096;       // candidates per pass (capped per model/view by pass_size() in api.hip)
     uint32_t last_pass = 0;     // pass size the last d2r_render_score used (for its stats read-back)

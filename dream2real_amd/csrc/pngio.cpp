@@ -1,0 +1,375 @@
+// pngio.cpp — the on-disk frame format of the path: cb_render/cb_rgb_%04d.png and best_render.png
+// (reference reconstruction/combined_rendering.py:157-159 writes them with cv2.imwrite one by one inside the
+// render loop; clip_scoring.py:89-104 reads them back with use_cache_renders, :222-223 writes best_render.png).
+// Host code only: 8-bit RGB PNG encode / decode on zlib, and a pool of worker threads that turns the frames a
+// render-and-score pass streams back into files while the GPU works on the next chunk.
+#include <stdio.h>
+#include <string.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "d2r_internal.h"
+#include "pngio.h"
+
+namespace {
+
+void put32(std::vector<uint8_t> &v, uint32_t x)
+{
+    v.push_back((uint8_t)(x >> 24));
+    v.push_back((uint8_t)(x >> 16));
+    v.push_back((uint8_t)(x >> 8));
+    v.push_back((uint8_t)x);
+}
+
+void chunk(std::vector<uint8_t> &out, const char type[4], const uint8_t *data, size_t n)
+{
+    put32(out, (uint32_t)n);
+    const size_t at = out.size();
+    out.insert(out.end(), type, type + 4);
+    if (n) out.insert(out.end(), data, data + n);
+    put32(out, (uint32_t)crc32(0L, out.data() + at, (uInt)(n + 4)));
+}
+
+}  // namespace
+
+// One RGB frame -> PNG bytes: colour type 2, bit depth 8, no interlace, filter type 0 on every scanline (what
+// cv2.imwrite does not promise, but any decoder returns the same pixels: PNG is lossless).
+int d2r_png_encode(const uint8_t *rgb, uint32_t w, uint32_t h, int level, std::vector<uint8_t> &out, std::string &err)
+{
+    if (!rgb || w == 0 || h == 0 || w > 32768 || h > 32768) {
+        err = "bad image size";
+        return D2R_ERR_INVALID;
+    }
+    const size_t row = (size_t)w * 3;
+    std::vector<uint8_t> raw((row + 1) * h);
+    for (uint32_t y = 0; y < h; y++) {
+        raw[(row + 1) * y] = 0;
+        memcpy(&raw[(row + 1) * y + 1], rgb + row * y, row);
+    }
+    uLongf cap = compressBound((uLong)raw.size());
+    std::vector<uint8_t> z(cap);
+    if (compress2(z.data(), &cap, raw.data(), (uLong)raw.size(), level < 0 ? 1 : std::min(level, 9)) != Z_OK) {
+        err = "zlib compress2 failed";
+        return D2R_ERR_MEMORY;
+    }
+    out.clear();
+    out.reserve(cap + 64);
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    out.insert(out.end(), sig, sig + 8);
+    std::vector<uint8_t> ihdr;
+    put32(ihdr, w);
+    put32(ihdr, h);
+    const uint8_t tail[5] = {8, 2, 0, 0, 0};
+    ihdr.insert(ihdr.end(), tail, tail + 5);
+    chunk(out, "IHDR", ihdr.data(), ihdr.size());
+    chunk(out, "IDAT", z.data(), cap);
+    chunk(out, "IEND", nullptr, 0);
+    return D2R_OK;
+}
+
+int d2r_png_write_file(const uint8_t *rgb, uint32_t w, uint32_t h, int level, const std::string &path, std::string &err)
+{
+    std::vector<uint8_t> bytes;
+    int rc = d2r_png_encode(rgb, w, h, level, bytes, err);
+    if (rc) return rc;
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f) {
+        err = "cannot open " + path + " for writing";
+        return D2R_ERR_INVALID;
+    }
+    const bool ok = fwrite(bytes.data(), 1, bytes.size(), f) == bytes.size();
+    if (fclose(f) != 0 || !ok) {
+        err = "short write to " + path;
+        return D2R_ERR_INVALID;
+    }
+    return D2R_OK;
+}
+
+// PNG bytes -> RGB.  Reads what PNG writers produce for 8-bit images without a palette: grey, grey + alpha, RGB,
+// RGBA (alpha dropped, grey replicated), all five scanline filters, IDAT split over any number of chunks.  Interlaced,
+// 16-bit and palette images are refused with a message (cv2.imwrite / PIL never write them for uint8 RGB arrays).
+int d2r_png_decode(const uint8_t *p, size_t n, uint32_t want_w, uint32_t want_h, uint8_t *rgb_out, uint32_t *w_out,
+                   uint32_t *h_out, std::string &err)
+{
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    if (!p || n < 8 + 25 || memcmp(p, sig, 8)) {
+        err = "not a PNG file";
+        return D2R_ERR_INVALID;
+    }
+    auto rd32 = [&](size_t at) { return ((uint32_t)p[at] << 24) | ((uint32_t)p[at + 1] << 16) | ((uint32_t)p[at + 2] << 8) | p[at + 3]; };
+    size_t at = 8;
+    uint32_t w = 0, h = 0, ch = 0;
+    std::vector<uint8_t> z;
+    bool have_hdr = false, done = false;
+    while (!done && at + 12 <= n) {
+        const uint32_t len = rd32(at);
+        if ((size_t)len > n - at - 12) {
+            err = "truncated PNG chunk";
+            return D2R_ERR_INVALID;
+        }
+        const uint8_t *type = p + at + 4, *data = p + at + 8;
+        if (rd32(at + 8 + len) != (uint32_t)crc32(0L, type, (uInt)(len + 4))) {
+            err = "PNG chunk CRC mismatch";
+            return D2R_ERR_INVALID;
+        }
+        if (!memcmp(type, "IHDR", 4)) {
+            if (len != 13) {
+                err = "bad IHDR";
+                return D2R_ERR_INVALID;
+            }
+            w = rd32(at + 8);
+            h = rd32(at + 12);
+            const uint8_t depth = data[8], ctype = data[9], interlace = data[12];
+            if (depth != 8 || interlace != 0 || (ctype != 0 && ctype != 2 && ctype != 4 && ctype != 6)) {
+                err = "unsupported PNG (need 8-bit grey / RGB with or without alpha, not interlaced)";
+                return D2R_ERR_UNSUPPORTED;
+            }
+            ch = ctype == 0 ? 1 : ctype == 4 ? 2 : ctype == 2 ? 3 : 4;
+            have_hdr = true;
+        } else if (!memcmp(type, "IDAT", 4)) {
+            z.insert(z.end(), data, data + len);
+        } else if (!memcmp(type, "IEND", 4)) {
+            done = true;
+        }
+        at += 12 + (size_t)len;
+    }
+    if (!have_hdr || !done || w == 0 || h == 0 || w > 32768 || h > 32768) {
+        err = "incomplete PNG";
+        return D2R_ERR_INVALID;
+    }
+    if (w_out) *w_out = w;
+    if (h_out) *h_out = h;
+    if (!rgb_out) return D2R_OK;
+    if ((want_w && want_w != w) || (want_h && want_h != h)) {
+        err = "PNG is " + std::to_string(w) + "x" + std::to_string(h) + ", expected " + std::to_string(want_w) + "x" + std::to_string(want_h);
+        return D2R_ERR_INVALID;
+    }
+    const size_t row = (size_t)w * ch;
+    std::vector<uint8_t> raw((row + 1) * h);
+    uLongf got = (uLongf)raw.size();
+    if (uncompress(raw.data(), &got, z.data(), (uLong)z.size()) != Z_OK || got != raw.size()) {
+        err = "PNG pixel data does not inflate to the size its header announces";
+        return D2R_ERR_INVALID;
+    }
+    std::vector<uint8_t> prev(row, 0), cur(row);
+    for (uint32_t y = 0; y < h; y++) {
+        const uint8_t ft = raw[(row + 1) * y];
+        const uint8_t *src = &raw[(row + 1) * y + 1];
+        for (size_t i = 0; i < row; i++) {
+            const int a = i >= ch ? cur[i - ch] : 0, b = prev[i], c = i >= ch ? prev[i - ch] : 0;
+            int pred;
+            switch (ft) {
+            case 0: pred = 0; break;
+            case 1: pred = a; break;
+            case 2: pred = b; break;
+            case 3: pred = (a + b) >> 1; break;
+            case 4: {
+                const int pa = abs(b - c), pb = abs(a - c), pc = abs(a + b - 2 * c);
+                pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+                break;
+            }
+            default:
+                err = "bad PNG scanline filter";
+                return D2R_ERR_INVALID;
+            }
+            cur[i] = (uint8_t)(src[i] + pred);
+        }
+        uint8_t *dst = rgb_out + (size_t)y * w * 3;
+        for (uint32_t x = 0; x < w; x++) {
+            const uint8_t *q = &cur[(size_t)x * ch];
+            if (ch <= 2) dst[3 * x] = dst[3 * x + 1] = dst[3 * x + 2] = q[0];
+            else { dst[3 * x] = q[0]; dst[3 * x + 1] = q[1]; dst[3 * x + 2] = q[2]; }
+        }
+        prev.swap(cur);
+    }
+    return D2R_OK;
+}
+
+int d2r_png_read_file(const std::string &path, uint32_t want_w, uint32_t want_h, uint8_t *rgb_out, uint32_t *w_out,
+                      uint32_t *h_out, std::string &err)
+{
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) {
+        err = "cannot open " + path;
+        return D2R_ERR_INVALID;
+    }
+    std::vector<uint8_t> bytes;
+    uint8_t buf[1 << 16];
+    size_t k;
+    while ((k = fread(buf, 1, sizeof buf, f)) > 0) bytes.insert(bytes.end(), buf, buf + k);
+    fclose(f);
+    int rc = d2r_png_decode(bytes.data(), bytes.size(), want_w, want_h, rgb_out, w_out, h_out, err);
+    if (rc) err = path + ": " + err;
+    return rc;
+}
+
+std::string d2r_png_name(const std::string &dir, uint32_t index)
+{
+    char name[64];
+    snprintf(name, sizeof name, "cb_rgb_%04u.png", index);         // the reference's '%04d' (combined_rendering.py:159)
+    return dir.empty() ? std::string(name) : dir + "/" + name;
+}
+
+// ------------------------------------------------------------------ worker pool
+
+struct D2rJobPool::Impl {
+    std::vector<std::thread> threads;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_idle;
+    std::deque<std::pair<int, std::function<int(std::string &)>>> q;     // (group, job)
+    size_t pending[D2R_POOL_GROUPS] = {};
+    bool stop = false;
+    int first_rc = 0;
+    std::string first_err;
+
+    void work()
+    {
+        for (;;) {
+            std::pair<int, std::function<int(std::string &)>> job;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_work.wait(lk, [&] { return stop || !q.empty(); });
+                if (q.empty()) return;
+                job = std::move(q.front());
+                q.pop_front();
+            }
+            std::string err;
+            int rc;
+            try {
+                rc = job.second(err);
+            } catch (const std::exception &e) {
+                rc = D2R_ERR_MEMORY;
+                err = e.what();
+            }
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (rc && !first_rc) {
+                    first_rc = rc;
+                    first_err = err;
+                }
+                pending[job.first]--;
+            }
+            cv_idle.notify_all();
+        }
+    }
+};
+
+D2rJobPool::D2rJobPool(int n_threads) : impl(new Impl())
+{
+    n = std::max(1, n_threads);
+    for (int i = 0; i < n; i++) impl->threads.emplace_back([this] { impl->work(); });
+}
+
+D2rJobPool::~D2rJobPool()
+{
+    {
+        std::lock_guard<std::mutex> lk(impl->mu);
+        impl->stop = true;
+    }
+    impl->cv_work.notify_all();
+    for (auto &t : impl->threads) t.join();
+    delete impl;
+}
+
+void D2rJobPool::submit(int group, std::function<int(std::string &)> job)
+{
+    {
+        std::lock_guard<std::mutex> lk(impl->mu);
+        impl->pending[group % D2R_POOL_GROUPS]++;
+        impl->q.emplace_back(group % D2R_POOL_GROUPS, std::move(job));
+    }
+    impl->cv_work.notify_one();
+}
+
+void D2rJobPool::wait(int group)
+{
+    std::unique_lock<std::mutex> lk(impl->mu);
+    impl->cv_idle.wait(lk, [&] {
+        if (group >= 0) return impl->pending[group % D2R_POOL_GROUPS] == 0;
+        for (size_t p : impl->pending)
+            if (p) return false;
+        return true;
+    });
+}
+
+int D2rJobPool::take_error(std::string &err)
+{
+    std::lock_guard<std::mutex> lk(impl->mu);
+    const int rc = impl->first_rc;
+    err = impl->first_err;
+    impl->first_rc = 0;
+    impl->first_err.clear();
+    return rc;
+}
+
+int d2r_default_io_threads()
+{
+    const unsigned hc = std::thread::hardware_concurrency();
+    return (int)std::min(64u, std::max(1u, hc ? hc - (hc > 4 ? 2 : 0) : 4u));
+}
+
+// ------------------------------------------------------------------ C ABI
+
+extern "C" {
+
+int d2r_png_write(const uint8_t *rgb, uint32_t w, uint32_t h, const char *path, int level)
+{
+    if (!rgb || !path) return d2r_fail(nullptr, D2R_ERR_INVALID, "null argument");
+    std::string err;
+    int rc = d2r_png_write_file(rgb, w, h, level, path, err);
+    return rc ? d2r_fail(nullptr, rc, err) : D2R_OK;
+}
+
+int d2r_png_write_batch(const uint8_t *frames, uint32_t n, uint32_t w, uint32_t h, const char *dir, uint32_t first_index,
+                        int threads, int level)
+{
+    if (!frames || !dir) return d2r_fail(nullptr, D2R_ERR_INVALID, "null argument");
+    if (n == 0) return D2R_OK;
+    const size_t fb = (size_t)w * h * 3;
+    D2rJobPool pool(std::min<int>((int)n, threads > 0 ? threads : d2r_default_io_threads()));
+    const std::string d(dir);
+    for (uint32_t i = 0; i < n; i++)
+        pool.submit(0, [=](std::string &err) { return d2r_png_write_file(frames + fb * i, w, h, level, d2r_png_name(d, first_index + i), err); });
+    pool.wait(-1);
+    std::string err;
+    int rc = pool.take_error(err);
+    return rc ? d2r_fail(nullptr, rc, err) : D2R_OK;
+}
+
+int d2r_png_read_batch(const char *dir, const uint32_t *indices, uint32_t first_index, uint32_t n, uint32_t w, uint32_t h,
+                       uint8_t *frames_out, int threads)
+{
+    if (!dir || !frames_out) return d2r_fail(nullptr, D2R_ERR_INVALID, "null argument");
+    if (n == 0) return D2R_OK;
+    if (w == 0 || h == 0) return d2r_fail(nullptr, D2R_ERR_INVALID, "bad image size");
+    const size_t fb = (size_t)w * h * 3;
+    D2rJobPool pool(std::min<int>((int)n, threads > 0 ? threads : d2r_default_io_threads()));
+    const std::string d(dir);
+    for (uint32_t i = 0; i < n; i++)
+        pool.submit(0, [=](std::string &err) {
+            return d2r_png_read_file(d2r_png_name(d, indices ? indices[i] : first_index + i), w, h, frames_out + fb * i, nullptr, nullptr, err);
+        });
+    pool.wait(-1);
+    std::string err;
+    int rc = pool.take_error(err);
+    return rc ? d2r_fail(nullptr, rc, err) : D2R_OK;
+}
+
+int d2r_png_size(const char *path, uint32_t *w, uint32_t *h)
+{
+    if (!path || !w || !h) return d2r_fail(nullptr, D2R_ERR_INVALID, "null argument");
+    std::string err;
+    int rc = d2r_png_read_file(path, 0, 0, nullptr, w, h, err);
+    return rc ? d2r_fail(nullptr, rc, err) : D2R_OK;
+}
+
+}  // extern "C"

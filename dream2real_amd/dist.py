@@ -21,6 +21,17 @@ def shard_range(n_items: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def process_rank() -> int:
+    """Rank of this process in the torch.distributed group (the launcher's RANK before the group exists; 0 outside one)."""
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank()
+    except ImportError:
+        pass
+    return int(os.environ.get("RANK", "0"))
+
+
 def init_from_env(backend: str | None = None):
     """torch.distributed process group from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*.
     Returns (rank, world, local_rank); a no-op (0, 1, 0) outside a launcher."""
@@ -164,6 +175,53 @@ class ShardGather:
             dist.all_gather_into_tensor(full.view(-1, self.C), loc)
             out = full.cpu().numpy()
         return out.reshape(-1, self.C)[self._rows]
+
+
+class PoseShard:
+    """This process' share of the valid poses inside optimise_pose_grid: `range(K)` = its contiguous block, `gather`
+    = the one collective (logits of every block, in pose order, on every rank), `barrier` = the process-group barrier.
+    `from_env` returns None unless a multi-rank process group exists (or can be created from the launcher's
+    environment); the C-ABI communicator (RCCL) of the context is brought up once and kept on it."""
+
+    def __init__(self, ctx, rank: int, world: int, use_c_abi: bool, device=None):
+        self.ctx, self.rank, self.world, self.use_c_abi, self.device = ctx, rank, world, use_c_abi, device
+
+    @classmethod
+    def from_env(cls, ctx):
+        import torch
+        import torch.distributed as dist
+        if int(os.environ.get("WORLD_SIZE", "1")) <= 1 and not (dist.is_available() and dist.is_initialized()):
+            return None
+        rank, world, _ = init_from_env()
+        if dist.is_initialized():
+            rank, world = dist.get_rank(), dist.get_world_size()
+        if world <= 1:
+            return None
+        have_gpu = ctx is not None and torch.cuda.is_available()
+        if have_gpu:
+            torch.cuda.set_device(ctx.device)
+        state = getattr(ctx, "_pose_shard_comm", None) if ctx is not None else None
+        if state is None:
+            state = init_comm(ctx, rank, world) if have_gpu else False
+            if ctx is not None:
+                ctx._pose_shard_comm = state
+        return cls(ctx, rank, world, bool(state), torch.device("cuda", ctx.device) if have_gpu else torch.device("cpu"))
+
+    def range(self, n_items: int):
+        return shard_range(n_items, self.rank, self.world)
+
+    def barrier(self):
+        import torch.distributed as dist
+        dist.barrier()
+
+    def gather(self, local_logits, n_total: int) -> np.ndarray:
+        import torch
+        loc = np.ascontiguousarray(local_logits, np.float32)
+        g = ShardGather(self.ctx, n_total, loc.shape[1], self.rank, self.world, self.device, self.use_c_abi)
+        g.local[: loc.shape[0]] = torch.from_numpy(loc).to(self.device)
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)       # the upload ran on torch's stream, the gather runs on the context's
+        return g.gather()
 
 
 def score_sharded(pose_batch: np.ndarray, score_fn, sample_res, has_norm: bool, n_goal: int = 1,

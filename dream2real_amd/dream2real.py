@@ -36,6 +36,7 @@ class PathConfig:
     physics_only: bool = False
     use_vis_pcds: bool = False
     resolution: Optional[Sequence[int]] = None         # renderer resolution (w, h); None = the reference's 336 x 336
+    save_renders: bool = True                          # cb_render/cb_rgb_%04d.png per valid pose (the reference always does: clip_scoring.py:140)
 
 
 def compose_checks(checks):
@@ -93,6 +94,8 @@ class ImaginationEngine:
             sample_res=list(cfg.sample_res), phys_check=phys_check, use_templates=False, scene_type=cfg.scene_type,
             use_vis_pcds=cfg.use_vis_pcds, use_cache_renders=cfg.use_cache_renders, smoothing=cfg.spatial_smoothing,
             physics_only=cfg.physics_only, scorer=self.scorer, text_embeds=self.text_embeds, text_encoder=self.text_encoder,
-            tokenizer=self.tokenizer)
-        clip_scoring.save_pose_outputs(self.data_dir, best_pose, pose_batch, pose_scores)         # :356-358
+            tokenizer=self.tokenizer, save_renders=cfg.save_renders)
+        from .dist import process_rank
+        if process_rank() == 0:        # pose-sharded runs: every rank holds the same result, one of them writes it
+            clip_scoring.save_pose_outputs(self.data_dir, best_pose, pose_batch, pose_scores)     # :356-358
         return best_pose, pose_batch, pose_scores

@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes as C
 import dataclasses
+import os
 
 import numpy as np
 
@@ -349,6 +350,29 @@ class TextEncoder:
         self.ctx.check(self.ctx.lib.d2r_text_encode(self.ctx.h, self.h, _lib.ptr(ids), C.c_uint32(Cn), C.c_uint32(T),
                                                     _lib.ptr(out)))
         return out
+
+
+def render_score_host(ctx: Context, fg: Testbed, scorer: ClipScorer, view: View, obj_pose_now, cam_pose, obj_poses,
+                      text_embeds, *, return_frames: bool = False, png_dir: str | None = None, png_first_index: int = 0,
+                      png_threads: int = 0, png_level: int = 1):
+    """The fused hot path for host arrays (d2r_render_score_host): K candidate poses (NGP convention) -> logits [K,C];
+    the frames stay on the GPU unless `return_frames` (-> uint8 [K,h,w,3] as well) or `png_dir` (cb_rgb_%04d.png files,
+    written by the library's worker threads while the GPU works on the next chunk).  Needs Context.set_background."""
+    a = np.ascontiguousarray(np.asarray(obj_pose_now, np.float64).reshape(16), np.float32)
+    c = np.ascontiguousarray(np.asarray(cam_pose, np.float64).reshape(16), np.float32)
+    p = np.ascontiguousarray(np.asarray(obj_poses, np.float64).reshape(-1, 16), np.float32)
+    t = np.ascontiguousarray(text_embeds, np.float32)
+    K, Cn = p.shape[0], t.shape[0]
+    logits = np.empty((K, Cn), np.float32)
+    frames = np.empty((K, view.height, view.width, 3), np.uint8) if return_frames else None
+    sink = None
+    if png_dir is not None:
+        sink = _lib.FrameSink(os.fsencode(png_dir), png_first_index, png_threads, png_level)
+    v = _lib.view_c(view)
+    ctx.check(ctx.lib.d2r_render_score_host(ctx.h, fg.h, scorer.h, C.byref(v), _lib.ptr(a), _lib.ptr(c), _lib.ptr(p),
+                                            C.c_uint32(K), _lib.ptr(t), C.c_uint32(Cn), C.c_float(scorer.logit_scale),
+                                            _lib.ptr(logits), _lib.ptr(frames), C.byref(sink) if sink is not None else None))
+    return (logits, frames) if return_frames else logits
 
 
 def render_score_device(ctx: Context, fg: Testbed, scorer: ClipScorer, view: View, obj_pose_now, cam_pose,

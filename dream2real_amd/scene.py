@@ -1,6 +1,6 @@
 """Scene description for the render-and-score path: hash-grid metadata, NeRF parameter
 containers and the camera/view state.  (The seeded synthetic scenes the tests and bench.py run on
-live in tests/scenes.py: they are fixtures, not product.)
+live in synthetic_scenes.py: they are fixtures, not product.)
 
 The reference consumes trained instant-ngp snapshots (`fg_base.ingp`, `bg_base.ingp`,
 reference reconstruction/ngp_visual_model.py:20-29).  None is available offline, so the

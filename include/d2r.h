@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 #define D2R_API __attribute__((visibility("default")))
-#define D2R_ABI_VERSION 5
+#define D2R_ABI_VERSION 6
 
 typedef enum {
     D2R_OK = 0,
@@ -278,12 +278,63 @@ D2R_API int d2r_text_encode(d2r_ctx *ctx, const d2r_text *text, const int32_t *i
  *   frames_out     host [K][h][w][3] uint8, optional (NULL in benchmark mode)
  * Asynchronous on the context's stream when frames_out is NULL; call
  * d2r_ctx_synchronize (or synchronise the caller-owned stream) before reading logits_dev.
+ * K is processed in chunks ("chunk" option); the render half of a chunk runs on a second, library-owned stream that
+ * forks from and joins the context's stream inside the call ("overlap" option).
  */
 D2R_API int d2r_render_score(d2r_ctx *ctx, const d2r_nerf *fg, const d2r_clip *clip,
                              const d2r_view *view, const float *obj_pose_now,
                              const float *cam_pose, const float *obj_poses_dev, uint32_t K,
                              const float *text_embeds, uint32_t C, float logit_scale,
                              float *logits_dev, uint8_t *frames_out);
+
+/*
+ * Where the composited frames of a pass go besides (or instead of) the caller's array: the files the reference's
+ * renderer writes inside its loop, `cb_render/cb_rgb_%04d.png` (reference reconstruction/combined_rendering.py:157-159),
+ * which a later run re-scores with use_cache_renders (clip_scoring.py:89-104).  The library encodes them on a pool of
+ * host threads while the GPU works on the next chunk.
+ */
+typedef struct {
+    const char *png_dir;        /* existing directory for cb_rgb_%04d.png; NULL = write no files */
+    uint32_t png_first_index;   /* file index of candidate 0 (a pose shard passes its first global render index) */
+    int32_t png_threads;        /* encoder threads; 0 = one per host core, at most 64 */
+    int32_t png_level;          /* zlib level 0..9; negative = 1 (PNG is lossless: the level only trades time for size) */
+} d2r_frame_sink;
+
+/*
+ * The same pass for a caller that holds HOST memory — what the Python host's optimise_pose_grid / renderer call
+ * (reference clip_scoring.py:136-185: `renderer.render(...)`, then the CLIP batches): candidate poses in, logits out,
+ * frames kept on the GPU unless asked for.  Synchronous.
+ *   obj_poses    host [K][16] fp32 candidate poses T_WO_2 (NGP convention)
+ *   logits_out   host [K][C]
+ *   frames_out   host [K][h][w][3] uint8, optional
+ *   sink         optional: PNG files of the frames (streamed chunk by chunk; the host never holds more than two chunks
+ *                of at most 1 GiB each in the library's pinned staging buffers)
+ */
+D2R_API int d2r_render_score_host(d2r_ctx *ctx, const d2r_nerf *fg, const d2r_clip *clip,
+                                  const d2r_view *view, const float *obj_pose_now, const float *cam_pose,
+                                  const float *obj_poses, uint32_t K, const float *text_embeds, uint32_t C,
+                                  float logit_scale, float *logits_out, uint8_t *frames_out,
+                                  const d2r_frame_sink *sink);
+
+/* ------------------------------------------------- frame files (host only: no device, no context) */
+
+/* One uint8 RGB image [h][w][3] -> an 8-bit RGB PNG file (best_render.png, reference clip_scoring.py:222-223). */
+D2R_API int d2r_png_write(const uint8_t *rgb, uint32_t w, uint32_t h, const char *path, int level);
+/* frames host [n][h][w][3] -> <dir>/cb_rgb_%04d.png for indices first_index .. first_index+n-1, encoded on `threads`
+ * host threads (0 = auto): what renderer.render(save=True) leaves behind (combined_rendering.py:157-159). */
+D2R_API int d2r_png_write_batch(const uint8_t *frames, uint32_t n, uint32_t w, uint32_t h, const char *dir,
+                                uint32_t first_index, int threads, int level);
+/* The reverse, for use_cache_renders (clip_scoring.py:95-104): n files of w x h -> frames_out host [n][h][w][3]; file i is
+ * cb_rgb_%04d.png of indices[i], or of first_index + i when indices is NULL.  Reads 8-bit grey / RGB PNGs with or without
+ * alpha, every scanline filter (what cv2.imwrite and PIL write); a file of another size, a missing file or an
+ * unsupported format is an error naming the file. */
+D2R_API int d2r_png_read_batch(const char *dir, const uint32_t *indices, uint32_t first_index, uint32_t n, uint32_t w,
+                               uint32_t h, uint8_t *frames_out, int threads);
+D2R_API int d2r_png_size(const char *path, uint32_t *w, uint32_t *h);
+/* np.savetxt(path, data) with numpy's defaults ('%.18e', ' ', '\n'), byte for byte: the format of goal_pose.txt,
+ * pose_batch.txt and pose_scores.txt (reference dream2real.py:356-358).  data host [rows][cols] fp64 (a 1-D array is
+ * rows x 1: one number per line); formatted in row blocks on `threads` host threads (0 = auto). */
+D2R_API int d2r_savetxt(const char *path, const double *data, uint64_t rows, uint64_t cols, int threads);
 
 /* Counters of the last d2r_render / d2r_render_composite / d2r_render_score call, for
  * roofline accounting (bench.py): rays generated, rays that reached occupied space,
@@ -334,6 +385,11 @@ D2R_API int d2r_get_timing(d2r_ctx *ctx, d2r_timing *out);
  * "prep_reuse" (default 1): in d2r_render_score, the rows of CLIP patches of a candidate frame that its object cannot have
  *     touched (outside the rectangle its rays are generated in) are copied from the background frame's own patches,
  *     computed once per d2r_set_background; bit-identical to resampling them.
+ * "overlap" (default 0): 1 = d2r_render_score / d2r_render_score_host run the render half of chunk i+1 (cameras, ray
+ *     generation, march, preprocess) on a second stream while the ViT scores chunk i; 0 = one stream, in program order.
+ *     Results do not depend on it; measured neutral on MI355X (the marcher and the persistent GEMMs each fill whole CUs —
+ *     LDS and registers — so the two streams time-share the CUs: DESIGN.md section 4).  Frames that leave the GPU are
+ *     copied on their own stream under the ViT either way.  "march_blocks" (default 0 = one per CU): workgroups of the persistent marcher.
  * "timing" (0/1): record HIP events per kernel group for d2r_get_timing.
  * Development builds of the library (make DEV=1) also know experiment switches — schedules that were measured no faster
  * and tile configurations kept for comparison; they are not part of this interface. */

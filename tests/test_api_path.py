@@ -1,0 +1,240 @@
+"""The drop-in API runs the path that is benchmarked: `optimise_pose_grid` / `renderer.render_score` go
+through ONE fused library call (d2r_render_score_host) — chunked, two-stream, frames streamed to cb_render/*.png by the
+library — and produce exactly what the reference's two-step route (`renderer.render`, then CLIP on the frames:
+reference clip_scoring.py:136-185) produces: bit-identical frames, logits, scores, files.  Host-only parts (PNG codec,
+renderer snapshot mode plumbing) run without a GPU."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from dream2real_amd import _lib
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ------------------------------------------------------------------ host only
+
+def test_png_codec_roundtrip_and_foreign_files(tmp_path):
+    """d2r_png_write_batch / read_batch against PIL both ways: our files decode to the same pixels in PIL; PIL's files
+    (adaptive filters, RGBA, grey) decode to the same pixels here; missing / wrong-size files are named errors."""
+    from PIL import Image
+    r = np.random.default_rng(0)
+    fr = r.integers(0, 256, (12, 54, 96, 3), dtype=np.uint8)
+    fr[:, :20] = 7                                            # long runs: exercises the deflate side
+    fr[3] = np.linspace(0, 255, 54 * 96 * 3).reshape(54, 96, 3).astype(np.uint8)    # smooth ramp: PIL picks sub / paeth filters
+    d = str(tmp_path)
+    _lib.png_write_batch(fr, d, first_index=3, threads=4)
+    assert sorted(os.listdir(d)) == [f"cb_rgb_{i:04d}.png" for i in range(3, 15)]
+    for i in range(12):
+        np.testing.assert_array_equal(np.asarray(Image.open(os.path.join(d, f"cb_rgb_{i + 3:04d}.png"))), fr[i])
+    np.testing.assert_array_equal(_lib.png_read_batch(d, 12, first_index=3), fr)
+    np.testing.assert_array_equal(_lib.png_read_batch(d, indices=[14, 3, 9]), fr[[11, 0, 6]])
+    for k, img in enumerate((fr[3], np.dstack([fr[1], fr[1][..., :1]]), fr[2][..., 0])):          # RGB (filtered), RGBA, grey
+        Image.fromarray(img).save(os.path.join(d, f"cb_rgb_{100 + k:04d}.png"))
+    b = _lib.png_read_batch(d, 3, first_index=100)
+    np.testing.assert_array_equal(b[0], fr[3])
+    np.testing.assert_array_equal(b[1], fr[1])
+    np.testing.assert_array_equal(b[2], np.repeat(fr[2][..., :1], 3, axis=2))
+    _lib.png_write(fr[5], os.path.join(d, "best_render.png"))
+    np.testing.assert_array_equal(np.asarray(Image.open(os.path.join(d, "best_render.png"))), fr[5])
+    assert _lib.png_size(os.path.join(d, "best_render.png")) == (96, 54)
+    with pytest.raises(_lib.D2RError, match="cb_rgb_005"):
+        _lib.png_read_batch(d, 2, first_index=50, size=(96, 54))
+    Image.fromarray(fr[0][:10]).save(os.path.join(d, "cb_rgb_0200.png"))
+    with pytest.raises(_lib.D2RError, match="expected 96x54"):
+        _lib.png_read_batch(d, 1, first_index=200, size=(96, 54))
+    open(os.path.join(d, "cb_rgb_0300.png"), "wb").write(b"not a png at all, but long enough to be read as one maybe....")
+    with pytest.raises(_lib.D2RError, match="not a PNG"):
+        _lib.png_read_batch(d, 1, first_index=300, size=(96, 54))
+    im = Image.fromarray(fr[0]).convert("P")
+    im.save(os.path.join(d, "cb_rgb_0400.png"))
+    with pytest.raises(_lib.D2RError, match="unsupported PNG"):
+        _lib.png_read_batch(d, 1, first_index=400, size=(96, 54))
+
+
+def test_cached_renders_are_read_in_sorted_name_order(tmp_path):
+    """use_cache_renders reads cb_render/ in SORTED NAME order like the reference (clip_scoring.py:97): index order up
+    to 9999, lexical beyond it."""
+    from dream2real_amd import clip_scoring
+    d = str(tmp_path)
+    idx = [0, 1, 2, 9999, 10000, 10001]
+    for i in idx:
+        _lib.png_write(np.full((4, 6, 3), i % 251, np.uint8), os.path.join(d, f"cb_rgb_{i:04d}.png"))
+    n, read = clip_scoring._cached_render_reader(d)
+    want = [int(f[7:-4]) % 251 for f in sorted(os.listdir(d))]            # 0000 0001 0002 10000 10001 9999
+    assert n == 6 and want == [0, 1, 2, 10000 % 251, 10001 % 251, 9999 % 251]
+    assert [int(f[0, 0, 0]) for f in read(0, 6)] == want and [int(f[0, 0, 0]) for f in read(3, 5)] == want[3:5]
+
+
+def test_convert_poses_writes_render_transforms(tmp_path):
+    """renderer.convert_poses (reference combined_rendering.py:211-247) on hand-written transforms files."""
+    from dream2real_amd.combined_rendering import INTRINSICS_CLIP_VIEW, renderer
+    m = (np.eye(4) + np.arange(16).reshape(4, 4) * 0.01).tolist()
+    for name in ("bg", "fg"):
+        json.dump({"fl_x": 1.0, "w": 1280, "h": 720, "aabb_scale": 1, "frames": [{"file_path": f"{i}.png", "transform_matrix": m} for i in range(3)]},
+                  open(tmp_path / f"{name}_transforms.json", "w"))
+    r = renderer.__new__(renderer)
+    r.root = str(tmp_path)
+    r.convert_poses()
+    bg = json.load(open(tmp_path / "bg_render_transforms.json"))
+    fg = json.load(open(tmp_path / "fg_render_transforms.json"))
+    assert len(bg["frames"]) == 1 and len(fg["frames"]) == 3 and bg["w"] == bg["h"] == fg["w"] == 336
+    assert bg["fl_x"] == INTRINSICS_CLIP_VIEW[0, 0] and fg["cy"] == 168.0 and bg["aabb_scale"] == 1
+    for i, f in enumerate(fg["frames"]):
+        want = np.array(m)
+        want[2, 3] -= 0.02 * i
+        want[1, 3] -= 0.02 * i
+        np.testing.assert_allclose(np.array(f["transform_matrix"]), want, rtol=0, atol=1e-15)
+    with pytest.raises(ValueError, match="ctx"):
+        renderer(str(tmp_path))                        # snapshot mode needs a context to load the .ingp files with
+    from dream2real_amd.ngp_visual_model import get_vis_ngps
+    with pytest.raises(NotImplementedError, match="NeRF training"):
+        get_vis_ngps(None, None, 0, use_cache=False, data_dir=str(tmp_path))
+    with pytest.raises(ValueError, match="ctx"):
+        get_vis_ngps(None, None, 0, use_cache=True, data_dir=str(tmp_path))
+
+
+# ------------------------------------------------------------------ GPU
+
+def _setup(W=96, H=54, clip="vit_tiny"):
+    from dream2real_amd import engine
+    from dream2real_amd.clip_model import CLIP_CONFIGS, random_clip_state_dict
+    from synthetic_scenes import make_scene, make_task, scene_text_embeds
+    scene = make_scene("shopping")
+    ctx = engine.Context(0)
+    fg, bg = engine.Testbed(ctx, scene.fg), engine.Testbed(ctx, scene.bg)
+    fg.background_color = list(scene.fg_background)
+    cfg = CLIP_CONFIGS[clip]
+    sc = engine.ClipScorer(ctx, cfg, random_clip_state_dict(cfg, seed=6))
+    task = make_task(scene, fg, bg)
+    text = scene_text_embeds(np.random.default_rng(3).standard_normal(cfg["proj"]))
+    return scene, ctx, fg, bg, sc, task, text
+
+
+@pytest.mark.gpu
+def test_fused_call_is_bit_identical_to_render_then_score(tmp_path):
+    """renderer.render_score (one d2r_render_score_host call: 5 chunks of 16 through the two-stream pipeline, frames
+    streamed back through the pinned double buffer, PNGs written by the library) == renderer.render + score_frames:
+    frames, logits and files bit for bit, with the pipeline's overlap on and off."""
+    from PIL import Image
+    from dream2real_amd import combined_rendering
+    from dream2real_amd.accio2ngp import converter
+    from dream2real_amd.obj_pose_opt import sample_poses_grid
+    from dream2real_amd.virtual_cam_pose_sample import get_virtual_cam_poses
+    scene, ctx, fg, bg, sc, task, text = _setup()
+    poses = converter(sample_poses_grid(task, [9, 8, 1, 1, 1, 1], scene.scene_type).reshape(-1, 4, 4))      # 72
+    rp = converter(get_virtual_cam_poses(task, [0]))
+    rend = combined_rendering.renderer(str(tmp_path), task, resolution=(96, 54))
+    frames_ref = np.stack(rend.render(poses, rp, [0], save=False))
+    logits_ref = sc.score_frames(frames_ref, text, rot90=True)
+    ctx.set_option("chunk", 16)
+    for overlap in (1, 0):
+        ctx.set_option("overlap", overlap)
+        logits, frames = rend.render_score(poses, rp, [0], sc, text, save=True, first_index=5, return_frames=True)
+        np.testing.assert_array_equal(frames, frames_ref)
+        np.testing.assert_array_equal(logits, logits_ref)
+        names = sorted(os.listdir(rend.out_render_path))
+        assert names == [f"cb_rgb_{i:04d}.png" for i in range(5, 77)]
+        for i in (0, 15, 16, 47, 71):                         # chunk boundaries included
+            np.testing.assert_array_equal(np.asarray(Image.open(os.path.join(rend.out_render_path, names[i]))), frames_ref[i])
+        # scores only: no frames leave the GPU, same logits; a ragged last chunk (72 = 4 x 16 + 8 above, 3 x 20 + 12 here)
+        ctx.set_option("chunk", 20)
+        np.testing.assert_array_equal(rend.render_score(poses, rp, [0], sc, text, save=False), logits_ref)
+        ctx.set_option("chunk", 16)
+    np.testing.assert_array_equal(rend.render_one(poses[33]), frames_ref[33])
+    with pytest.raises(_lib.D2RError, match="cannot open"):   # a PNG job that fails is reported, not swallowed
+        from dream2real_amd.engine import render_score_host
+        view, cam = rend._last
+        render_score_host(ctx, fg, sc, view, rend._T_WO_1(), cam, poses[:4], text, png_dir=str(tmp_path / "no_such_dir"))
+    sc.close(); fg.close(); bg.close(); ctx.close()
+
+
+@pytest.mark.gpu
+def test_optimise_pose_grid_fused_equals_two_step(tmp_path):
+    """optimise_pose_grid through the fused call == through the reference's two-step route (a renderer without
+    render_score): scores, best pose, best_render.png, cb_render files; with sensor depth + movable mask as the
+    background depth (the caller always passes depths_gt, reference dream2real.py:117-118,344); then use_cache_renders
+    on the files the fused call wrote gives the same scores again."""
+    from PIL import Image
+    from dream2real_amd import clip_scoring, combined_rendering
+    scene, ctx, fg, bg, sc, task, text = _setup()
+    task.text_embeds = text
+    r = np.random.default_rng(1)
+    depths = [(0.55 + 0.1 * r.random((72, 128))).astype(np.float32)]
+    mask = np.ones((72, 128), np.uint8)
+    mask[20:50, 40:90] = 0
+    task.movable_masks = [mask]
+    res = [6, 5, 2, 1, 1, 1]
+    invalid = np.zeros(60, bool)
+    invalid[[0, 17, 44]] = True
+
+    def phys(pose_batch, tm, valid):
+        import torch
+        return valid & ~torch.from_numpy(invalid)
+
+    class TwoStep:                                              # the same renderer, without the fused entry
+        def __init__(self, inner):
+            self.inner = inner
+
+        def render(self, *a, **k):
+            return self.inner.render(*a, **k)
+
+        def wait_saved(self):
+            self.inner.wait_saved()
+
+    ctx.set_option("chunk", 16)
+    out = {}
+    for name in ("fused", "two_step"):
+        d = str(tmp_path / name)
+        os.makedirs(d)
+        rend = combined_rendering.renderer(d, task, resolution=(96, 54))
+        best, pb, scores = clip_scoring.optimise_pose_grid(rend if name == "fused" else TwoStep(rend), depths, [0], task, d, sample_res=res,
+                                                           phys_check=phys, scene_type=scene.scene_type, scorer=sc)
+        files = sorted(os.listdir(os.path.join(d, "cb_render")))
+        out[name] = (best.numpy(), scores.numpy(), _lib.png_read_batch(os.path.join(d, "cb_render"), len(files)),
+                     np.asarray(Image.open(os.path.join(d, "best_render.png"))))
+        assert len(files) == 57 and (scores.numpy()[invalid] == 0).all() and (scores.numpy()[~invalid] != 0).all()
+    for a, b in zip(out["fused"], out["two_step"]):
+        np.testing.assert_array_equal(a, b)
+    # cached renders: scores from the files alone
+    d = str(tmp_path / "fused")
+    np.savetxt(os.path.join(d, "pose_scores.txt"), out["fused"][1])
+    _, _, s2 = clip_scoring.optimise_pose_grid(None, None, [0], task, d, sample_res=res, scene_type=scene.scene_type,
+                                               use_cache_renders=True, scorer=sc)
+    np.testing.assert_array_equal(s2.numpy(), out["fused"][1])
+    sc.close(); fg.close(); bg.close(); ctx.close()
+
+
+def _run_api_bench(tmp_path, tag, *flags, timeout=900):
+    root = str(tmp_path / tag)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--api", "--api-dir", root, "--steps", "1", "--warmup", "0", *flags],
+                       env=env, capture_output=True, text=True, timeout=timeout, cwd=REPO)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0]), os.path.join(root, "run")
+
+
+@pytest.mark.gpu
+def test_api_bench_two_ranks_equal_one(tmp_path):
+    """`bench.py --api` (ImaginationEngine.dream_best_pose with the physics pre-filter on the mesh files) on one rank and
+    pose-sharded over two ranks (sharing this box's GPU: gloo gather; on two GPUs: d2r_allgather_scores): the same
+    pose_scores.txt, goal_pose.txt and the same PNG per valid pose, each rank having written its own block."""
+    common = ["--sample-res", "9,8,2,1,1,1", "--clip", "vit_tiny", "--width", "96", "--height", "54", "--api-save", "1", "--chunk", "16"]
+    o1, d1 = _run_api_bench(tmp_path, "one", *common)
+    o2, d2 = _run_api_bench(tmp_path, "two", "--gpus", "2", *common)
+    assert o1["n_gpus"] == 1 and o2["n_gpus"] == 2 and o1["config"]["poses_sampled"] == 144
+    assert 10 < o1["config"]["poses_valid"] < 144 and o1["config"]["physics"] and o1["value"] > 0
+    assert o1["config"]["poses_valid"] == o2["config"]["poses_valid"] and o1["argmax_pose"] == o2["argmax_pose"]
+    for name in ("pose_scores.txt", "goal_pose.txt", "pose_batch.txt"):
+        np.testing.assert_array_equal(np.loadtxt(os.path.join(d1, name)), np.loadtxt(os.path.join(d2, name)))
+    f1, f2 = sorted(os.listdir(os.path.join(d1, "cb_render"))), sorted(os.listdir(os.path.join(d2, "cb_render")))
+    assert f1 == f2 == [f"cb_rgb_{i:04d}.png" for i in range(o1["config"]["poses_valid"])]
+    n = len(f1)
+    np.testing.assert_array_equal(_lib.png_read_batch(os.path.join(d1, "cb_render"), n), _lib.png_read_batch(os.path.join(d2, "cb_render"), n))
+    assert open(os.path.join(d1, "best_render.png"), "rb").read() == open(os.path.join(d2, "best_render.png"), "rb").read()

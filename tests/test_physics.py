@@ -7,19 +7,12 @@ import pytest
 from oracle import host_ref, phys_ref
 
 
-def box(lo, hi):
-    lo, hi = np.asarray(lo, float), np.asarray(hi, float)
-    return np.array([[x, y, z] for x in (lo[0], hi[0]) for y in (lo[1], hi[1]) for z in (lo[2], hi[2])])
+from synthetic_scenes import box, icosphere  # noqa: E402,F401
 
 
 def rot_z(a):
     c, s = np.cos(a), np.sin(a)
     return np.array([[c, -s, 0], [s, c, 0], [0, 0, 1.0]])
-
-
-def icosphere(centre, r, n=40, seed=0):
-    g = np.random.default_rng(seed).standard_normal((n, 3))
-    return np.asarray(centre) + r * g / np.linalg.norm(g, axis=1, keepdims=True)
 
 
 def test_hull_intersection_known_answers():

@@ -4,7 +4,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from dream2real_amd import engine, physics_utils, obj_pose_opt
-from tests.test_physics import box, icosphere
+from synthetic_scenes import box, icosphere
 import types, torch
 
 ctx = engine.Context(0)
