@@ -202,6 +202,109 @@ def shard_plan(sample_res, world: int, partition: int) -> dict:
     return {"order": order, "shards": shards, "run_idx": run_idx, "n_run": int(len(run_idx))}
 
 
+class Watchdog:
+    """An N > 1 run happens on a node the builder never sees: nothing may hang.  Every stage that can block on another
+    rank (rendezvous, communicator init, a step with its collective, the barriers) runs under a deadline; when one passes,
+    this rank prints ONE JSON line naming the stage, itself, its GPU and its HSA_* / NCCL_* environment, and exits
+    non-zero — the launcher then stops the other ranks instead of leaving them in a barrier."""
+
+    def __init__(self):
+        import threading
+        self.stage_name, self.deadline, self.device = None, None, None
+        self.scale = float(os.environ.get("D2R_WATCHDOG_SCALE", "1"))
+        self._lock = threading.Lock()
+        threading.Thread(target=self._run, name="d2r-watchdog", daemon=True).start()
+
+    def stage(self, name, seconds):
+        with self._lock:
+            self.stage_name, self.deadline = name, time.monotonic() + seconds * self.scale
+
+    def done(self):
+        with self._lock:
+            self.stage_name, self.deadline = None, None
+
+    def _run(self):
+        while True:
+            time.sleep(0.5)
+            with self._lock:
+                name, dl = self.stage_name, self.deadline
+            if dl is not None and time.monotonic() > dl:
+                report_failure(name, f"no progress within the stage's deadline ({self.scale}x scale): a rank is stuck or gone", self.device, code=3)
+
+
+def report_failure(stage, err, device_index, code=1):
+    """One JSON line on stdout (and stderr) describing a failed multi-rank run, then exit non-zero NOW (os._exit: the
+    interpreter may be blocked inside a collective)."""
+    from dream2real_amd import dist as d2r_dist
+    line = {"collective_error": str(err), "stage": stage}
+    try:
+        line.update(d2r_dist.describe_environment(device_index))
+        line["comm_report"] = dict(d2r_dist.LAST_COMM_REPORT)
+    except Exception as e:                    # the report must come out whatever else is broken
+        line["describe_environment_failed"] = repr(e)
+    txt = json.dumps(line)
+    print(txt, flush=True)
+    print(txt, file=sys.stderr, flush=True)
+    os._exit(code)
+
+
+def run_dry_collective(args, wd):
+    """--dry-collective: ONLY what N > 1 adds to the path — rendezvous, the C-ABI communicator (d2r_comm_init: RCCL over
+    xGMI), one 1 MiB all-gather through d2r_allgather_scores, and agreement of every rank on the argmax of the gathered
+    buffer.  Separates "the collective is broken on this node" from "the path is broken" when a scaling run fails."""
+    import torch
+    from dream2real_amd import dist as d2r_dist
+    from dream2real_amd import engine
+    wd.stage("rendezvous (torch.distributed.init_process_group)", 300)
+    rank, world, local = d2r_dist.init_from_env()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    local = local % torch.cuda.device_count()
+    torch.cuda.set_device(local)
+    wd.device = local
+    dev = torch.device("cuda", local)
+    ctx = engine.Context(local)
+    wd.stage("d2r_comm_init (ncclCommInitRank)", 300)
+    use_c_abi = d2r_dist.init_comm(ctx, rank, world)
+    n_total = 131072                                       # x 2 captions x 4 B = 1 MiB gathered
+    g = d2r_dist.ShardGather(ctx, n_total, 2, rank, world, dev, use_c_abi)
+    lo, hi = g.lo, g.hi
+    vals = torch.arange(lo, hi, dtype=torch.float32, device=dev)
+    g.local[: hi - lo, 0] = torch.sin(vals * 0.001)
+    g.local[: hi - lo, 1] = vals
+    torch.cuda.synchronize(dev)
+    wd.stage("all-gather of 1 MiB (d2r_allgather_scores)", 120)
+    times = []
+    for _ in range(5):
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            torch.distributed.barrier()
+        t0 = time.perf_counter()
+        full = g.gather()
+        times.append(time.perf_counter() - t0)
+    want = np.stack([np.sin(np.arange(n_total, dtype=np.float32) * np.float32(0.001)), np.arange(n_total, dtype=np.float32)], 1)
+    exact = bool(np.allclose(full[:, 0], want[:, 0], atol=1e-6) and (full[:, 1] == want[:, 1]).all())
+    best = int(np.argmax(full[:, 0]))
+    wd.stage("argmax agreement (all_reduce)", 120)
+    agree = True
+    if world > 1:
+        t = torch.tensor([best, -best], dtype=torch.int64, device=dev if torch.distributed.get_backend() == "nccl" else "cpu")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        agree = int(t[0].item()) == best and int(-t[1].item()) == best
+    wd.done()
+    if not (exact and agree):
+        report_failure("dry collective check", f"gathered buffer exact={exact}, argmax agreement={agree}", local)
+    if rank == 0:
+        print(json.dumps({"dry_collective": "ok", "n_gpus": world, "bytes_gathered": n_total * 8,
+                          "collective": "d2r_allgather_scores (ncclAllGather, RCCL)" if use_c_abi and world > 1 else
+                                        ("device copy (one rank)" if world == 1 else f"torch.distributed all_gather ({torch.distributed.get_backend()})"),
+                          "gather_ms": [round(t * 1e3, 3) for t in times], "argmax": best,
+                          "comm_report": dict(d2r_dist.LAST_COMM_REPORT), **d2r_dist.describe_environment(local)}), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        ctx.comm_destroy()
+        torch.distributed.destroy_process_group()
+
+
 # The reference's own workload (configs/shopping_demo.json:28, combined_rendering.py:86, clip_scoring.py:150-151): pose grid
 # [100,100,7,1,1,1] = 70 000 poses, 336x336 renders, openai/clip-vit-large-patch14-336, physics pre-filter on.
 REFERENCE_WORKLOAD = dict(scene="shopping", sample_res=[100, 100, 7, 1, 1, 1], width=336, height=336, clip="vit_l14_336",
@@ -209,7 +312,7 @@ REFERENCE_WORKLOAD = dict(scene="shopping", sample_res=[100, 100, 7, 1, 1, 1], w
                                "336x336, ViT-L/14-336, physics pre-filter on")
 
 
-def run_api(args):
+def run_api(args, wd):
     """--api: the number a caller of the drop-in API gets.  One step = one `ImaginationEngine.dream_best_pose` call
     (reference dream2real.py:286-358): physics pre-filter on the objects' mesh files -> renderer -> optimise_pose_grid (the
     fused, chunked d2r_render_score_host call; pose-sharded with ONE all-gather under a launcher) -> smoothing -> argmax ->
@@ -226,10 +329,13 @@ def run_api(args):
     from dream2real_amd.clip_model import CLIP_CONFIGS, random_clip_state_dict
     from synthetic_scenes import make_scene, make_task, scene_text_embeds, write_phys_meshes
 
+    wd.stage("rendezvous (torch.distributed.init_process_group)", 300)
     rank, world, local = d2r_dist.init_from_env()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
+    wd.device = local
+    wd.stage("setup + dream_best_pose calls (the API brings the communicator up itself)", 3600)
     base = dict(REFERENCE_WORKLOAD if args.config is None else BASELINE_CONFIGS[args.config])
     scene_name, clip_name = args.scene or base["scene"], args.clip or base["clip"]
     W, H = args.width or base["width"], args.height or base["height"]
@@ -325,6 +431,7 @@ def run_api(args):
         print(json.dumps(out), flush=True)
         if not args.api_dir:
             shutil.rmtree(root, ignore_errors=True)
+    wd.done()
     if world > 1:
         torch.distributed.barrier()
         ctx.comm_destroy()
@@ -361,11 +468,29 @@ def main():
     ap.add_argument("--api-save", type=int, default=0, help="--api: 1 = write cb_render/*.png for every valid pose, as the reference does")
     ap.add_argument("--api-phys", type=int, default=1, help="--api: 0 = skip the physics pre-filter (every pose valid)")
     ap.add_argument("--api-dir", default=None, help="--api: data_dir root (default: a temporary directory, removed afterwards)")
+    ap.add_argument("--dry-collective", action="store_true",
+                    help="only rendezvous + communicator init + one 1 MiB all-gather + argmax agreement (diagnoses a failed --gpus N run)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args.gpus)
-    if args.api:
-        return run_api(args)
+    wd = Watchdog()
+    try:
+        if args.dry_collective:
+            return run_dry_collective(args, wd)
+        if args.api:
+            return run_api(args, wd)
+        return run_kernel_bench(args, wd)
+    except SystemExit:
+        raise
+    except BaseException as e:              # N > 1: say what broke, on which rank and GPU, and leave at once so that no rank waits in a barrier
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            import traceback
+            traceback.print_exc()
+            report_failure(wd.stage_name or "setup", f"{type(e).__name__}: {e}", wd.device)
+        raise
+
+
+def run_kernel_bench(args, wd):
 
     import torch
     from dream2real_amd import dist as d2r_dist
@@ -376,10 +501,13 @@ def main():
     from dream2real_amd.geometry_utils import spatially_smooth_heatmap
     from synthetic_scenes import make_scene, make_task, scene_text_embeds
 
+    wd.stage("rendezvous (torch.distributed.init_process_group)", 300)
     rank, world, local = d2r_dist.init_from_env()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     local = local % torch.cuda.device_count()      # several ranks may share a GPU in smoke runs (gloo)
     torch.cuda.set_device(local)
+    wd.device = local
+    wd.stage("setup (scene, models, background)", 900)
     dev = torch.device("cuda", local)
 
     # ---------------- which workload
@@ -444,7 +572,9 @@ def main():
     ctx.set_stream(stream.cuda_stream)
     # the one collective: the C-ABI communicator (RCCL over xGMI); torch.distributed only bootstraps it
     # (id blob) and provides the timing barrier
+    wd.stage("d2r_comm_init (ncclCommInitRank)", 300)
     c_abi_comm = d2r_dist.init_comm(ctx, rank, world)
+    wd.stage("warmup steps (render + score + all-gather)", 900)
     # gathered layout: `world` shards of the partition in rank order (padded to the largest inside the exchange)
     N_gather = N_run
     gather = d2r_dist.ShardGather(ctx, N_gather, text.shape[0], rank, world, dev, c_abi_comm)
@@ -470,11 +600,13 @@ def main():
         step()
     ctx.set_option("timing", 1)
     barrier()
+    wd.stage("timed steps (render + score + all-gather)", 600 + 120 * args.steps)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         best, scores = step()
     barrier()
     elapsed = time.perf_counter() - t0
+    wd.stage("result reduction (all_reduce) and report", 1200)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64,
                          device=dev if torch.distributed.get_backend() == "nccl" else "cpu")
@@ -495,14 +627,14 @@ def main():
     def recorded_traffic():
         """HBM-side bytes per k_march launch from the committed PMC passes (bench.py cannot run
         under --pmc itself); only reported when it was measured on this exact workload."""
-        for name in ("r03_march_traffic.json", "r01_march_traffic.json"):
+        for name in ("r04_march_traffic.json", "r03_march_traffic.json", "r01_march_traffic.json"):
             try:
                 t = json.load(open(os.path.join(REPO, "profiles", name)))
             except OSError:
                 continue
             wl = t["workload"]
             if (wl["scene"], wl["width"], wl["height"], wl["chunk"], wl["clip"]) != (scene_name, W, H, per_launch, clip_name):
-                return None, None
+                continue
             return t["traffic_bytes_per_launch"], f"profiles/{name} ({t.get('how', 'FETCH_SIZE+WRITE_SIZE')})"
         return None, None
 
@@ -557,7 +689,11 @@ def main():
                          "samples_per_launch": int(samples_per_launch),
                          "lane_utilisation": round(stats["samples"] / max(1, 64 * stats["wave_iters"]), 4),
                          "avg_launch_ms": round(march_avg_s * 1e3, 4),
-                         "mlp_tflops": round(samples_per_launch * MLP_FLOP_PER_SAMPLE / march_avg_s / 1e12, 3) if march_avg_s > 0 else None},
+                         "mlp_tflops": round(samples_per_launch * MLP_FLOP_PER_SAMPLE / march_avg_s / 1e12, 3) if march_avg_s > 0 else None,
+                         # the same kernel priced on the bytes the memory system actually moved (PMC FETCH_SIZE + WRITE_SIZE per
+                         # launch / launch time / peak): 10 of 16 levels are served from LDS bricks, so this is far below `frac`
+                         "traffic_frac": round(traffic / march_avg_s / 1e9 / HBM_PEAK_GBPS, 5) if (traffic and march_avg_s > 0) else None,
+                         "vit": None},
             "roofline_vit": {"bound": "mfma", "gflop_per_image": round(vit_gflop(cfg, executed=cls_last), 2),
                              "gflop_per_image_architecture": round(vit_gflop(cfg), 2),
                              "note": "last block: q, attention output, out-proj and MLP on the class token only (exact: the head reads nothing else)",
@@ -568,6 +704,9 @@ def main():
             "render_stats_per_step": stats,
             "argmax_pose": best,
         }
+        # the step's DOMINANT kernel family is the ViT's GEMMs (MFMA-bound by shape): its fraction rides inside `roofline` so
+        # that a record which keeps only that object keeps it (`roofline_vit` stays as the same object for older readers)
+        out["roofline"]["vit"] = out["roofline_vit"]
         if world == 1:
             out["power"] = power_probe(step, dev.index or 0, args.power_seconds)
         if world == 1 and args.cpu_sample > 0:
@@ -586,6 +725,7 @@ def main():
             np.savez(args.dump, logits=step.logits, scores=scores, run_idx=run_idx, sample_res=np.asarray(sample_res), best=best,
                      pose_batch=pose_batch)
         print(json.dumps(out), flush=True)
+    wd.done()
     if world > 1:
         torch.distributed.barrier()
         ctx.comm_destroy()

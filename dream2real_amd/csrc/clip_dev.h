@@ -1,5 +1,7 @@
-// clip_dev.h — measurement switches of clip.hip.  DEVELOPMENT BUILDS ONLY (make DEV=1, or GEMM_ABLATE= / ATTN_ABLATE= /
-// EXTRA=-DD2R_GEMM_STAMPS): the product library is built without this file.
+// clip_dev.h — measurement switches of clip.hip.  DEVELOPMENT BUILDS ONLY (make DEV=1, GEMM_ABLATE=<mask>, ATTN_ABLATE=<mask>,
+// or DEV=1 EXTRA=-DD2R_GEMM_STAMPS — the stamps need the development build): the product library is built with every
+// switch here off.  The Makefile keeps the flags of the last build in _build/flags.stamp, so changing any of them
+// rebuilds every object.
 //
 // D2R_GEMM_ABLATE (bitmask) — k_gemm8 and the shared epilogue: 1 no LDS-DMA, 2 no fragment ds_reads, 4 no epilogue,
 //   8 no MFMA, 128 no global loads/stores in the epilogue, 256 no LDS transposes in the epilogue.

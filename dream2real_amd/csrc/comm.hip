@@ -26,6 +26,7 @@ struct RcclApi {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    const char *(*GetLastError)(ncclComm_t) = nullptr;       // optional: RCCL's own description of what went wrong
     std::string error;
 };
 
@@ -54,6 +55,7 @@ RcclApi &rccl()
         api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
         api.AllGather = (decltype(api.AllGather))sym("ncclAllGather");
         api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+        api.GetLastError = (decltype(api.GetLastError))dlsym(api.handle, "ncclGetLastError");
     });
     return api;
 }
@@ -61,7 +63,12 @@ RcclApi &rccl()
 int rccl_fail(d2r_ctx *ctx, const char *what, ncclResult_t r)
 {
     RcclApi &R = rccl();
-    return d2r_fail(ctx, D2R_ERR_DEVICE, std::string(what) + ": " + (R.GetErrorString ? R.GetErrorString(r) : "RCCL error"));
+    std::string msg = std::string(what) + ": " + (R.GetErrorString ? R.GetErrorString(r) : "RCCL error");
+    if (R.GetLastError) {                      // the line RCCL logged for the failure, when it keeps one
+        const char *last = R.GetLastError(ctx ? (ncclComm_t)ctx->comm : nullptr);
+        if (last && *last) msg += std::string(" [") + last + "]";
+    }
+    return d2r_fail(ctx, D2R_ERR_DEVICE, msg);
 }
 
 }  // namespace

@@ -75,6 +75,40 @@ def allgather_logits(local_logits, n_total: int, rank: int, world: int):
     return torch.cat(parts, 0)
 
 
+def _machine_id() -> str:
+    """Names the MACHINE (not the container): the kernel's boot id is shared by every container on a host and differs
+    between hosts, whatever their hostnames are."""
+    try:
+        return open("/proc/sys/kernel/random/boot_id").read().strip()
+    except OSError:
+        return socket.gethostname()
+
+
+LAST_COMM_REPORT: dict = {}      # how the last init_comm decided: path taken, why, what every rank held
+
+
+def describe_environment(device_index=None) -> dict:
+    """What a failed N > 1 run needs in its log: who this rank is, which GPU it holds, the runtime versions and every
+    HSA_* / NCCL_* / RCCL_* / HIP_* / ROCR_* / MASTER_* variable of its environment."""
+    import torch
+    out = {"rank": int(os.environ.get("RANK", "0")), "local_rank": int(os.environ.get("LOCAL_RANK", "0")),
+           "world": int(os.environ.get("WORLD_SIZE", "1")), "host": socket.gethostname(), "machine": _machine_id(),
+           "torch": torch.__version__, "hip": getattr(torch.version, "hip", None), "device_count": torch.cuda.device_count()}
+    try:
+        out["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+    except Exception:
+        out["rccl_version"] = None
+    if device_index is not None and torch.cuda.is_available():
+        try:
+            out["device_identity"] = _device_identity(device_index)
+            out["device_name"] = torch.cuda.get_device_name(device_index)
+        except Exception as e:
+            out["device_identity"] = f"unavailable: {e}"
+    out["env"] = {k: v for k, v in sorted(os.environ.items())
+                  if k.startswith(("HSA_", "NCCL_", "RCCL_", "HIP_", "ROCR_", "MASTER_", "D2R_", "GPU_", "CUDA_VISIBLE"))}
+    return out
+
+
 def _device_identity(index: int) -> str:
     """Something that names the physical GPU behind torch device `index` whatever HIP_VISIBLE_DEVICES maps it to:
     every identifying property the runtime reports (UUID, PCI domain / bus / device), concatenated — a runtime that
@@ -109,30 +143,46 @@ def init_comm(ctx, rank: int, world: int) -> bool:
     # on one physical GPU; whether that is the case is decided from what the ranks actually hold — (host, device
     # identity) pairs gathered over the process group — not from device_count(), which is 1 on every rank when a
     # launcher gives each rank its own HIP_VISIBLE_DEVICES and says nothing about other nodes
-    mine = (socket.gethostname(), _device_identity(ctx.device) if ctx is not None and torch.cuda.is_available() else "no-gpu")
+    # (the machine is named by its boot id: containers of one host have different hostnames but share it, and two
+    # hosts with equal hostnames do not)
+    if dist.get_backend() == "nccl" and ctx is not None:
+        torch.cuda.set_device(ctx.device)           # object collectives on the nccl backend stage through the current device
+    mine = (_machine_id(), _device_identity(ctx.device) if ctx is not None and torch.cuda.is_available() else "no-gpu")
     held = [None] * world
     dist.all_gather_object(held, mine)
     shared = len(set(held)) < world
-    blob = [None]
+    report = {"world": world, "held": [list(h) for h in held], "shared_gpu": shared, "path": None, "reason": None, "error": None}
+    LAST_COMM_REPORT.clear()
+    LAST_COMM_REPORT.update(report)
+
+    def decided(path, reason, error=None):
+        LAST_COMM_REPORT.update(path=path, reason=reason, error=error)
+        if rank == 0 or error:
+            print(f"[d2r dist] rank {rank}/{world}: gather path = {path} ({reason})" + (f"; error: {error}" if error else ""),
+                  file=__import__("sys").stderr, flush=True)
+        return path == "rccl"
+
+    blob, err = [None], None
     if rank == 0 and not shared:
         try:
             blob[0] = ctx.comm_unique_id()
-        except _lib.D2RError:
-            blob[0] = None
+        except _lib.D2RError as e:
+            blob[0], err = None, str(e)
     dist.broadcast_object_list(blob, src=0)
     if blob[0] is None:
-        return False
-    ok = 1
+        return decided("torch-gather", "several ranks hold one physical GPU (RCCL refuses that)" if shared
+                       else "rank 0 could not draw an RCCL id", err)
+    ok, err = 1, None
     try:
         ctx.comm_init(blob[0], rank, world)
-    except _lib.D2RError:
-        ok = 0
+    except _lib.D2RError as e:
+        ok, err = 0, str(e)
     t = torch.tensor([ok], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MIN)
     if int(t.item()) == 0:
         ctx.comm_destroy()
-        return False
-    return True
+        return decided("torch-gather", "ncclCommInitRank failed on at least one rank", err)
+    return decided("rccl", "d2r_comm_init: ncclCommInitRank succeeded on every rank")
 
 
 class ShardGather:

@@ -81,6 +81,38 @@ def object_hulls(obj) -> list:
     return hulls_from_obj(model)
 
 
+def _np(x):
+    return x.detach().cpu().numpy() if hasattr(x, "detach") else np.asarray(x)
+
+
+def _as_parts(hulls, what):
+    """One hull ([V,3] array, nested list or tensor) or a sequence of hulls -> list of [V,3] float64 arrays.  A bare
+    [V,3] list-of-lists is ONE hull (iterating it would give V one-point 'hulls' that pass validation and collide wrongly)."""
+    if hasattr(hulls, "detach") or isinstance(hulls, np.ndarray):
+        hulls = _np(hulls)
+    else:
+        try:
+            arr = np.asarray([_np(h) for h in hulls], np.float64)
+        except (ValueError, TypeError):
+            arr = None                                   # ragged: a real sequence of hulls
+        if arr is not None and arr.ndim == 2 and arr.shape[1] == 3:
+            hulls = arr
+    if isinstance(hulls, np.ndarray):
+        if hulls.ndim == 2 and hulls.shape[1] == 3:
+            hulls = [hulls]
+        elif hulls.ndim == 3 and hulls.shape[2] == 3:
+            hulls = list(hulls)
+        else:
+            raise ValueError(f"{what}: expected [V,3] vertices or a sequence of such arrays, got shape {hulls.shape}")
+    parts = []
+    for k, h in enumerate(hulls):
+        a = np.asarray(_np(h), np.float64)
+        if a.ndim != 2 or a.shape[1] != 3 or a.shape[0] < 1:
+            raise ValueError(f"{what}: part {k} must be a [V,3] array with at least one vertex, got shape {a.shape}")
+        parts.append(a)
+    return parts
+
+
 def _pack(hulls):
     hs = [np.asarray(h, np.float64).reshape(-1, 3) for h in hulls]
     off = np.zeros(len(hs) + 1, np.uint32)
@@ -94,8 +126,8 @@ class PhysicsShapes:
 
     def __init__(self, ctx, movable_hulls, static_hulls):
         self.ctx = ctx
-        if isinstance(movable_hulls, np.ndarray) and movable_hulls.ndim == 2:
-            movable_hulls = [movable_hulls]                       # a single hull
+        movable_hulls = _as_parts(movable_hulls, "movable_hulls")      # a single hull in any array-like form, or parts
+        static_hulls = _as_parts(static_hulls, "static_hulls") if len(static_hulls) else []
         mv, moff = _pack(movable_hulls)
         sv, soff = _pack(static_hulls)
         h = C.c_void_p()

@@ -68,3 +68,103 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
     want_g = np.arange(7, dtype=np.float32)[:, None] * np.array([1.0, 10.0], np.float32)
     np.testing.assert_array_equal(np.load(tmp_path / "gather_0.npy"), want_g)
     np.testing.assert_array_equal(np.load(tmp_path / "gather_1.npy"), want_g)
+
+
+def test_stuck_rendezvous_is_reported_not_hung(tmp_path):
+    """bench.py under a launcher whose other rank never arrives: the watchdog prints ONE JSON line naming the stage,
+    the rank and the HSA_* / NCCL_* / MASTER_* environment and exits non-zero instead of waiting in the rendezvous."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               D2R_WATCHDOG_SCALE="0.02", NCCL_DEBUG="WARN", D2R_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--dry-collective"], env=env,
+                       capture_output=True, text=True, timeout=300, cwd=repo)
+    assert r.returncode == 3, (r.returncode, r.stdout[-1500:], r.stderr[-1500:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert "no progress" in d["collective_error"] and d["stage"].startswith("rendezvous")
+    assert d["rank"] == 0 and d["world"] == 2 and d["env"]["MASTER_PORT"] == str(port) and d["env"]["NCCL_DEBUG"] == "WARN"
+    assert d["machine"] and "torch" in d
+
+
+API_WORKER = r'''
+import os, sys, types, numpy as np, torch
+sys.path.insert(0, os.environ["D2R_REPO"])
+from dream2real_amd import clip_scoring, dist as dd
+rank, world, _ = dd.init_from_env("gloo")
+out = os.environ["D2R_OUT"]
+
+class FusedRenderer:                      # the surface optimise_pose_grid's fused branch uses, logits a function of the pose
+    def __init__(self, root):
+        self.fg_obj = types.SimpleNamespace(vis_model=types.SimpleNamespace(ctx=None))
+        self.out_render_path = os.path.join(root, "cb_render")
+        self.calls = []
+    def _clear_renders(self):
+        import shutil
+        shutil.rmtree(self.out_render_path, ignore_errors=True)
+        os.makedirs(self.out_render_path)
+    def render_score(self, valid_poses, render_poses, idx, scorer, text, depths_gt=None, movable_masks=None, save=True, first_index=0, clear=True, return_frames=False):
+        self.calls.append((len(valid_poses), first_index, clear))
+        if save and clear:
+            self._clear_renders()
+        p = np.asarray(valid_poses, np.float32).reshape(-1, 16)
+        if save:
+            for i in range(len(p)):
+                open(os.path.join(self.out_render_path, f"cb_rgb_{first_index + i:04d}.png"), "w").write(str(rank))
+        return np.stack([20 + p[:, 3] * 3 + p[:, 7], 18 + 0.1 * p[:, 11]], 1).astype(np.float32)
+    def render_one(self, pose):
+        return np.zeros((4, 6, 3), np.uint8)
+
+sm = types.SimpleNamespace(scene_centre=torch.tensor([0.5, 0.0, 0.035]), opt_cam_poses=[torch.eye(4)])
+task = types.SimpleNamespace(scene_model=sm, goal_caption="g", norm_captions=["n"], movable_masks=None,
+                             movable_obj=types.SimpleNamespace(pose=torch.eye(4)))
+mask = np.ones(70, bool); mask[[1, 8, 40, 41, 69]] = False
+def phys(pose_batch, tm, valid):
+    return valid & torch.from_numpy(mask)
+rend = FusedRenderer(out)
+best, poses, scores = clip_scoring.optimise_pose_grid(rend, None, [0], task, out, sample_res=[7, 5, 2, 1, 1, 1], phys_check=phys, scene_type=3,
+                                                      scorer=types.SimpleNamespace(h=1), text_embeds=np.eye(2, 8, dtype=np.float32))
+np.save(os.path.join(out, f"api_scores_{rank}.npy"), scores.numpy())
+np.save(os.path.join(out, f"api_best_{rank}.npy"), best.numpy())
+open(os.path.join(out, f"api_calls_{rank}.txt"), "w").write(repr(rend.calls))
+'''
+
+
+def test_optimise_pose_grid_shards_inside_the_api(tmp_path):
+    """optimise_pose_grid under a 2-rank launcher (gloo, CPU; fake fused renderer): every rank renders + scores its
+    contiguous block of the VALID poses with the right first file index, logits are gathered once, and scores / best
+    pose / files equal the single-process run on every rank; rank 0 alone writes best_render.png."""
+    import ast
+    script = tmp_path / "api_worker.py"
+    script.write_text(API_WORKER)
+    outs = {}
+    for world in (1, 2):
+        out = tmp_path / f"w{world}"
+        out.mkdir()
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+        env.update(D2R_REPO=REPO, D2R_OUT=str(out))
+        cmd = [sys.executable, str(script)] if world == 1 else \
+            [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+             "--master-port", "29713", str(script)]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs[world] = out
+    one = np.load(outs[1] / "api_scores_0.npy")
+    assert (one != 0).sum() == 65
+    for rank in (0, 1):
+        np.testing.assert_array_equal(np.load(outs[2] / f"api_scores_{rank}.npy"), one)
+        np.testing.assert_array_equal(np.load(outs[2] / f"api_best_{rank}.npy"), np.load(outs[1] / "api_best_0.npy"))
+    assert ast.literal_eval((outs[1] / "api_calls_0.txt").read_text()) == [(65, 0, True)]
+    assert ast.literal_eval((outs[2] / "api_calls_0.txt").read_text()) == [(33, 0, False)]
+    assert ast.literal_eval((outs[2] / "api_calls_1.txt").read_text()) == [(32, 33, False)]
+    files = sorted(os.listdir(outs[2] / "cb_render"))
+    assert files == [f"cb_rgb_{i:04d}.png" for i in range(65)]
+    assert [(outs[2] / "cb_render" / f).read_text() for f in files] == ["0"] * 33 + ["1"] * 32
+    assert (outs[1] / "best_render.png").exists() and (outs[2] / "best_render.png").exists()
