@@ -20,7 +20,7 @@ EXPORTS = [
     "d2r_text_destroy", "d2r_text_encode", "d2r_comm_get_unique_id", "d2r_comm_init", "d2r_comm_destroy",
     "d2r_allgather_scores", "d2r_phys_create", "d2r_phys_destroy", "d2r_phys_check", "d2r_nerf_load_ingp",
     "d2r_rectify_background_depth", "d2r_ingp_inspect", "d2r_render_score_host", "d2r_png_write", "d2r_png_write_batch",
-    "d2r_png_read_batch", "d2r_png_size", "d2r_savetxt",
+    "d2r_png_read_batch", "d2r_png_size", "d2r_savetxt", "d2r_ingp_validate",
 ]
 
 
@@ -69,7 +69,8 @@ class IngpView(C.Structure):
 class IngpInfo(C.Structure):
     _fields_ = [("n_levels", C.c_uint32), ("n_features", C.c_uint32), ("aabb_scale", C.c_uint32),
                 ("has_background", C.c_int32), ("dataset_scale", C.c_double), ("dataset_offset", C.c_double * 3),
-                ("background_color", C.c_float * 4), ("n_views", C.c_uint32), ("n_views_written", C.c_uint32)]
+                ("background_color", C.c_float * 4), ("n_views", C.c_uint32), ("n_views_written", C.c_uint32),
+                ("n_unknown_keys", C.c_uint32)]
 
 
 class FrameSink(C.Structure):
@@ -182,6 +183,16 @@ def savetxt(path: str, array):
     a = np.ascontiguousarray(a, np.float64)
     rows, cols = (a.shape[0], 1) if a.ndim == 1 else a.shape
     check(load().d2r_savetxt(os.fsencode(path), ptr(a), C.c_uint64(rows), C.c_uint64(cols), C.c_int(0)))
+
+
+def ingp_validate(data: bytes) -> IngpInfo:
+    """d2r_ingp_validate: raises D2RError with the loader's message (naming the key) when d2r_nerf_load_ingp would refuse
+    the snapshot; returns what the loader would report about it otherwise.  Host only."""
+    info = IngpInfo()
+    lib = load()
+    lib.d2r_ingp_validate.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p]
+    check(lib.d2r_ingp_validate(data, len(data), C.byref(info)))
+    return info
 
 
 def check(rc: int, ctx=None):

@@ -40,6 +40,36 @@ struct Node {
     std::string str() const { return kind == STR ? std::string((const char *)p, n) : std::string(); }
 };
 
+const char *kind_name_of(const Node &n)
+{
+    switch (n.kind) {
+        case Node::NIL: return "nil";
+        case Node::BOOL: return "bool";
+        case Node::INT: return "int";
+        case Node::FLOAT: return "float";
+        case Node::STR: return "str";
+        case Node::BIN: return "bin";
+        case Node::ARR: return "array";
+        default: return "map";
+    }
+}
+
+std::string scalar_text_of(const Node &n)
+{
+    char buf[64];
+    switch (n.kind) {
+        case Node::BOOL: return n.i ? "true" : "false";
+        case Node::INT: snprintf(buf, sizeof buf, "%lld", (long long)n.i); return buf;
+        case Node::FLOAT: snprintf(buf, sizeof buf, "%.9g", n.f); return buf;
+        case Node::STR: {
+            std::string t = n.str().substr(0, 48);
+            for (char &c : t) if ((unsigned char)c < 0x20 || c == 0x7f) c = '?';
+            return "\"" + t + "\"";
+        }
+        default: return "";
+    }
+}
+
 struct Reader {
     const uint8_t *p, *end;
     bool ok = true;
@@ -207,6 +237,158 @@ void d2r_grid_levels(uint32_t L, uint32_t log2_hashmap, uint32_t base, double pe
     n_entries = (uint32_t)off;
 }
 
+// ---- what of a snapshot defines the rendered function, and what this library implements of it.
+// The layout is BELIEVED (no instant-ngp source or file offline): nothing is defaulted silently.  Keys that define the
+// network or the frame are either READ (required, error naming the key when absent or of the wrong kind) or CHECKED
+// (optional, but when present they must carry the one value the kernels implement); an unknown key inside a section
+// that defines the function (encoding / network / rgb_network / dir_encoding) is an error; unknown keys elsewhere are
+// counted (d2r_ingp_info.n_unknown_keys) and listed by d2r_ingp_inspect with a '?'.
+namespace {
+
+void walk(const Node &n, const std::string &path, std::string &out, uint32_t *unknown = nullptr);   // defined with d2r_ingp_inspect
+
+struct Audit {
+    std::string err;          // first failure ("" = none)
+    uint32_t unknown = 0;     // keys that are neither read, checked nor known to be irrelevant to rendering
+    bool fail(const std::string &m)
+    {
+        if (err.empty()) err = m;
+        return false;
+    }
+};
+
+const Node *need(Audit &A, const Node *m, const char *section, const char *key, int kind /* Node::Kind, or -1 = number */)
+{
+    const Node *v = m ? m->get(key) : nullptr;
+    if (!v) {
+        A.fail(std::string("snapshot: required key ") + section + "." + key + " is missing");
+        return nullptr;
+    }
+    const bool ok = kind < 0 ? v->number() : (int)v->kind == kind;
+    if (!ok) {
+        A.fail(std::string("snapshot: ") + section + "." + key + " has msgpack kind '" + kind_name_of(*v) + "', expected " +
+               (kind < 0 ? "a number" : kind == Node::STR ? "a string" : kind == Node::BIN ? "binary" : kind == Node::ARR ? "an array" : "a map"));
+        return nullptr;
+    }
+    return v;
+}
+
+// optional key that must, when present, hold one of the accepted strings
+void check_text(Audit &A, const Node *m, const char *section, const char *key, std::initializer_list<const char *> accepted)
+{
+    const Node *v = m ? m->get(key) : nullptr;
+    if (!v) return;
+    std::string got = v->kind == Node::STR ? v->str() : std::string("<") + kind_name_of(*v) + ">";
+    for (const char *a : accepted)
+        if (got == a) return;
+    std::string list;
+    for (const char *a : accepted) list += std::string(list.empty() ? "" : " / ") + a;
+    A.fail(std::string("snapshot: ") + section + "." + key + " = '" + got + "' is not implemented (only " + list + ")");
+}
+
+// optional key that must, when present, be a number equal to `want`
+void check_num(Audit &A, const Node *m, const char *section, const char *key, double want, const char *why)
+{
+    const Node *v = m ? m->get(key) : nullptr;
+    if (!v) return;
+    if (!v->number() || v->num() != want)
+        A.fail(std::string("snapshot: ") + section + "." + key + " = " + (v->number() ? scalar_text_of(*v) : std::string("<") + kind_name_of(*v) + ">") +
+               " is not implemented (" + why + ")");
+}
+
+void only_keys(Audit &A, const Node *m, const char *section, std::initializer_list<const char *> known)
+{
+    if (!m || m->kind != Node::MAP) return;
+    for (const auto &kv : m->map) {
+        bool ok = false;
+        for (const char *k : known) ok = ok || kv.first == k;
+        if (!ok) A.fail(std::string("snapshot: unknown key ") + section + "." + kv.first + " in a section that defines the network: refusing to guess what it changes");
+    }
+}
+
+bool is_identity3(const Node *m)
+{
+    if (!m || m->kind != Node::ARR) return false;
+    std::vector<double> v;
+    for (const Node &r : m->arr) {
+        if (r.kind == Node::ARR) for (const Node &e : r.arr) v.push_back(e.num());
+        else v.push_back(r.num());
+    }
+    if (v.size() != 9) return false;
+    for (int k = 0; k < 9; k++)
+        if (fabs(v[k] - (k % 4 == 0 ? 1.0 : 0.0)) > 1e-6) return false;
+    return true;
+}
+
+// rendering-relevant state outside the network sections: must be absent or at the value that leaves the frame unchanged
+void audit_render_state(Audit &A, const Node *snap, const Node *nerf, const Node *ds)
+{
+    for (const Node *m : {snap, ds})
+        if (m && m->get("render_aabb_to_local") && !is_identity3(m->get("render_aabb_to_local")))
+            A.fail(std::string("snapshot: ") + (m == snap ? "snapshot" : "snapshot.nerf.dataset") + ".render_aabb_to_local is not the identity: a rotated crop box is not implemented");
+    check_num(A, snap, "snapshot", "exposure", 0.0, "frames are rendered at exposure 0");
+    check_num(A, ds, "snapshot.nerf.dataset", "n_extra_learnable_dims", 0.0, "extra network input dimensions change the colour network's input width");
+    check_num(A, nerf, "snapshot.nerf", "n_extra_dims", 0.0, "extra network input dimensions change the colour network's input width");
+    check_num(A, ds, "snapshot.nerf.dataset", "envmap_resolution", 0.0, "environment maps are not implemented");
+    for (const char *flag : {"is_hdr", "from_mitsuba"}) {
+        const Node *v = ds ? ds->get(flag) : nullptr;
+        if (v && v->number() && v->num() != 0.0)
+            A.fail(std::string("snapshot: snapshot.nerf.dataset.") + flag + " is set: " +
+                   (flag[0] == 'i' ? "HDR (linear-colour) datasets are not implemented" : "mitsuba camera conventions are not implemented"));
+    }
+    // tiny-cuda-nn activation enums as instant-ngp stores them (ENerfActivation: None 0, ReLU 1, Logistic 2, Exponential 3)
+    check_num(A, nerf, "snapshot.nerf", "rgb_activation", 2.0, "colour = sigmoid(network output)");
+    check_num(A, nerf, "snapshot.nerf", "density_activation", 3.0, "sigma = exp(network output)");
+    const Node *rl = nerf ? nerf->get("render_with_lens_distortion") : nullptr;
+    if (rl && rl->number() && rl->num() != 0.0)
+        A.fail("snapshot: snapshot.nerf.render_with_lens_distortion is set: lens distortion is not implemented (the reference's cached-snapshot path renders without it)");
+}
+
+void audit_networks(Audit &A, const Node *enc, const Node *net, const Node *rgb, const Node *dir)
+{
+    only_keys(A, enc, "encoding", {"otype", "type", "n_levels", "n_features_per_level", "log2_hashmap_size", "base_resolution",
+                                   "per_level_scale", "interpolation", "n_dims_to_encode"});
+    check_text(A, enc, "encoding", "otype", {"HashGrid", "Grid"});
+    check_text(A, enc, "encoding", "type", {"Hash"});
+    check_text(A, enc, "encoding", "interpolation", {"Linear"});
+    check_num(A, enc, "encoding", "n_dims_to_encode", 3.0, "positions are 3-D");
+    for (const Node *m : {net, rgb}) {
+        const char *sec = m == net ? "network" : "rgb_network";
+        only_keys(A, m, sec, {"otype", "activation", "output_activation", "n_neurons", "n_hidden_layers"});
+        check_text(A, m, sec, "otype", {"FullyFusedMLP", "CutlassMLP"});
+        check_text(A, m, sec, "activation", {"ReLU"});
+        check_text(A, m, sec, "output_activation", {"None"});
+    }
+    // direction encoding: spherical harmonics of degree 4 on the 3 direction inputs, alone or as the first member of a
+    // Composite whose other members are Identity encodings of the (zero) extra dimensions
+    auto sh4 = [&](const Node *m, const char *sec) {
+        only_keys(A, m, sec, {"otype", "degree", "n_dims_to_encode"});
+        check_num(A, m, sec, "n_dims_to_encode", 3.0, "directions are 3-D");
+        const Node *dg = need(A, m, sec, "degree", -1);
+        if (dg && dg->num() != 4.0) A.fail(std::string("snapshot: ") + sec + ".degree = " + scalar_text_of(*dg) + " is not implemented (spherical harmonics of degree 4 only)");
+    };
+    const Node *ot = need(A, dir, "dir_encoding", "otype", Node::STR);
+    if (!ot) return;
+    if (ot->str() == "SphericalHarmonics") sh4(dir, "dir_encoding");
+    else if (ot->str() == "Composite") {
+        only_keys(A, dir, "dir_encoding", {"otype", "nested"});
+        const Node *ns = need(A, dir, "dir_encoding", "nested", Node::ARR);
+        if (!ns) return;
+        if (ns->arr.empty() || ns->arr[0].kind != Node::MAP || !ns->arr[0].get("otype") || ns->arr[0].get("otype")->str() != "SphericalHarmonics")
+            A.fail("snapshot: dir_encoding.nested[0] must be the SphericalHarmonics encoding of the direction");
+        else sh4(&ns->arr[0], "dir_encoding.nested[0]");
+        for (size_t k = 1; k < ns->arr.size(); k++) {
+            const Node *o = ns->arr[k].kind == Node::MAP ? ns->arr[k].get("otype") : nullptr;
+            if (!o || o->str() != "Identity")
+                A.fail("snapshot: dir_encoding.nested[" + std::to_string(k) + "] is not an Identity encoding of the (absent) extra dimensions: not implemented");
+        }
+    } else {
+        A.fail("snapshot: dir_encoding.otype = '" + ot->str() + "' is not implemented (SphericalHarmonics, or Composite of it)");
+    }
+}
+
+}  // namespace
+
 static int load_ingp(d2r_ctx *ctx, const void *bytes, size_t len, d2r_nerf **out, d2r_ingp_info *info,
                      d2r_ingp_view *views, uint32_t views_cap)
 {
@@ -223,30 +405,50 @@ static int load_ingp(d2r_ctx *ctx, const void *bytes, size_t len, d2r_nerf **out
     Reader rd{raw.data(), raw.data() + raw.size()};
     const Node cfg = rd.parse();
     if (!rd.ok || cfg.kind != Node::MAP) return d2r_fail(ctx, D2R_ERR_INVALID, "snapshot: not a msgpack map");
-    const Node *snap = cfg.get("snapshot"), *enc = cfg.get("encoding"), *net = cfg.get("network"), *rgb = cfg.get("rgb_network");
-    if (!snap || !enc || !net || !rgb) return d2r_fail(ctx, D2R_ERR_INVALID, "snapshot: encoding / network / rgb_network / snapshot missing");
+    Audit A;
+    const Node *snap = need(A, &cfg, "<root>", "snapshot", Node::MAP), *enc = need(A, &cfg, "<root>", "encoding", Node::MAP),
+               *net = need(A, &cfg, "<root>", "network", Node::MAP), *rgb = need(A, &cfg, "<root>", "rgb_network", Node::MAP),
+               *dir = need(A, &cfg, "<root>", "dir_encoding", Node::MAP);
+    if (!A.err.empty()) return d2r_fail(ctx, D2R_ERR_INVALID, A.err);
     auto num = [](const Node *m, const char *k, double dflt) { const Node *v = m ? m->get(k) : nullptr; return v && v->number() ? v->num() : dflt; };
-    auto text = [](const Node *m, const char *k, const char *dflt) { const Node *v = m ? m->get(k) : nullptr; return v && v->kind == Node::STR ? v->str() : std::string(dflt); };
-    const std::string otype = text(enc, "otype", "HashGrid"), etype = text(enc, "type", "Hash");
-    if ((otype != "HashGrid" && otype != "Grid") || etype != "Hash") return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "snapshot: unsupported position encoding");
-    if (num(net, "n_neurons", 64) != 64 || num(rgb, "n_neurons", 64) != 64 || num(net, "n_hidden_layers", 1) != 1 || num(rgb, "n_hidden_layers", 2) != 2)
-        return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "snapshot: only the 32->64->16 density and 32->64->64->16 colour MLPs are implemented");
-    const Node *nerf = snap->get("nerf"), *ds = nerf ? nerf->get("dataset") : nullptr;
-    const double aabb_d = num(nerf, "aabb_scale", num(ds, "aabb_scale", 1));
+    auto req = [&](const Node *m, const char *sec, const char *k) { const Node *v = need(A, m, sec, k, -1); return v ? v->num() : 0.0; };
+    audit_networks(A, enc, net, rgb, dir);
+    const double nn = req(net, "network", "n_neurons"), nh = req(net, "network", "n_hidden_layers"),
+                 rn = req(rgb, "rgb_network", "n_neurons"), rh = req(rgb, "rgb_network", "n_hidden_layers");
+    const double L_d = req(enc, "encoding", "n_levels"), F_d = req(enc, "encoding", "n_features_per_level"),
+                 log2_hash = req(enc, "encoding", "log2_hashmap_size"), base_res = req(enc, "encoding", "base_resolution"),
+                 pls = num(enc, "per_level_scale", 0.0);        // optional: instant-ngp derives it from aabb_scale when absent
+    const Node *nerf = need(A, snap, "snapshot", "nerf", Node::MAP), *ds = need(A, nerf, "snapshot.nerf", "dataset", Node::MAP);
+    if (!A.err.empty()) return d2r_fail(ctx, D2R_ERR_INVALID, A.err);
+    audit_render_state(A, snap, nerf, ds);
+    if (!A.err.empty()) return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, A.err);
+    if (nn != 64 || rn != 64 || nh != 1 || rh != 2)
+        return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "snapshot: only the 32->64->16 density and 32->64->64->16 colour MLPs are implemented (network.n_neurons " +
+                        std::to_string((long long)nn) + ", n_hidden_layers " + std::to_string((long long)nh) + "; rgb_network.n_neurons " + std::to_string((long long)rn) +
+                        ", n_hidden_layers " + std::to_string((long long)rh) + ")");
+    // aabb_scale lives on the NeRF state and on its dataset; at least one must be there, and they must agree
+    const Node *a1 = nerf->get("aabb_scale"), *a2 = ds->get("aabb_scale");
+    if (!a1 && !a2) return d2r_fail(ctx, D2R_ERR_INVALID, "snapshot: required key snapshot.nerf.aabb_scale (or snapshot.nerf.dataset.aabb_scale) is missing");
+    if (a1 && a2 && a1->num() != a2->num())
+        return d2r_fail(ctx, D2R_ERR_INVALID, "snapshot: snapshot.nerf.aabb_scale and snapshot.nerf.dataset.aabb_scale disagree");
+    const double aabb_d = (a1 ? a1 : a2)->number() ? (a1 ? a1 : a2)->num() : 0.0;
     const uint32_t aabb = aabb_d >= 1 && aabb_d <= 128 && aabb_d == floor(aabb_d) ? (uint32_t)aabb_d : 0;
     if (aabb == 0 || (aabb & (aabb - 1)) || aabb > 128) return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "snapshot: aabb_scale must be a power of two <= 128");
     uint32_t n_casc = 1;
     while ((1u << (n_casc - 1)) < aabb) n_casc++;
-    const double L_d = num(enc, "n_levels", 16), F_d = num(enc, "n_features_per_level", 2);
+    // the marcher's step rule is tied to the box: constant steps for aabb_scale 1, cone angle 1/256 beyond it
+    check_num(A, nerf, "snapshot.nerf", "cone_angle_constant", aabb <= 1 ? 0.0 : 1.0 / 256.0,
+              aabb <= 1 ? "aabb_scale 1 marches with constant steps" : "aabb_scale >= 2 marches with cone angle 1/256");
+    if (!A.err.empty()) return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, A.err);
     const uint32_t L = L_d >= 1 && L_d <= 64 ? (uint32_t)L_d : 0, F = F_d >= 1 && F_d <= 16 ? (uint32_t)F_d : 0;
-    if (!((L == 16 && F == 2) || (L == 8 && F == 4))) return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "snapshot: hash grid layout must be L=16,F=2 or L=8,F=4");
+    if (!((L == 16 && F == 2) || (L == 8 && F == 4)))
+        return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "snapshot: hash grid layout must be L=16,F=2 or L=8,F=4 (encoding.n_levels " + std::to_string((long long)L_d) +
+                        ", n_features_per_level " + std::to_string((long long)F_d) + ")");
     std::vector<float> scale;
     std::vector<uint32_t> res, size, offset;
     uint32_t n_entries = 0;
     // the level table is computed from these three: refuse values its arithmetic is not defined for (shift counts,
     // float -> integer conversions of inf / NaN) instead of deriving a table from them
-    const double log2_hash = num(enc, "log2_hashmap_size", 19), base_res = num(enc, "base_resolution", 16),
-                 pls = num(enc, "per_level_scale", 0.0);
     if (!(log2_hash >= 1 && log2_hash <= 24) || log2_hash != floor(log2_hash))
         return d2r_fail(ctx, D2R_ERR_INVALID, "snapshot: log2_hashmap_size must be an integer in 1..24");
     if (!(base_res >= 1 && base_res <= 65536) || base_res != floor(base_res))
@@ -254,16 +456,35 @@ static int load_ingp(d2r_ctx *ctx, const void *bytes, size_t len, d2r_nerf **out
     if (!(pls == 0.0 || (std::isfinite(pls) && pls >= 1.0 && pls <= 16.0)))      // 0 = absent: derived from aabb_scale
         return d2r_fail(ctx, D2R_ERR_INVALID, "snapshot: per_level_scale must be finite, in 1..16");
     d2r_grid_levels(L, (uint32_t)log2_hash, (uint32_t)base_res, pls, aabb, scale, res, size, offset, n_entries);
-    if (text(snap, "params_type", "__half") != "__half") return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "snapshot: params_type must be __half");
-    const Node *pb = snap->get("params_binary"), *db = snap->get("density_grid_binary");
-    if (!pb || pb->kind != Node::BIN || !db || db->kind != Node::BIN) return d2r_fail(ctx, D2R_ERR_INVALID, "snapshot: params_binary / density_grid_binary missing");
+    const Node *pt = need(A, snap, "snapshot", "params_type", Node::STR);
+    const Node *pb = need(A, snap, "snapshot", "params_binary", Node::BIN), *db = need(A, snap, "snapshot", "density_grid_binary", Node::BIN);
+    const double dgs = req(snap, "snapshot", "density_grid_size");
+    if (!A.err.empty()) return d2r_fail(ctx, D2R_ERR_INVALID, A.err);
     const size_t n_in = (size_t)L * F, sizes[6] = {64 * n_in, 16 * 64, 64 * 32, 64 * 64, 16 * 64, (size_t)n_entries * F};
     size_t total = 0;
     for (size_t s : sizes) total += s;
-    if (pb->n != total * 2) return d2r_fail(ctx, D2R_ERR_INVALID, "snapshot: params_binary holds " + std::to_string(pb->n / 2) + " halves, expected " + std::to_string(total));
-    if (num(snap, "density_grid_size", 128) != (double)D2R_GRID) return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "snapshot: density_grid_size must be 128");
+    if (pt->str() != "__half")
+        return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "snapshot: snapshot.params_type = '" + pt->str() + "': only __half (fp16) parameters are implemented" +
+                        (pb->n == total * 4 ? " (params_binary has the size of fp32 parameters)" : ""));
+    if (const Node *np = snap->get("n_params"))
+        if (np->number() && np->num() != (double)total)
+            return d2r_fail(ctx, D2R_ERR_INVALID, "snapshot: snapshot.n_params = " + scalar_text_of(*np) + ", but the encoding / network sections describe " +
+                            std::to_string(total) + " parameters (density MLP, colour MLP, hash tables): the parameter layout is not the one this loader knows");
+    if (pb->n != total * 2)
+        return d2r_fail(ctx, D2R_ERR_INVALID, "snapshot: snapshot.params_binary holds " + std::to_string(pb->n / 2) + " halves, expected " + std::to_string(total) +
+                        " (density MLP " + std::to_string(sizes[0] + sizes[1]) + " + colour MLP " + std::to_string(sizes[2] + sizes[3] + sizes[4]) + " + hash tables " +
+                        std::to_string(sizes[5]) + ")" + (pb->n == total * 4 ? ": the size of fp32 parameters" : ""));
+    if (dgs != (double)D2R_GRID) return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "snapshot: snapshot.density_grid_size must be 128");
     const size_t cells = (size_t)D2R_GRID * D2R_GRID * D2R_GRID;
-    if (db->n != (size_t)n_casc * cells * 2) return d2r_fail(ctx, D2R_ERR_INVALID, "snapshot: density grid must hold 128^3 values per cascade");
+    if (db->n != (size_t)n_casc * cells * 2)
+        return d2r_fail(ctx, D2R_ERR_INVALID, "snapshot: snapshot.density_grid_binary holds " + std::to_string(db->n) + " bytes, expected fp16 x 128^3 x " +
+                        std::to_string(n_casc) + " cascade(s) = " + std::to_string((size_t)n_casc * cells * 2) +
+                        (db->n == (size_t)n_casc * cells * 4 ? " (it has the size of fp32 densities)" : db->n == (size_t)n_casc * cells / 8 ? " (it has the size of a bitfield)" : ""));
+    // what nerf_matrix_to_ngp needs of the dataset
+    const double ds_scale = req(ds, "snapshot.nerf.dataset", "scale");
+    const Node *offn = need(A, ds, "snapshot.nerf.dataset", "offset", Node::ARR);
+    if (A.err.empty() && offn->arr.size() != 3) A.fail("snapshot: snapshot.nerf.dataset.offset must hold 3 numbers");
+    if (!A.err.empty()) return d2r_fail(ctx, D2R_ERR_INVALID, A.err);
     // params: copies (msgpack payloads are not aligned)
     std::vector<uint16_t> params(total);
     memcpy(params.data(), pb->p, pb->n);
@@ -321,14 +542,18 @@ static int load_ingp(d2r_ctx *ctx, const void *bytes, size_t len, d2r_nerf **out
             if (!whole) memcpy(desc.render_aabb, v, sizeof v);
         }
     }
-    int rc = d2r_nerf_create(ctx, &desc, out);
+    // ctx == nullptr: d2r_ingp_validate — everything above ran (every check a load makes on the file), nothing is created
+    int rc = ctx ? d2r_nerf_create(ctx, &desc, out) : D2R_OK;
     if (rc) return rc;
     if (info) {
         memset(info, 0, sizeof *info);
+        {
+            std::string listing;
+            walk(cfg, "", listing, &info->n_unknown_keys);
+        }
         info->n_levels = L; info->n_features = F; info->aabb_scale = aabb;
-        info->dataset_scale = num(ds, "scale", 1.0);
-        const Node *offn = ds ? ds->get("offset") : nullptr;
-        for (int k = 0; k < 3; k++) info->dataset_offset[k] = offn && offn->arr.size() == 3 ? offn->arr[k].num() : 0.5;
+        info->dataset_scale = ds_scale;
+        for (int k = 0; k < 3; k++) info->dataset_offset[k] = offn->arr[k].num();
         if (const Node *bc = snap->get("background_color"))
             if (bc->kind == Node::ARR && bc->arr.size() == 4) {
                 info->has_background = 1;
@@ -336,11 +561,20 @@ static int load_ingp(d2r_ctx *ctx, const void *bytes, size_t len, d2r_nerf **out
             }
         const Node *md = ds ? ds->get("metadata") : nullptr;
         info->n_views = md && md->kind == Node::ARR ? (uint32_t)md->arr.size() : 0;
-        for (uint32_t k = 0; k < info->n_views && k < views_cap && views; k++) {
+        for (uint32_t k = 0; k < info->n_views && (ctx ? (k < views_cap && views) : true); k++) {
             const Node &m = md->arr[k];
             const Node *r = m.get("resolution"), *fl = m.get("focal_length"), *pp = m.get("principal_point");
-            if (!r || !fl || !pp || r->arr.size() != 2 || fl->arr.size() != 2 || pp->arr.size() != 2) continue;
-            d2r_ingp_view &v = views[info->n_views_written++];
+            if (!r || !fl || !pp || r->arr.size() != 2 || fl->arr.size() != 2 || pp->arr.size() != 2) {
+                if (ctx) {
+                    d2r_nerf_destroy(*out);
+                    *out = nullptr;
+                }
+                return d2r_fail(ctx, D2R_ERR_INVALID, "snapshot: snapshot.nerf.dataset.metadata[" + std::to_string(k) + "] lacks " +
+                                (!r || r->arr.size() != 2 ? "resolution" : !fl || fl->arr.size() != 2 ? "focal_length" : "principal_point") +
+                                " (2 numbers): set_camera_to_training_view cannot take its intrinsics from it");
+            }
+            d2r_ingp_view scratch;
+            d2r_ingp_view &v = (views && k < views_cap) ? views[info->n_views_written++] : scratch;
             const double rw = r->arr[0].num(), rh = r->arr[1].num();
             v.w = rw >= 0 && rw < 4294967296.0 ? (uint32_t)rw : 0; v.h = rh >= 0 && rh < 4294967296.0 ? (uint32_t)rh : 0;
             v.fx = fl->arr[0].num(); v.fy = fl->arr[1].num();
@@ -353,9 +587,9 @@ static int load_ingp(d2r_ctx *ctx, const void *bytes, size_t len, d2r_nerf **out
 // ---- d2r_ingp_inspect: what is in a snapshot, and what of it the loader above reads (host only, no device)
 namespace {
 
-// every msgpack path load_ingp() looks at ("[]" = each element of an array of maps)
+// every msgpack path load_ingp() reads ("[]" = each element of an array of maps)
 const char *const kPathsRead[] = {
-    "encoding.otype", "encoding.type", "encoding.n_levels", "encoding.n_features_per_level", "encoding.log2_hashmap_size",
+    "encoding.n_levels", "encoding.n_features_per_level", "encoding.log2_hashmap_size",
     "encoding.base_resolution", "encoding.per_level_scale", "network.n_neurons", "network.n_hidden_layers",
     "rgb_network.n_neurons", "rgb_network.n_hidden_layers", "snapshot.params_type", "snapshot.params_binary",
     "snapshot.density_grid_binary", "snapshot.density_grid_size", "snapshot.render_aabb", "snapshot.render_aabb.min",
@@ -363,60 +597,71 @@ const char *const kPathsRead[] = {
     "snapshot.nerf.dataset.scale", "snapshot.nerf.dataset.offset", "snapshot.nerf.dataset.metadata[].resolution",
     "snapshot.nerf.dataset.metadata[].focal_length", "snapshot.nerf.dataset.metadata[].principal_point",
 };
+// paths the loader CHECKS: they change the rendered function, and only one value of each is implemented (an error otherwise)
+const char *const kPathsChecked[] = {
+    "encoding.otype", "encoding.type", "encoding.interpolation", "encoding.n_dims_to_encode",
+    "network.otype", "network.activation", "network.output_activation",
+    "rgb_network.otype", "rgb_network.activation", "rgb_network.output_activation",
+    "dir_encoding.otype", "dir_encoding.degree", "dir_encoding.n_dims_to_encode", "dir_encoding.nested[].otype",
+    "dir_encoding.nested[].degree", "dir_encoding.nested[].n_dims_to_encode",
+    "snapshot.n_params", "snapshot.exposure", "snapshot.render_aabb_to_local", "snapshot.nerf.dataset.render_aabb_to_local",
+    "snapshot.nerf.dataset.n_extra_learnable_dims", "snapshot.nerf.n_extra_dims", "snapshot.nerf.dataset.envmap_resolution",
+    "snapshot.nerf.dataset.is_hdr", "snapshot.nerf.dataset.from_mitsuba", "snapshot.nerf.rgb_activation",
+    "snapshot.nerf.density_activation", "snapshot.nerf.render_with_lens_distortion", "snapshot.nerf.cone_angle_constant",
+};
+// prefixes known NOT to change what d2r renders through the path's entry points: training state, optimiser / loss
+// configuration, the GUI's own camera and lights, bookkeeping.  (dataset.up / up_dir rotate the GUI's orbit and the
+// poses instant-ngp READS from a transforms file; the path hands camera matrices to set_nerf_camera_matrix, which
+// applies scale / offset / axis cycle only.  Per-image lens parameters matter only with render_with_lens_distortion,
+// which is checked.)
+const char *const kPrefixesIrrelevant[] = {
+    "loss", "optimizer", "envmap", "distortion_map", "parent", "snapshot.version", "snapshot.mode", "snapshot.camera", "snapshot.up_dir",
+    "snapshot.sun_dir", "snapshot.aabb", "snapshot.bounding_radius", "snapshot.training_step", "snapshot.loss",
+    "snapshot.density_grid_ema_step", "snapshot.nerf.dataset.paths", "snapshot.nerf.dataset.xforms", "snapshot.nerf.dataset.n_images",
+    "snapshot.nerf.dataset.up", "snapshot.nerf.dataset.wants_importance_sampling", "snapshot.nerf.dataset.has_rays",
+    "snapshot.nerf.dataset.metadata[].lens", "snapshot.nerf.dataset.metadata[].rolling_shutter", "snapshot.nerf.dataset.metadata[].light_dir",
+    "snapshot.nerf.dataset.metadata[].depth_scale", "snapshot.nerf.dataset.render_aabb", "snapshot.nerf.cam_", "snapshot.nerf.extra_dims_opt",
+    "snapshot.nerf.rgb", "snapshot.nerf.training", "snapshot.nerf.sharpen", "snapshot.nerf.density_grid", "dir_encoding.nested[].n_bins",
+    "dir_encoding.nested", "snapshot.nerf.dataset.metadata",
+};
 
-const char *kind_name(const Node &n)
+// 'R' read, 'C' checked, '-' known not to affect rendering, '?' unknown
+char classify(const std::string &path)
 {
-    switch (n.kind) {
-        case Node::NIL: return "nil";
-        case Node::BOOL: return "bool";
-        case Node::INT: return "int";
-        case Node::FLOAT: return "float";
-        case Node::STR: return "str";
-        case Node::BIN: return "bin";
-        case Node::ARR: return "array";
-        default: return "map";
+    for (const char *r : kPathsRead)
+        if (path == r) return 'R';
+    for (const char *r : kPathsChecked)
+        if (path == r) return 'C';
+    for (const char *r : kPrefixesIrrelevant) {
+        const size_t n = strlen(r);
+        if (path.compare(0, n, r) == 0 && (path.size() == n || path[n] == '.' || path[n] == '[' || r[n - 1] == '_')) return '-';
     }
+    return '?';
 }
 
-std::string scalar_text(const Node &n)
-{
-    char buf[64];
-    switch (n.kind) {
-        case Node::BOOL: return n.i ? "true" : "false";
-        case Node::INT: snprintf(buf, sizeof buf, "%lld", (long long)n.i); return buf;
-        case Node::FLOAT: snprintf(buf, sizeof buf, "%.9g", n.f); return buf;
-        case Node::STR: {
-            std::string t = n.str().substr(0, 48);
-            for (char &c : t) if ((unsigned char)c < 0x20 || c == 0x7f) c = '?';
-            return "\"" + t + "\"";
-        }
-        default: return "";
-    }
-}
-
-void walk(const Node &n, const std::string &path, std::string &out)
+void walk(const Node &n, const std::string &path, std::string &out, uint32_t *unknown)
 {
     if (n.kind == Node::MAP) {
-        for (const auto &kv : n.map) walk(kv.second, path.empty() ? kv.first : path + "." + kv.first, out);
+        for (const auto &kv : n.map) walk(kv.second, path.empty() ? kv.first : path + "." + kv.first, out, unknown);
         return;
     }
     bool maps = n.kind == Node::ARR && !n.arr.empty();
     for (const Node &e : n.arr) maps = maps && e.kind == Node::MAP;
     if (maps) {                                    // array of maps (per-image metadata): the first element stands for all
         out += "- array " + std::to_string(n.arr.size()) + " " + path + "[]\n";
-        walk(n.arr[0], path + "[]", out);
+        walk(n.arr[0], path + "[]", out, unknown);
         return;
     }
-    bool read = false;
-    for (const char *r : kPathsRead) read = read || path == r;
+    const char cls = classify(path);
+    if (cls == '?' && unknown) ++*unknown;
     const size_t size = n.kind == Node::ARR ? n.arr.size() : (n.kind == Node::BIN || n.kind == Node::STR) ? n.n : 1;
-    std::string value = scalar_text(n);
+    std::string value = scalar_text_of(n);
     if (n.kind == Node::ARR && n.arr.size() <= 16) {
         value = "[";
-        for (size_t k = 0; k < n.arr.size(); k++) value += (k ? "," : "") + (n.arr[k].kind == Node::ARR ? std::string("[..]") : scalar_text(n.arr[k]));
+        for (size_t k = 0; k < n.arr.size(); k++) value += (k ? "," : "") + (n.arr[k].kind == Node::ARR ? std::string("[..]") : scalar_text_of(n.arr[k]));
         value += "]";
     }
-    out += std::string(read ? "R " : "- ") + kind_name(n) + " " + std::to_string(size) + " " + path + (value.empty() ? "" : " = " + value) + "\n";
+    out += std::string(1, cls) + " " + kind_name_of(n) + " " + std::to_string(size) + " " + path + (value.empty() ? "" : " = " + value) + "\n";
 }
 
 int inspect_ingp(const void *bytes, size_t len, std::string &text)
@@ -431,9 +676,12 @@ int inspect_ingp(const void *bytes, size_t len, std::string &text)
     Reader rd{raw.data(), raw.data() + raw.size()};
     const Node cfg = rd.parse();
     if (!rd.ok || cfg.kind != Node::MAP) return d2r_fail(nullptr, D2R_ERR_INVALID, "snapshot: not a msgpack map");
-    text = "# d2r_ingp_inspect: <R = read by d2r_nerf_load_ingp | - = ignored> <kind> <elements or bytes> <path> [= value]\n";
+    text = "# d2r_ingp_inspect: <R = read by d2r_nerf_load_ingp | C = checked: changes the rendered function, one value implemented | - = known not to "
+           "affect rendering | ? = unknown to the loader> <kind> <elements or bytes> <path> [= value]\n";
     text += "# inflated_bytes " + std::to_string(raw.size()) + " trailing_bytes " + std::to_string((size_t)(rd.end - rd.p)) + "\n";
-    walk(cfg, "", text);
+    uint32_t unknown = 0;
+    walk(cfg, "", text, &unknown);
+    text += "# unknown_keys " + std::to_string(unknown) + " (keys marked '?': not known to the loader, not known to be harmless)\n";
     // what the loader would derive, next to what the file holds
     auto num = [](const Node *m, const char *k, double dflt) { const Node *v = m ? m->get(k) : nullptr; return v && v->number() ? v->num() : dflt; };
     const Node *enc = cfg.get("encoding"), *snap = cfg.get("snapshot");
@@ -504,5 +752,22 @@ extern "C" int d2r_nerf_load_ingp(d2r_ctx *ctx, const void *bytes, size_t len, d
         return d2r_fail(ctx, D2R_ERR_INVALID, std::string("snapshot: malformed (") + e.what() + ")");
     } catch (...) {
         return d2r_fail(ctx, D2R_ERR_INVALID, "snapshot: malformed");
+    }
+}
+
+// Host only: would d2r_nerf_load_ingp take these bytes?  Runs every check the loader makes on the file (layout, kinds,
+// sizes, the values of keys that change the rendered function) without a device; the message of a refusal names the key.
+extern "C" int d2r_ingp_validate(const void *bytes, size_t len, d2r_ingp_info *info)
+{
+    if (!bytes || len < 4) return d2r_fail(nullptr, D2R_ERR_INVALID, "null argument");
+    try {
+        d2r_ingp_info local;
+        return load_ingp(nullptr, bytes, len, nullptr, info ? info : &local, nullptr, 0);
+    } catch (const std::bad_alloc &) {
+        return d2r_fail(nullptr, D2R_ERR_MEMORY, "snapshot: out of host memory");
+    } catch (const std::exception &e) {
+        return d2r_fail(nullptr, D2R_ERR_INVALID, std::string("snapshot: malformed (") + e.what() + ")");
+    } catch (...) {
+        return d2r_fail(nullptr, D2R_ERR_INVALID, "snapshot: malformed");
     }
 }

@@ -188,6 +188,11 @@ class Testbed:
         tb = cls.__new__(cls)
         tb.ctx, tb.model, tb._keep, tb.h = ctx, None, {}, h
         tb._init_state(tv or None, float(info.dataset_scale), tuple(float(x) for x in info.dataset_offset))
+        tb.snapshot_unknown_keys = int(info.n_unknown_keys)
+        if info.n_unknown_keys:
+            import warnings
+            warnings.warn(f"{path}: {info.n_unknown_keys} key(s) this loader does not know (neither read, checked nor known to be "
+                          "irrelevant to rendering); list them with dream2real_amd._lib.ingp_inspect(open(path, 'rb').read())")
         if info.has_background:            # a Testbed restores the colour the snapshot was saved with
             tb.background_color = [float(x) for x in info.background_color]
         return tb

@@ -96,6 +96,12 @@ D2R_API void d2r_nerf_destroy(d2r_nerf *m);
  * bitfield (instant-ngp's threshold rule and cascade max-pool), render_aabb -> d2r_nerf_create.  `info` / `views`
  * (optional) receive what a Testbed keeps beside the model: dataset scale/offset for nerf_matrix_to_ngp, the saved
  * background colour, per-training-view intrinsics for set_camera_to_training_view.
+ * The layout is the BELIEVED one (no instant-ngp file or source offline), so nothing is defaulted: every key the loader
+ * needs must be there with the right msgpack kind and size (params_binary: fp16, density MLP | colour MLP | hash tables;
+ * density_grid_binary: fp16 128^3 per cascade), every key that changes the rendered function must carry the value the
+ * kernels implement (activations, interpolation, SH degree, exposure 0, no envmap / extra dims / lens distortion /
+ * rotated crop box, cone angle tied to aabb_scale), unknown keys inside encoding / network / rgb_network / dir_encoding
+ * are refused; each failure returns D2R_ERR_INVALID / D2R_ERR_UNSUPPORTED with a d2r_last_error message naming the key.
  */
 typedef struct { double fx, fy, cx, cy; uint32_t w, h; } d2r_ingp_view;   /* pixels at the training resolution */
 typedef struct {
@@ -105,6 +111,8 @@ typedef struct {
     float background_color[4];
     uint32_t n_views;            /* training views in the snapshot */
     uint32_t n_views_written;    /* how many of them went into `views` (at most views_cap) */
+    uint32_t n_unknown_keys;     /* keys of the snapshot the loader neither reads, checks nor knows to be irrelevant to
+                                  * rendering (d2r_ingp_inspect lists them with a '?') */
 } d2r_ingp_info;
 D2R_API int d2r_nerf_load_ingp(d2r_ctx *ctx, const void *bytes, size_t len, d2r_nerf **out, d2r_ingp_info *info,
                                d2r_ingp_view *views, uint32_t views_cap);
@@ -113,11 +121,17 @@ D2R_API int d2r_nerf_load_ingp(d2r_ctx *ctx, const void *bytes, size_t len, d2r_
  * `method_out/<scene>/{fg,bg}_base.ingp` (reference install.sh:38-50), since the loader is written against the believed
  * layout.  HOST ONLY: needs no device and no context (errors go to d2r_last_error(NULL)).  Writes NUL-terminated text
  * into out[cap] (truncated if short; *needed = bytes for all of it): one line per leaf of the msgpack tree,
- * "<R|-> <kind> <elements or bytes> <path> [= value]" with R = read by the loader, then "# derived:" lines with the
+ * "<R|C|-|?> <kind> <elements or bytes> <path> [= value]" with R = read by the loader, C = checked (changes the rendered
+ * function; one value implemented, anything else is a load error), - = known not to affect rendering (training state,
+ * GUI camera, ...), ? = unknown to the loader; then "# unknown_keys N" and "# derived:" lines with the
  * parameter / density-grid counts and the level table the loader computes from the config, beside the sizes of
  * params_binary / density_grid_binary.  Malformed or truncated input returns D2R_ERR_INVALID.
  */
 D2R_API int d2r_ingp_inspect(const void *bytes, size_t len, char *out, size_t cap, size_t *needed);
+/* HOST ONLY: every check d2r_nerf_load_ingp makes on the bytes, without a device and without creating a model — 0 when the
+ * loader would take the snapshot, else the loader's error (message in d2r_last_error(NULL), naming the key).  info
+ * (optional) is filled as the loader would fill it. */
+D2R_API int d2r_ingp_validate(const void *bytes, size_t len, d2r_ingp_info *info);
 
 /* Camera state set on a Testbed before render(): set_camera_to_training_view (intrinsics),
  * background_color, nerf.render_min_transmittance, dataset scale/offset used by

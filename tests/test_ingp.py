@@ -123,7 +123,9 @@ def test_c_inspect_lists_the_tree_and_what_the_loader_reads(tmp_path):
     path = str(tmp_path / "fg_base.ingp")
     save_ingp(path, scene.fg, training_views=[dict(fx=900.0, fy=910.0, cx=640.0, cy=350.0, w=1280, h=720)] * 3)
     cfg = msgpack.unpackb(zlib.decompress(open(path, "rb").read()), raw=False)
-    cfg["snapshot"]["nerf"]["cone_angle_constant"] = 0.00390625          # keys the loader does not know
+    cfg["snapshot"]["nerf"]["cone_angle_constant"] = 0.0                 # checked: tied to aabb_scale
+    cfg["snapshot"]["camera"] = {"fov_axis": 1, "zoom": 1.0}             # the GUI's own camera: known not to matter
+    cfg["snapshot"]["mystery"] = {"knob": 3}                             # a key the loader has never heard of
     cfg["dir_encoding"] = {"otype": "SphericalHarmonics", "degree": 4}
     blob = zlib.compress(msgpack.packb(cfg, use_bin_type=True), 1)
     text = _lib.ingp_inspect(blob)
@@ -132,8 +134,12 @@ def test_c_inspect_lists_the_tree_and_what_the_loader_reads(tmp_path):
     assert by_path["snapshot.params_binary"].startswith("R bin ")
     assert by_path["snapshot.density_grid_binary"].startswith("R bin ")
     assert by_path["encoding.n_levels"].startswith("R int 1 ") and by_path["encoding.n_levels"].endswith("= 16")
-    assert by_path["snapshot.nerf.cone_angle_constant"].startswith("- float ")
-    assert by_path["dir_encoding.degree"].startswith("- int ") and by_path["dir_encoding.otype"].endswith('= "SphericalHarmonics"')
+    assert by_path["snapshot.nerf.cone_angle_constant"].startswith("C float ")
+    assert by_path["snapshot.camera.zoom"].startswith("- float ") and by_path["snapshot.mystery.knob"].startswith("? int ")
+    assert by_path["dir_encoding.degree"].startswith("C int ") and by_path["dir_encoding.otype"].endswith('= "SphericalHarmonics"')
+    assert "# unknown_keys 1 " in text
+    info = _lib.ingp_validate(blob)
+    assert info.n_unknown_keys == 1 and info.n_views == 3 and (info.n_levels, info.n_features, info.aabb_scale) == (16, 2, 1)
     assert by_path["snapshot.nerf.dataset.metadata[]"] == "- array 3 snapshot.nerf.dataset.metadata[]"
     assert by_path["snapshot.nerf.dataset.metadata[].focal_length"].startswith("R array 2 ")
     derived = [ln for ln in text.splitlines() if ln.startswith("# derived: grid_entries")][0].split()
@@ -177,3 +183,98 @@ def test_c_reader_returns_errors_on_truncated_and_malformed_input(tmp_path):
             _lib.ingp_inspect(data)
     # sanity: the intact file still reads
     assert "snapshot.params_binary" in _lib.ingp_inspect(blob)
+
+
+def test_c_loader_names_the_key_it_refuses(tmp_path):
+    """The layout is believed, so nothing is defaulted: d2r_ingp_validate (every check d2r_nerf_load_ingp makes, host only)
+    on mutated snapshots — missing keys, fp32 parameters, wrong kinds and sizes, extra network input dimensions, another
+    activation / interpolation / SH degree, a rotated crop box, exposure, lens distortion, unknown keys in the sections
+    that define the network — each refusal names the key."""
+    import copy
+    import msgpack, zlib
+    from dream2real_amd import _lib
+    scene = make_scene("pool_triangle")
+    path = str(tmp_path / "fg_base.ingp")
+    save_ingp(path, scene.fg)
+    base = msgpack.unpackb(zlib.decompress(open(path, "rb").read()), raw=False)
+    pack = lambda c: zlib.compress(msgpack.packb(c, use_bin_type=True), 1)
+    _lib.ingp_validate(pack(base))                                      # the intact file passes
+
+    def mutated(fn):
+        c = copy.deepcopy(base)
+        fn(c)
+        return pack(c)
+
+    def drop(*keys):
+        def fn(c):
+            for k in keys[:-1]:
+                c = c[k]
+            del c[keys[-1]]
+        return fn
+
+    def put(value, *keys):
+        def fn(c):
+            for k in keys[:-1]:
+                c = c.setdefault(k, {})
+            c[keys[-1]] = value
+        return fn
+
+    n_half = len(base["snapshot"]["params_binary"]) // 2
+    cases = [
+        (drop("encoding", "n_levels"), "encoding.n_levels is missing"),
+        (drop("encoding", "log2_hashmap_size"), "encoding.log2_hashmap_size is missing"),
+        (drop("network", "n_neurons"), "network.n_neurons is missing"),
+        (drop("rgb_network"), "<root>.rgb_network is missing"),
+        (drop("dir_encoding"), "<root>.dir_encoding is missing"),
+        (drop("snapshot", "params_type"), "snapshot.params_type is missing"),
+        (drop("snapshot", "density_grid_size"), "snapshot.density_grid_size is missing"),
+        (drop("snapshot", "density_grid_binary"), "snapshot.density_grid_binary is missing"),
+        (drop("snapshot", "nerf", "dataset", "scale"), "snapshot.nerf.dataset.scale is missing"),
+        (drop("snapshot", "nerf", "dataset", "offset"), "snapshot.nerf.dataset.offset is missing"),
+        (lambda c: (c["snapshot"]["nerf"].pop("aabb_scale"), c["snapshot"]["nerf"]["dataset"].pop("aabb_scale")), "aabb_scale"),
+        (put(2, "snapshot", "nerf", "dataset", "aabb_scale"), "disagree"),
+        (put("float", "snapshot", "params_type"), "snapshot.params_type = 'float'"),
+        (lambda c: (put("float", "snapshot", "params_type")(c), put(np.zeros(n_half, np.float32).tobytes(), "snapshot", "params_binary")(c)),
+         "size of fp32 parameters"),
+        (put(np.zeros(n_half, np.float32).tobytes(), "snapshot", "params_binary"), "the size of fp32 parameters"),
+        (put(n_half + 64, "snapshot", "n_params"), "snapshot.n_params"),
+        (put("abc", "snapshot", "params_binary"), "snapshot.params_binary has msgpack kind 'str'"),
+        (put(np.zeros(128 ** 3, np.float32).tobytes(), "snapshot", "density_grid_binary"), "size of fp32 densities"),
+        (put(np.zeros(128 ** 3 // 8, np.uint8).tobytes(), "snapshot", "density_grid_binary"), "size of a bitfield"),
+        (put(1, "snapshot", "nerf", "dataset", "n_extra_learnable_dims"), "n_extra_learnable_dims"),
+        (put(4, "snapshot", "nerf", "n_extra_dims"), "snapshot.nerf.n_extra_dims"),
+        (put("Squareplus", "network", "activation"), "network.activation = 'Squareplus'"),
+        (put("Sigmoid", "rgb_network", "output_activation"), "rgb_network.output_activation"),
+        (put("Smoothstep", "encoding", "interpolation"), "encoding.interpolation = 'Smoothstep'"),
+        (put("Tiled", "encoding", "type"), "encoding.type = 'Tiled'"),
+        (put(2, "encoding", "n_dims_to_encode"), "encoding.n_dims_to_encode"),
+        (put(True, "encoding", "stochastic_interpolation"), "unknown key encoding.stochastic_interpolation"),
+        (put(0.1, "network", "dropout"), "unknown key network.dropout"),
+        (put({"otype": "SphericalHarmonics", "degree": 3}, "dir_encoding"), "dir_encoding.degree = 3"),
+        (put({"otype": "Frequency", "n_frequencies": 4}, "dir_encoding"), "dir_encoding.otype = 'Frequency'"),
+        (put({"otype": "Composite", "nested": [{"otype": "SphericalHarmonics", "degree": 4, "n_dims_to_encode": 3}, {"otype": "OneBlob", "n_bins": 4}]},
+             "dir_encoding"), "dir_encoding.nested[1]"),
+        (put([[0, 1, 0], [-1, 0, 0], [0, 0, 1]], "snapshot", "render_aabb_to_local"), "snapshot.render_aabb_to_local is not the identity"),
+        (put(1.5, "snapshot", "exposure"), "snapshot.exposure = 1.5"),
+        (put(True, "snapshot", "nerf", "render_with_lens_distortion"), "render_with_lens_distortion"),
+        (put(True, "snapshot", "nerf", "dataset", "is_hdr"), "is_hdr"),
+        (put(512, "snapshot", "nerf", "dataset", "envmap_resolution"), "envmap_resolution"),
+        (put(0.00390625, "snapshot", "nerf", "cone_angle_constant"), "snapshot.nerf.cone_angle_constant"),
+        (put(1, "snapshot", "nerf", "rgb_activation"), "snapshot.nerf.rgb_activation"),
+        (put(256, "snapshot", "density_grid_size"), "density_grid_size must be 128"),
+        (lambda c: c["snapshot"]["nerf"]["dataset"]["metadata"][0].pop("focal_length"), "metadata[0] lacks focal_length"),
+        (put([0.0, 0.3], "snapshot", "nerf", "dataset", "offset"), "offset must hold 3 numbers"),
+        (put(128, "network", "n_neurons"), "network.n_neurons 128"),
+        (put(12, "encoding", "n_levels"), "encoding.n_levels 12"),
+    ]
+    for k, (fn, needle) in enumerate(cases):
+        with pytest.raises(_lib.D2RError, match=__import__("re").escape(needle)):
+            _lib.ingp_validate(mutated(fn))
+    # accepted variations: identity crop rotation, per_level_scale written back by instant-ngp, a Composite direction
+    # encoding with the Identity member base.json carries, CutlassMLP
+    ok = mutated(lambda c: (put([[1, 0, 0], [0, 1, 0], [0, 0, 1]], "snapshot", "render_aabb_to_local")(c), put(0.0, "snapshot", "exposure")(c),
+                            put("CutlassMLP", "network", "otype")(c), put("Linear", "encoding", "interpolation")(c),
+                            put({"otype": "Composite", "nested": [{"n_dims_to_encode": 3, "otype": "SphericalHarmonics", "degree": 4},
+                                                                  {"otype": "Identity", "n_bins": 4, "degree": 4}]}, "dir_encoding")(c),
+                            put(3, "snapshot", "nerf", "density_activation")(c), put(0.0, "snapshot", "nerf", "cone_angle_constant")(c)))
+    assert _lib.ingp_validate(ok).n_unknown_keys == 0
