@@ -205,6 +205,9 @@ int d2r_ctx_set_option(d2r_ctx *ctx, const char *key, int64_t value)
         ctx->prep_reuse = value != 0;
     } else if (!strcmp(key, "cls_last")) {
         ctx->cls_last = value != 0;
+    } else if (!strcmp(key, "attn_rem")) {
+        if (value < 0 || value > 4) return d2r_fail(ctx, D2R_ERR_INVALID, "attn_rem must be 0..4");
+        ctx->attn_rem = value;
     } else if (!strcmp(key, "overlap")) {
         ctx->overlap = value != 0;
     } else if (!strcmp(key, "march_blocks")) {

@@ -1532,36 +1532,51 @@ __device__ __forceinline__ void ats_softmax(f32x16 &sacc, f32x16 &o0, f32x16 &o1
     }
 }
 
-// grid (heads, images, ceil(n_qt / 8)); block 512; dynamic LDS ATS_STAGES * ATS_SLOT
-__global__ __launch_bounds__(ATS_THREADS, 4) void k_attention_s(const uint16_t *__restrict__ QKV, uint16_t *__restrict__ AO, uint32_t T,
-                                                               uint32_t d, uint32_t M_pad)
+// grid (heads, images, groups of NW query tiles starting at tile qt0); block NW * 64; dynamic LDS ATS_STAGES * ATS_SLOT.
+// NW = 8: the main launch (full groups of eight query tiles).  NW = 1 / 2 / 4: the LEFTOVER launch for sequences whose tile
+// count is 8g + r with a small r (257 tokens: r = 1; 577: r = 3) — the same per-wave arithmetic in a workgroup with as many
+// waves as it has query tiles, every wave staging 8 / NW slices of each key tile, so that a CU holds four such workgroups
+// (LDS-limited) with every wave computing, instead of two eight-wave workgroups with one active wave each.
+template <int NW>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void k_attention_s(const uint16_t *__restrict__ QKV, uint16_t *__restrict__ AO, uint32_t T,
+                                                                          uint32_t d, uint32_t M_pad, uint32_t qt0)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr int NS = 8 / NW;                            // key-tile slices (1 KiB each: eight K or eight V rows) a wave stages
     const uint32_t head = blockIdx.x, img = blockIdx.y;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 31, hi = lane >> 5;
     const size_t row_base = (size_t)img * T;
     const uint32_t H = d >> 6;
     const uint32_t n_kt = (T + 31) / 32;
-    const uint32_t qt = blockIdx.z * 8 + wave;
+    const uint32_t qt = qt0 + blockIdx.z * NW + wave;
     const bool active = qt < n_kt;                        // query tiles = key tiles = ceil(T / 32)
     const uint32_t qrow = qt * 32 + li;
     const uint16_t *Qg = QKV + ((size_t)head * M_pad + row_base) * 64;
-    // this wave's slice of every key tile: waves 0-3 eight K rows each, waves 4-7 eight V rows each; a lane fetches the
-    // 16-byte chunk whose swizzled position in the slot is (its row, lane & 7)
-    const uint32_t r_loc = (wave & 3) * 8 + (lane >> 3);
-    const bool is_v = wave >= 4;
-    const uint32_t src_chunk = (lane & 7) ^ (is_v ? ((r_loc >> 1) & 1u) << 2 : (r_loc >> 1) & 7u);
-    const uint16_t *src_plane = QKV + ((size_t)((is_v ? 2 * H : H) + head) * M_pad + row_base) * 64 + src_chunk * 8;
+    // slice c of a key tile (c = 0..3: eight K rows each, 4..7: eight V rows each) is staged by wave c % NW; a lane fetches
+    // the 16-byte chunk whose swizzled position in the slot is (its row, lane & 7)
+    const uint16_t *src_k = QKV + ((size_t)(H + head) * M_pad + row_base) * 64, *src_v = QKV + ((size_t)(2 * H + head) * M_pad + row_base) * 64;
     const uint32_t smem0 = __builtin_amdgcn_readfirstlane(lds_addr(smem));
-    const uint32_t dst_off = (is_v ? 4096u : 0u) + (wave & 3) * 1024u;
     // ring positions as running byte offsets (scalar add + wrap; a modulo by five per use costs a multiply-high and a
     // vector add per LDS address): slot_req = where the next request lands, slot_k / slot_v = the slots the K
     // fragments are read from next and this tile's V is read from
     uint32_t slot_req = 0, slot_k = 0, slot_v = 0;
     auto advance = [](uint32_t &slot) { slot = slot + ATS_SLOT == ATS_STAGES * ATS_SLOT ? 0u : slot + ATS_SLOT; };
+    uint32_t src_off[NS], dst_off[NS], r_loc[NS];         // per slice: element offset inside a row (the swizzled chunk), LDS offset, row in the tile
+    bool is_v[NS];
+#pragma unroll
+    for (int j = 0; j < NS; j++) {
+        const uint32_t c = wave + (uint32_t)j * NW;
+        r_loc[j] = (c & 3) * 8 + (lane >> 3);
+        is_v[j] = c >= 4;
+        src_off[j] = ((lane & 7) ^ (is_v[j] ? ((r_loc[j] >> 1) & 1u) << 2 : (r_loc[j] >> 1) & 7u)) * 8;
+        dst_off[j] = (is_v[j] ? 4096u : 0u) + (c & 3) * 1024u;
+    }
     auto request = [&](uint32_t kt) {                    // key tile kt -> the next ring slot (rows >= T repeat row T-1: masked / P = 0)
-        const uint32_t row = kt * 32 + r_loc;
-        if (!(D2R_ATTN_ABLATE & 16)) glds16(src_plane + (size_t)(row < T ? row : T - 1) * 64, smem0 + slot_req + dst_off);
+#pragma unroll
+        for (int j = 0; j < NS; j++) {
+            const uint32_t row = kt * 32 + r_loc[j];
+            if (!(D2R_ATTN_ABLATE & 16)) glds16((is_v[j] ? src_v : src_k) + (size_t)(row < T ? row : T - 1) * 64 + src_off[j], smem0 + slot_req + dst_off[j]);
+        }
         advance(slot_req);
     };
     // Q fragments (B operand of S^T = K Q^T: lane (q, hi) holds Q[q][16s + 8hi .. +8)) first: oldest in the vmcnt order.
@@ -1586,8 +1601,8 @@ __global__ __launch_bounds__(ATS_THREADS, 4) void k_attention_s(const uint16_t *
     for (uint32_t c = 0; c < ATS_STAGES - 1; c++) request(c);
     // the Q loads are older than the four requests: done when only those remain outstanding; then tile 0 (the oldest
     // request), published by the first barrier
-    asm volatile("s_waitcnt vmcnt(4)" : "+v"(qv[0]), "+v"(qv[1]), "+v"(qv[2]), "+v"(qv[3]) : : "memory");
-    wait_vmcnt<3>();
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(qv[0]), "+v"(qv[1]), "+v"(qv[2]), "+v"(qv[3]) : "n"(4 * NS) : "memory");
+    wait_vmcnt<3 * NS>();
     __syncthreads();
     uint4 qf[4];
 #pragma unroll
@@ -1641,7 +1656,7 @@ __global__ __launch_bounds__(ATS_THREADS, 4) void k_attention_s(const uint16_t *
         constexpr int WAIT = decltype(wait_tag)::value;
         constexpr bool LAST = decltype(last_tag)::value, REQ = decltype(req_tag)::value;
         if constexpr (!LAST) {
-            wait_vmcnt<WAIT>();
+            wait_vmcnt<WAIT * NS>();
             if (!(D2R_ATTN_ABLATE & 256)) __syncthreads();
             if constexpr (REQ) request(kt + ATS_STAGES - 1);
             read_k();
@@ -2140,8 +2155,16 @@ static int launch_gemm(d2r_ctx *ctx, const uint16_t *A, const uint16_t *W, const
 static void launch_attention_vision(d2r_ctx *ctx, const uint16_t *QKV, uint16_t *AO, uint32_t T, uint32_t d, uint32_t M_pad,
                                     uint32_t n_heads, uint32_t n)
 {
-    const uint32_t n_qt = (T + 31) / 32;
-    hipLaunchKernelGGL(k_attention_s, dim3(n_heads, n, (n_qt + 7) / 8), dim3(ATS_THREADS), ATS_STAGES * ATS_SLOT, ctx->stream, QKV, AO, T, d, M_pad);
+    // n_qt = 8 g + r query tiles: g full groups on the eight-wave kernel; a short remainder (r <= 4) on workgroups of
+    // r (rounded up to 1 / 2 / 4) waves, r >= 5 as one more eight-wave group
+    const uint32_t n_qt = (T + 31) / 32, r = n_qt % 8, g = r == 0 || r > (uint32_t)ctx->attn_rem ? (n_qt + 7) / 8 : n_qt / 8;
+    const uint32_t lds = ATS_STAGES * ATS_SLOT;
+    if (g) hipLaunchKernelGGL((k_attention_s<8>), dim3(n_heads, n, g), dim3(512), lds, ctx->stream, QKV, AO, T, d, M_pad, 0u);
+    if (g * 8 < n_qt) {
+        if (r == 1) hipLaunchKernelGGL((k_attention_s<1>), dim3(n_heads, n, 1), dim3(64), lds, ctx->stream, QKV, AO, T, d, M_pad, g * 8);
+        else if (r == 2) hipLaunchKernelGGL((k_attention_s<2>), dim3(n_heads, n, 1), dim3(128), lds, ctx->stream, QKV, AO, T, d, M_pad, g * 8);
+        else hipLaunchKernelGGL((k_attention_s<4>), dim3(n_heads, n, 1), dim3(256), lds, ctx->stream, QKV, AO, T, d, M_pad, g * 8);
+    }
 }
 
 // LDS footprint of the resident k_attention (text tower) for a padded sequence length, and the one-time opt-in to

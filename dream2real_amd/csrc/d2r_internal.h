@@ -134,6 +134,7 @@ struct d2r_ctx {
     int64_t gemm_stagger = 0;      // persistent GEMM: stagger the workgroups' first tile over a tile period (epilogues spread in time)
     int64_t gemm_group = 65535;    // persistent GEMM: column tiles per group of the tile order (large = the plain column-fastest order, the default; 0 = the width a simple L2 model picks: a third fewer L2 misses, same time)
     int64_t gemm_nsplit = 0;     // column sections of the persistent GEMM's tile order (XCD sets own column ranges): 0 = two where the XCDs and the column tiles divide evenly, 1 = none
+    int64_t attn_rem = 1;          // attention: a remainder of at most this many query tiles (sequence = 8 g + r tiles) runs on workgroups of r waves instead of one more eight-wave group
     int64_t cls_last = 1;          // vision tower: run the last block on the class-token rows only (the head reads nothing else)
     int64_t gemm_cfg = 0;      // experiment switch for the GEMM tile configuration (0 = default)
     int64_t use_bricks = 1;

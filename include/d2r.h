@@ -399,6 +399,9 @@ D2R_API int d2r_get_timing(d2r_ctx *ctx, d2r_timing *out);
  * "prep_reuse" (default 1): in d2r_render_score, the rows of CLIP patches of a candidate frame that its object cannot have
  *     touched (outside the rectangle its rays are generated in) are copied from the background frame's own patches,
  *     computed once per d2r_set_background; bit-identical to resampling them.
+ * "attn_rem" (default 1, 0..4): vision-tower attention on a sequence of 8 g + r query tiles of 32: a remainder of at most this
+ *     many tiles runs on workgroups of r waves (each staging whole key tiles itself) instead of one more eight-wave
+ *     workgroup with 8 - r idle waves; 257 tokens (r = 1): -7 % kernel time, 577 tokens (r = 3): neutral.  Bit-identical.
  * "overlap" (default 0): 1 = d2r_render_score / d2r_render_score_host run the render half of chunk i+1 (cameras, ray
  *     generation, march, preprocess) on a second stream while the ViT scores chunk i; 0 = one stream, in program order.
  *     Results do not depend on it; measured neutral on MI355X (the marcher and the persistent GEMMs each fill whole CUs —

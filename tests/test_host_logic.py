@@ -125,3 +125,17 @@ def test_synthetic_scene_is_deterministic():
     np.testing.assert_array_equal(a.fg.occ_bits, b.fg.occ_bits)
     assert 300 < a.fg.occupancy_bool().sum() < 2000
     assert make_scene("pool_triangle").scene_type == 0
+
+
+def test_smoothing_on_the_full_six_dof_grid_of_config4():
+    """BASELINE.json configs[4]'s grid [16,16,16,4,4,4] = 262 144 poses: the product's spatially_smooth_heatmap against the
+    oracle's restatement (reference geometry_utils.py:252-269: [Z * O, 1, X, Y] sheets, min-nonzero padding, 3x3 Gaussian)
+    with a quarter of the poses invalid (score 0)."""
+    from dream2real_amd.geometry_utils import spatially_smooth_heatmap
+    res = [16, 16, 16, 4, 4, 4]
+    r = np.random.Generator(np.random.PCG64(9))
+    s = (0.9 + 0.2 * r.random(262144)).astype(np.float32)
+    s[r.random(262144) < 0.25] = 0.0
+    got, want = spatially_smooth_heatmap(s.copy(), res), host_ref.spatially_smooth_heatmap(s.copy(), res)
+    np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-7)
+    assert ((got == 0) == (s == 0)).all()
