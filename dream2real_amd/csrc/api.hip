@@ -197,7 +197,7 @@ int d2r_ctx_set_option(d2r_ctx *ctx, const char *key, int64_t value)
         if (value < 1 || value > 64) return d2r_fail(ctx, D2R_ERR_INVALID, "refill_min must be in [1, 64]");
         ctx->refill_min = value;
     } else if (!strcmp(key, "ln_fold")) {
-        if (value < 0 || value > 3) return d2r_fail(ctx, D2R_ERR_INVALID, "ln_fold must be 0..3");
+        if (value < 0 || value > 4) return d2r_fail(ctx, D2R_ERR_INVALID, "ln_fold must be 0..4");
         ctx->ln_fold = value;
     } else if (!strcmp(key, "gemm_nsplit")) {
         ctx->gemm_nsplit = value;

@@ -255,6 +255,21 @@ __global__ void k_patchify(const float *__restrict__ pv, uint32_t n, uint32_t S,
 
 // ------------------------------------------------------------------ GEMM
 
+// EPI_RESID_STATS_SPLIT8: byte offset of the lo byte of residual element (row, col) — [col / 64][M_pad / 64][row % 32]
+// [(col % 64) / 8][(row / 32) % 2][col % 8]: the 8 columns a lane of the residual epilogue owns, for the row pair
+// (r, r + 32) it handles in one group, are 16 contiguous bytes
+__device__ __forceinline__ size_t lo8_off(uint32_t M_pad, size_t row, uint32_t col)
+{
+    return ((((size_t)(col >> 6) * (M_pad >> 6)) + (row >> 6)) << 12) + ((row & 31) << 7) + (((col & 63) >> 3) << 4) + (((row >> 5) & 1) << 3) + (col & 7);
+}
+__device__ __forceinline__ float split8_value(uint32_t hi16, int32_t lo8) { return __uint_as_float((hi16 << 16) + (uint32_t)(lo8 << 8)); }
+// bits 8..15 of the result are the lo byte (the caller picks byte 1): round to nearest, saturating at +127
+__device__ __forceinline__ int32_t split8_round(float x, uint32_t hi_bits /* hi16 << 16 */)
+{
+    const int32_t dlt = (int32_t)__float_as_uint(x) - (int32_t)hi_bits;
+    return min(dlt + 0x80, 0x7fff);
+}
+
 // Epilogues.  0-3: the plain ones.  4-7: the LayerNorm-folded transformer block —
 //   LN(x) W^T + b = rstd (x (gamma o W)^T - mu colsum(gamma o W)) + (b + W beta)
 // so the GEMM that follows a LayerNorm takes the RAW residual row (bf16) as its A operand and applies
@@ -262,12 +277,16 @@ __global__ void k_patchify(const float *__restrict__ pv, uint32_t n, uint32_t S,
 // operand copy and per-row partial sums (EPI_RESID_STATS_*): no LayerNorm kernel, no LN round trip
 // through HBM.  _F32X keeps the fp32 residual stream next to the bf16 copy, _BF16 keeps only bf16, _SPLIT keeps
 // the residual as TWO bf16 arrays, x ~ hi + lo with hi = bf16(x) (the operand copy) and lo = bf16(x - hi): 16
-// mantissa bits for the bytes of one fp32 array, i.e. a third less residual traffic than _F32X.
+// mantissa bits for the bytes of one fp32 array, i.e. a third less residual traffic than _F32X.  _SPLIT8 keeps lo in ONE
+// byte: with hi = bf16(x) rounded to nearest, the fp32 BIT PATTERN of x lies within +-0x8000 of (hi << 16), and lo8 =
+// round((bits(x) - (hi << 16)) / 256) in [-128, 127]; x' = as_float((hi << 16) + (lo8 << 8)) is x rounded to 16 significant
+// bits (relative error <= 2^-17, the fp16-lo pair's is comparable), integer arithmetic only on both sides, and a quarter
+// less residual traffic again (hi 2 + lo 1 bytes read and written per element instead of 2 + 2).
 enum { EPI_F32 = 0, EPI_BIAS_BF16 = 1, EPI_BIAS_GELU_BF16 = 2, EPI_BIAS_RESID_F32 = 3,
        EPI_LN_BIAS_BF16 = 4, EPI_LN_BIAS_GELU_BF16 = 5, EPI_RESID_STATS_F32X = 6, EPI_RESID_STATS_BF16 = 7,
-       EPI_RESID_STATS_SPLIT = 8, EPI_KINDS = 9 };
+       EPI_RESID_STATS_SPLIT = 8, EPI_RESID_STATS_SPLIT8 = 9, EPI_KINDS = 10 };
 #define EPI_IS_LN(E) ((E) == EPI_LN_BIAS_BF16 || (E) == EPI_LN_BIAS_GELU_BF16)
-#define EPI_IS_STATS(E) ((E) == EPI_RESID_STATS_F32X || (E) == EPI_RESID_STATS_BF16 || (E) == EPI_RESID_STATS_SPLIT)
+#define EPI_IS_STATS(E) ((E) == EPI_RESID_STATS_F32X || (E) == EPI_RESID_STATS_BF16 || (E) == EPI_RESID_STATS_SPLIT || (E) == EPI_RESID_STATS_SPLIT8)
 #define EPI_IS_F32_LAYOUT(E) ((E) == EPI_F32 || (E) == EPI_BIAS_RESID_F32)
 
 // operands of the folded epilogues
@@ -276,7 +295,8 @@ struct EpiAux {
     const float2 *ab;      // EPI_LN_*: [M_pad] per row (rstd, -rstd * mean) of the residual row
     uint16_t *xb;          // EPI_RESID_STATS_*: bf16 residual, tile-major [N / 64][M_pad][64] (read + written by _BF16 / _SPLIT, written by _F32X)
     float2 *part;          // EPI_RESID_STATS_*: [N / 64][M_pad] partial (sum, sum of squares) per 64-column group (needs hm_rows = M_pad)
-    uint16_t *xlo;         // EPI_RESID_STATS_SPLIT: low half of the split residual, same layout
+    uint16_t *xlo;         // EPI_RESID_STATS_SPLIT: low half of the split residual, same layout; _SPLIT8: the lo BYTES in the
+                           // layout of lo8_off() below (a lane's 16-byte access = its 8 columns of rows r and r + 32)
     // Layout of bf16 activations.  "Tile-major" = [cols / 64][M_pad][64]: the 64-column group a wave tile produces
     // (one attention head; one K-tile of the GEMM that consumes it) is a contiguous plane, so an epilogue writes
     // whole 128-byte rows back to back and the consumer's LDS-DMA reads 8 KiB runs, instead of 128-byte pieces
@@ -443,11 +463,71 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], float *ep, u
         // tile took 160 half-width memory instructions per wave and its epilogue 32 k cycles, against 5-8 k for the
         // bf16 outputs).  The residual rows of two m-tiles (16 loads per lane) are requested before the first transpose.
         constexpr bool SPLIT = EPI == EPI_RESID_STATS_SPLIT;
+        constexpr bool SPLIT8 = EPI == EPI_RESID_STATS_SPLIT8;
         constexpr bool F32X = EPI == EPI_RESID_STATS_F32X;
         const uint32_t c8 = (lane & 7) * 8, rl0 = lane >> 3;
         const uint32_t col = col0 + c8;
         float4 b0 = *(const float4 *)(bias + col), b1 = *(const float4 *)(bias + col + 4);
         asm volatile("" : "+v"(b0.x), "+v"(b0.y), "+v"(b0.z), "+v"(b0.w), "+v"(b1.x), "+v"(b1.y), "+v"(b1.z), "+v"(b1.w));
+      if constexpr (SPLIT8) {
+        // hi as in _SPLIT; lo bytes: ONE 16-byte access per (group of two m-tiles, k) covers this lane's 8 columns of rows
+        // r (m-tile ih) and r + 32 (m-tile ih + 1), so the loop runs k outside, the m-tile pair inside
+        static_assert(MT % 2 == 0, "the lo-byte layout pairs rows r and r + 32");
+        constexpr uint32_t xs = 128u;
+        const uint32_t x0 = (((col0 >> 6) * aux.hm_rows + row0 + rl0) * 64u + c8) * 2u;
+        const uint32_t p0 = ((col0 >> 6) * aux.hm_rows + row0 + rl0) * 8u;
+        const uint32_t l0 = (((col0 >> 6) * (aux.hm_rows >> 6) + (row0 >> 6)) << 12) + rl0 * 128u + (lane & 7) * 16u;
+        char *xb_b = (char *)aux.xb, *xlo_b = (char *)aux.xlo, *part_b = (char *)aux.part;
+#pragma unroll
+        for (int ih = 0; ih < MT; ih += 2) {
+            uint4 xh[2][4], xl[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                xh[0][k] = *(const uint4 *)(xb_b + x0 + (ih * 32 + 8 * k) * xs);
+                xh[1][k] = *(const uint4 *)(xb_b + x0 + ((ih + 1) * 32 + 8 * k) * xs);
+                xl[k] = *(const uint4 *)(xlo_b + l0 + (ih >> 1) * 4096u + k * 1024u);
+            }
+            if (ih == MT - 2) hook();
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                uint32_t lo_out[4];
+#pragma unroll
+                for (int ii = 0; ii < 2; ii++) {
+                    transpose_in(ih + ii, k);
+                    const uint32_t rr = (ih + ii) * 32 + 8 * k;
+                    const float4 u = *(const float4 *)(ep + ep_at(rl0, c8));
+                    const float4 w = *(const float4 *)(ep + ep_at(rl0, c8) + 4);
+                    float f[8] = {u.x + b0.x, u.y + b0.y, u.z + b0.z, u.w + b0.w, w.x + b1.x, w.y + b1.y, w.z + b1.z, w.w + b1.w};
+                    const uint32_t hw[4] = {xh[ii][k].x, xh[ii][k].y, xh[ii][k].z, xh[ii][k].w};
+                    const uint32_t lw[2] = {ii ? xl[k].z : xl[k].x, ii ? xl[k].w : xl[k].y};
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        const uint32_t hb = (e & 1) ? (hw[e >> 1] & 0xffff0000u) : (hw[e >> 1] << 16);
+                        const int32_t t = __builtin_amdgcn_sbfe((int32_t)lw[e >> 2], 8 * (e & 3), 8);
+                        f[e] += __uint_as_float(hb + (uint32_t)(t << 8));
+                    }
+                    const uint4 hv = make_uint4(pack2(f[0], f[1]), pack2(f[2], f[3]), pack2(f[4], f[5]), pack2(f[6], f[7]));
+                    *(uint4 *)(xb_b + x0 + rr * xs) = hv;
+                    const uint32_t nh[4] = {hv.x, hv.y, hv.z, hv.w};
+                    int32_t q[8];
+#pragma unroll
+                    for (int e = 0; e < 8; e++) q[e] = split8_round(f[e], (e & 1) ? (nh[e >> 1] & 0xffff0000u) : (nh[e >> 1] << 16));
+                    // byte 1 of each q: two v_perm_b32 + one shift-or per four elements
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const uint32_t a = __builtin_amdgcn_perm((uint32_t)q[4 * h + 1], (uint32_t)q[4 * h], 0x0c0c0501u);
+                        const uint32_t b = __builtin_amdgcn_perm((uint32_t)q[4 * h + 3], (uint32_t)q[4 * h + 2], 0x0c0c0501u);
+                        lo_out[2 * ii + h] = a | (b << 16);
+                    }
+                    const float sm = row8_sum(((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7])));
+                    const float sq = row8_sum((fmaf(f[0], f[0], f[1] * f[1]) + fmaf(f[2], f[2], f[3] * f[3])) +
+                                              (fmaf(f[4], f[4], f[5] * f[5]) + fmaf(f[6], f[6], f[7] * f[7])));
+                    if ((lane & 7) == 0) *(float2 *)(part_b + p0 + rr * 8u) = make_float2(sm, sq);
+                }
+                *(uint4 *)(xlo_b + l0 + (ih >> 1) * 4096u + k * 1024u) = make_uint4(lo_out[0], lo_out[1], lo_out[2], lo_out[3]);
+            }
+        }
+      } else {
         // BYTE offsets in 32 bits on top of the uniform array bases (SGPR base + VGPR offset addressing, no 64-bit
         // address per access; launch_gemm checks that the arrays are < 4 GiB and tile-major): this lane's 8 columns of
         // the wave tile's row rl0 in plane col0 / 64; rows are 128 B apart, so the row of an access is an immediate
@@ -530,6 +610,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], float *ep, u
                     if ((lane & 7) == 0) *(float2 *)(part_b + p0 + rr * 8u) = make_float2(sm, sq);      // coalesced for k_rowstats
                 }
         }
+      }
     } else {
         // bf16 outputs: a lane owns 8 columns (one 16-byte store), 8 lanes a 128-byte row segment
         constexpr bool LN = EPI_IS_LN(EPI);
@@ -1079,7 +1160,7 @@ __global__ __launch_bounds__(256) void k_embed_ln(const float *__restrict__ patc
                                                   const float *__restrict__ pos, const float *__restrict__ w,
                                                   const float *__restrict__ b, float *__restrict__ X, uint32_t rows,
                                                   uint32_t T, uint32_t d, uint16_t *__restrict__ Xb,
-                                                  float2 *__restrict__ AB, uint16_t *__restrict__ Xlo, uint32_t M_pad)
+                                                  float2 *__restrict__ AB, uint16_t *__restrict__ Xlo, uint32_t M_pad, int lo8 = 0)
 {
     // X (fp32 residual stream) and Xb/AB (LayerNorm-folded path: bf16 operand copy of the row and the
     // (rstd, -rstd*mean) of the row for the first block's layer_norm1) are each optional
@@ -1123,7 +1204,12 @@ __global__ __launch_bounds__(256) void k_embed_ln(const float *__restrict__ patc
                 const uint2 hv = make_uint2(pack2(o[i].x, o[i].y), pack2(o[i].z, o[i].w));
                 const size_t xo = ((size_t)(c0 >> 6) * M_pad + row) * 64 + (c0 & 63);       // tile-major [d/64][M_pad][64]
                 *(uint2 *)(Xb + xo) = hv;
-                if (Xlo)
+                if (Xlo && lo8) {              // EPI_RESID_STATS_SPLIT8's lo bytes: 4 columns of this row = one 4-byte store
+                    const uint32_t q0 = (uint32_t)split8_round(o[i].x, hv.x << 16), q1 = (uint32_t)split8_round(o[i].y, hv.x & 0xffff0000u);
+                    const uint32_t q2 = (uint32_t)split8_round(o[i].z, hv.y << 16), q3 = (uint32_t)split8_round(o[i].w, hv.y & 0xffff0000u);
+                    *(uint32_t *)((uint8_t *)Xlo + lo8_off(M_pad, row, c0)) =
+                        __builtin_amdgcn_perm(q1, q0, 0x0c0c0501u) | (__builtin_amdgcn_perm(q3, q2, 0x0c0c0501u) << 16);
+                } else if (Xlo)
                     *(uint2 *)(Xlo + xo) = make_uint2(pack2(o[i].x - bf_lo(hv.x), o[i].y - bf_hi(hv.x)),
                                                                          pack2(o[i].z - bf_lo(hv.y), o[i].w - bf_hi(hv.y)));
             }
@@ -1802,7 +1888,7 @@ __global__ __launch_bounds__(256) void k_attention_cls(const uint16_t *__restric
 
 // class-token rows of the residual stream -> compact fp32 [n][d] (bf16 hi (+ lo) tile-major planes, or fp32 row-major X)
 __global__ void k_gather_cls(const float *__restrict__ X, const uint16_t *__restrict__ Xhi, const uint16_t *__restrict__ Xlo,
-                             uint32_t M_pad, uint32_t T, uint32_t d, uint32_t n, float *__restrict__ X_cls)
+                             uint32_t M_pad, uint32_t T, uint32_t d, uint32_t n, float *__restrict__ X_cls, int lo8 = 0)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n * d) return;
@@ -1812,7 +1898,8 @@ __global__ void k_gather_cls(const float *__restrict__ X, const uint16_t *__rest
     if (Xhi) {
         const size_t xo = ((size_t)(c >> 6) * M_pad + row) * 64 + (c & 63);
         v = __uint_as_float((uint32_t)Xhi[xo] << 16);
-        if (Xlo) v += __uint_as_float((uint32_t)Xlo[xo] << 16);
+        if (Xlo && lo8) v = split8_value(Xhi[xo], ((const int8_t *)Xlo)[lo8_off(M_pad, row, c)]);
+        else if (Xlo) v += __uint_as_float((uint32_t)Xlo[xo] << 16);
     } else {
         v = X[row * d + c];
     }
@@ -1844,7 +1931,7 @@ __global__ __launch_bounds__(HEAD_THREADS) void k_head(const float *__restrict__
                                                        const float *__restrict__ lw, const float *__restrict__ lb,
                                                        const float *__restrict__ proj, uint32_t D,
                                                        const float *__restrict__ text, uint32_t C, float logit_scale,
-                                                       float *__restrict__ logits, float *__restrict__ embeds)
+                                                       float *__restrict__ logits, float *__restrict__ embeds, int lo8 = 0)
 {
     __shared__ float xs[1024];
     __shared__ float es[1024];
@@ -1858,7 +1945,8 @@ __global__ __launch_bounds__(HEAD_THREADS) void k_head(const float *__restrict__
     if (tid < d) {
         const size_t xo = ((size_t)(tid >> 6) * M_pad + xrow) * 64 + (tid & 63);                                // bf16 residual: tile-major
         xv = Xb ? __uint_as_float((uint32_t)Xb[xo] << 16) : X[xrow * d + tid];
-        if (Xb && Xlo) xv += __uint_as_float((uint32_t)Xlo[xo] << 16);
+        if (Xb && Xlo && lo8) xv = split8_value(Xb[xo], ((const int8_t *)Xlo)[lo8_off(M_pad, xrow, tid)]);
+        else if (Xb && Xlo) xv += __uint_as_float((uint32_t)Xlo[xo] << 16);
     }
     float s = wave_sum(xv);
     if (lane == 0) red[wave] = s;
@@ -2188,12 +2276,12 @@ static int attention_setup(d2r_ctx *ctx, uint32_t T_pad, size_t *lds_out)
 // Hc (bf16 [n_pad][mlp]) — all row-major, padded rows hold finite leftovers.
 static int last_block_cls(d2r_ctx *ctx, const d2r_clip_desc &D, const ClipWeights::Layer &L, uint32_t n, uint32_t T, uint32_t rows_pad,
                           const uint16_t *QKV, const uint16_t *Qc, const float *X, const uint16_t *Xhi, const uint16_t *Xlo, float *Xc,
-                          uint16_t *AOc, uint16_t *Xnc, uint16_t *Hc)
+                          uint16_t *AOc, uint16_t *Xnc, uint16_t *Hc, int lo8 = 0)
 {
     const uint32_t d = D.hidden_size, mlp = D.mlp_size, items = n * D.num_heads;
     int rc;
     hipLaunchKernelGGL(k_attention_cls, dim3((items + 3) / 4), dim3(256), 0, ctx->stream, QKV, Qc, AOc, T, d, rows_pad, D.num_heads, items);
-    hipLaunchKernelGGL(k_gather_cls, dim3((n * d + 255) / 256), dim3(256), 0, ctx->stream, X, Xhi, Xlo, rows_pad, T, d, n, Xc);
+    hipLaunchKernelGGL(k_gather_cls, dim3((n * d + 255) / 256), dim3(256), 0, ctx->stream, X, Xhi, Xlo, rows_pad, T, d, n, Xc, lo8);
     if ((rc = launch_gemm<EPI_BIAS_RESID_F32>(ctx, AOc, L.w_o, L.b_o, Xc, n, d, d))) return rc;
     hipLaunchKernelGGL(k_layernorm, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, Xc, L.ln2_w, L.ln2_b, Xnc, n, d);
     if ((rc = launch_gemm<EPI_BIAS_GELU_BF16>(ctx, Xnc, L.w_fc1, L.b_fc1, Hc, n, mlp, d))) return rc;
@@ -2265,11 +2353,13 @@ int d2r_clip_forward(d2r_ctx *ctx, const d2r_clip *clip, const uint16_t *patches
     const uint32_t np = d / 64;
     if ((rc = d2r_reserve(ctx, ctx->clipws[7], (size_t)rows_pad * np * 8 + (size_t)rows_pad * 8))) return rc;
     float2 *part = (float2 *)ctx->clipws[7].p, *AB = part + (size_t)rows_pad * np;
-    // fold 1: residual = hi (Xn, the operand copy) + lo (bf16 array in X's workspace); fold 2: hi only; fold 3: fp32 X + hi
-    const bool xf32 = fold == 3, split = fold == 1;
+    // fold 1: residual = hi (Xn, the operand copy) + lo (bf16 array in X's workspace); fold 2: hi only; fold 3: fp32 X + hi;
+    // fold 4: hi + one lo BYTE per element (EPI_RESID_STATS_SPLIT8, byte array in X's workspace)
+    const bool xf32 = fold == 3, split8 = fold == 4, split = fold == 1 || split8;
+    const int lo8 = split8 ? 1 : 0;
     uint16_t *Xlo = split ? (uint16_t *)X : (uint16_t *)nullptr;
     hipLaunchKernelGGL(k_embed_ln, dim3((rows + 3) / 4), dim3(256), 0, ctx->stream, patch_out, clip->w.cls, clip->w.pos,
-                       clip->w.pre_w, clip->w.pre_b, xf32 ? X : (float *)nullptr, rows, T, d, Xn, AB, Xlo, rows_pad);
+                       clip->w.pre_w, clip->w.pre_b, xf32 ? X : (float *)nullptr, rows, T, d, Xn, AB, Xlo, rows_pad, lo8);
     EpiAux ln = out_tm, st = a_tm;                // LN-folded GEMMs: A = tile-major residual copy, output tile-major
     ln.a_rs = a_tm.a_rs;
     ln.a_ks = a_tm.a_ks;
@@ -2298,12 +2388,13 @@ int d2r_clip_forward(d2r_ctx *ctx, const d2r_clip *clip, const uint16_t *patches
             lq.ab = ABq;
             if ((rc = launch_gemm<EPI_LN_BIAS_BF16>(ctx, Xq, L.wf_qkv, L.bf_qkv, Qc, n, d, d, lq))) return rc;
             // (the gather reads the residual rows out of Xn / Xlo before Xn's first rows are reused for the LayerNorm output)
-            if ((rc = last_block_cls(ctx, D, L, n, T, rows_pad, QKV, Qc, X, xf32 ? nullptr : Xn, Xlo, patch_out, AO, Xn, H))) return rc;
+            if ((rc = last_block_cls(ctx, D, L, n, T, rows_pad, QKV, Qc, X, xf32 ? nullptr : Xn, Xlo, patch_out, AO, Xn, H, lo8))) return rc;
             break;
         }
         if ((rc = launch_gemm<EPI_LN_BIAS_BF16>(ctx, Xn, L.wf_qkv, L.bf_qkv, QKV, rows, 3 * d, d, ln))) return rc;
         launch_attention_vision(ctx, QKV, AO, T, d, rows_pad, D.num_heads, n);
         if (xf32) rc = launch_gemm<EPI_RESID_STATS_F32X>(ctx, AO, L.w_o, L.b_o, X, rows, d, d, st);
+        else if (split8) rc = launch_gemm<EPI_RESID_STATS_SPLIT8>(ctx, AO, L.w_o, L.b_o, Xn, rows, d, d, st);
         else if (split) rc = launch_gemm<EPI_RESID_STATS_SPLIT>(ctx, AO, L.w_o, L.b_o, Xn, rows, d, d, st);
         else rc = launch_gemm<EPI_RESID_STATS_BF16>(ctx, AO, L.w_o, L.b_o, Xn, rows, d, d, st);
         if (rc) return rc;
@@ -2311,6 +2402,7 @@ int d2r_clip_forward(d2r_ctx *ctx, const d2r_clip *clip, const uint16_t *patches
         ln.cs = L.cs_fc1;
         if ((rc = launch_gemm<EPI_LN_BIAS_GELU_BF16>(ctx, Xn, L.wf_fc1, L.bf_fc1, H, rows, mlp, d, ln))) return rc;
         if (xf32) rc = launch_gemm<EPI_RESID_STATS_F32X>(ctx, H, L.w_fc2, L.b_fc2, X, rows, d, mlp, st);
+        else if (split8) rc = launch_gemm<EPI_RESID_STATS_SPLIT8>(ctx, H, L.w_fc2, L.b_fc2, Xn, rows, d, mlp, st);
         else if (split) rc = launch_gemm<EPI_RESID_STATS_SPLIT>(ctx, H, L.w_fc2, L.b_fc2, Xn, rows, d, mlp, st);
         else rc = launch_gemm<EPI_RESID_STATS_BF16>(ctx, H, L.w_fc2, L.b_fc2, Xn, rows, d, mlp, st);
         if (rc) return rc;
@@ -2324,7 +2416,7 @@ int d2r_clip_forward(d2r_ctx *ctx, const d2r_clip *clip, const uint16_t *patches
     else
     hipLaunchKernelGGL(k_head, dim3(n), dim3(HEAD_THREADS), 0, ctx->stream, X, xf32 ? (const uint16_t *)nullptr : (const uint16_t *)Xn,
                        (const uint16_t *)Xlo, rows_pad, (const uint32_t *)nullptr, T, d, clip->w.post_w, clip->w.post_b, clip->w.proj, D.proj_dim, text_dev, C,
-                       logit_scale, logits_dev, embeds_dev);
+                       logit_scale, logits_dev, embeds_dev, lo8);
     D2R_HIP(ctx, hipGetLastError());
     return D2R_OK;
 }

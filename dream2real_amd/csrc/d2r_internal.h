@@ -130,7 +130,7 @@ struct d2r_ctx {
     int64_t march_blocks = 0;  // 0 = auto
     int64_t refill_min = 64;   // measured on MI355X: a refill (queue + camera loads, ray setup, SH) costs several iterations,
                                // so a wave runs its 64 rays to the end (lane utilisation 0.79) rather than topping up at 16 free lanes (0.90)
-    int64_t ln_fold = 1;       // vision tower: 0 LayerNorm kernels + fp32 residual; LayerNorm folded into the GEMMs with 1 a split (hi + lo) bf16 residual, 2 a bf16 residual, 3 an fp32 residual + bf16 copy
+    int64_t ln_fold = 4;       // vision tower: 0 LayerNorm kernels + fp32 residual; LayerNorm folded into the GEMMs with 1 a split (hi + lo) bf16 residual, 2 a bf16 residual, 3 an fp32 residual + bf16 copy, 4 bf16 hi + one lo byte
     int64_t gemm_stagger = 0;      // persistent GEMM: stagger the workgroups' first tile over a tile period (epilogues spread in time)
     int64_t gemm_group = 65535;    // persistent GEMM: column tiles per group of the tile order (large = the plain column-fastest order, the default; 0 = the width a simple L2 model picks: a third fewer L2 misses, same time)
     int64_t gemm_nsplit = 0;     // column sections of the persistent GEMM's tile order (XCD sets own column ranges): 0 = two where the XCDs and the column tiles divide evenly, 1 = none

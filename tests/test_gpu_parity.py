@@ -1274,7 +1274,7 @@ def test_argmax_pose_identical_with_vit_b16_on_a_16x16_grid(gpu, tmp_path):
 def test_vit_layernorm_fold_modes_match_oracle(gpu, name, n):
     """The vision-tower schedules — ln_fold 0: LayerNorm kernels + fp32 residual stream; 1 (default): LayerNorm
     folded into the QKV / fc1 GEMMs (row statistics from the residual GEMMs' epilogues), residual kept as a
-    split hi + lo bf16 pair; 3: the same with an fp32 residual; 2: folded + bf16-only residual (an option: 24 bf16 roundings of the residual stream put
+    split hi + lo bf16 pair; 4: hi + one lo BYTE (the fp32 bit pattern's next 8 bits, rounded); 3: the same with an fp32 residual; 2: folded + bf16-only residual (an option: 24 bf16 roundings of the residual stream put
     its logit error at sigma ~ 4e-4 of the logit scale, i.e. past the 1e-3 bar in the tail — measured
     9.9e-4 on 15 samples) — against the fp32 oracle.  n = 300 runs every GEMM on the
     persistent 256x256 kernel, the small batches on the 256x128 one."""
@@ -1290,7 +1290,7 @@ def test_vit_layernorm_fold_modes_match_oracle(gpu, name, n):
     text = random_unit_text_embeds(cfg["proj"], 3)
     errs = {}
     try:
-        for mode in (0, 1, 2, 3):
+        for mode in (0, 1, 2, 3, 4):
             ctx.set_option("ln_fold", mode)
             got = sc.embed_pixels(pv)
             again = sc.embed_pixels(pv)
@@ -1300,7 +1300,7 @@ def test_vit_layernorm_fold_modes_match_oracle(gpu, name, n):
             logit_err = float(np.abs((got[idx] - want) @ text.T).max())                   # = |dlogit| / logit_scale
             errs[mode] = (cos_err, logit_err)
     finally:
-        ctx.set_option("ln_fold", 1)
+        ctx.set_option("ln_fold", 4)
     print(f"ln_fold errors {name} n={n}: " + ", ".join(f"mode {k}: 1-cos {a:.2e} dlogit/scale {b:.2e}" for k, (a, b) in errs.items()))
     for mode, (cos_err, logit_err) in errs.items():
         # mode 2 (bf16-only residual) is an OPTION that trades accuracy for speed, documented as past the bar in the tail
