@@ -444,6 +444,7 @@ int d2r_nerf_create(d2r_ctx *ctx, const d2r_nerf_desc *d, d2r_nerf **out)
         sm.bnx[h] = (uint32_t)n[0];
         sm.bnxy[h] = (uint32_t)(n[0] * n[1]);
         sm.bbase[h] = (int32_t)((int64_t)base - ((int64_t)g0[0] + (int64_t)n[0] * g0[1] + (int64_t)n[0] * n[1] * g0[2]));
+
         for (int z = 0; z < n[2]; z++)
             for (int y = 0; y < n[1]; y++)
                 for (int x = 0; x < n[0]; x++) {
