@@ -357,8 +357,19 @@ def run_api(args, wd):
     bg_rgba, bg_depth = bg.render_batch(cam_ngp[None, :3], W, H)
     view = fg.view(W, H)
     ctx.set_background(view, bg_rgba[0], bg_depth[0])
-    _, e0 = scorer.score_frames(fg.render_composite(view, T1, cam_ngp, T1[None]), np.zeros((1, cfg["proj"]), np.float32), return_embeds=True)
-    task.text_embeds = scene_text_embeds(e0[0])
+    text_encoder = tokenizer = None
+    if args.api_text == "tower":
+        # the captions of the task through the library's own BPE tokenizer and text tower (random weights of the same
+        # checkpoint, the byte-level BPE vocabulary committed under tests/golden/ as data): the whole caption -> score path
+        # inside the timed call.  Random-weight towers have no language prior, so the scores mean nothing; the work is real.
+        from dream2real_amd.tokenizer import ClipBpeTokenizer
+        g = os.path.join(REPO, "tests", "golden")
+        tokenizer = ClipBpeTokenizer.from_files(os.path.join(g, "bpe_vocab.json"), os.path.join(g, "bpe_merges.txt"), context_length=32)
+        tcfg = dict(cfg, vocab=len(tokenizer.vocab), ctx=32)
+        text_encoder = engine.TextEncoder(ctx, tcfg, random_clip_state_dict(tcfg, seed=6))
+    else:
+        _, e0 = scorer.score_frames(fg.render_composite(view, T1, cam_ngp, T1[None]), np.zeros((1, cfg["proj"]), np.float32), return_embeds=True)
+        task.text_embeds = scene_text_embeds(e0[0])
     root = args.api_dir or tempfile.mkdtemp(prefix="d2r_api_")
     data_dir = os.path.join(root, "run")
     if rank == 0:
@@ -372,13 +383,18 @@ def run_api(args, wd):
         torch.distributed.barrier()
     pcfg = dream2real.PathConfig(data_dir=data_dir, sample_res=sample_res, scene_type=scene.scene_type, resolution=(W, H),
                                  use_phys=use_phys, save_renders=bool(args.api_save))
-    eng = dream2real.ImaginationEngine(pcfg, ctx, scorer)
+    eng = dream2real.ImaginationEngine(pcfg, ctx, scorer, text_encoder=text_encoder, tokenizer=tokenizer)
     stages = {}
+
+    from dream2real_amd import clip_scoring
 
     def one():
         t0 = time.perf_counter()
         best, pose_batch, scores = eng.dream_best_pose(task)
-        stages["last_s"] = time.perf_counter() - t0
+        total = time.perf_counter() - t0
+        stages.clear()
+        stages.update({k: round(v * 1e3, 2) for k, v in clip_scoring.LAST_TIMINGS.items()})
+        stages["physics_setup_renderer_and_txt_files"] = round((total - sum(clip_scoring.LAST_TIMINGS.values())) * 1e3, 2)
         return best, pose_batch, scores
 
     def barrier():
@@ -419,10 +435,13 @@ def run_api(args, wd):
                        "api": "dream2real_amd.dream2real.ImaginationEngine.dream_best_pose", "scene": scene_name, "clip": clip_name,
                        "width": W, "height": H, "poses_sampled": N, "poses_valid": n_valid, "sample_res": sample_res,
                        "save_renders": bool(args.api_save), "physics": use_phys,
+                       "text_embeds": ("captions -> ClipBpeTokenizer -> d2r_text_encode (random-weight text tower) inside the timed call" if args.api_text == "tower"
+                                       else "2 seeded unit vectors correlated with the scene's image embedding, cached on the task"),
                        "parallelism": f"pose-shard x{world}" if world > 1 else "single GPU"},
             "poses_sampled_per_s": round(N * args.steps / elapsed, 2),
             "device_ms_per_step": {k.replace("_ms", ""): round(v / args.steps, 3) for k, v in timing.items() if k.endswith("_ms")},
             "note_device_ms": "with the two-stream pipeline the render half (march / raygen / prep) overlaps the ViT of the previous chunk: the parts do not add up to the step",
+            "host_ms_last_step": dict(stages),
             "peak_host_rss_gb": round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1048576, 2),
             "argmax_pose": int(np.argmax(sc)),
             "roofline": None, "cpu_baseline": None,
@@ -467,6 +486,8 @@ def main():
                          "the reference's own workload (70 000 poses, 336x336, ViT-L/14-336, physics on)")
     ap.add_argument("--api-save", type=int, default=0, help="--api: 1 = write cb_render/*.png for every valid pose, as the reference does")
     ap.add_argument("--api-phys", type=int, default=1, help="--api: 0 = skip the physics pre-filter (every pose valid)")
+    ap.add_argument("--api-text", choices=("cached", "tower"), default="cached",
+                    help="--api: 'tower' = tokenise the task's captions and run the library's text tower inside the timed call")
     ap.add_argument("--api-dir", default=None, help="--api: data_dir root (default: a temporary directory, removed afterwards)")
     ap.add_argument("--dry-collective", action="store_true",
                     help="only rendezvous + communicator init + one 1 MiB all-gather + argmax agreement (diagnoses a failed --gpus N run)")

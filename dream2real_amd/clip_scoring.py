@@ -68,6 +68,8 @@ def save_pose_outputs(data_dir, best_pose, pose_batch, pose_scores):
     _lib.savetxt(os.path.join(data_dir, "pose_scores.txt"), arr(pose_scores))
 
 
+LAST_TIMINGS: dict = {}      # seconds per stage of the last optimise_pose_grid call (bench.py --api reports them)
+
 CACHE_READ_CHUNK = 2048      # cached renders are read and scored this many at a time (host memory stays bounded)
 
 
@@ -101,13 +103,23 @@ def optimise_pose_grid(renderer, depths_gt, render_cam_pose_idx, task_model, dat
     `score_frames`).  Under a launcher with WORLD_SIZE > 1 (or an explicit `shard`, a dist.PoseShard) the valid poses are
     split in contiguous blocks over the ranks, logits are all-gathered ONCE, and ratio / scatter / smoothing / argmax run
     identically on every rank; rank 0 writes best_render.png."""
+    import time
     import torch
     from . import _lib
+
+    LAST_TIMINGS.clear()
+    t_mark = [time.perf_counter()]
+
+    def lap(name):
+        now = time.perf_counter()
+        LAST_TIMINGS[name] = LAST_TIMINGS.get(name, 0.0) + now - t_mark[0]
+        t_mark[0] = now
 
     if sample_res is None:
         sample_res = [40, 40, 1, 1, 1, 1]
     pose_batch = sample_poses_grid(task_model, sample_res, scene_type=scene_type)
     N = pose_batch.shape[0]
+    lap("sample_poses_grid")
 
     def text_embeddings():
         if scorer is None:
@@ -148,6 +160,7 @@ def optimise_pose_grid(renderer, depths_gt, render_cam_pose_idx, task_model, dat
         is_valid = phys_check(torch.from_numpy(pose_batch), task_model, valid_so_far)
         valid_idxs = np.nonzero(np.asarray(is_valid, bool))[0]
         valid_poses = pose_batch[valid_idxs]
+        lap("phys_check")
         if valid_idxs.shape[0] == 0:
             print("No poses passed pre-render checks. Exiting.")
             raise Exception
@@ -161,6 +174,7 @@ def optimise_pose_grid(renderer, depths_gt, render_cam_pose_idx, task_model, dat
         valid_poses_ngp = accio2ngp.converter(valid_poses.reshape(-1, 4, 4))
         K = valid_poses_ngp.shape[0]
         te, n_goal = text_embeddings()
+        lap("convert_poses_and_text")
         if hasattr(task_model, "free_visual_models"):
             pass    # the reference frees the NeRFs here to make room for CLIP; 288 GB makes that unnecessary
         fused = hasattr(renderer, "render_score") and hasattr(scorer, "h") and len(render_cam_pose_idx) == 1
@@ -178,7 +192,9 @@ def optimise_pose_grid(renderer, depths_gt, render_cam_pose_idx, task_model, dat
                 shard.barrier()
             local = renderer.render_score(valid_poses_ngp[lo:hi], render_poses_ngp, render_cam_pose_idx, scorer, te,
                                           depths_gt, masks, save=save_renders, first_index=lo, clear=shard is None)
+            lap("render_score")
             all_logits = local if shard is None else shard.gather(local, K)
+            lap("gather")
             fetch_render = lambda j: renderer.render_one(valid_poses_ngp[j])
         else:
             if world > 1:
@@ -199,6 +215,7 @@ def optimise_pose_grid(renderer, depths_gt, render_cam_pose_idx, task_model, dat
         pose_scores = spatially_smooth_heatmap(pose_scores, sample_res)
     best_pose_idx = int(np.argmax(pose_scores))
     best_pose = valid_poses[render_idxs[best_pose_idx]]
+    lap("reduce_scatter_smooth_argmax")
     if rank == 0:
         best_render = np.rot90(fetch_render(int(render_idxs[best_pose_idx])), k=1, axes=(0, 1))
         _lib.png_write(np.ascontiguousarray(best_render), os.path.join(data_dir, "best_render.png"))
@@ -209,5 +226,6 @@ def optimise_pose_grid(renderer, depths_gt, render_cam_pose_idx, task_model, dat
         renderer.wait_saved()          # cb_render/*.png are complete when the call returns, as in the reference
     if shard is not None:
         shard.barrier()
+    lap("best_render_png")
     return (torch.from_numpy(best_pose.reshape(4, 4).copy()), torch.from_numpy(pose_batch),
             torch.from_numpy(pose_scores))

@@ -154,7 +154,53 @@ def test_bad_arguments_return_error_codes():
     for data in (b"\x81\xd9\xc8abc", b"\x78\x9c" + b"\x00" * 40, bytes(range(256)) * 8):
         buf = np.frombuffer(data, np.uint8)
         assert lib.d2r_nerf_load_ingp(h, _lib.ptr(buf), C.c_size_t(buf.size), C.byref(out), C.byref(info), views, 4) == INVALID
+    # the host-array form of the fused pass: null poses / logits, a bad frame sink; no background on ctx2
+    lg2 = np.zeros((2, 2), np.float32)
+    args = lambda c, nerf, p, l, sink: lib.d2r_render_score_host(c, nerf, sc.h, C.byref(view), _lib.ptr(eye), _lib.ptr(eye), p, 2, _lib.ptr(text), 2,
+                                                                C.c_float(100.0), l, None, sink)
+    assert args(h, tb.h, None, _lib.ptr(lg2), None) == INVALID
+    assert args(h, tb.h, _lib.ptr(poses), None, None) == INVALID
+    assert args(h, null, _lib.ptr(poses), _lib.ptr(lg2), None) == INVALID
+    bad_sink = _lib.FrameSink(b"/tmp", 0, 0, 12)
+    assert args(h, tb.h, _lib.ptr(poses), _lib.ptr(lg2), C.byref(bad_sink)) == INVALID and "d2r_frame_sink" in msg()
+    sc2 = engine.ClipScorer(ctx2, cfg, sd)
+    assert lib.d2r_render_score_host(ctx2.h, tb2.h, sc2.h, C.byref(view), _lib.ptr(eye), _lib.ptr(eye), _lib.ptr(poses), 2, _lib.ptr(text), 2,
+                                     C.c_float(100.0), _lib.ptr(lg2), None, None) == INVALID and "background" in lib.d2r_last_error(ctx2.h).decode()
+    sc2.close()
     # the context still works after all of that
     r2, d2 = tb.render_batch(cams.reshape(1, 3, 4), 32, 18)
     assert np.isfinite(r2).all()
     sc.close(); tb.close(); tb2.close(); ctx2.close(); ctx.close()
+
+
+def test_host_only_entries_return_error_codes(tmp_path):
+    """The host-only entries (frame files, text files, snapshot validation) need no device: bad arguments come back as
+    negative codes with a message, like everything else behind the ABI."""
+    import numpy as np
+    C = ctypes
+    lib = _lib.load()
+    img = np.zeros((4, 6, 3), np.uint8)
+    err = lambda: lib.d2r_last_error(None).decode()
+    assert lib.d2r_png_write(None, 6, 4, b"/tmp/x.png", 1) == -1
+    assert lib.d2r_png_write(_lib.ptr(img), 0, 4, os.fsencode(str(tmp_path / "a.png")), 1) == -1 and "size" in err()
+    assert lib.d2r_png_write(_lib.ptr(img), 6, 4, os.fsencode(str(tmp_path / "no_dir" / "a.png")), 1) == -1 and "cannot open" in err()
+    assert lib.d2r_png_write_batch(_lib.ptr(img), 1, 6, 4, None, 0, 0, 1) == -1
+    assert lib.d2r_png_write_batch(_lib.ptr(img), 0, 6, 4, os.fsencode(str(tmp_path)), 0, 0, 1) == 0        # nothing to do
+    assert lib.d2r_png_read_batch(os.fsencode(str(tmp_path)), None, 0, 1, 6, 4, None, 0) == -1
+    assert lib.d2r_png_read_batch(os.fsencode(str(tmp_path)), None, 7, 1, 6, 4, _lib.ptr(img), 0) == -1 and "cb_rgb_0007.png" in err()
+    w, h = C.c_uint32(), C.c_uint32()
+    assert lib.d2r_png_size(os.fsencode(str(tmp_path / "missing.png")), C.byref(w), C.byref(h)) == -1
+    lib.d2r_savetxt.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int]
+    a = np.arange(6, dtype=np.float64)
+    assert lib.d2r_savetxt(None, _lib.ptr(a), 2, 3, 0) == -1
+    assert lib.d2r_savetxt(os.fsencode(str(tmp_path / "t.txt")), None, 2, 3, 0) == -1
+    assert lib.d2r_savetxt(os.fsencode(str(tmp_path / "t.txt")), _lib.ptr(a), 2, 0, 0) == -1
+    assert lib.d2r_savetxt(os.fsencode(str(tmp_path / "no_dir" / "t.txt")), _lib.ptr(a), 2, 3, 0) == -1 and "cannot open" in err()
+    assert lib.d2r_savetxt(os.fsencode(str(tmp_path / "empty.txt")), None, 0, 3, 0) == 0 and open(tmp_path / "empty.txt").read() == ""
+    assert lib.d2r_savetxt(os.fsencode(str(tmp_path / "t.txt")), _lib.ptr(a), 2, 3, 1) == 0
+    np.testing.assert_array_equal(np.loadtxt(tmp_path / "t.txt"), a.reshape(2, 3))
+    lib.d2r_ingp_validate.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p]
+    assert lib.d2r_ingp_validate(None, 100, None) == -1 and lib.d2r_ingp_validate(b"abc", 3, None) == -1
+    assert lib.d2r_ingp_validate(bytes(range(64)), 64, None) == -1 and "snapshot" in err()
+    with pytest.raises(ValueError):
+        _lib.savetxt(str(tmp_path / "z.txt"), np.float64(3.0))                 # 0-d, like np.savetxt
