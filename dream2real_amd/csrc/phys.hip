@@ -28,6 +28,7 @@ struct d2r_phys {
     float *d_stat = nullptr;       // static hull vertices, concatenated
     uint32_t *d_off = nullptr;     // [n_stat + 1] first vertex of each static hull
     uint32_t n_stat = 0, n_stat_verts = 0;
+    float *d_stat_box = nullptr;   // [n_stat][6] axis-aligned box of each static hull (lo xyz, hi xyz)
 };
 
 struct PhysKernelParams {
@@ -64,10 +65,94 @@ __device__ __forceinline__ V3 hull_support(const float *__restrict__ verts, uint
     return {verts[3 * bi], verts[3 * bi + 1], verts[3 * bi + 2]};
 }
 
+// ---- closest point to the origin on a simplex of 2 / 3 / 4 points (Ericson, Real-Time Collision Detection 5.1.2, 5.1.5,
+// 5.1.6: Voronoi-region tests).  The simplex is reduced in place to the sub-simplex that carries the closest point; the
+// functions return that point.  Wave-uniform: every lane runs the same scalar arithmetic.
+
+__device__ V3 closest_segment(V3 *s, int &n)
+{
+    const V3 a = s[0], b = s[1], ab = b - a;
+    const float t = dot(neg(a), ab), den = dot(ab, ab);
+    if (t <= 0.f || den <= 0.f) { n = 1; return a; }
+    if (t >= den) { s[0] = b; n = 1; return b; }
+    const float u = t / den;
+    return {fmaf(u, ab.x, a.x), fmaf(u, ab.y, a.y), fmaf(u, ab.z, a.z)};
+}
+
+__device__ V3 closest_triangle(V3 *s, int &n)
+{
+    const V3 a = s[0], b = s[1], c = s[2], ab = b - a, ac = c - a;
+    const float d1 = dot(ab, neg(a)), d2 = dot(ac, neg(a));
+    if (d1 <= 0.f && d2 <= 0.f) { n = 1; return a; }
+    const float d3 = dot(ab, neg(b)), d4 = dot(ac, neg(b));
+    if (d3 >= 0.f && d4 <= d3) { s[0] = b; n = 1; return b; }
+    const float vc = d1 * d4 - d3 * d2;
+    if (vc <= 0.f && d1 >= 0.f && d3 <= 0.f) {
+        const float v = d1 / (d1 - d3);
+        n = 2;                                                     // edge ab: s[0], s[1] stay
+        return {fmaf(v, ab.x, a.x), fmaf(v, ab.y, a.y), fmaf(v, ab.z, a.z)};
+    }
+    const float d5 = dot(ab, neg(c)), d6 = dot(ac, neg(c));
+    if (d6 >= 0.f && d5 <= d6) { s[0] = c; n = 1; return c; }
+    const float vb = d5 * d2 - d1 * d6;
+    if (vb <= 0.f && d2 >= 0.f && d6 <= 0.f) {
+        const float w = d2 / (d2 - d6);
+        s[1] = c; n = 2;                                           // edge ac
+        return {fmaf(w, ac.x, a.x), fmaf(w, ac.y, a.y), fmaf(w, ac.z, a.z)};
+    }
+    const float va = d3 * d6 - d5 * d4;
+    if (va <= 0.f && (d4 - d3) >= 0.f && (d5 - d6) >= 0.f) {
+        const float w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+        const V3 bc = c - b;
+        s[0] = b; s[1] = c; n = 2;                                 // edge bc
+        return {fmaf(w, bc.x, b.x), fmaf(w, bc.y, b.y), fmaf(w, bc.z, b.z)};
+    }
+    const float den = 1.f / (va + vb + vc), v = vb * den, w = vc * den;
+    return {fmaf(w, ac.x, fmaf(v, ab.x, a.x)), fmaf(w, ac.y, fmaf(v, ab.y, a.y)), fmaf(w, ac.z, fmaf(v, ab.z, a.z))};
+}
+
+// false: the origin is inside the tetrahedron (the caller reports an intersection)
+__device__ bool closest_tetrahedron(V3 *s, int &n, V3 &out)
+{
+    const V3 p[4] = {s[0], s[1], s[2], s[3]};
+    const int face[4][4] = {{0, 1, 2, 3}, {0, 2, 3, 1}, {0, 3, 1, 2}, {1, 3, 2, 0}};      // three face vertices, then the opposite one
+    float best = INFINITY;
+    bool outside_any = false;
+    V3 bs[3];
+    int bn = 0;
+#pragma unroll
+    for (int f = 0; f < 4; f++) {
+        const V3 a = p[face[f][0]], b = p[face[f][1]], c = p[face[f][2]], d = p[face[f][3]];
+        const V3 nrm = cross(b - a, c - a);
+        const float sp = dot(neg(a), nrm), sd = dot(d - a, nrm);
+        if (sp * sd < 0.f || sd == 0.f) {                          // the origin lies beyond this face (a flat tetrahedron counts as outside)
+            outside_any = true;
+            V3 t[3] = {a, b, c};
+            int tn = 3;
+            const V3 q = closest_triangle(t, tn);
+            const float qq = dot(q, q);
+            if (qq < best) {
+                best = qq;
+                out = q;
+                bn = tn;
+                bs[0] = t[0]; bs[1] = t[1]; bs[2] = t[2];
+            }
+        }
+    }
+    if (!outside_any) return false;
+    n = bn;
+    for (int i = 0; i < bn; i++) s[i] = bs[i];
+    return true;
+}
+
 // Do hull A (vertices a, moved by x -> R x + t) and hull B come within `margin2` of each other (margin2 = 0: do they
-// intersect)?  Boolean GJK on the Minkowski difference A - B, inflated by a sphere of radius margin2 through its support
-// function (Bullet gives every convex shape a collision margin; two shapes are in contact when their cores are closer
-// than the sum of the margins).
+// intersect)?  Distance GJK on the Minkowski difference of the two CORES, as Bullet does it: every convex shape carries a
+// collision margin and two shapes are in contact when their cores are closer than the sum of the margins.  The
+// difference of two polytopes is a polytope, so the iteration ends after finitely many support points; it also ends
+// early as soon as the two bounds it carries decide the question — |v| (an upper bound of the distance: v is a point of
+// the difference) at or below margin2: contact; v.w / |v| (a lower bound: w is the support point along -v) above
+// margin2: none.  Pairs whose distance lies within rounding of margin2 (float32 on metre-sized coordinates: ~1e-6 m) may
+// fall either way; everything else is exact.
 __device__ bool gjk_intersect(const float *__restrict__ a, uint32_t na, const float R[9], V3 t,
                               const float *__restrict__ b, uint32_t nb, uint32_t lane, float margin2)
 {
@@ -80,86 +165,54 @@ __device__ bool gjk_intersect(const float *__restrict__ a, uint32_t na, const fl
                        fmaf(R[3], va.x, fmaf(R[4], va.y, fmaf(R[5], va.z, t.y))),
                        fmaf(R[6], va.x, fmaf(R[7], va.y, fmaf(R[8], va.z, t.z)))};
         const V3 vb = hull_support(b, nb, neg(d), lane);
-        V3 p = wa - vb;
-        if (margin2 > 0.f) {
-            const float k = margin2 * rsqrtf(dot(d, d));
-            p = {fmaf(k, d.x, p.x), fmaf(k, d.y, p.y), fmaf(k, d.z, p.z)};
-        }
-        return p;
+        return wa - vb;
     };
+    const float m2 = margin2 * margin2;
     V3 s[4];
     int n = 1;
-    V3 d = {1.f, 0.f, 0.f};
-    s[0] = support(d);
-    d = neg(s[0]);
-    for (int it = 0; it < 64; it++) {
-        const float dd = dot(d, d);
-        if (dd < 1e-20f) return true;                         // the origin lies on the simplex
-        const V3 p = support(d);
-        const float pd = dot(p, d);
-        if (pd < 0.f) return false;                           // a separating direction
-        // Progress test: d points from the simplex's closest feature towards the origin.  Were the origin strictly
-        // inside, the support point along d would lie beyond the origin, hence strictly beyond every simplex point;
-        // a support point that is no further along d than the simplex already reaches (to 1e-7 m) means the simplex
-        // holds the closest feature and the origin is outside, or on the boundary to within rounding: no contact.
-        // Without this test near-touching pairs cycle until the iteration cap.
-        float reach = dot(s[0], d);
-        for (int i = 1; i < n; i++) reach = fmaxf(reach, dot(s[i], d));
-        if (pd - reach <= 1e-7f * sqrtf(dd)) return false;
-        s[n++] = p;
-        const V3 A = s[n - 1], AO = neg(A);
-        if (n == 4) {
-            // faces through the newest point, normals turned away from the opposite vertex
-            const V3 B = s[2], C = s[1], D = s[0];
-            const V3 f[3][3] = {{B, C, D}, {C, D, B}, {D, B, C}};
-            int out = -1;
+    s[0] = support({1.f, 0.f, 0.f});
+    V3 v = s[0];
+    for (int it = 0; it < 48; it++) {
+        const float vv = dot(v, v);
+        if (vv <= m2 || vv < 1e-18f) return true;             // a point of the difference within margin2 of the origin
+        const V3 w = support(neg(v));
+        const float vw = dot(v, w);
+        if (vw > 0.f && vw * vw > m2 * vv) return false;      // the whole difference lies beyond the plane through w: distance > margin2
+        // converged: w reaches no further towards the origin than the simplex already does -> |v| is the distance (> margin2 here)
+        if (vv - vw <= 1e-6f * vv) return false;
+        for (int i = 0; i < n; i++)
+            if (s[i].x == w.x && s[i].y == w.y && s[i].z == w.z) return false;       // the same vertex again: no further progress possible
+        s[n++] = w;
+        if (n == 2) v = closest_segment(s, n);
+        else if (n == 3) v = closest_triangle(s, n);
+        else if (!closest_tetrahedron(s, n, v)) return true;  // the origin is inside the simplex: the cores intersect
+    }
+    return dot(v, v) <= m2;
+}
+
+// axis-aligned box of a rotated hull R v (no translation), all 64 lanes cooperating; the same six values in every lane
+__device__ __forceinline__ void hull_aabb_rotated(const float *__restrict__ verts, uint32_t n, const float R[9], uint32_t lane, float lo[3], float hi[3])
+{
+    float l[3] = {INFINITY, INFINITY, INFINITY}, h[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t i = lane; i < n; i += 64) {
+        const float x = verts[3 * i], y = verts[3 * i + 1], z = verts[3 * i + 2];
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
-                V3 nrm = cross(f[k][0] - A, f[k][1] - A);
-                if (dot(nrm, f[k][2] - A) > 0.f) nrm = neg(nrm);
-                if (out < 0 && dot(nrm, AO) > 0.f) out = k;
-            }
-            if (out < 0) return true;                         // inside the tetrahedron
-            s[0] = f[out][1];
-            s[1] = f[out][0];
-            s[2] = A;
-            n = 3;
-        }
-        if (n == 3) {
-            const V3 B = s[1], C = s[0], AB = B - A, AC = C - A, ABC = cross(AB, AC);
-            bool edge_ab = false;
-            if (dot(cross(ABC, AC), AO) > 0.f) {
-                if (dot(AC, AO) > 0.f) {
-                    s[0] = C; s[1] = A; n = 2;
-                    d = cross(cross(AC, AO), AC);
-                } else edge_ab = true;
-            } else if (dot(cross(AB, ABC), AO) > 0.f) {
-                edge_ab = true;
-            } else {
-                d = dot(ABC, AO) > 0.f ? ABC : neg(ABC);      // above or below the triangle
-            }
-            if (edge_ab) {
-                if (dot(AB, AO) > 0.f) {
-                    s[0] = B; s[1] = A; n = 2;
-                    d = cross(cross(AB, AO), AB);
-                } else {
-                    s[0] = A; n = 1;
-                    d = AO;
-                }
-            }
-        } else if (n == 2) {
-            const V3 B = s[0], AB = B - A;
-            if (dot(AB, AO) > 0.f) {
-                d = cross(cross(AB, AO), AB);
-            } else {
-                s[0] = A; n = 1;
-                d = AO;
-            }
+        for (int k = 0; k < 3; k++) {
+            const float c = fmaf(R[3 * k], x, fmaf(R[3 * k + 1], y, R[3 * k + 2] * z));
+            l[k] = fminf(l[k], c);
+            h[k] = fmaxf(h[k], c);
         }
     }
-    // the cap is only reached by an inflated (curved) difference whose boundary passes within rounding of the origin:
-    // a touch at exactly the margin distance, reported like the stalled case above
-    return false;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            l[k] = fminf(l[k], __shfl_xor(l[k], o));
+            h[k] = fmaxf(h[k], __shfl_xor(h[k], o));
+        }
+        lo[k] = l[k];
+        hi[k] = h[k];
+    }
 }
 
 // block = 256 threads = 4 waves, one pose per wave
@@ -167,8 +220,11 @@ __global__ __launch_bounds__(256) void k_phys_check(PhysKernelParams P, const fl
                                                     const uint8_t *__restrict__ ori_mask,
                                                     const float *__restrict__ mov, const uint32_t *__restrict__ moff, uint32_t n_mov,
                                                     const float *__restrict__ stat, const uint32_t *__restrict__ off,
-                                                    uint32_t n_stat, uint8_t *__restrict__ valid)
+                                                    uint32_t n_stat, const float *__restrict__ stat_box, uint8_t *__restrict__ valid)
 {
+    // per wave: the boxes of the rotated movable parts (relative to the pose's translation), for the pair early-out
+    constexpr uint32_t BOX_PARTS = 16;
+    __shared__ float mbox[4][BOX_PARTS][6];
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t pose = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (pose >= n_poses) return;
@@ -189,13 +245,34 @@ __global__ __launch_bounds__(256) void k_phys_check(PhysKernelParams P, const fl
                                      fmaf(M[i * 4 + 2], P.inv_init[2 * 4 + j], M[i * 4 + 3] * P.inv_init[3 * 4 + j])));
     const float R[9] = {T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10]};
     const V3 pos = {T[3], T[7], T[11]};
+    float (*mb)[6] = mbox[threadIdx.x >> 6];
+    for (uint32_t m = 0; m < n_mov && m < BOX_PARTS; m++) {
+        float lo[3], hi[3];
+        hull_aabb_rotated(mov + 3 * (size_t)moff[m], moff[m + 1] - moff[m], R, lane, lo, hi);
+        if (lane == 0)
+            for (int k = 0; k < 3; k++) {
+                mb[m][k] = lo[k];
+                mb[m][3 + k] = hi[k];
+            }
+    }
+    __builtin_amdgcn_wave_barrier();
     // PyBullet's pairwise test between two bodies is true when ANY pair of their convex parts is in contact
     auto touches_any = [&](V3 t) -> bool {
+        const float tt[3] = {t.x, t.y, t.z};
         for (uint32_t m = 0; m < n_mov; m++)
-            for (uint32_t h = 0; h < n_stat; h++)
+            for (uint32_t h = 0; h < n_stat; h++) {
+                if (m < BOX_PARTS) {               // boxes (widened by a hair beyond the contact distance) apart: no GJK needed
+                    const float *sb = stat_box + 6 * (size_t)h;
+                    const float slack = P.margin2 + 1e-5f;
+                    bool apart = false;
+#pragma unroll
+                    for (int k = 0; k < 3; k++) apart = apart || mb[m][k] + tt[k] > sb[3 + k] + slack || sb[k] > mb[m][3 + k] + tt[k] + slack;
+                    if (apart) continue;
+                }
                 if (gjk_intersect(mov + 3 * (size_t)moff[m], moff[m + 1] - moff[m], R, t, stat + 3 * (size_t)off[h], off[h + 1] - off[h],
                                   lane, P.margin2))
                     return true;
+            }
         return false;
     };
     bool ok = !touches_any(pos);                              // in collision -> invalid
@@ -238,11 +315,24 @@ int d2r_phys_create(d2r_ctx *ctx, const float *movable_verts, const uint32_t *mo
     bool ok = hipMalloc(&p->d_mov, (size_t)p->n_mov_verts * 12) == hipSuccess &&
               hipMalloc(&p->d_moff, ((size_t)n_movable + 1) * 4) == hipSuccess &&
               hipMalloc(&p->d_stat, std::max<size_t>(1, (size_t)p->n_stat_verts * 12)) == hipSuccess &&
-              hipMalloc(&p->d_off, ((size_t)n_static + 1) * 4) == hipSuccess;
+              hipMalloc(&p->d_off, ((size_t)n_static + 1) * 4) == hipSuccess &&
+              hipMalloc(&p->d_stat_box, std::max<size_t>(1, (size_t)n_static) * 24) == hipSuccess;
+    std::vector<float> boxes((size_t)std::max<uint32_t>(1, n_static) * 6, 0.f);
+    for (uint32_t h = 0; h < n_static; h++)
+        for (int k = 0; k < 3; k++) {
+            float lo = INFINITY, hi = -INFINITY;
+            for (uint32_t i = static_offsets[h]; i < static_offsets[h + 1]; i++) {
+                lo = std::min(lo, static_verts[3 * (size_t)i + k]);
+                hi = std::max(hi, static_verts[3 * (size_t)i + k]);
+            }
+            boxes[6 * (size_t)h + k] = lo;
+            boxes[6 * (size_t)h + 3 + k] = hi;
+        }
     ok = ok && hipMemcpy(p->d_mov, movable_verts, (size_t)p->n_mov_verts * 12, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(p->d_moff, movable_offsets, ((size_t)n_movable + 1) * 4, hipMemcpyHostToDevice) == hipSuccess &&
          (p->n_stat_verts == 0 || hipMemcpy(p->d_stat, static_verts, (size_t)p->n_stat_verts * 12, hipMemcpyHostToDevice) == hipSuccess) &&
-         hipMemcpy(p->d_off, n_static ? static_offsets : &zero, ((size_t)n_static + 1) * 4, hipMemcpyHostToDevice) == hipSuccess;
+         hipMemcpy(p->d_off, n_static ? static_offsets : &zero, ((size_t)n_static + 1) * 4, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(p->d_stat_box, boxes.data(), boxes.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
     if (!ok) {
         d2r_phys_destroy(p);
         return d2r_fail(ctx, D2R_ERR_MEMORY, "device allocation/upload failed for the physics shapes");
@@ -258,6 +348,7 @@ void d2r_phys_destroy(d2r_phys *p)
     if (p->d_moff) (void)hipFree(p->d_moff);
     if (p->d_stat) (void)hipFree(p->d_stat);
     if (p->d_off) (void)hipFree(p->d_off);
+    if (p->d_stat_box) (void)hipFree(p->d_stat_box);
     delete p;
 }
 
@@ -352,7 +443,7 @@ int d2r_phys_check(d2r_ctx *ctx, const d2r_phys *phys, const d2r_phys_params *pr
     D2R_HIP(ctx, hipMemcpyAsync(d_mask, mask.data(), oris, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_phys_check, dim3((N + 3) / 4), dim3(256), 0, ctx->stream, P, (const float *)ctx->poses.p, N,
                        (const uint8_t *)d_mask, (const float *)phys->d_mov, (const uint32_t *)phys->d_moff, phys->n_mov, (const float *)phys->d_stat,
-                       (const uint32_t *)phys->d_off, phys->n_stat, d_valid);
+                       (const uint32_t *)phys->d_off, phys->n_stat, (const float *)phys->d_stat_box, d_valid);
     D2R_HIP(ctx, hipGetLastError());
     D2R_HIP(ctx, hipMemcpyAsync(valid_io, d_valid, N, hipMemcpyDeviceToHost, ctx->stream));
     D2R_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -160,6 +160,26 @@ def test_oracle_flow_on_a_table_scene():
     assert not phys_ref.unsupcol_check(poses, init, movable, statics, res, v0, table_z=-0.3)[0]
 
 
+BAND = 5e-6      # metres of collision margin = 1e-5 m of hull distance
+
+
+def assert_equal_away_from_band(got, want_fn, margin, what=""):
+    """The GPU decides contact by float32 distance GJK, the oracle by an LP / QP in double: a pair whose hull distance lies
+    within BAND-rounding of the contact distance 2 * margin may fall either way; everywhere else the masks must be EQUAL.
+    Checked as: every pose's GPU answer equals the oracle's answer for the margin itself or for a margin BAND smaller or
+    larger (a contact distance within +-1e-5 m)."""
+    w0 = want_fn(margin)
+    ok = got == w0
+    n_off = int((~ok).sum())
+    if n_off:
+        ok |= got == want_fn(max(0.0, margin - BAND))
+        ok |= got == want_fn(margin + BAND)
+    print(f"[parity] physics {what} margin {margin}: {n_off} of {len(got)} poses differ from the oracle at the margin itself, "
+          f"{int((~ok).sum())} outside the +-{2 * BAND:.0e} m band")
+    assert ok.all(), (what, margin, np.nonzero(~ok)[0][:10])
+    return w0
+
+
 @pytest.mark.gpu
 def test_gpu_prefilter_matches_oracle_on_hulls_and_grids():
     from dream2real_amd import engine, physics_utils
@@ -192,9 +212,8 @@ def test_gpu_prefilter_matches_oracle_on_hulls_and_grids():
     sh = physics_utils.PhysicsShapes(ctx, mov, [shelf, blob])
     for regrasp in (False, True):
         got = sh.check(poses, v0, res, init, 0.2, disallow_regrasp=regrasp)
-        want = phys_ref.unsupcol_check(poses, init, mov, [shelf, blob], res, v0, 0.2, disallow_regrasp=regrasp)
-        # fp32 GJK vs an LP in double: hulls within ~1e-6 of touching may fall either way
-        assert (got != want).mean() < 0.005, ((got != want).sum(), len(want))
+        want = assert_equal_away_from_band(got, lambda m: phys_ref.unsupcol_check(poses, init, mov, [shelf, blob], res, v0, 0.2, disallow_regrasp=regrasp, margin=m),
+                                           0.0, f"six-DoF grid, regrasp={regrasp}")
         assert (got & ~v0).sum() == 0
     assert want.sum() > 0
     # (3) the closure optimise_pose_grid takes as phys_check
@@ -237,8 +256,8 @@ def test_gpu_prefilter_with_margins_compound_parts_and_mesh_files(tmp_path):
     results = {}
     for m in (0.0, 0.001, 0.004):
         got = sh.check(poses, v0, res, init, -0.3, margin=m)
-        want = phys_ref.unsupcol_check(poses, init, [part_a, part_b], [table, block, post], res, v0, -0.3, margin=m)
-        assert (got != want).mean() < 0.005, (m, np.nonzero(got != want)[0][:10])
+        want = assert_equal_away_from_band(got, lambda mm: phys_ref.unsupcol_check(poses, init, [part_a, part_b], [table, block, post], res, v0, -0.3, margin=mm),
+                                           m, "compound movable object")
         results[m] = want
     assert (results[0.0] != results[0.001]).any() and (results[0.001] != results[0.004]).any()     # the margin matters on this grid
     # the compound is not its hull: with the pebble under the plate beside the leg a pose is valid only as two parts
@@ -255,7 +274,8 @@ def test_gpu_prefilter_with_margins_compound_parts_and_mesh_files(tmp_path):
     task = types.SimpleNamespace(movable_obj=movable, task_bground_obj=bground, scene_model=scene_model)
     check, static_handles, movable_handles = physics_utils.create_unsupcol_check(ctx, task, res, embodied=False, lazy_phys_mods=True)
     out = check(torch.from_numpy(poses), task, torch.from_numpy(v0)).numpy()
-    assert (out != results[physics_utils.PYBULLET_MESH_MARGIN]).mean() < 0.005
+    assert_equal_away_from_band(out, lambda mm: results[mm] if mm in results else phys_ref.unsupcol_check(
+        poses, init, [part_a, part_b], [table, block, post], res, v0, -0.3, margin=mm), physics_utils.PYBULLET_MESH_MARGIN, "mesh files, lazy_phys_mods")
     assert [len(p) for p in static_handles] == [3] and [len(p) for p in movable_handles] == [2]
     check.shapes.close()
     # lazy_phys_mods=False: every scene object is its own body, all but the movable one static (:235-245)

@@ -231,7 +231,12 @@ def test_dream_best_pose_flow_with_mesh_file_physics(tmp_path):
                                     np.ones(84, bool), float(c[2]), margin=physics_utils.PYBULLET_MESH_MARGIN)
     got = scores.numpy()
     assert 5 < valid.sum() < 80, valid.sum()
-    assert ((got != 0) == valid).mean() > 0.97                       # hulls within rounding of the contact distance may fall either way
+    # equal to the oracle's mask except where a hull pair lies within rounding of the contact distance (the oracle's answer
+    # for a margin 5e-6 m smaller or larger)
+    m0 = physics_utils.PYBULLET_MESH_MARGIN
+    near = [phys_ref.unsupcol_check(pose_batch.numpy(), np.asarray(scene.obj_pose, np.float32), [apple], [table] + blobs, sample_res,
+                                    np.ones(84, bool), float(c[2]), margin=m) for m in (m0 - 5e-6, m0 + 5e-6)]
+    assert (((got != 0) == valid) | ((got != 0) == near[0]) | ((got != 0) == near[1])).all()
     both = valid & (got != 0)
     frames = pipe.frames(pose_batch.numpy()[both])
     lg, _ = oracle_logits(frames, cfg_clip, sd, task.text_embeds)
