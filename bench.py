@@ -38,6 +38,30 @@ import os
 import sys
 import time
 
+
+def effective_cpus() -> int:
+    """CPUs this process may actually use: the scheduler affinity, capped by the container's CPU quota (cgroup v2 cpu.max,
+    v1 cpu.cfs_quota_us) — a 256-core host that grants the container 16 CPUs' worth of time runs 128 threads SLOWER than 16."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+# the CPU-baseline leg (oracle: OpenMP render + BLAS ViT) gets the CPUs the box really grants, unless the caller chose
+for _k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_k, str(effective_cpus()))
+
 import numpy as np
 
 REPO = os.path.dirname(os.path.abspath(__file__))
@@ -133,12 +157,14 @@ def cpu_baseline(scene, W, H, cfg, sd, text, poses_world, n_sample):
         blas = max([int(i.get("num_threads", 0)) for i in threadpool_info() if i.get("user_api") == "blas"] or [0]) or None
     except Exception:
         pass
-    return {"value": round(len(idx) / dt, 4), "unit": "candidates/s", "cores": os.cpu_count(),
+    return {"value": round(len(idx) / dt, 4), "unit": "candidates/s", "cores": max(render_ref.num_threads(), blas or 1),
+            "host_cpus": os.cpu_count(), "cpu_quota": effective_cpus(),
             "threads": {"render_openmp": render_ref.num_threads(), "vit_blas": blas},
             "kind": "port",
             "sample": f"{len(idx)} of the {len(poses_world)} candidates at {W}x{H}: oracle C render+composite "
                       f"(OpenMP, {render_ref.num_threads()} threads, {t_render:.1f}s) + numpy fp32 ViT "
-                      f"(BLAS, {blas} threads, {t_clip:.1f}s); `cores` = os.cpu_count() of the box, `threads` = what the two legs used"}, frames, lg, idx
+                      f"(BLAS, {blas} threads, {t_clip:.1f}s); `cores` = threads used = the CPUs the container's quota grants "
+                      f"({effective_cpus()} of the host's {os.cpu_count()})"}, frames, lg, idx
 
 
 def self_launch(n: int):
@@ -738,7 +764,7 @@ def run_kernel_bench(args, wd):
             out["parity_vs_oracle"] = {"max_cosine_err": float(np.abs(lg_gpu - lg_o).max() / scorer.logit_scale),
                                        "n": int(len(idx))}
         elif world > 1:
-            out["cpu_baseline"] = {"value": None, "unit": "candidates/s", "cores": os.cpu_count(), "kind": "port",
+            out["cpu_baseline"] = {"value": None, "unit": "candidates/s", "cores": effective_cpus(), "kind": "port",
                                    "sample": "timed on rank 0 at n_gpus = 1 only: see the n_gpus = 1 line of the same --config"}
         else:
             out["cpu_baseline"] = None

