@@ -14,7 +14,8 @@ int d2r_launch_preprocess(d2r_ctx *, d2r_clip *, const uint8_t *frames_dev, uint
                           int rot90, uint16_t *patches_dev, float *pixel_values_dev, const void *rects_dev = nullptr,
                           const uint16_t *bg_patches_dev = nullptr);
 int d2r_clip_forward(d2r_ctx *, const d2r_clip *, const uint16_t *patches_dev, uint32_t n, const float *text_dev,
-                     uint32_t C, float logit_scale, float *logits_dev, float *embeds_dev);
+                     uint32_t C, float logit_scale, float *logits_dev, float *embeds_dev, const ClipL0Reuse *reuse = nullptr);
+int d2r_clip_layer0_background(d2r_ctx *, const d2r_clip *, const uint16_t *bg_patches_dev, ClipL0Reuse *out);
 int d2r_launch_patchify(d2r_ctx *, const d2r_clip *, const float *pv_dev, uint32_t n, uint16_t *patches_dev);
 size_t d2r_clip_patch_bytes(const d2r_clip *, uint32_t n);
 int d2r_launch_eval_points(d2r_ctx *, const d2r_nerf *, const float *xyz, const float *dirs, uint32_t n, float *out);
@@ -150,7 +151,7 @@ void d2r_ctx_destroy(d2r_ctx *c)
     delete c->pool;
     d2r_ctx::Buf *bufs[] = {&c->cams, &c->queue, &c->counters, &c->frames, &c->rgba, &c->depth, &c->poses,
                             &c->text, &c->logits, &c->pix, &c->bg_rgba, &c->bg_depth, &c->bg_u8, &c->rects, &c->bg_patches, &c->rect_ws,
-                            &c->patches2, &c->frames2};
+                            &c->patches2, &c->frames2, &c->bg_l0, &c->l0_a1, &c->l0_q2, &c->l0_misc};
     for (auto *b : bufs)
         if (b->p) hipFree(b->p);
     for (auto &b : c->clipws)
@@ -205,6 +206,8 @@ int d2r_ctx_set_option(d2r_ctx *ctx, const char *key, int64_t value)
         ctx->prep_reuse = value != 0;
     } else if (!strcmp(key, "cls_last")) {
         ctx->cls_last = value != 0;
+    } else if (!strcmp(key, "l0_reuse")) {
+        ctx->l0_reuse = value != 0;
     } else if (!strcmp(key, "attn_rem")) {
         if (value < 0 || value > 4) return d2r_fail(ctx, D2R_ERR_INVALID, "attn_rem must be 0..4");
         ctx->attn_rem = value;
@@ -876,13 +879,30 @@ static int render_score_core(d2r_ctx *ctx, const d2r_nerf *fg, const d2r_clip *c
     // have touched are copies of these (k_preprocess)
     const bool reuse_bg = ctx->prep_reuse && ctx->raygen_rect && ctx->bg_w == V.W && ctx->bg_h == V.H && ctx->bg_u8.p;
     if (reuse_bg) {
-        if ((rc = d2r_reserve(ctx, ctx->rects, (size_t)cap * 16))) return rc;
+        if ((rc = d2r_reserve(ctx, ctx->rects, (size_t)cap * 16 * 2))) return rc;      // two halves: the ViT of chunk i reads its rectangles while chunk i+1 is rendered ("overlap")
         if (ctx->bg_patches_for != (const void *)clip) {
             if ((rc = d2r_reserve(ctx, ctx->bg_patches, d2r_clip_patch_bytes(clip, 1)))) return rc;
             if ((rc = d2r_launch_preprocess(ctx, (d2r_clip *)clip, (const uint8_t *)ctx->bg_u8.p, 1, V.W, V.H, 1,
                                             (uint16_t *)ctx->bg_patches.p, nullptr)))
                 return rc;
             ctx->bg_patches_for = (const void *)clip;
+            ctx->bg_l0_for = nullptr;
+        }
+    }
+    // layer-0 reuse: the background's own pre-LayerNorm rows and q / k / v rows, once per (background, CLIP model)
+    ClipL0Reuse l0{};
+    const bool use_l0 = reuse_bg && ctx->l0_reuse && ctx->ln_fold == 4;
+    if (use_l0) {
+        if (ctx->bg_l0_for != (const void *)clip) {
+            rc = d2r_clip_layer0_background(ctx, clip, (const uint16_t *)ctx->bg_patches.p, &ctx->bg_l0_desc);
+            if (rc == D2R_OK) ctx->bg_l0_for = (const void *)clip;
+            else if (rc != D2R_ERR_UNSUPPORTED) return rc;     // (more than 1024 patches per image: plain forward)
+        }
+        if (ctx->bg_l0_for == (const void *)clip) {
+            l0 = ctx->bg_l0_desc;
+            l0.w = V.W;
+            l0.h = V.H;
+            l0.rects = ctx->rects.p;
         }
     }
     ctx->stats = d2r_render_stats{0, 0, 0, 0};
@@ -898,14 +918,14 @@ static int render_score_core(d2r_ctx *ctx, const d2r_nerf *fg, const d2r_clip *c
         const int b = (int)(ci & 1u), pb = two ? b : 0, fbuf = (to_host && nchunks > 1) ? b : 0;
         uint8_t *frames_dev = (uint8_t *)(fbuf ? ctx->frames2.p : ctx->frames.p);
         uint16_t *patches = (uint16_t *)(pb ? ctx->patches2.p : ctx->clipws[6].p);
+        void *rects = reuse_bg ? (void *)((uint8_t *)ctx->rects.p + (size_t)pb * cap * 16) : nullptr;
         if (to_host && ci >= 2) ctx->pool->wait(b);                 // pinned buffer b: chunk ci-2's files are written
         {
             StreamSwap sw(ctx, rs);
             if (to_host && ci >= 2) D2R_HIP(ctx, hipStreamWaitEvent(rs, ctx->ev_copy[b], 0));   // frames buffer b has left the GPU
             if ((rc = d2r_launch_cameras_virtual(ctx, V, obj_pose_now, cam_pose, poses_dev + (size_t)c0 * 16, nc, (float *)ctx->cams.p)))
                 return rc;
-            if ((rc = d2r_launch_render(ctx, fg, V, (const float *)ctx->cams.p, nc, true, nullptr, nullptr, frames_dev,
-                                        reuse_bg ? ctx->rects.p : nullptr)))
+            if ((rc = d2r_launch_render(ctx, fg, V, (const float *)ctx->cams.p, nc, true, nullptr, nullptr, frames_dev, rects)))
                 return rc;
             // keep this chunk's counters for the stats read-back at the end
             D2R_HIP(ctx, hipMemcpyAsync((uint8_t *)ctx->counters.p + 64 + 32 * (size_t)ci, ctx->counters.p, 32,
@@ -918,16 +938,17 @@ static int render_score_core(d2r_ctx *ctx, const d2r_nerf *fg, const d2r_clip *c
             }
             if (two && ci >= 2) D2R_HIP(ctx, hipStreamWaitEvent(rs, ctx->ev_clip[pb], 0));      // patch buffer pb: chunk ci-2 is scored
             size_t tp = ctx->timing_begin(D2R_T_PREP);
-            if ((rc = d2r_launch_preprocess(ctx, (d2r_clip *)clip, frames_dev, nc, V.W, V.H, 1, patches, nullptr,
-                                            reuse_bg ? ctx->rects.p : nullptr, reuse_bg ? (const uint16_t *)ctx->bg_patches.p : nullptr)))
+            if ((rc = d2r_launch_preprocess(ctx, (d2r_clip *)clip, frames_dev, nc, V.W, V.H, 1, patches, nullptr, rects,
+                                            reuse_bg ? (const uint16_t *)ctx->bg_patches.p : nullptr)))
                 return rc;
             ctx->timing_end(tp);
             if (two) D2R_HIP(ctx, hipEventRecord(ctx->ev_prep[pb], rs));
         }
         if (two) D2R_HIP(ctx, hipStreamWaitEvent(main, ctx->ev_prep[pb], 0));
         size_t tc = ctx->timing_begin(D2R_T_CLIP);
+        if (l0.rects) l0.rects = rects;                    // this chunk's half of the rectangle buffer
         if ((rc = d2r_clip_forward(ctx, clip, patches, nc, (const float *)ctx->text.p, C, logit_scale,
-                                   logits_dev + (size_t)c0 * C, nullptr)))
+                                   logits_dev + (size_t)c0 * C, nullptr, l0.rects ? &l0 : nullptr)))
             return rc;
         ctx->timing_end(tc);
         if (two) D2R_HIP(ctx, hipEventRecord(ctx->ev_clip[pb], main));

@@ -24,6 +24,8 @@
 #include <type_traits>
 
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #include <algorithm>
 #include <deque>
@@ -303,6 +305,8 @@ struct EpiAux {
     // at a row stride of 1.5-6 KiB (HBM delivers about half its streaming rate on those).
     uint32_t hm_rows;      // bf16 output (and xb / xlo) tile-major with this many rows per plane (M_pad); 0 = row-major
     uint32_t a_rs, a_ks;   // A operand: elements between rows, and between K-tiles (row-major: K, 64; tile-major: 64, 64 M_pad); 0,0 = row-major
+    const uint32_t *m_dev; // k_gemm only: the number of live rows, in DEVICE memory (a product over a compacted row list whose length the
+                           // host does not know: the grid covers the worst case and workgroups whose row tile starts at or beyond it leave at once)
 };
 
 // Measurement switches (ablation masks, cycle stamps) live in clip_dev.h, which only development builds (make DEV=1,
@@ -724,13 +728,22 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void k_gemm(const uint16_t *__re
     // contiguous run of tiles, n fastest so neighbours reuse the same A row panel.
     const uint32_t nwg = gridDim.x, tiles_n = N / TBN;
     const uint32_t xcd = blockIdx.x % n_xcd, loc = blockIdx.x / n_xcd, q = nwg / n_xcd, rr = nwg % n_xcd;
-    const uint32_t tile = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
-    const uint32_t m0 = (tile / tiles_n) * TBM, n0 = (tile % tiles_n) * TBN;
-
+    uint32_t tile = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + loc;
+    // Device-sized products (aux.m_dev: a compacted row list whose length the host does not know): the grid is a FIXED set of
+    // workgroups that walk the live tiles — launching one workgroup per worst-case tile and letting the idle ones leave costs a
+    // dispatch per tile (tens of thousands of 144 KiB-LDS workgroups at one per CU: milliseconds of nothing).
+    uint32_t live_tiles = 0xffffffffu;
+    if (aux.m_dev) {
+        live_tiles = ((*aux.m_dev + TBM - 1) / TBM) * tiles_n;
+        tile = blockIdx.x;
+    }
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // 0..NWAVE-1
     const uint32_t wm = (wave / WGN) * (MT * 32), wn = (wave % WGN) * 64;
     const uint32_t li = lane & 31, hi = lane >> 5;
+  for (;; tile += gridDim.x) {                                         // ONE pass unless the row count is device-sized
+    if (tile >= live_tiles) break;
+    const uint32_t m0 = (tile / tiles_n) * TBM, n0 = (tile % tiles_n) * TBN;
 
     f32x16 acc[MT][2];
 #pragma unroll
@@ -845,6 +858,9 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void k_gemm(const uint16_t *__re
             if (h + lane < MT * 32) abw[h + lane] = aux.ab[m0 + wm + h + lane];
     }
     gemm_epilogue<EPI, MT>(acc, (float *)smem + wave * EP_WAVE_FLOATS, lane, m0 + wm, n0 + wn, bias, Cout, N, aux, abw);
+    if (!aux.m_dev) break;
+    __syncthreads();                  // the ring and the transpose buffers serve the next tile
+  }
 }
 
 // ---- 256x256x64 GEMM with a half-tile staging ring that never drains ("8-phase" K loop) ----
@@ -1160,15 +1176,31 @@ __global__ __launch_bounds__(256) void k_embed_ln(const float *__restrict__ patc
                                                   const float *__restrict__ pos, const float *__restrict__ w,
                                                   const float *__restrict__ b, float *__restrict__ X, uint32_t rows,
                                                   uint32_t T, uint32_t d, uint16_t *__restrict__ Xb,
-                                                  float2 *__restrict__ AB, uint16_t *__restrict__ Xlo, uint32_t M_pad, int lo8 = 0)
+                                                  float2 *__restrict__ AB, uint16_t *__restrict__ Xlo, uint32_t M_pad, int lo8 = 0,
+                                                  const uint32_t *__restrict__ list = nullptr, const uint32_t *__restrict__ list_n = nullptr)
 {
     // X (fp32 residual stream) and Xb/AB (LayerNorm-folded path: bf16 operand copy of the row and the
-    // (rstd, -rstd*mean) of the row for the first block's layer_norm1) are each optional
+    // (rstd, -rstd*mean) of the row for the first block's layer_norm1) are each optional.
+    // list (layer-0 reuse): entry i = image * (T - 1) + patch of a token whose patch embedding is row i of patch_out; only
+    // those *list_n tokens are written (the others hold the background's own rows already)
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const uint32_t bi = row / T, t = row % T;
-    const float *src = t == 0 ? cls : patch_out + ((size_t)bi * (T - 1) + (t - 1)) * d;
+  // (list mode: a fixed grid walks the list — one workgroup per worst-case entry would be a dispatch per idle workgroup)
+  for (uint32_t item = blockIdx.x * 4 + (threadIdx.x >> 6);; item += gridDim.x * 4) {
+    uint32_t row = item;
+    const float *src;
+    uint32_t t;
+    if (list) {
+        if (row >= *list_n) return;
+        const uint32_t e = list[row], bi = e / (T - 1);
+        t = 1 + (e - bi * (T - 1));
+        src = patch_out + (size_t)row * d;
+        row = bi * T + t;
+    } else {
+        if (row >= rows) return;
+        const uint32_t bi = row / T;
+        t = row % T;
+        src = t == 0 ? cls : patch_out + ((size_t)bi * (T - 1) + (t - 1)) * d;
+    }
     float4 v[4], o[4];
     for (int i = 0; i < 4; i++) {
         uint32_t c0 = (lane + 64 * i) * 4;
@@ -1228,6 +1260,8 @@ __global__ __launch_bounds__(256) void k_embed_ln(const float *__restrict__ patc
         const float m2 = s2 / (float)d, r2 = 1.0f / sqrtf(fmaxf(q2 / (float)d - m2 * m2, 0.f) + 1e-5f);
         if (lane == 0) AB[row] = make_float2(r2, -r2 * m2);
     }
+    if (!list) return;
+  }
 }
 
 // per row: the d/64 partial (sum, sum of squares) pairs an EPI_RESID_STATS_* GEMM wrote ([d/64][rows]) -> (rstd, -rstd*mean)
@@ -1244,6 +1278,119 @@ __global__ void k_rowstats(const float2 *__restrict__ part, uint32_t np, uint32_
     }
     const float mu = s * inv_d, r = 1.0f / sqrtf(fmaxf(q * inv_d - mu * mu, 0.f) + 1e-5f);
     AB[row] = make_float2(r, -r * mu);
+}
+
+// ---- layer-0 reuse of background tokens (d2r_render_score) ----
+//
+// A composited candidate differs from the background frame only inside the rectangle its rays were generated in
+// (k_raygen_rect).  A patch whose resampling footprint does not meet that rectangle is the background's own patch, so its
+// patch embedding, its pre-LayerNorm residual row and its layer-0 q / k / v rows are the background's own rows — computed
+// once per background (d2r_clip_layer0_background) and broadcast, while the patch-embedding and QKV products of layer 0 run on
+// the TOUCHED tokens only (about a tenth of them for a 60-pixel object at 640x360), compacted into a list whose length stays in
+// device memory.  Exact: every kernel involved computes a row from that row alone (tests hold the logits bit-identical).
+
+// one block per image: the touched patches of the image -> list (image * g2 + patch), length added to *cnt
+__global__ __launch_bounds__(256) void k_touch_list(const int4 *__restrict__ rects, uint32_t w, ResampleTables R, uint32_t S, uint32_t P,
+                                                    uint32_t *__restrict__ cnt, uint32_t *__restrict__ list)
+{
+    __shared__ uint32_t ids[1024], n_ids, base;
+    const uint32_t img = blockIdx.x, g = S / P, g2 = g * g;
+    if (threadIdx.x == 0) n_ids = 0;
+    __syncthreads();
+    const int4 rc = rects[img];
+    const bool empty = rc.x > rc.z || rc.y > rc.w;
+    // the rectangle in the rotated source (rot90 maps frame column x to row w-1-x, frame row y to column y)
+    const int rlo = (int)w - 1 - rc.z, rhi = (int)w - 1 - rc.x, clo = rc.y, chi = rc.w;
+    for (uint32_t p = threadIdx.x; p < g2 && !empty; p += blockDim.x) {
+        const uint32_t pr = p / g, pcol = p - pr * g;
+        int ys, ye, xs, xe;                                   // source rows / columns the patch's pixels are resampled from: [s, e)
+        if (R.need_v) {
+            ys = R.bounds_v[2 * (R.top + pr * P)];
+            const int last = R.top + pr * P + P - 1;
+            ye = R.bounds_v[2 * last] + R.bounds_v[2 * last + 1];
+        } else { ys = R.top + pr * P; ye = ys + P; }
+        if (R.need_h) {
+            xs = R.bounds_h[2 * (R.left + pcol * P)];
+            const int last = R.left + pcol * P + P - 1;
+            xe = R.bounds_h[2 * last] + R.bounds_h[2 * last + 1];
+        } else { xs = R.left + pcol * P; xe = xs + P; }
+        if (!(rhi < ys || rlo >= ye || chi < xs || clo >= xe)) ids[atomicAdd(&n_ids, 1u)] = img * g2 + p;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) base = n_ids ? atomicAdd(cnt, n_ids) : 0u;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n_ids; i += blockDim.x) list[base + i] = ids[i];
+}
+
+// rows list[i] of a row-major bf16 matrix [..][row_elems] -> rows i of `out` (one wave per row, 16-byte pieces)
+__global__ __launch_bounds__(256) void k_gather_rows(const uint16_t *__restrict__ src, uint32_t row_elems, const uint32_t *__restrict__ list,
+                                                     const uint32_t *__restrict__ cnt, uint16_t *__restrict__ out)
+{
+    const uint32_t lane = threadIdx.x & 63, n = *cnt, per = row_elems / 8;
+    for (uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += gridDim.x * 4) {
+        const uint4 *s = (const uint4 *)(src + (size_t)list[i] * row_elems);
+        uint4 *o = (uint4 *)(out + (size_t)i * row_elems);
+        for (uint32_t c = lane; c < per; c += 64) o[c] = s[c];
+    }
+}
+
+// every token row r = image * T + t <- the background's row t: bf16 hi (tile-major), lo bytes (lo8_off layout), (rstd, -rstd mean)
+__global__ __launch_bounds__(256) void k_bcast_x0(const uint16_t *__restrict__ bg_hi, const uint8_t *__restrict__ bg_lo, const float2 *__restrict__ bg_ab,
+                                                  uint32_t bg_rows, uint16_t *__restrict__ Xhi, uint8_t *__restrict__ Xlo, float2 *__restrict__ AB,
+                                                  uint32_t rows, uint32_t M_pad, uint32_t T, uint32_t d)
+{
+    const uint32_t lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const uint32_t t = row % T;
+    for (uint32_t c8 = lane; c8 < d / 8; c8 += 64) {            // 8 columns: 16 bytes of hi, 8 bytes of lo
+        const uint32_t c = c8 * 8;
+        *(uint4 *)(Xhi + ((size_t)(c >> 6) * M_pad + row) * 64 + (c & 63)) = *(const uint4 *)(bg_hi + ((size_t)(c >> 6) * bg_rows + t) * 64 + (c & 63));
+        *(uint2 *)(Xlo + lo8_off(M_pad, row, c)) = *(const uint2 *)(bg_lo + lo8_off(bg_rows, t, c));
+    }
+    if (lane == 0) AB[row] = bg_ab[t];
+}
+
+// every token's layer-0 q / k / v rows <- the background's: planes [3 d / 64][M_pad][64] bf16 (one thread per 16 bytes)
+__global__ __launch_bounds__(256) void k_bcast_qkv(const uint16_t *__restrict__ bg_qkv, uint32_t bg_rows, uint16_t *__restrict__ QKV, uint32_t rows,
+                                                   uint32_t M_pad, uint32_t T, uint32_t planes)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;          // (plane, row, piece of 8)
+    const size_t total = (size_t)planes * rows * 8;
+    if (i >= total) return;
+    const uint32_t piece = (uint32_t)(i & 7);
+    const size_t pr = i >> 3;
+    const uint32_t row = (uint32_t)(pr % rows), plane = (uint32_t)(pr / rows);
+    *(uint4 *)(QKV + ((size_t)plane * M_pad + row) * 64 + piece * 8) = *(const uint4 *)(bg_qkv + ((size_t)plane * bg_rows + row % T) * 64 + piece * 8);
+}
+
+// the touched tokens' operand rows (tile-major hi) and LayerNorm pairs -> compact tile-major [d / 64][cap_pad][64], [cap_pad]
+__global__ __launch_bounds__(256) void k_gather_operand_rows(const uint16_t *__restrict__ Xhi, const float2 *__restrict__ AB, uint32_t M_pad, uint32_t T,
+                                                             const uint32_t *__restrict__ list, const uint32_t *__restrict__ cnt,
+                                                             uint16_t *__restrict__ A2, float2 *__restrict__ AB2, uint32_t cap_pad, uint32_t d)
+{
+    const uint32_t lane = threadIdx.x & 63, n = *cnt;
+    for (uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += gridDim.x * 4) {
+        const uint32_t e = list[i], bi = e / (T - 1), row = bi * T + 1 + (e - bi * (T - 1));
+        for (uint32_t c8 = lane; c8 < d / 8; c8 += 64) {
+            const uint32_t c = c8 * 8;
+            *(uint4 *)(A2 + ((size_t)(c >> 6) * cap_pad + i) * 64 + (c & 63)) = *(const uint4 *)(Xhi + ((size_t)(c >> 6) * M_pad + row) * 64 + (c & 63));
+        }
+        if (lane == 0) AB2[i] = AB[row];
+    }
+}
+
+// compact q / k / v rows [planes][cap_pad][64] -> the touched tokens' rows of QKV [planes][M_pad][64]
+__global__ __launch_bounds__(256) void k_scatter_qkv(const uint16_t *__restrict__ Q2, uint32_t cap_pad, const uint32_t *__restrict__ list,
+                                                     const uint32_t *__restrict__ cnt, uint16_t *__restrict__ QKV, uint32_t M_pad, uint32_t T, uint32_t planes)
+{
+    const uint32_t lane = threadIdx.x & 63, n = *cnt;
+    for (uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += gridDim.x * 4) {
+        const uint32_t e = list[i], bi = e / (T - 1), row = bi * T + 1 + (e - bi * (T - 1));
+        for (uint32_t j = lane; j < planes * 8; j += 64) {
+            const uint32_t plane = j >> 3, piece = j & 7;
+            *(uint4 *)(QKV + ((size_t)plane * M_pad + row) * 64 + piece * 8) = *(const uint4 *)(Q2 + ((size_t)plane * cap_pad + i) * 64 + piece * 8);
+        }
+    }
 }
 
 // LayerNorm folding of a Linear that follows a LayerNorm (weights prepared once at create):
@@ -2174,8 +2321,9 @@ static int launch_gemm_cfg(d2r_ctx *ctx, const uint16_t *A, const uint16_t *W, c
     attr_set.run(ctx->device, [] {
         (void)hipFuncSetAttribute((const void *)k_gemm<EPI, WGM, WGN, MT, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     });
-    hipLaunchKernelGGL((k_gemm<EPI, WGM, WGN, MT, STAGES>), dim3(nwg), dim3(WGM * WGN * 64), LDS, ctx->stream, A, W, bias, C,
-                       M_pad, N, K, (uint32_t)ctx->n_xcd, aux);
+    // (a device-sized product runs on one workgroup per CU walking the live tiles)
+    hipLaunchKernelGGL((k_gemm<EPI, WGM, WGN, MT, STAGES>), dim3(aux.m_dev ? std::min<uint32_t>(nwg, (uint32_t)ctx->n_cu) : nwg), dim3(WGM * WGN * 64), LDS,
+                       ctx->stream, A, W, bias, C, M_pad, N, K, (uint32_t)ctx->n_xcd, aux);
     D2R_HIP(ctx, hipGetLastError());
     return D2R_OK;
 }
@@ -2291,8 +2439,46 @@ static int last_block_cls(d2r_ctx *ctx, const d2r_clip_desc &D, const ClipWeight
 
 // patches (bf16 [n*(T-1) padded to 128][Kp_pad]) -> logits/embeds.  Workspaces:
 //  clipws[0] patch_out f32, [1] X f32, [2] Xn bf16, [3] QKV bf16, [4] AO bf16, [5] H bf16
+// The background's own layer-0 rows for ClipL0Reuse: patch embedding -> + position, pre-LayerNorm -> bf16 hi + lo bytes and LayerNorm
+// pairs -> layer-0 q / k / v, of ONE image (the background frame's patches), with the kernels the batched forward uses (a row's
+// result does not depend on the batch it is computed in).  Buffers live in ctx->bg_l0; rows padded to a multiple of 256.
+int d2r_clip_layer0_background(d2r_ctx *ctx, const d2r_clip *clip, const uint16_t *bg_patches_dev, ClipL0Reuse *out)
+{
+    const d2r_clip_desc &D = clip->desc;
+    const uint32_t d = D.hidden_size, T = clip->T, R = round_up(T, BM);
+    if (T > 1025 || D.num_layers < 1) return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "layer-0 reuse needs at most 1024 patches per image");
+    const size_t b_hi = (size_t)R * d * 2, b_lo = (size_t)R * d, b_ab = (size_t)R * 8, b_qkv = (size_t)R * 3 * d * 2, b_po = (size_t)R * d * 4;
+    int rc;
+    if ((rc = d2r_reserve(ctx, ctx->bg_l0, b_hi + b_lo + b_ab + b_qkv + b_po + 1024))) return rc;
+    uint8_t *base = (uint8_t *)ctx->bg_l0.p;
+    uint16_t *hi = (uint16_t *)base;
+    uint8_t *lo = base + b_hi;
+    float2 *ab = (float2 *)(lo + b_lo);
+    uint16_t *qkv = (uint16_t *)((uint8_t *)ab + b_ab);
+    float *po = (float *)((uint8_t *)qkv + b_qkv);
+    if ((rc = launch_gemm<EPI_F32>(ctx, bg_patches_dev, clip->w.w_patch, nullptr, po, T - 1, d, clip->Kp_pad))) return rc;
+    hipLaunchKernelGGL(k_embed_ln, dim3((T + 3) / 4), dim3(256), 0, ctx->stream, po, clip->w.cls, clip->w.pos, clip->w.pre_w, clip->w.pre_b,
+                       (float *)nullptr, T, T, d, hi, ab, (uint16_t *)lo, R, 1);
+    const ClipWeights::Layer &L = clip->layers[0];
+    EpiAux ln{};
+    ln.hm_rows = R;
+    ln.a_rs = 64;
+    ln.a_ks = 64 * R;
+    ln.ab = ab;
+    ln.cs = L.cs_qkv;
+    if ((rc = launch_gemm<EPI_LN_BIAS_BF16>(ctx, hi, L.wf_qkv, L.bf_qkv, qkv, T, 3 * d, d, ln))) return rc;
+    D2R_HIP(ctx, hipGetLastError());
+    out->bg_hi = hi;
+    out->bg_lo = lo;
+    out->bg_ab = ab;
+    out->bg_qkv = qkv;
+    out->bg_rows = R;
+    return D2R_OK;
+}
+
 int d2r_clip_forward(d2r_ctx *ctx, const d2r_clip *clip, const uint16_t *patches_dev, uint32_t n,
-                     const float *text_dev, uint32_t C, float logit_scale, float *logits_dev, float *embeds_dev)
+                     const float *text_dev, uint32_t C, float logit_scale, float *logits_dev, float *embeds_dev,
+                     const ClipL0Reuse *reuse)
 {
     const d2r_clip_desc &D = clip->desc;
     const uint32_t d = D.hidden_size, T = clip->T, mlp = D.mlp_size;
@@ -2309,9 +2495,35 @@ int d2r_clip_forward(d2r_ctx *ctx, const d2r_clip *clip, const uint16_t *patches
     uint16_t *Xn = (uint16_t *)ctx->clipws[2].p, *QKV = (uint16_t *)ctx->clipws[3].p;
     uint16_t *AO = (uint16_t *)ctx->clipws[4].p, *H = (uint16_t *)ctx->clipws[5].p;
 
-    if ((rc = launch_gemm<EPI_F32>(ctx, patches_dev, clip->w.w_patch, nullptr, patch_out, prow, d, clip->Kp_pad)))
-        return rc;
     const int fold = (int)ctx->ln_fold;
+    // layer-0 reuse (see k_touch_list): needs the hi + lo-byte residual, square images cut into whole patches, a second layer
+    const uint32_t g2 = T - 1;
+    const bool l0 = reuse && reuse->rects && fold == 4 && D.num_layers >= 2 && (D.image_size / D.patch_size) * (D.image_size / D.patch_size) == g2 &&
+                    g2 <= 1024 && T <= reuse->bg_rows;
+    uint32_t *l0_cnt = nullptr, *l0_list = nullptr;
+    const uint32_t cap_pad = round_up(prow, BM);
+    if (l0) {
+        const PrepCache *pc = nullptr;
+        if ((rc = prep_tables(ctx, (d2r_clip *)clip, reuse->w, reuse->h, 1, &pc))) return rc;
+        if ((rc = d2r_reserve(ctx, ctx->l0_misc, 256 + (size_t)prow * 4 + (size_t)cap_pad * 8))) return rc;
+        if ((rc = d2r_reserve(ctx, ctx->l0_a1, (size_t)cap_pad * clip->Kp_pad * 2))) return rc;
+        if ((rc = d2r_reserve(ctx, ctx->l0_q2, (size_t)cap_pad * 3 * d * 2))) return rc;
+        l0_cnt = (uint32_t *)ctx->l0_misc.p;
+        l0_list = l0_cnt + 64;
+        D2R_HIP(ctx, hipMemsetAsync(l0_cnt, 0, 4, ctx->stream));
+        hipLaunchKernelGGL(k_touch_list, dim3(n), dim3(256), 0, ctx->stream, (const int4 *)reuse->rects, reuse->w, pc->R, D.image_size, D.patch_size, l0_cnt, l0_list);
+        hipLaunchKernelGGL(k_gather_rows, dim3(2048), dim3(256), 0, ctx->stream, patches_dev, clip->Kp_pad, l0_list, l0_cnt, (uint16_t *)ctx->l0_a1.p);
+        if (getenv("D2R_L0_DEBUG")) {                          // development aid: how many tokens the chunk touched
+            uint32_t c = 0;
+            (void)hipMemcpyAsync(&c, l0_cnt, 4, hipMemcpyDeviceToHost, ctx->stream);
+            (void)hipStreamSynchronize(ctx->stream);
+            fprintf(stderr, "[d2r l0_reuse] %u of %u patch tokens touched (%.1f %%)\n", c, prow, 100.0 * c / prow);
+        }
+        EpiAux a1{};
+        a1.m_dev = l0_cnt;
+        if ((rc = launch_gemm_cfg<EPI_F32, 4, 2, 2, 3>(ctx, (const uint16_t *)ctx->l0_a1.p, clip->w.w_patch, nullptr, patch_out, prow, d, clip->Kp_pad, a1))) return rc;
+    } else if ((rc = launch_gemm<EPI_F32>(ctx, patches_dev, clip->w.w_patch, nullptr, patch_out, prow, d, clip->Kp_pad)))
+        return rc;
     // the last block runs on the class-token rows only (last_block_cls); needs its small workspaces to fit what exists
     const bool cls_last = ctx->cls_last && D.num_layers >= 1 && T <= 1024 && round_up(n, BM) <= round_up(prow, BM);
     // bf16 activations between kernels are tile-major ([cols/64][rows_pad][64], see EpiAux): QKV, AO, H and the bf16
@@ -2358,6 +2570,13 @@ int d2r_clip_forward(d2r_ctx *ctx, const d2r_clip *clip, const uint16_t *patches
     const bool xf32 = fold == 3, split8 = fold == 4, split = fold == 1 || split8;
     const int lo8 = split8 ? 1 : 0;
     uint16_t *Xlo = split ? (uint16_t *)X : (uint16_t *)nullptr;
+    if (l0) {
+        // every row <- the background's row of its token, then the touched tokens' own rows over them
+        hipLaunchKernelGGL(k_bcast_x0, dim3((rows + 3) / 4), dim3(256), 0, ctx->stream, reuse->bg_hi, reuse->bg_lo, reuse->bg_ab, reuse->bg_rows, Xn,
+                           (uint8_t *)Xlo, AB, rows, rows_pad, T, d);
+        hipLaunchKernelGGL(k_embed_ln, dim3(std::min<uint32_t>((prow + 3) / 4, 4096u)), dim3(256), 0, ctx->stream, patch_out, clip->w.cls, clip->w.pos, clip->w.pre_w,
+                           clip->w.pre_b, (float *)nullptr, rows, T, d, Xn, AB, Xlo, rows_pad, lo8, (const uint32_t *)l0_list, (const uint32_t *)l0_cnt);
+    } else
     hipLaunchKernelGGL(k_embed_ln, dim3((rows + 3) / 4), dim3(256), 0, ctx->stream, patch_out, clip->w.cls, clip->w.pos,
                        clip->w.pre_w, clip->w.pre_b, xf32 ? X : (float *)nullptr, rows, T, d, Xn, AB, Xlo, rows_pad, lo8);
     EpiAux ln = out_tm, st = a_tm;                // LN-folded GEMMs: A = tile-major residual copy, output tile-major
@@ -2391,7 +2610,23 @@ int d2r_clip_forward(d2r_ctx *ctx, const d2r_clip *clip, const uint16_t *patches
             if ((rc = last_block_cls(ctx, D, L, n, T, rows_pad, QKV, Qc, X, xf32 ? nullptr : Xn, Xlo, patch_out, AO, Xn, H, lo8))) return rc;
             break;
         }
-        if ((rc = launch_gemm<EPI_LN_BIAS_BF16>(ctx, Xn, L.wf_qkv, L.bf_qkv, QKV, rows, 3 * d, d, ln))) return rc;
+        if (l0 && l == 0) {
+            // layer 0: the background's q / k / v rows everywhere, then the touched tokens' own (a product over the compact list)
+            const uint32_t planes = 3 * d / 64;
+            const size_t pieces = (size_t)planes * rows * 8;
+            hipLaunchKernelGGL(k_bcast_qkv, dim3((uint32_t)((pieces + 255) / 256)), dim3(256), 0, ctx->stream, reuse->bg_qkv, reuse->bg_rows, QKV, rows, rows_pad, T, planes);
+            float2 *AB2 = (float2 *)((uint8_t *)ctx->l0_misc.p + 256 + (size_t)prow * 4);
+            hipLaunchKernelGGL(k_gather_operand_rows, dim3(2048), dim3(256), 0, ctx->stream, Xn, AB, rows_pad, T, (const uint32_t *)l0_list, (const uint32_t *)l0_cnt,
+                               AO, AB2, cap_pad, d);
+            EpiAux l2 = ln;
+            l2.a_ks = 64 * cap_pad;
+            l2.hm_rows = cap_pad;
+            l2.ab = AB2;
+            l2.m_dev = l0_cnt;
+            if ((rc = launch_gemm_cfg<EPI_LN_BIAS_BF16, 4, 2, 2, 3>(ctx, AO, L.wf_qkv, L.bf_qkv, ctx->l0_q2.p, prow, 3 * d, d, l2))) return rc;
+            hipLaunchKernelGGL(k_scatter_qkv, dim3(8192), dim3(256), 0, ctx->stream, (const uint16_t *)ctx->l0_q2.p, cap_pad, (const uint32_t *)l0_list,
+                               (const uint32_t *)l0_cnt, QKV, rows_pad, T, planes);
+        } else if ((rc = launch_gemm<EPI_LN_BIAS_BF16>(ctx, Xn, L.wf_qkv, L.bf_qkv, QKV, rows, 3 * d, d, ln))) return rc;
         launch_attention_vision(ctx, QKV, AO, T, d, rows_pad, D.num_heads, n);
         if (xf32) rc = launch_gemm<EPI_RESID_STATS_F32X>(ctx, AO, L.w_o, L.b_o, X, rows, d, d, st);
         else if (split8) rc = launch_gemm<EPI_RESID_STATS_SPLIT8>(ctx, AO, L.w_o, L.b_o, Xn, rows, d, d, st);
@@ -2557,6 +2792,7 @@ extern "C" void d2r_clip_destroy(d2r_clip *c)
 {
     if (!c) return;
     if (c->ctx && c->ctx->bg_patches_for == (const void *)c) c->ctx->bg_patches_for = nullptr;   // a later model may reuse the address
+    if (c->ctx && c->ctx->bg_l0_for == (const void *)c) c->ctx->bg_l0_for = nullptr;
     for (void *p : c->allocs) hipFree(p);
     delete c;
 }

@@ -83,6 +83,18 @@ struct ViewParams {
 
 struct ClipParams;   // clip.hip
 
+// Layer-0 reuse of background tokens inside d2r_render_score (clip.hip "layer-0 reuse"): the frame rectangles the candidates
+// of the chunk touched, and the background's own pre-LayerNorm residual rows and layer-0 q / k / v rows (d2r_clip_layer0_background)
+struct ClipL0Reuse {
+    const void *rects;           // device int4 [n]: x0, y0, x1, y1 in frame pixels, inclusive (k_raygen_rect)
+    uint32_t w, h;               // frame size
+    const uint16_t *bg_hi;       // [d / 64][bg_rows][64] bf16
+    const uint8_t *bg_lo;        // lo bytes, lo8_off(bg_rows, ..) layout
+    const float2 *bg_ab;         // [bg_rows] (rstd, -rstd * mean)
+    const uint16_t *bg_qkv;      // [3 d / 64][bg_rows][64] bf16
+    uint32_t bg_rows;            // tokens per image, rounded up to a multiple of 256
+};
+
 struct d2r_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -104,6 +116,10 @@ struct d2r_ctx {
     Buf rects;                   // per candidate of a pass: frame rectangle (x0, y0, x1, y1) its rays were generated in
     Buf bg_patches;              // CLIP patches of the background frame itself (one image)
     const void *bg_patches_for = nullptr;   // the d2r_clip they were computed with (nullptr = stale)
+    Buf bg_l0, l0_a1, l0_q2, l0_misc;       // layer-0 reuse: the background's rows; gathered patch rows; compact q / k / v; count + list + pairs
+    const void *bg_l0_for = nullptr;        // the d2r_clip bg_l0 was computed with (nullptr = stale)
+    ClipL0Reuse bg_l0_desc{};               // pointers into bg_l0
+    int64_t l0_reuse = 1;        // d2r_render_score: patch embedding + layer-0 QKV on the touched tokens only
     int64_t prep_reuse = 1;      // k_preprocess copies the background's patch rows for bands a candidate cannot have touched
     uint32_t bg_w = 0, bg_h = 0;
     d2r_render_stats stats{};

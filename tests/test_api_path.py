@@ -238,3 +238,34 @@ def test_api_bench_two_ranks_equal_one(tmp_path):
     n = len(f1)
     np.testing.assert_array_equal(_lib.png_read_batch(os.path.join(d1, "cb_render"), n), _lib.png_read_batch(os.path.join(d2, "cb_render"), n))
     assert open(os.path.join(d1, "best_render.png"), "rb").read() == open(os.path.join(d2, "best_render.png"), "rb").read()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("clip,W,H,n", [("vit_b16", 640, 360, 40), ("vit_tiny", 96, 54, 72), ("vit_l14_x2", 336, 336, 12)])
+def test_layer0_background_token_reuse_is_bit_identical(clip, W, H, n, tmp_path):
+    """"l0_reuse": patch embedding, pre-LayerNorm rows and layer-0 q / k / v of the patches a candidate cannot have touched are
+    broadcast from the background's own rows, the products run on the touched tokens only (a device-sized compact list).  The
+    logits must be BIT-IDENTICAL to the plain forward — in one chunk, in several chunks, with the two-stream pipeline on —
+    and the touched fraction must be small on this scene (the point of the exercise)."""
+    from dream2real_amd import combined_rendering
+    from dream2real_amd.accio2ngp import converter
+    from dream2real_amd.obj_pose_opt import sample_poses_grid
+    from dream2real_amd.virtual_cam_pose_sample import get_virtual_cam_poses
+    scene, ctx, fg, bg, sc, task, text = _setup(W, H, clip)
+    res = {40: [8, 5, 1, 1, 1, 1], 72: [9, 8, 1, 1, 1, 1], 12: [4, 3, 1, 1, 1, 1]}[n]
+    poses = converter(sample_poses_grid(task, res, scene.scene_type).reshape(-1, 4, 4))
+    rp = converter(get_virtual_cam_poses(task, [0]))
+    rend = combined_rendering.renderer(str(tmp_path), task, resolution=(W, H))
+    try:
+        ctx.set_option("l0_reuse", 0)
+        base = rend.render_score(poses, rp, [0], sc, text, save=False)
+        for chunk, overlap in ((4096, 0), (16, 0), (16, 1)):
+            ctx.set_option("l0_reuse", 1)
+            ctx.set_option("chunk", chunk)
+            ctx.set_option("overlap", overlap)
+            got = rend.render_score(poses, rp, [0], sc, text, save=False)
+            np.testing.assert_array_equal(got, base, err_msg=f"chunk {chunk} overlap {overlap}")
+        assert np.ptp(base[:, 0]) > 0                                     # the candidates do differ
+    finally:
+        ctx.set_option("l0_reuse", 1); ctx.set_option("chunk", 4096); ctx.set_option("overlap", 0)
+        sc.close(); fg.close(); bg.close(); ctx.close()
