@@ -12,7 +12,8 @@
 struct d2r_clip;
 int d2r_launch_preprocess(d2r_ctx *, d2r_clip *, const uint8_t *frames_dev, uint32_t n, uint32_t w, uint32_t h,
                           int rot90, uint16_t *patches_dev, float *pixel_values_dev, const void *rects_dev = nullptr,
-                          const uint16_t *bg_patches_dev = nullptr);
+                          const uint16_t *bg_patches_dev = nullptr, bool touched_only = false);
+bool d2r_clip_l0_supported(const d2r_ctx *, const d2r_clip *);
 int d2r_clip_forward(d2r_ctx *, const d2r_clip *, const uint16_t *patches_dev, uint32_t n, const float *text_dev,
                      uint32_t C, float logit_scale, float *logits_dev, float *embeds_dev, const ClipL0Reuse *reuse = nullptr);
 int d2r_clip_layer0_background(d2r_ctx *, const d2r_clip *, const uint16_t *bg_patches_dev, ClipL0Reuse *out);
@@ -891,7 +892,7 @@ static int render_score_core(d2r_ctx *ctx, const d2r_nerf *fg, const d2r_clip *c
     }
     // layer-0 reuse: the background's own pre-LayerNorm rows and q / k / v rows, once per (background, CLIP model)
     ClipL0Reuse l0{};
-    const bool use_l0 = reuse_bg && ctx->l0_reuse && ctx->ln_fold == 4;
+    const bool use_l0 = reuse_bg && ctx->l0_reuse && d2r_clip_l0_supported(ctx, clip);
     if (use_l0) {
         if (ctx->bg_l0_for != (const void *)clip) {
             rc = d2r_clip_layer0_background(ctx, clip, (const uint16_t *)ctx->bg_patches.p, &ctx->bg_l0_desc);
@@ -938,8 +939,9 @@ static int render_score_core(d2r_ctx *ctx, const d2r_nerf *fg, const d2r_clip *c
             }
             if (two && ci >= 2) D2R_HIP(ctx, hipStreamWaitEvent(rs, ctx->ev_clip[pb], 0));      // patch buffer pb: chunk ci-2 is scored
             size_t tp = ctx->timing_begin(D2R_T_PREP);
+            // (with layer-0 reuse only the touched patches are produced: nothing downstream reads the others)
             if ((rc = d2r_launch_preprocess(ctx, (d2r_clip *)clip, frames_dev, nc, V.W, V.H, 1, patches, nullptr, rects,
-                                            reuse_bg ? (const uint16_t *)ctx->bg_patches.p : nullptr)))
+                                            reuse_bg ? (const uint16_t *)ctx->bg_patches.p : nullptr, l0.rects != nullptr)))
                 return rc;
             ctx->timing_end(tp);
             if (two) D2R_HIP(ctx, hipEventRecord(ctx->ev_prep[pb], rs));

@@ -122,12 +122,13 @@ __global__ __launch_bounds__(256) void k_preprocess(const uint8_t *__restrict__ 
                                                     int rot90, ResampleTables R, uint32_t S, uint32_t P,
                                                     uint32_t band, uint16_t *__restrict__ patches,
                                                     uint32_t Kp_pad, float *__restrict__ pixel_values,
-                                                    const int4 *__restrict__ rects, const uint16_t *__restrict__ bg_patches)
+                                                    const int4 *__restrict__ rects, const uint16_t *__restrict__ bg_patches, int touched_only)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t tmp[];
     const uint32_t img = blockIdx.y;
     const uint32_t row0 = blockIdx.x * band;                 // first output row (cropped coords)
     const uint32_t nrows = min(band, S - row0);
+    uint32_t x_lo = 0, x_n = S;                              // output columns this workgroup produces
     // Composited candidates differ from the background frame only inside the rectangle their rays were generated in
     // (rects[img] = x0, y0, x1, y1 in frame pixels, inclusive; k_raygen_rect).  A band (= one row of patches) whose
     // source rows do not meet that rectangle resamples background pixels only: it is the background's own patch row
@@ -147,7 +148,25 @@ __global__ __launch_bounds__(256) void k_preprocess(const uint8_t *__restrict__ 
         // the rectangle's rows in the (rotated) source: rot90 maps frame column x to row w-1-x
         const int rlo = rot90 ? (int)w - 1 - rc.z : rc.y, rhi = rot90 ? (int)w - 1 - rc.x : rc.w;
         const bool untouched = rc.x > rc.z || rc.y > rc.w || rhi < ys || rlo >= ye;
-        if (untouched) {
+        if (touched_only) {
+            // layer-0 reuse (k_touch_list): only the TOUCHED patches' rows are read downstream — an untouched band needs
+            // nothing, a touched band only the patch columns whose footprint meets the rectangle (an interval: the same test)
+            if (untouched) return;
+            const int clo = rot90 ? rc.y : rc.x, chi = rot90 ? rc.w : rc.z;
+            uint32_t p_lo = S / P, p_hi = 0;
+            for (uint32_t pcol = 0; pcol < S / P; pcol++) {
+                int xs, xe;
+                if (R.need_h) {
+                    xs = R.bounds_h[2 * (R.left + pcol * P)];
+                    const int last = R.left + pcol * P + P - 1;
+                    xe = R.bounds_h[2 * last] + R.bounds_h[2 * last + 1];
+                } else { xs = R.left + pcol * P; xe = xs + P; }
+                if (!(chi < xs || clo >= xe)) { p_lo = min(p_lo, pcol); p_hi = max(p_hi, pcol + 1); }
+            }
+            if (p_lo >= p_hi) return;
+            x_lo = p_lo * P;
+            x_n = (p_hi - p_lo) * P;
+        } else if (untouched) {
             const uint32_t g = S / P;
             const size_t n16 = (size_t)g * Kp_pad * 2 / 16;                         // one patch row, in 16-byte words
             const uint4 *src16 = (const uint4 *)(bg_patches + (size_t)blockIdx.x * g * Kp_pad);
@@ -171,9 +190,10 @@ __global__ __launch_bounds__(256) void k_preprocess(const uint8_t *__restrict__ 
     const uint32_t ld = (uint32_t)R.max_rows;                // bytes per LDS column
     const uint32_t plane = S * ld;
     // pass 1: horizontal filter (or copy) into LDS, columns [left, left+S)
-    for (uint32_t i = threadIdx.x; i < trows * S; i += blockDim.x) {
+    for (uint32_t i = threadIdx.x; i < trows * x_n; i += blockDim.x) {
         uint32_t ty, tx;
-        if (rot90) { tx = i / trows; ty = i - tx * trows; } else { ty = i / S; tx = i - ty * S; }
+        if (rot90) { tx = i / trows; ty = i - tx * trows; } else { ty = i / x_n; tx = i - ty * x_n; }
+        tx += x_lo;
         const int sy = y_first + (int)ty;      // row in rotated source
         const int ox = R.left + (int)tx;       // column in resized image
         uint32_t o0, o1, o2;
@@ -208,8 +228,8 @@ __global__ __launch_bounds__(256) void k_preprocess(const uint8_t *__restrict__ 
     const float mean[3] = {0.48145466f, 0.4578275f, 0.40821073f};
     const float stdv[3] = {0.26862954f, 0.26130258f, 0.27577711f};
     const uint32_t g = S / P;
-    for (uint32_t i = threadIdx.x; i < nrows * S; i += blockDim.x) {
-        const uint32_t ry = i / S, rx = i % S;
+    for (uint32_t i = threadIdx.x; i < nrows * x_n; i += blockDim.x) {
+        const uint32_t ry = i / x_n, rx = x_lo + i % x_n;
         const uint32_t oy = row0 + ry;
         uint32_t q[3];
         const uint8_t *col = tmp + rx * ld;
@@ -2290,7 +2310,7 @@ static int prep_tables(d2r_ctx *ctx, d2r_clip *clip, uint32_t w, uint32_t h, int
 // frames (device, [n][h][w][3] u8) -> patches (bf16 [n*g*g][Kp_pad]) and/or pixel_values
 int d2r_launch_preprocess(d2r_ctx *ctx, d2r_clip *clip, const uint8_t *frames_dev, uint32_t n, uint32_t w,
                           uint32_t h, int rot90, uint16_t *patches_dev, float *pixel_values_dev, const void *rects_dev,
-                          const uint16_t *bg_patches_dev)
+                          const uint16_t *bg_patches_dev, bool touched_only)
 {
     const uint32_t S = clip->desc.image_size, P = clip->desc.patch_size;
     const PrepCache *pc = nullptr;
@@ -2305,7 +2325,8 @@ int d2r_launch_preprocess(d2r_ctx *ctx, d2r_clip *clip, const uint8_t *frames_de
         (void)hipFuncSetAttribute((const void *)k_preprocess, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     });
     hipLaunchKernelGGL(k_preprocess, dim3((S + band - 1) / band, n), dim3(256), lds, ctx->stream, frames_dev, w, h,
-                       rot90, R, S, P, band, patches_dev, clip->Kp_pad, pixel_values_dev, (const int4 *)rects_dev, bg_patches_dev);
+                       rot90, R, S, P, band, patches_dev, clip->Kp_pad, pixel_values_dev, (const int4 *)rects_dev, bg_patches_dev,
+                       touched_only ? 1 : 0);
     D2R_HIP(ctx, hipGetLastError());
     return D2R_OK;
 }
@@ -2439,6 +2460,14 @@ static int last_block_cls(d2r_ctx *ctx, const d2r_clip_desc &D, const ClipWeight
 
 // patches (bf16 [n*(T-1) padded to 128][Kp_pad]) -> logits/embeds.  Workspaces:
 //  clipws[0] patch_out f32, [1] X f32, [2] Xn bf16, [3] QKV bf16, [4] AO bf16, [5] H bf16
+// can d2r_clip_forward take a ClipL0Reuse for this model under the context's options?
+bool d2r_clip_l0_supported(const d2r_ctx *ctx, const d2r_clip *clip)
+{
+    const d2r_clip_desc &D = clip->desc;
+    const uint32_t g = D.image_size / D.patch_size;
+    return ctx->ln_fold == 4 && D.num_layers >= 2 && g * g == clip->T - 1 && g * g <= 1024;
+}
+
 // The background's own layer-0 rows for ClipL0Reuse: patch embedding -> + position, pre-LayerNorm -> bf16 hi + lo bytes and LayerNorm
 // pairs -> layer-0 q / k / v, of ONE image (the background frame's patches), with the kernels the batched forward uses (a row's
 // result does not depend on the batch it is computed in).  Buffers live in ctx->bg_l0; rows padded to a multiple of 256.
@@ -2498,8 +2527,9 @@ int d2r_clip_forward(d2r_ctx *ctx, const d2r_clip *clip, const uint16_t *patches
     const int fold = (int)ctx->ln_fold;
     // layer-0 reuse (see k_touch_list): needs the hi + lo-byte residual, square images cut into whole patches, a second layer
     const uint32_t g2 = T - 1;
-    const bool l0 = reuse && reuse->rects && fold == 4 && D.num_layers >= 2 && (D.image_size / D.patch_size) * (D.image_size / D.patch_size) == g2 &&
-                    g2 <= 1024 && T <= reuse->bg_rows;
+    const bool l0 = reuse && reuse->rects;
+    if (l0 && (!d2r_clip_l0_supported(ctx, clip) || T > reuse->bg_rows))
+        return d2r_fail(ctx, D2R_ERR_INVALID, "d2r_clip_forward: layer-0 reuse requested for a model / option set that does not support it");
     uint32_t *l0_cnt = nullptr, *l0_list = nullptr;
     const uint32_t cap_pad = round_up(prow, BM);
     if (l0) {
