@@ -46,8 +46,10 @@ def test_snapshot_section_runs_without_a_gpu(tmp_path):
     open(p, "wb").write(zlib.compress(msgpack.packb(cfg, use_bin_type=True), 1))
     rc, rep = run_tool("--method-out", d, "--no-gpu")
     bg = rep["sections"]["a_snapshots"]["bg"]
-    assert rc == 1 and not rep["ok"] and "params_binary holds" in bg["problems"][0]
-    assert any("snapshot.some_new_field" in k for k in bg["keys_ignored"])
+    assert rc == 1 and not rep["ok"] and any("params_binary holds" in p for p in bg["problems"])
+    assert any("would refuse" in p and "snapshot.params_binary" in p for p in bg["problems"])            # the loader's own verdict, naming the key
+    assert any("snapshot.some_new_field" in k for k in bg["keys_unknown"])                                 # '?': unknown to the loader
+    assert any("dir_encoding" in k for k in bg["keys_checked"]) and any("snapshot.version" in k for k in bg["keys_ignored"])
     # an empty directory: nothing to do
     rc, rep = run_tool("--method-out", str(tmp_path / "nothing"), "--no-gpu")
     assert rc == 2

@@ -45,8 +45,9 @@ sys.path.insert(0, REPO)
 def inspect_snapshot(path: str) -> dict:
     """Section (a), host side: what the file holds vs what the loader reads and derives."""
     from dream2real_amd import _lib
-    text = _lib.ingp_inspect(open(path, "rb").read())
-    ignored, read, derived = [], [], {}
+    data = open(path, "rb").read()
+    text = _lib.ingp_inspect(data)
+    ignored, read, checked, unknown, derived = [], [], [], [], {}
     for ln in text.splitlines():
         if ln.startswith("# derived:"):
             t = ln.split()[2:]
@@ -57,7 +58,15 @@ def inspect_snapshot(path: str) -> dict:
             ignored.append(ln[2:])
         elif ln.startswith("R "):
             read.append(ln[2:])
+        elif ln.startswith("C "):
+            checked.append(ln[2:])
+        elif ln.startswith("? "):
+            unknown.append(ln[2:])
     problems = []
+    try:                                   # the loader's own verdict (every check d2r_nerf_load_ingp makes, host only)
+        _lib.ingp_validate(data)
+    except _lib.D2RError as e:
+        problems.append(f"d2r_nerf_load_ingp would refuse the file: {e}")
     if "n_params_expected" in derived and derived["n_params_expected"] != derived.get("params_binary_halves"):
         problems.append(f"params_binary holds {derived.get('params_binary_halves')} halves, the reader derives {derived['n_params_expected']}")
     if "density_grid_halves_expected" in derived and derived["density_grid_halves_expected"] != derived.get("density_grid_binary_halves"):
@@ -65,7 +74,8 @@ def inspect_snapshot(path: str) -> dict:
                         f"{derived['density_grid_halves_expected']}")
     if not derived:
         problems.append("the encoding fields are outside what the reader accepts")
-    return {"file": path, "keys_read": read, "keys_ignored": ignored, "derived": derived, "problems": problems}
+    return {"file": path, "keys_read": read, "keys_checked": checked, "keys_ignored": ignored, "keys_unknown": unknown, "derived": derived,
+            "problems": problems}
 
 
 def load_frames(render_dir: str):
