@@ -79,7 +79,7 @@ class FrameSink(C.Structure):
 
 class RenderStats(C.Structure):
     _fields_ = [("rays_total", C.c_uint64), ("rays_alive", C.c_uint64), ("samples", C.c_uint64),
-                ("wave_iters", C.c_uint64)]
+                ("wave_iters", C.c_uint64), ("l0_tokens", C.c_uint64), ("l0_touched", C.c_uint64)]
 
 
 class Timing(C.Structure):

@@ -23,6 +23,7 @@ int d2r_launch_eval_points(d2r_ctx *, const d2r_nerf *, const float *xyz, const 
 uint32_t d2r_clip_image_size(const d2r_clip *);
 uint32_t d2r_clip_proj_dim(const d2r_clip *);
 uint32_t d2r_clip_max_images(const d2r_clip *);
+uint32_t d2r_clip_tokens(const d2r_clip *);
 
 // Candidates (images) per pass: the "chunk" option, capped so that one pass stays inside the 32-bit
 // indexing of the ray queue (rays) and of the GEMM outputs (rows x widest layer).
@@ -558,7 +559,7 @@ static int fetch_stats(d2r_ctx *ctx, uint64_t rays_total, bool accumulate)
     uint64_t samples, iters;
     memcpy(&samples, &c[2], 8);
     memcpy(&iters, &c[4], 8);
-    if (!accumulate) ctx->stats = d2r_render_stats{0, 0, 0, 0};
+    if (!accumulate) ctx->stats = d2r_render_stats{};
     ctx->stats.rays_total += rays_total;
     ctx->stats.rays_alive += c[0];
     ctx->stats.samples += samples;
@@ -576,7 +577,7 @@ int d2r_render(d2r_ctx *ctx, const d2r_nerf *model, const d2r_view *view, const 
     hipSetDevice(ctx->device);
     const ViewParams V = d2r_view_params(view);
     const size_t px = (size_t)V.W * V.H;
-    ctx->stats = d2r_render_stats{0, 0, 0, 0};
+    ctx->stats = d2r_render_stats{};
     ctx->last_chunks = 0;
     // bound the pass size: 2^31 rays and ~1 GiB of fp32 frames
     uint32_t per = (uint32_t)std::max<size_t>(1, std::min<size_t>(n, (64u << 20) / px + 1));
@@ -650,7 +651,7 @@ int d2r_render_composite(d2r_ctx *ctx, const d2r_nerf *fg, const d2r_view *view,
     hipSetDevice(ctx->device);
     const ViewParams V = d2r_view_params(view);
     const size_t px = (size_t)V.W * V.H;
-    ctx->stats = d2r_render_stats{0, 0, 0, 0};
+    ctx->stats = d2r_render_stats{};
     ctx->last_chunks = 0;
     const uint32_t per = pass_size(ctx, nullptr, px);
     for (uint32_t c0 = 0; c0 < K; c0 += per) {
@@ -906,7 +907,7 @@ static int render_score_core(d2r_ctx *ctx, const d2r_nerf *fg, const d2r_clip *c
             l0.rects = ctx->rects.p;
         }
     }
-    ctx->stats = d2r_render_stats{0, 0, 0, 0};
+    ctx->stats = d2r_render_stats{};
     hipStream_t main = ctx->stream, rs = two ? ctx->render_stream : main, xs = ctx->copy_stream;
     if (rs != main) {       // the render stream starts after whatever the caller queued before this call (pose upload, text)
         D2R_HIP(ctx, hipEventRecord(ctx->ev_fork, main));
@@ -948,7 +949,10 @@ static int render_score_core(d2r_ctx *ctx, const d2r_nerf *fg, const d2r_clip *c
         }
         if (two) D2R_HIP(ctx, hipStreamWaitEvent(main, ctx->ev_prep[pb], 0));
         size_t tc = ctx->timing_begin(D2R_T_CLIP);
-        if (l0.rects) l0.rects = rects;                    // this chunk's half of the rectangle buffer
+        if (l0.rects) {
+            l0.rects = rects;                              // this chunk's half of the rectangle buffer
+            l0.touched_out = (uint32_t *)((uint8_t *)ctx->counters.p + 64 + 32 * (size_t)ci) + 6;      // word 6 of the chunk's counter record
+        }
         if ((rc = d2r_clip_forward(ctx, clip, patches, nc, (const float *)ctx->text.p, C, logit_scale,
                                    logits_dev + (size_t)c0 * C, nullptr, l0.rects ? &l0 : nullptr)))
             return rc;
@@ -976,6 +980,7 @@ static int render_score_core(d2r_ctx *ctx, const d2r_nerf *fg, const d2r_clip *c
         if (prc) return d2r_fail(ctx, prc, err);
     }
     ctx->stats.rays_total = (uint64_t)K * px;
+    ctx->stats.l0_tokens = l0.rects ? (uint64_t)K * (d2r_clip_tokens(clip) - 1) : 0;
     return D2R_OK;
 }
 
@@ -1038,7 +1043,9 @@ int d2r_collect_render_stats(d2r_ctx *ctx, uint32_t K)
     ctx->stats.rays_alive = 0;
     ctx->stats.samples = 0;
     ctx->stats.wave_iters = 0;
+    ctx->stats.l0_touched = 0;
     for (uint32_t i = 0; i < nchunks; i++) {
+        if (ctx->stats.l0_tokens) ctx->stats.l0_touched += c[i * 8 + 6];
         uint64_t s, it;
         memcpy(&s, &c[i * 8 + 2], 8);
         memcpy(&it, &c[i * 8 + 4], 8);

@@ -2543,6 +2543,7 @@ int d2r_clip_forward(d2r_ctx *ctx, const d2r_clip *clip, const uint16_t *patches
         D2R_HIP(ctx, hipMemsetAsync(l0_cnt, 0, 4, ctx->stream));
         hipLaunchKernelGGL(k_touch_list, dim3(n), dim3(256), 0, ctx->stream, (const int4 *)reuse->rects, reuse->w, pc->R, D.image_size, D.patch_size, l0_cnt, l0_list);
         hipLaunchKernelGGL(k_gather_rows, dim3(2048), dim3(256), 0, ctx->stream, patches_dev, clip->Kp_pad, l0_list, l0_cnt, (uint16_t *)ctx->l0_a1.p);
+        if (reuse->touched_out) D2R_HIP(ctx, hipMemcpyAsync(reuse->touched_out, l0_cnt, 4, hipMemcpyDeviceToDevice, ctx->stream));
         if (getenv("D2R_L0_DEBUG")) {                          // development aid: how many tokens the chunk touched
             uint32_t c = 0;
             (void)hipMemcpyAsync(&c, l0_cnt, 4, hipMemcpyDeviceToHost, ctx->stream);
@@ -2694,6 +2695,8 @@ int d2r_launch_patchify(d2r_ctx *ctx, const d2r_clip *clip, const float *pv_dev,
     D2R_HIP(ctx, hipGetLastError());
     return D2R_OK;
 }
+
+uint32_t d2r_clip_tokens(const d2r_clip *clip) { return clip->T; }
 
 // largest image count whose GEMM outputs (rows padded to BM x the widest layer) keep 32-bit indices
 uint32_t d2r_clip_max_images(const d2r_clip *clip)

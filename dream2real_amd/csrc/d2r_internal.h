@@ -93,6 +93,7 @@ struct ClipL0Reuse {
     const float2 *bg_ab;         // [bg_rows] (rstd, -rstd * mean)
     const uint16_t *bg_qkv;      // [3 d / 64][bg_rows][64] bf16
     uint32_t bg_rows;            // tokens per image, rounded up to a multiple of 256
+    uint32_t *touched_out;       // device, optional: receives the chunk's touched-token count (render statistics)
 };
 
 struct d2r_ctx {

@@ -61,7 +61,7 @@ class Context:
         s = _lib.RenderStats()
         self.check(self.lib.d2r_get_render_stats(self.h, C.byref(s)))
         return {"rays_total": s.rays_total, "rays_alive": s.rays_alive, "samples": s.samples,
-                "wave_iters": s.wave_iters}
+                "wave_iters": s.wave_iters, "l0_tokens": s.l0_tokens, "l0_touched": s.l0_touched}
 
     def timing(self) -> dict:
         """Device time per kernel family since set_option("timing", 1) (synchronises)."""
@@ -370,6 +370,8 @@ def render_score_host(ctx: Context, fg: Testbed, scorer: ClipScorer, view: View,
     K, Cn = p.shape[0], t.shape[0]
     logits = np.empty((K, Cn), np.float32)
     frames = np.empty((K, view.height, view.width, 3), np.uint8) if return_frames else None
+    if K == 0:                                        # nothing to render: no call, no files
+        return (logits, frames) if return_frames else logits
     sink = None
     if png_dir is not None:
         sink = _lib.FrameSink(os.fsencode(png_dir), png_first_index, png_threads, png_level)

@@ -358,6 +358,8 @@ typedef struct {
     uint64_t rays_alive;
     uint64_t samples;
     uint64_t wave_iters;   /* marcher wave-iterations; lane utilisation = samples / (64 * wave_iters) */
+    uint64_t l0_tokens;    /* d2r_render_score with "l0_reuse": patch tokens of the pass (0 when the reuse did not run) ... */
+    uint64_t l0_touched;   /* ... and how many of them were recomputed (the others took the background's layer-0 rows) */
 } d2r_render_stats;
 D2R_API int d2r_get_render_stats(d2r_ctx *ctx, d2r_render_stats *out);
 /* After an asynchronous d2r_render_score over K poses: synchronises the stream and gathers

@@ -269,3 +269,32 @@ def test_layer0_background_token_reuse_is_bit_identical(clip, W, H, n, tmp_path)
     finally:
         ctx.set_option("l0_reuse", 1); ctx.set_option("chunk", 4096); ctx.set_option("overlap", 0)
         sc.close(); fg.close(); bg.close(); ctx.close()
+
+
+@pytest.mark.gpu
+def test_fused_call_edge_cases(tmp_path):
+    """Ragged and degenerate pose batches through d2r_render_score_host with layer-0 reuse on: no candidate (K = 0), one
+    candidate, and candidates whose object is off screen (an EMPTY touched-token list: every token row is the background's) mixed
+    with visible ones — each equal to the two-step route bit for bit."""
+    from dream2real_amd import combined_rendering
+    from dream2real_amd.accio2ngp import converter
+    from dream2real_amd.obj_pose_opt import sample_poses_grid
+    from dream2real_amd.virtual_cam_pose_sample import get_virtual_cam_poses
+    scene, ctx, fg, bg, sc, task, text = _setup()
+    rp = converter(get_virtual_cam_poses(task, [0]))
+    rend = combined_rendering.renderer(str(tmp_path), task, resolution=(96, 54))
+    poses_w = sample_poses_grid(task, [3, 2, 1, 1, 1, 1], scene.scene_type).reshape(-1, 4, 4)
+    far = poses_w.copy()
+    far[:, :3, 3] += np.array([5.0, 5.0, 0.0], np.float32)                 # metres away: outside every view
+    for name, pw in (("none", poses_w[:0]), ("one", poses_w[:1]), ("off screen", far), ("mixed", np.concatenate([far[:2], poses_w, far[2:3]]))):
+        poses = converter(pw) if len(pw) else np.zeros((0, 4, 4), np.float32)
+        got, frames = rend.render_score(poses, rp, [0], sc, text, save=False, return_frames=True)
+        assert got.shape == (len(pw), 2) and frames.shape[0] == len(pw), name
+        if len(pw):
+            ref_frames = np.stack(rend.render(poses, rp, [0], save=False))
+            np.testing.assert_array_equal(frames, ref_frames, err_msg=name)
+            np.testing.assert_array_equal(got, sc.score_frames(ref_frames, text, rot90=True), err_msg=name)
+            np.testing.assert_array_equal(rend.render_score(poses, rp, [0], sc, text, save=False), got, err_msg=name + " (scores only)")
+        if name == "off screen":
+            assert (frames == frames[0]).all() and (got == got[0]).all()              # the background, six times
+    sc.close(); fg.close(); bg.close(); ctx.close()
