@@ -208,6 +208,8 @@ int d2r_ctx_set_option(d2r_ctx *ctx, const char *key, int64_t value)
         ctx->prep_reuse = value != 0;
     } else if (!strcmp(key, "cls_last")) {
         ctx->cls_last = value != 0;
+    } else if (!strcmp(key, "vit_fp8")) {
+        ctx->vit_fp8 = value != 0;
     } else if (!strcmp(key, "l0_reuse")) {
         ctx->l0_reuse = value != 0;
     } else if (!strcmp(key, "attn_rem")) {

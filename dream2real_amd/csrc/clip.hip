@@ -80,6 +80,10 @@ struct d2r_clip {
     std::vector<ClipWeights::Layer> layers;
     std::deque<PrepCache> prep;      // resampling tables per (w, h, rot90), built on first use (deque: stable references)
     std::mutex prep_mu;              // two threads may score different frame sizes with one model
+    // "fp8 blocks": e4m3 copies of the four Linear weights of every layer + their per-matrix scales, built on first use
+    struct F8Layer { const uint8_t *w_qkv, *w_o, *w_fc1, *w_fc2; float s_qkv, s_o, s_fc1, s_fc2; };
+    std::vector<F8Layer> f8;
+    std::mutex f8_mu;
 };
 
 __device__ __forceinline__ uint16_t f2bf(float x)
@@ -306,9 +310,12 @@ __device__ __forceinline__ int32_t split8_round(float x, uint32_t hi_bits /* hi1
 // less residual traffic again (hi 2 + lo 1 bytes read and written per element instead of 2 + 2).
 enum { EPI_F32 = 0, EPI_BIAS_BF16 = 1, EPI_BIAS_GELU_BF16 = 2, EPI_BIAS_RESID_F32 = 3,
        EPI_LN_BIAS_BF16 = 4, EPI_LN_BIAS_GELU_BF16 = 5, EPI_RESID_STATS_F32X = 6, EPI_RESID_STATS_BF16 = 7,
-       EPI_RESID_STATS_SPLIT = 8, EPI_RESID_STATS_SPLIT8 = 9, EPI_KINDS = 10 };
+       EPI_RESID_STATS_SPLIT = 8, EPI_RESID_STATS_SPLIT8 = 9,
+       // fp8 operands (k_gemm8 only; see "fp8 blocks" below): the accumulator is multiplied by the weight matrix's scale first
+       EPI_F8_BIAS_BF16 = 10, EPI_F8_BIAS_GELU_Q8 = 11, EPI_F8_RESID_STATS_SPLIT8 = 12, EPI_KINDS = 13 };
+#define EPI_IS_F8(E) ((E) >= EPI_F8_BIAS_BF16)
 #define EPI_IS_LN(E) ((E) == EPI_LN_BIAS_BF16 || (E) == EPI_LN_BIAS_GELU_BF16)
-#define EPI_IS_STATS(E) ((E) == EPI_RESID_STATS_F32X || (E) == EPI_RESID_STATS_BF16 || (E) == EPI_RESID_STATS_SPLIT || (E) == EPI_RESID_STATS_SPLIT8)
+#define EPI_IS_STATS(E) ((E) == EPI_RESID_STATS_F32X || (E) == EPI_RESID_STATS_BF16 || (E) == EPI_RESID_STATS_SPLIT || (E) == EPI_RESID_STATS_SPLIT8 || (E) == EPI_F8_RESID_STATS_SPLIT8)
 #define EPI_IS_F32_LAYOUT(E) ((E) == EPI_F32 || (E) == EPI_BIAS_RESID_F32)
 
 // operands of the folded epilogues
@@ -327,7 +334,34 @@ struct EpiAux {
     uint32_t a_rs, a_ks;   // A operand: elements between rows, and between K-tiles (row-major: K, 64; tile-major: 64, 64 M_pad); 0,0 = row-major
     const uint32_t *m_dev; // k_gemm only: the number of live rows, in DEVICE memory (a product over a compacted row list whose length the
                            // host does not know: the grid covers the worst case and workgroups whose row tile starts at or beyond it leave at once)
+    // EPI_F8_*: A = e4m3 bytes in planes [K / 64][M_pad][64], W = e4m3 bytes [N][K]
+    const uint32_t *a_scale; // E8M0 scale bytes of A per (row, 64-column group), in the layout of q8_scale_off()
+    float w_scale;           // the weight matrix's (per-tensor, power-of-two) scale: result = acc * w_scale + bias
+    uint8_t *q8;             // EPI_F8_BIAS_GELU_Q8: e4m3 output planes [N / 64][hm_rows][64] ...
+    uint8_t *q8_scale;       // ... and its scale bytes (q8_scale_off)
 };
+
+// ---- fp8 activations (OCP e4m3): one E8M0 scale byte per (row, group of 64 columns), 2^(byte - 127) >= amax / 448 ----
+__device__ __forceinline__ uint32_t q8_scale_byte(float amax)
+{
+    const int e = (int)((__float_as_uint(amax) + 0x200000u) >> 23);          // biased exponent of amax, one more when its mantissa is >= 1.75
+    return (uint32_t)min(max(e - 8, 1), 253);
+}
+__device__ __forceinline__ float q8_inv_scale(uint32_t byte) { return __uint_as_float((254u - byte) << 23); }     // 2^(127 - byte)
+// scale bytes: [group / 2][M_pad / 64][32][4] — the dword of (K-tile = group pair, row % 32 of a 64-row block) holds the bytes of rows
+// (r, r + 32) x groups (even, odd): what one lane of the GEMM's 32x32x64 MFMAs needs for its two m-tiles and a K-tile's two MFMAs
+__device__ __forceinline__ size_t q8_scale_off(uint32_t M_pad, size_t row, uint32_t group)
+{
+    return ((((size_t)(group >> 1) * (M_pad >> 6) + (row >> 6)) * 32 + (row & 31)) << 2) + (((row >> 5) & 1) << 1) + (group & 1u);
+}
+__device__ __forceinline__ uint2 q8_pack8(const float (&f)[8], float inv)
+{
+    uint32_t a = __builtin_amdgcn_cvt_pk_fp8_f32(f[0] * inv, f[1] * inv, 0, false);
+    a = __builtin_amdgcn_cvt_pk_fp8_f32(f[2] * inv, f[3] * inv, a, true);
+    uint32_t b = __builtin_amdgcn_cvt_pk_fp8_f32(f[4] * inv, f[5] * inv, 0, false);
+    b = __builtin_amdgcn_cvt_pk_fp8_f32(f[6] * inv, f[7] * inv, b, true);
+    return make_uint2(a, b);
+}
 
 // Measurement switches (ablation masks, cycle stamps) live in clip_dev.h, which only development builds (make DEV=1,
 // or any ablation mask) include; a product build sees the masks as the constant 0 and no stamp code at all.
@@ -400,6 +434,13 @@ __device__ __forceinline__ float row8_sum(float x)
     x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xf, 0xf, false));    // quad_perm:[1,0,3,2]
     x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xf, 0xf, false));    // quad_perm:[2,3,0,1]
     x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x141, 0xf, 0xf, false));   // row_half_mirror
+    return x;
+}
+__device__ __forceinline__ float row8_max(float x)
+{
+    x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xf, 0xf, false)));
+    x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xf, 0xf, false)));
+    x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x141, 0xf, 0xf, false)));
     return x;
 }
 __device__ __forceinline__ float bf_lo(uint32_t u) { return __uint_as_float(u << 16); }
@@ -487,8 +528,9 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], float *ep, u
         // tile took 160 half-width memory instructions per wave and its epilogue 32 k cycles, against 5-8 k for the
         // bf16 outputs).  The residual rows of two m-tiles (16 loads per lane) are requested before the first transpose.
         constexpr bool SPLIT = EPI == EPI_RESID_STATS_SPLIT;
-        constexpr bool SPLIT8 = EPI == EPI_RESID_STATS_SPLIT8;
+        constexpr bool SPLIT8 = EPI == EPI_RESID_STATS_SPLIT8 || EPI == EPI_F8_RESID_STATS_SPLIT8;
         constexpr bool F32X = EPI == EPI_RESID_STATS_F32X;
+        const float ws = EPI_IS_F8(EPI) ? aux.w_scale : 1.0f;
         const uint32_t c8 = (lane & 7) * 8, rl0 = lane >> 3;
         const uint32_t col = col0 + c8;
         float4 b0 = *(const float4 *)(bias + col), b1 = *(const float4 *)(bias + col + 4);
@@ -522,6 +564,10 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], float *ep, u
                     const float4 u = *(const float4 *)(ep + ep_at(rl0, c8));
                     const float4 w = *(const float4 *)(ep + ep_at(rl0, c8) + 4);
                     float f[8] = {u.x + b0.x, u.y + b0.y, u.z + b0.z, u.w + b0.w, w.x + b1.x, w.y + b1.y, w.z + b1.z, w.w + b1.w};
+                    if constexpr (EPI_IS_F8(EPI)) {
+                        f[0] = fmaf(u.x, ws, b0.x); f[1] = fmaf(u.y, ws, b0.y); f[2] = fmaf(u.z, ws, b0.z); f[3] = fmaf(u.w, ws, b0.w);
+                        f[4] = fmaf(w.x, ws, b1.x); f[5] = fmaf(w.y, ws, b1.y); f[6] = fmaf(w.z, ws, b1.z); f[7] = fmaf(w.w, ws, b1.w);
+                    }
                     const uint32_t hw[4] = {xh[ii][k].x, xh[ii][k].y, xh[ii][k].z, xh[ii][k].w};
                     const uint32_t lw[2] = {ii ? xl[k].z : xl[k].x, ii ? xl[k].w : xl[k].y};
 #pragma unroll
@@ -638,7 +684,9 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], float *ep, u
     } else {
         // bf16 outputs: a lane owns 8 columns (one 16-byte store), 8 lanes a 128-byte row segment
         constexpr bool LN = EPI_IS_LN(EPI);
-        constexpr bool GELU = EPI == EPI_BIAS_GELU_BF16 || EPI == EPI_LN_BIAS_GELU_BF16;
+        constexpr bool GELU = EPI == EPI_BIAS_GELU_BF16 || EPI == EPI_LN_BIAS_GELU_BF16 || EPI == EPI_F8_BIAS_GELU_Q8;
+        constexpr bool Q8 = EPI == EPI_F8_BIAS_GELU_Q8;
+        const float ws = EPI_IS_F8(EPI) ? aux.w_scale : 1.0f;
         const uint32_t c8 = (lane & 7) * 8, rl0 = lane >> 3;
         const uint32_t col = col0 + c8;
         float4 b0 = *(const float4 *)(bias + col), b1 = *(const float4 *)(bias + col + 4);
@@ -703,6 +751,9 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], float *ep, u
                 f[2] = fmaf(ab.x, u.z, fmaf(ab.y, s0.z, b0.z)); f[3] = fmaf(ab.x, u.w, fmaf(ab.y, s0.w, b0.w));
                 f[4] = fmaf(ab.x, w.x, fmaf(ab.y, s1.x, b1.x)); f[5] = fmaf(ab.x, w.y, fmaf(ab.y, s1.y, b1.y));
                 f[6] = fmaf(ab.x, w.z, fmaf(ab.y, s1.z, b1.z)); f[7] = fmaf(ab.x, w.w, fmaf(ab.y, s1.w, b1.w));
+            } else if (EPI_IS_F8(EPI)) {
+                f[0] = fmaf(u.x, ws, b0.x); f[1] = fmaf(u.y, ws, b0.y); f[2] = fmaf(u.z, ws, b0.z); f[3] = fmaf(u.w, ws, b0.w);
+                f[4] = fmaf(w.x, ws, b1.x); f[5] = fmaf(w.y, ws, b1.y); f[6] = fmaf(w.z, ws, b1.z); f[7] = fmaf(w.w, ws, b1.w);
             } else {
                 f[0] = u.x + b0.x; f[1] = u.y + b0.y; f[2] = u.z + b0.z; f[3] = u.w + b0.w;
                 f[4] = w.x + b1.x; f[5] = w.y + b1.y; f[6] = w.z + b1.z; f[7] = w.w + b1.w;
@@ -712,6 +763,16 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], float *ep, u
 #pragma unroll
                 for (int e = 0; e < 8; e++)
                     f[e] *= __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930156f * f[e]));
+            }
+            if constexpr (Q8) {
+                // e4m3 + one scale byte per (row, this wave tile's 64 columns): the 8 lanes of a row agree on the largest magnitude
+                const float am = row8_max(fmaxf(fmaxf(fmaxf(fabsf(f[0]), fabsf(f[1])), fmaxf(fabsf(f[2]), fabsf(f[3]))),
+                                                fmaxf(fmaxf(fabsf(f[4]), fabsf(f[5])), fmaxf(fabsf(f[6]), fabsf(f[7])))));
+                const uint32_t sb = q8_scale_byte(am);
+                const uint32_t row = row0 + (uint32_t)((g >> 2) * 32 + (g & 3) * 8) + rl0;
+                *(uint2 *)(aux.q8 + (((size_t)(col0 >> 6) * aux.hm_rows + row) << 6) + c8) = q8_pack8(f, q8_inv_scale(sb));
+                if ((lane & 7) == 0) aux.q8_scale[q8_scale_off(aux.hm_rows, row, col0 >> 6)] = (uint8_t)sb;
+                continue;
             }
             const uint4 pk = make_uint4(pack2(f[0], f[1]), pack2(f[2], f[3]), pack2(f[4], f[5]), pack2(f[6], f[7]));
 #if (D2R_GEMM_ABLATE & 128) && defined(__HIP_DEVICE_COMPILE__)
@@ -901,6 +962,8 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void k_gemm(const uint16_t *__re
 // are in flight at every barrier and no wait ever drains the queue until the last K-tile pair.
 // Quadrant order (0,0)(0,1)(1,1)(1,0) | (0,1)(0,0)(1,0)(1,1) makes the register set that a phase
 // overwrites the one its MFMAs do not read.  Requires K % 128 == 0, N % 256 == 0.
+typedef int v8i32 __attribute__((ext_vector_type(8)));
+#define F8_B_SCALE 0x7f7f7f7f         /* the W-side scale operand: 1 (its scale is applied in the epilogue) */
 __device__ __forceinline__ void glds16s(uint32_t voff, const void *sbase, uint32_t lds_byte_addr)
 {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
@@ -1189,6 +1252,264 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
     wait_vmcnt<0>();          // the last pair's (unused) requests must have landed before the LDS is given back
 }
 
+// ---- the persistent 256x256 kernel on fp8 operands ("fp8 blocks", below) ----
+//
+// Same tile walk, staging ring, phase schedule and epilogues as k_gemm8; what differs:
+//   operands   a slot row is still 128 BYTES = now 128 elements of K.  A comes in planes [K / 64][M_pad][64 bytes] (chunks 0-3 of a slot
+//              row from one plane, 4-7 from the next: what the producers' 64-column wave tiles write), W row-major [N][K bytes].
+//   MFMA       v_mfma_scale_f32_32x32x64_f8f6f4 (16 passes, 64 elements of K: twice the bf16 instruction's work per cycle).  A lane's 32
+//              operand bytes are two of its 16-byte chunks — for MFMA s2 of a K-tile the chunks (4 s2 + hi, 4 s2 + 2 + hi), for A and for W
+//              alike, so the pairing of K elements is the same on both sides (a dot product does not care in which order) — i.e. the
+//              fragment reads are EXACTLY k_gemm8's conflict-free 16-byte reads; MFMA s2 covers the row's 64-column group 2 kt + s2.
+//   fragments  live in the FIXED registers v[160:255], named explicitly in inline asm: the instruction wants 8 consecutive registers per
+//              operand, and with 128 accumulators + 96 fragment registers of a 256-register budget hipcc cannot place 8-register tuples
+//              assembled from two 16-byte reads (it spilled 220-330 registers inside the counted-vmcnt loop; AGPRs are no way out — a
+//              kernel that names one gets its budget split 128 + 128).  fa[h][mt][s4] = v[160 + 32 h + 16 mt + 4 s4 ..+3], fb[h][s4] =
+//              v[224 + 16 h + 4 s4 ..+3].  EVERY asm statement of the K loop (reads, MFMAs, staging requests, scale loads) lists
+//              v160-v255 as clobbered, so nothing of the compiler's that is live across or feeds any of them can sit there: it keeps the
+//              accumulators, addresses and scales in v0-v159, and the epilogue has all 256 again.  tests/test_isa.py checks that no
+//              compiler-generated instruction between the loop's first and last asm statement touches v160-v255, and that the loop spills nothing.
+//   scales     one E8M0 byte per (row of A, 64-column group), applied by the MFMA (its scale operand is per lane = per row, op_sel picks the
+//              byte): one dword per (A half, K-tile) and lane, bytes (m-tile, MFMA of the K-tile) — see q8_scale_off.  The two dwords of a
+//              K-tile are re-requested (global_load_dword from inline asm, hand-counted like the staging requests) as soon as the K-tile's
+//              last quadrant has used them — K-tile 1's at the top of phase 0, K-tile 0's (of the next pair / tile) at the top of phase 4 —
+//              and are needed four phases later: every five-phase window of requests holds exactly one such batch, so every counted wait
+//              is vmcnt(12) where k_gemm8 has 10.  W's scale operand is 1; the matrix's scale is applied by the epilogue.
+#define F8_CL_FRAG "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255"
+#define F8_READ_A(name, r)                                                                                                                   \
+    template <int OFF> __device__ __forceinline__ void name(uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3)                             \
+    {                                                                                                                                        \
+        asm volatile("ds_read_b128 v[" #r "+0:" #r "+3], %0 offset:%4\n\tds_read_b128 v[" #r "+4:" #r "+7], %1 offset:%4\n\t"               \
+                     "ds_read_b128 v[" #r "+8:" #r "+11], %2 offset:%4\n\tds_read_b128 v[" #r "+12:" #r "+15], %3 offset:%4\n\t"            \
+                     "ds_read_b128 v[" #r "+16:" #r "+19], %0 offset:%5\n\tds_read_b128 v[" #r "+20:" #r "+23], %1 offset:%5\n\t"           \
+                     "ds_read_b128 v[" #r "+24:" #r "+27], %2 offset:%5\n\tds_read_b128 v[" #r "+28:" #r "+31], %3 offset:%5"               \
+                     : : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "n"(OFF), "n"(OFF + 4096) : "memory", F8_CL_FRAG);                             \
+    }
+#define F8_READ_B(name, r)                                                                                                                   \
+    template <int OFF> __device__ __forceinline__ void name(uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3)                             \
+    {                                                                                                                                        \
+        asm volatile("ds_read_b128 v[" #r "+0:" #r "+3], %0 offset:%4\n\tds_read_b128 v[" #r "+4:" #r "+7], %1 offset:%4\n\t"               \
+                     "ds_read_b128 v[" #r "+8:" #r "+11], %2 offset:%4\n\tds_read_b128 v[" #r "+12:" #r "+15], %3 offset:%4"                \
+                     : : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "n"(OFF) : "memory", F8_CL_FRAG);                                              \
+    }
+F8_READ_A(f8_read_a0, 160)
+F8_READ_A(f8_read_a1, 192)
+F8_READ_B(f8_read_b0, 224)
+F8_READ_B(f8_read_b1, 240)
+// the four MFMAs of quadrant (mh, nh): m-tiles 0 / 1 alternate (two independent chains), op_sel = 2 mt + s2 picks the scale byte
+#define F8_MFMA_Q(name, ra, rb)                                                                                                              \
+    __device__ __forceinline__ void name(f32x16 &c0, f32x16 &c1, int sa, int sb)                                                            \
+    {                                                                                                                                        \
+        asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, v[" #ra "+0:" #ra "+7], v[" #rb "+0:" #rb "+7], %0, %2, %3 op_sel_hi:[0,0,0]\n\t"  \
+                     "v_mfma_scale_f32_32x32x64_f8f6f4 %1, v[" #ra "+16:" #ra "+23], v[" #rb "+0:" #rb "+7], %1, %2, %3 op_sel_hi:[1,0,0]\n\t" \
+                     "v_mfma_scale_f32_32x32x64_f8f6f4 %0, v[" #ra "+8:" #ra "+15], v[" #rb "+8:" #rb "+15], %0, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,0,0]\n\t" \
+                     "v_mfma_scale_f32_32x32x64_f8f6f4 %1, v[" #ra "+24:" #ra "+31], v[" #rb "+8:" #rb "+15], %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" \
+                     : "+v"(c0), "+v"(c1) : "v"(sa), "v"(sb) : F8_CL_FRAG);                                                                  \
+    }
+F8_MFMA_Q(f8_mfma_00, 160, 224)
+F8_MFMA_Q(f8_mfma_01, 160, 240)
+F8_MFMA_Q(f8_mfma_10, 192, 224)
+F8_MFMA_Q(f8_mfma_11, 192, 240)
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void k_gemm8f(const uint8_t *__restrict__ A, const uint8_t *__restrict__ W, const float *__restrict__ bias,
+                                                  void *__restrict__ Cout, uint32_t M_pad, uint32_t N, uint32_t K, uint32_t n_xcd, EpiAux aux,
+                                                  uint32_t gn_split)
+{
+    static_assert(EPI_IS_F8(EPI), "fp8 epilogues only");
+    constexpr uint32_t SLOT = 128 * 128;             // 16 KiB: 128 rows x 128 bytes
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    // (tile order: see k_gemm8)
+    const uint32_t n_split = max(1u, gn_split >> 16), gn = gn_split & 0xffffu;
+    const uint32_t tiles_n = N / 256 / n_split, mp_all = M_pad / 256;
+    const uint32_t xcd = blockIdx.x % n_xcd, loc = blockIdx.x / n_xcd, per_xcd = gridDim.x / n_xcd;
+    const uint32_t csec = xcd % n_split, xr = xcd / n_split, n_xr = n_xcd / n_split;
+    const uint32_t mp_lo = (uint32_t)((uint64_t)mp_all * xr / n_xr), mp_cnt = (uint32_t)((uint64_t)mp_all * (xr + 1) / n_xr) - mp_lo;
+    const uint32_t t_end = mp_cnt * tiles_n;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t wm = wave >> 2, wn = wave & 3;
+
+    f32x16 acc[4][2];
+
+    // Per-lane state of the K loop (staging offsets, fragment addresses, scale offset): set up afresh for every tile from a lane id the
+    // optimiser cannot see through, so that none of it is live across the epilogue — which needs all 128 registers for the accumulators
+    // and more, and would otherwise push these values to scratch and reload them INSIDE the loop (scratch loads share vmcnt with the
+    // hand-counted requests).
+    // staging: a piece = 8 slot rows x 128 bytes per wave instruction (two pieces, 64 slot rows apart, per wave and half-tile)
+    const uint32_t a_plane = M_pad * 64u;                                     // bytes per plane of A (4 planes < 2^32: checked on the host)
+    uint32_t voffA = 0, voffB = 0, aoff[4] = {0, 0, 0, 0};
+    auto lane_setup = [&]() {
+        uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        asm volatile("" : "+v"(lane));
+        const uint32_t li = lane & 31, hi = lane >> 5, r_in = lane >> 3, pc = lane & 7;
+        const uint32_t sr = wave * 8 + r_in;
+        const uint32_t chunk = pc ^ ((sr >> 1) & 7u);
+        voffA = sr * 64u + (chunk >> 2) * a_plane + (chunk & 3u) * 16u;
+        voffB = ((sr >> 5) * 64 + (sr & 31)) * K + chunk * 16u;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) aoff[s4] = (wm * 64 + li) * 128 + (((2 * s4 + hi) ^ ((li >> 1) & 7u)) << 4);
+    };
+    lane_setup();
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+    const uint32_t nk = K / 128u;
+    uint32_t m0 = 0, n0 = 0;
+    const uint8_t *src[8];
+    auto kind_is_a = [](int kind) { return kind == 0 || kind == 3 || kind == 4 || kind == 7; };
+    auto seat = [&](int kind, uint32_t tm, uint32_t tn) -> const uint8_t * {
+        const uint32_t h = (kind == 2 || kind == 3 || kind == 5 || kind == 7) ? 1u : 0u;
+        return kind_is_a(kind) ? A + (size_t)(tm + h * 64) * 64u + (kind >= 4 ? 2 * (size_t)a_plane : (size_t)0)
+                               : W + (size_t)(tn + h * 32) * K + (kind >= 4 ? (size_t)128 : (size_t)0);
+    };
+    auto stage = [&](int kind) {
+        const bool isA = kind_is_a(kind);
+        const uint8_t *base = src[kind];
+        src[kind] = base + (isA ? 4 * (size_t)a_plane : (size_t)256);        // two K-tiles on
+#pragma unroll
+        for (int qq = 0; qq < 2; qq++)
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                         : : "v"(isA ? voffA : voffB), "s"(base + (size_t)qq * 128 * (isA ? (size_t)64 : (size_t)K)), "s"(lds0 + kind * SLOT + (wave + qq * 8) * 1024)
+                         : "memory", F8_CL_FRAG);
+    };
+    // scale dwords [K-tile parity][A half]; "+v": a loop-carried value that the asm rewrites keeps ONE register
+    int sc[2][2] = {{0, 0}, {0, 0}};
+    const uint32_t sc_kt = M_pad >> 1;                // dwords between K-tiles
+    const uint32_t *sc_src[2] = {nullptr, nullptr};
+    auto load_scales = [&](int kt) {
+        // dword (64-row block 2 wm + mh, lane li) of a K-tile's array, mh: + 128 bytes; (wm * 64 + li) * 4 from a fragment address (the
+        // swizzle term is < 128) rather than one more register held through the loop
+        const uint32_t sc_voff = (aoff[0] >> 5) & ~3u;
+        asm volatile("global_load_dword %0, %2, %3\n\tglobal_load_dword %1, %2, %3 offset:128"
+                     : "+v"(sc[kt][0]), "+v"(sc[kt][1]) : "v"(sc_voff), "s"(sc_src[kt]) : "memory", F8_CL_FRAG);
+        sc_src[kt] += 2 * (size_t)sc_kt;
+    };
+    auto tile_origin = [&](uint32_t t, uint32_t &tm, uint32_t &tn) {
+        const uint32_t per_group = mp_cnt * gn;
+        const uint32_t g = t / per_group, r = t - g * per_group;
+        const uint32_t gw = min(gn, tiles_n - g * gn);
+        const uint32_t mi = r / gw;
+        tm = (mp_lo + mi) * 256;
+        tn = (csec * tiles_n + g * gn + (r - mi * gw)) * 256;
+    };
+    const uint32_t d_ab = (wn * 32 - wm * 64) * 128;          // B addresses = A addresses + this (wave-uniform, modulo 2^32)
+    auto bar = [&]() {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    using std::integral_constant;
+    // fragment reads of half-tile `kind` (slot kind: kinds 4-7 lie beyond the 64 KiB reach of the offset field)
+    auto read_pos = [&](auto kind_tag) {
+        constexpr int KIND = decltype(kind_tag)::value;
+        constexpr bool isA = KIND == 0 || KIND == 3 || KIND == 4 || KIND == 7;
+        constexpr int h = (KIND == 2 || KIND == 3 || KIND == 5 || KIND == 7) ? 1 : 0;
+        constexpr int OFF = (KIND & 3) * (int)SLOT;
+        uint32_t add = (isA ? 0u : d_ab) + (KIND >= 4 ? 65536u : 0u);
+        if (isA) asm volatile("" : "+v"(add));       // not loop-invariant for the optimiser: four temporaries, not sixteen address registers
+        else asm volatile("" : "+s"(add));
+        if constexpr (isA && h == 0) f8_read_a0<OFF>(aoff[0] + add, aoff[1] + add, aoff[2] + add, aoff[3] + add);
+        else if constexpr (isA) f8_read_a1<OFF>(aoff[0] + add, aoff[1] + add, aoff[2] + add, aoff[3] + add);
+        else if constexpr (h == 0) f8_read_b0<OFF>(aoff[0] + add, aoff[1] + add, aoff[2] + add, aoff[3] + add);
+        else f8_read_b1<OFF>(aoff[0] + add, aoff[1] + add, aoff[2] + add, aoff[3] + add);
+    };
+
+    uint32_t t = loc;
+    if (t >= t_end) return;
+    tile_origin(t, m0, n0);
+#pragma unroll
+    for (int kind = 0; kind < 8; kind++) {
+        src[kind] = seat(kind, m0, n0);
+        stage(kind);
+    }
+    float *ep = (float *)(smem + 8 * SLOT) + wave * EP_WAVE_FLOATS;
+
+    for (;;) {
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    if (t != loc) lane_setup();                       // (the first tile's was needed by the prologue's requests)
+    int b_scale = 0x7f7f7f7f;                         // W-side scale operand: 1 (scale operands must be VGPRs)
+    asm volatile("" : "+v"(b_scale));
+    // the scale registers start afresh too (nothing of the K loop's is live across an epilogue): the first K-tile's are requested here
+    // and drained with everything else just below
+    sc[0][0] = sc[0][1] = sc[1][0] = sc[1][1] = 0;
+    asm volatile("" : "+v"(sc[0][0]), "+v"(sc[0][1]), "+v"(sc[1][0]), "+v"(sc[1][1]));
+    sc_src[0] = aux.a_scale + (m0 >> 1);              // (m0 / 64) blocks x 32 dwords
+    sc_src[1] = sc_src[0] + sc_kt;
+    load_scales(0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): the previous tile's epilogue stores, the staged first K-tile pair
+    wait_vmcnt<0>();
+    bar();
+    read_pos(integral_constant<int, 0>{});
+    read_pos(integral_constant<int, 1>{});
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    bar();
+    if (wm == 1) bar();                               // the wave rows run half a phase apart (k_gemm8)
+    if (wm == 0) __builtin_amdgcn_s_setprio(1);
+
+    const uint32_t t_next = t + per_xcd;
+    const bool has_next = t_next < t_end;
+    uint32_t m0n = 0, n0n = 0;
+    if (has_next) tile_origin(t_next, m0n, n0n);
+    const uint32_t n_iter = nk / 2;
+    for (uint32_t u = 0; u < n_iter; u++) {
+        const bool last = u + 1 == n_iter;
+        auto phase = [&](auto p_tag) {
+            constexpr int P = decltype(p_tag)::value;
+            // K-tile 1's scales of THIS pair at the top of phase 0, K-tile 0's of the NEXT pair at the top of phase 4: each into the
+            // registers whose last reader was the phase before
+            if constexpr (P == 0) load_scales(1);
+            if constexpr (P == 4) {
+                if (last) sc_src[0] = aux.a_scale;    // two requests all the same (the waits count them): valid, never used, and kept
+                load_scales(0);                       // "live" until they have landed (below) so that nothing else is given their registers
+            }
+            if (!(last && P >= 6)) read_pos(integral_constant<int, (P + 2) & 7>{});
+            if (last) src[P] = seat(P, m0n, n0n);
+            stage(P);
+            wait_vmcnt<12>();
+            __builtin_amdgcn_sched_barrier(0);
+            bar();
+            constexpr int mh = (P == 2 || P == 3 || P == 6 || P == 7) ? 1 : 0;
+            constexpr int nh = (P == 1 || P == 2 || P == 4 || P == 7) ? 1 : 0;
+            constexpr int kt = P >= 4 ? 1 : 0;
+            if constexpr (mh == 0 && nh == 0) f8_mfma_00(acc[0][0], acc[1][0], sc[kt][0], b_scale);
+            else if constexpr (mh == 0) f8_mfma_01(acc[0][1], acc[1][1], sc[kt][0], b_scale);
+            else if constexpr (nh == 0) f8_mfma_10(acc[2][0], acc[3][0], sc[kt][1], b_scale);
+            else f8_mfma_11(acc[2][1], acc[3][1], sc[kt][1], b_scale);
+            __builtin_amdgcn_sched_barrier(0);
+            wait_vmcnt<12>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            bar();
+        };
+        phase(integral_constant<int, 0>{});
+        phase(integral_constant<int, 1>{});
+        phase(integral_constant<int, 2>{});
+        phase(integral_constant<int, 3>{});
+        phase(integral_constant<int, 4>{});
+        phase(integral_constant<int, 5>{});
+        phase(integral_constant<int, 6>{});
+        phase(integral_constant<int, 7>{});
+    }
+    if (wm == 0) bar();
+    __builtin_amdgcn_s_setprio(0);
+    wait_vmcnt<8>();          // every scale request has landed (only the last four phases' staging requests are younger)
+    asm volatile("" : : "v"(sc[0][0]), "v"(sc[0][1]), "v"(sc[1][0]), "v"(sc[1][1]));
+    // the MFMAs above are inline asm: hipcc does not know that they wrote the accumulators and pads no MFMA -> VALU / LDS hazard
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    const uint32_t em = m0 + wm * 128, en = n0 + wn * 64;
+    uint32_t lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(lane_e));          // nothing of the epilogue's per-lane addressing is hoisted above the K loop (it has 128 registers)
+    gemm_epilogue<EPI, 4>(acc, ep, lane_e, em, en, bias, Cout, N, aux, (const float2 *)nullptr);
+    if (!has_next) break;
+    t = t_next;
+    m0 = m0n;
+    n0 = n0n;
+    }
+    wait_vmcnt<0>();          // the last pair's (unused) requests must have landed before the LDS is given back
+}
+
 // -------------------------------------------------------- embeddings + LN
 
 // X[b*T + t] = pre_layrnorm( (t==0 ? class_embedding : patch_out[b*(T-1)+t-1]) + position[t] )
@@ -1298,6 +1619,101 @@ __global__ void k_rowstats(const float2 *__restrict__ part, uint32_t np, uint32_
     }
     const float mu = s * inv_d, r = 1.0f / sqrtf(fmaxf(q * inv_d - mu * mu, 0.f) + 1e-5f);
     AB[row] = make_float2(r, -r * mu);
+}
+
+// ---- fp8 blocks (option "vit_fp8": BASELINE.json configs[4] names an "fp8 MFMA ViT") ----
+//
+// The four Linear products of a transformer block on the MX-scaled fp8 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4, twice the bf16 rate):
+//   activations  OCP e4m3, one E8M0 scale byte per (row, group of 64 columns): 2^(byte - 127) is the smallest power of two with
+//                amax / scale <= 448 (q8_scale_byte), the element = round-to-nearest-even e4m3 of x / scale.  Bytes in planes
+//                [cols / 64][M_pad][64]; scale bytes [cols / 256][M_pad][4] (the consumer fetches one dword per row and K-tile pair)
+//   weights      e4m3 of w / s_w, s_w = ONE power of two per matrix (a floating-point format loses nothing to a coarse scale while the
+//                values stay in its normal range: 2^-6 .. 448, a factor 28 672 under the matrix's largest weight); row-major [N][K]
+//   accumulation fp32; the epilogue multiplies by s_w, adds the bias and goes on as the bf16 kernels do (the residual stream, the
+//                LayerNorm statistics, q / k / v and the attention arithmetic stay as they are)
+// Producers: k_ln_q8 (LayerNorm -> operand of QKV and fc1), k_attention_s<NW, true> (-> operand of the out-projection),
+// EPI_F8_BIAS_GELU_Q8 (fc1 -> operand of fc2).  The quantisation is a bit-level specification (oracle/clip_fp8.py restates it): the
+// parity tests hold the HIP path to that restatement at the bf16 path's bar and REPORT what the specification costs against fp32.
+
+// LayerNorm of the residual's bf16 hi copy -> e4m3 operand: y = (x * rstd - rstd * mean) * gamma + beta with the row's (rstd, -rstd * mean)
+// from k_rowstats.  A work item = 64 rows of one 64-column plane; a thread takes 8 columns of rows r and r + 32, the 8 lanes of a row
+// agree on its scale.  Persistent grid (one item per workgroup would be two million dispatches per call at configs[4]).
+__global__ __launch_bounds__(256) void k_ln_q8(const uint16_t *__restrict__ Xhi, const float2 *__restrict__ AB, const float *__restrict__ gamma,
+                                               const float *__restrict__ beta, uint32_t M_pad, uint32_t d, uint8_t *__restrict__ A8,
+                                               uint8_t *__restrict__ SA)
+{
+    const uint32_t planes = d >> 6, items = planes * (M_pad >> 6);
+    const uint32_t c8 = (threadIdx.x & 7) * 8, r = threadIdx.x >> 3;
+    for (uint32_t it = blockIdx.x; it < items; it += gridDim.x) {
+        const uint32_t p = it % planes, b = it / planes;
+        const float4 g0 = *(const float4 *)(gamma + p * 64 + c8), g1 = *(const float4 *)(gamma + p * 64 + c8 + 4);
+        const float4 e0 = *(const float4 *)(beta + p * 64 + c8), e1 = *(const float4 *)(beta + p * 64 + c8 + 4);
+        const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bt[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+        uint4 h[2];
+        float2 ab[2];
+#pragma unroll
+        for (int ii = 0; ii < 2; ii++) {
+            const size_t row = (size_t)b * 64 + r + 32 * ii;
+            h[ii] = *(const uint4 *)(Xhi + ((size_t)p * M_pad + row) * 64 + c8);
+            ab[ii] = AB[row];
+        }
+#pragma unroll
+        for (int ii = 0; ii < 2; ii++) {
+            const size_t row = (size_t)b * 64 + r + 32 * ii;
+            const uint32_t hw[4] = {h[ii].x, h[ii].y, h[ii].z, h[ii].w};
+            float f[8];
+            float am = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const float x = (e & 1) ? bf_hi(hw[e >> 1]) : bf_lo(hw[e >> 1]);
+                f[e] = fmaf(fmaf(x, ab[ii].x, ab[ii].y), gm[e], bt[e]);
+                am = fmaxf(am, fabsf(f[e]));
+            }
+            const uint32_t sb = q8_scale_byte(row8_max(am));
+            *(uint2 *)(A8 + (((size_t)p * M_pad + row) << 6) + c8) = q8_pack8(f, q8_inv_scale(sb));
+            if ((threadIdx.x & 7) == 0) SA[q8_scale_off(M_pad, row, p)] = (uint8_t)sb;
+        }
+    }
+}
+
+// weights: largest magnitude of a bf16 matrix (as the bits of its fp32 value), then e4m3 of w / 2^(scale byte - 127)
+__global__ __launch_bounds__(256) void k_amax_bf16(const uint16_t *__restrict__ W, size_t n, uint32_t *__restrict__ amax_bits)
+{
+    uint32_t m = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) m = max(m, (uint32_t)(W[i] & 0x7fffu) << 16);
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(amax_bits, m);
+}
+__global__ __launch_bounds__(256) void k_quant_w8(const uint16_t *__restrict__ W, size_t n, const uint32_t *__restrict__ amax_bits,
+                                                  uint8_t *__restrict__ W8)
+{
+    const float inv = q8_inv_scale(q8_scale_byte(__uint_as_float(*amax_bits)));
+    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * blockDim.x * 4) {
+        const uint2 w = *(const uint2 *)(W + i);
+        uint32_t q = __builtin_amdgcn_cvt_pk_fp8_f32(bf_lo(w.x) * inv, bf_hi(w.x) * inv, 0, false);
+        q = __builtin_amdgcn_cvt_pk_fp8_f32(bf_lo(w.y) * inv, bf_hi(w.y) * inv, q, true);
+        *(uint32_t *)(W8 + i) = q;
+    }
+}
+// parity hook (d2r_debug_gemm_fp8): fp32 row-major [M][K] -> the activation format above; rows >= M are written as zeros
+__global__ __launch_bounds__(256) void k_quant_rows_q8(const float *__restrict__ A, uint32_t M, uint32_t K, uint32_t M_pad, uint8_t *__restrict__ A8,
+                                                       uint8_t *__restrict__ SA)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;           // (row, 8-column group)
+    const uint32_t per_row = K >> 3;
+    const size_t row = t / per_row;
+    if (row >= M_pad) return;
+    const uint32_t col = (uint32_t)(t - row * per_row) * 8;
+    float f[8];
+    float am = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        f[e] = row < M ? A[row * K + col + e] : 0.f;
+        am = fmaxf(am, fabsf(f[e]));
+    }
+    const uint32_t sb = q8_scale_byte(row8_max(am));
+    *(uint2 *)(A8 + (((size_t)(col >> 6) * M_pad + row) << 6) + (col & 63)) = q8_pack8(f, q8_inv_scale(sb));
+    if ((col & 63) == 0) SA[q8_scale_off(M_pad, row, col >> 6)] = (uint8_t)sb;
 }
 
 // ---- layer-0 reuse of background tokens (d2r_render_score) ----
@@ -1790,9 +2206,10 @@ __device__ __forceinline__ void ats_softmax(f32x16 &sacc, f32x16 &o0, f32x16 &o1
 // count is 8g + r with a small r (257 tokens: r = 1; 577: r = 3) — the same per-wave arithmetic in a workgroup with as many
 // waves as it has query tiles, every wave staging 8 / NW slices of each key tile, so that a CU holds four such workgroups
 // (LDS-limited) with every wave computing, instead of two eight-wave workgroups with one active wave each.
-template <int NW>
+// Q8: the output as the fp8 blocks' e4m3 operand (planes of 64 BYTES per row, AOS = the scale bytes; see "fp8 blocks")
+template <int NW, bool Q8 = false>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void k_attention_s(const uint16_t *__restrict__ QKV, uint16_t *__restrict__ AO, uint32_t T,
-                                                                          uint32_t d, uint32_t M_pad, uint32_t qt0)
+                                                                          uint32_t d, uint32_t M_pad, uint32_t qt0, uint8_t *__restrict__ AOS = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int NS = 8 / NW;                            // key-tile slices (1 KiB each: eight K or eight V rows) a wave stages
@@ -1973,6 +2390,33 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void k_attention_s(const 
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     const uint32_t lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     const uint32_t qrow_e = qt * 32 + (lane_e & 31);
+    if constexpr (Q8) {
+        // reg 4j + i of o_t <-> dim 32t + 8j + 4hi + i: a dword of four e4m3 per (t, j); the halves swap dwords so that a lane stores 8
+        // consecutive dims (hi = 0: 16g .. 16g+7, hi = 1: 16g+8 .. 16g+15 of each 32-dim tile)
+        float am = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) am = fmaxf(am, fmaxf(fabsf(o0[r]), fabsf(o1[r])));
+        am *= inv_l;
+        const u32x2 ams = __builtin_amdgcn_permlane32_swap(__float_as_uint(am), __float_as_uint(am), false, false);
+        const uint32_t sb = q8_scale_byte(fmaxf(__uint_as_float(ams[0]), __uint_as_float(ams[1])));
+        const float sc = inv_l * q8_inv_scale(sb);
+        uint8_t *dst8 = (uint8_t *)AO + (((size_t)head * M_pad + row_base + qrow_e) << 6) + 8 * (lane_e >> 5);
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const f32x16 &o = t ? o1 : o0;
+#pragma unroll
+            for (int g = 0; g < 2; g++) {
+                uint32_t a = __builtin_amdgcn_cvt_pk_fp8_f32(o[8 * g + 0] * sc, o[8 * g + 1] * sc, 0, false);
+                a = __builtin_amdgcn_cvt_pk_fp8_f32(o[8 * g + 2] * sc, o[8 * g + 3] * sc, a, true);
+                uint32_t b = __builtin_amdgcn_cvt_pk_fp8_f32(o[8 * g + 4] * sc, o[8 * g + 5] * sc, 0, false);
+                b = __builtin_amdgcn_cvt_pk_fp8_f32(o[8 * g + 6] * sc, o[8 * g + 7] * sc, b, true);
+                const u32x2 x = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+                if (qrow_e < T) *(uint2 *)(dst8 + 32 * t + 16 * g) = make_uint2(x[0], x[1]);
+            }
+        }
+        if (qrow_e < T && lane_e < 32) AOS[q8_scale_off(M_pad, row_base + qrow_e, head)] = (uint8_t)sb;
+        return;
+    }
     uint16_t *dst = AO + ((size_t)head * M_pad + row_base + qrow_e) * 64 + 8 * (lane_e >> 5);   // tile-major: head h is plane h of [d/64][M_pad][64]
 #pragma unroll
     for (int t = 0; t < 2; t++) {
@@ -2349,6 +2793,55 @@ static int launch_gemm_cfg(d2r_ctx *ctx, const uint16_t *A, const uint16_t *W, c
     return D2R_OK;
 }
 
+// the persistent 256x256 kernel (bf16 operands: K % 128 == 0; fp8 operands, EPI_F8_*: K in bytes, K % 256 == 0); N % 256 == 0
+template <int EPI>
+static int launch_gemm8(d2r_ctx *ctx, const uint16_t *A, const uint16_t *W, const float *bias, void *C, uint32_t M_real, uint32_t N, uint32_t K,
+                        const EpiAux &aux)
+{
+    const uint64_t tiles256 = (uint64_t)(round_up(M_real, BM) / 256) * (N / 256);
+    constexpr uint32_t ELEM = EPI_IS_F8(EPI) ? 1u : 2u;          // operand bytes per element
+    const uint32_t M_pad = round_up(M_real, BM);
+    constexpr uint32_t LDS8 = 128 * 1024 + 8 * EP_WAVE_FLOATS * 4 + 8 * 1024;     // ring + transpose buffers + (rstd, -rstd*mean) strips
+    static PerDeviceOnce attr8;
+    attr8.run(ctx->device, [] {
+        if constexpr (EPI_IS_F8(EPI)) (void)hipFuncSetAttribute((const void *)k_gemm8f<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS8);
+        else (void)hipFuncSetAttribute((const void *)k_gemm8<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS8);
+    });
+    // persistent: one workgroup per CU (a multiple of the XCD count, so every XCD gets the same number)
+    const uint32_t nwg8 = (uint32_t)(ctx->n_cu / ctx->n_xcd * ctx->n_xcd);
+    // one eighth of a tile period in s_sleep(127) units (8 128 cycles each): a K-tile costs ~2.9 k cycles, an epilogue 5-18 k
+    const uint32_t tiles_per_wg = (uint32_t)((tiles256 + nwg8 - 1) / nwg8);
+    const uint32_t period = (K * ELEM / 128u) * 2900u + 9000u;
+    const uint32_t sleeps = (ctx->gemm_stagger && tiles_per_wg >= 4) ? std::max(1u, period / 8u / 8128u) : 0u;
+    // column tiles per group of the tile order: the choice that misses the L2 least by a simple model —
+    // every group re-reads A once; a group whose W panels (gn * K * 512 B) fit beside the streaming A stays
+    // resident, a wider one is re-read every round of workgroups
+    uint32_t gn = (uint32_t)ctx->gemm_group;
+    if (gn == 0) {
+        const uint32_t tn = N / 256;
+        const double a_bytes = (double)M_pad * K * ELEM, w_bytes = (double)N * K * ELEM;
+        const double rounds = (double)tiles256 / (double)nwg8 * ctx->n_xcd, l2_budget = 2.0 * 1024 * 1024;
+        double best = 1e300;
+        for (uint32_t g = 1; g <= tn; g++) {
+            const double cost = a_bytes * ((tn + g - 1) / g) + ((double)g * K * 256.0 * ELEM <= l2_budget ? w_bytes : w_bytes * rounds);
+            if (cost < best) { best = cost; gn = g; }
+        }
+    }
+    gn = std::max(1u, std::min(gn, N / 256));
+    // column sections: only when they divide the XCDs and the column tiles evenly
+    uint32_t ns = (uint32_t)ctx->gemm_nsplit;
+    if (ns == 0) ns = 2;            // default: two sections where they fit (fc1: -0.2 ms per launch; four measure the same)
+    if (ns < 1 || (uint32_t)ctx->n_xcd % ns || (N / 256) % ns) ns = 1;
+    if constexpr (EPI_IS_F8(EPI))
+        hipLaunchKernelGGL((k_gemm8f<EPI>), dim3(nwg8), dim3(512), LDS8, ctx->stream, (const uint8_t *)A, (const uint8_t *)W, bias, C, M_pad, N, K,
+                           (uint32_t)ctx->n_xcd, aux, (ns << 16) | std::min(gn, 0xffffu));
+    else
+    hipLaunchKernelGGL((k_gemm8<EPI>), dim3(nwg8), dim3(512), LDS8, ctx->stream, A, W, bias, C, M_pad, N, K,
+                       (uint32_t)ctx->n_xcd, aux, sleeps, (ns << 16) | std::min(gn, 0xffffu));
+    D2R_HIP(ctx, hipGetLastError());
+    return D2R_OK;
+}
+
 template <int EPI>
 static int launch_gemm(d2r_ctx *ctx, const uint16_t *A, const uint16_t *W, const float *bias, void *C,
                        uint32_t M_real, uint32_t N, uint32_t K, const EpiAux &aux = EpiAux{})
@@ -2366,61 +2859,55 @@ static int launch_gemm(d2r_ctx *ctx, const uint16_t *A, const uint16_t *W, const
     // 256x256 tiles whenever they still cover the 256 CUs at least ~4 times, else 256x128
     const uint64_t tiles256 = (uint64_t)(round_up(M_real, BM) / 256) * (N / 256);
     if (N % 256 == 0 && (N >= 2048 || tiles256 >= 1024)) {
-        if (K % 128 == 0 && ctx->gemm_cfg != 1) {         // gemm_cfg 1 = the two-stage K loop (kept for comparison)
-            const uint32_t M_pad = round_up(M_real, BM);
-            constexpr uint32_t LDS8 = 128 * 1024 + 8 * EP_WAVE_FLOATS * 4 + 8 * 1024;     // ring + transpose buffers + (rstd, -rstd*mean) strips
-            static PerDeviceOnce attr8;
-            attr8.run(ctx->device, [] {
-                (void)hipFuncSetAttribute((const void *)k_gemm8<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS8);
-            });
-            // persistent: one workgroup per CU (a multiple of the XCD count, so every XCD gets the same number)
-            const uint32_t nwg8 = (uint32_t)(ctx->n_cu / ctx->n_xcd * ctx->n_xcd);
-            // one eighth of a tile period in s_sleep(127) units (8 128 cycles each): a K-tile costs ~2.9 k cycles, an epilogue 5-18 k
-            const uint32_t tiles_per_wg = (uint32_t)((tiles256 + nwg8 - 1) / nwg8);
-            const uint32_t period = (K / BK) * 2900u + 9000u;
-            const uint32_t sleeps = (ctx->gemm_stagger && tiles_per_wg >= 4) ? std::max(1u, period / 8u / 8128u) : 0u;
-            // column tiles per group of the tile order: the choice that misses the L2 least by a simple model —
-            // every group re-reads A once; a group whose W panels (gn * K * 512 B) fit beside the streaming A stays
-            // resident, a wider one is re-read every round of workgroups
-            uint32_t gn = (uint32_t)ctx->gemm_group;
-            if (gn == 0) {
-                const uint32_t tn = N / 256;
-                const double a_bytes = (double)M_pad * K * 2.0, w_bytes = (double)N * K * 2.0;
-                const double rounds = (double)tiles256 / (double)nwg8 * ctx->n_xcd, l2_budget = 2.0 * 1024 * 1024;
-                double best = 1e300;
-                for (uint32_t g = 1; g <= tn; g++) {
-                    const double cost = a_bytes * ((tn + g - 1) / g) + ((double)g * K * 512.0 <= l2_budget ? w_bytes : w_bytes * rounds);
-                    if (cost < best) { best = cost; gn = g; }
-                }
-            }
-            gn = std::max(1u, std::min(gn, N / 256));
-            // column sections: only when they divide the XCDs and the column tiles evenly
-            uint32_t ns = (uint32_t)ctx->gemm_nsplit;
-            if (ns == 0) ns = 2;            // default: two sections where they fit (fc1: -0.2 ms per launch; four measure the same)
-            if (ns < 1 || (uint32_t)ctx->n_xcd % ns || (N / 256) % ns) ns = 1;
-            hipLaunchKernelGGL((k_gemm8<EPI>), dim3(nwg8), dim3(512), LDS8, ctx->stream, A, W, bias, C, M_pad, N, K,
-                               (uint32_t)ctx->n_xcd, aux, sleeps, (ns << 16) | std::min(gn, 0xffffu));
-            D2R_HIP(ctx, hipGetLastError());
-            return D2R_OK;
-        }
+        if (K % 128 == 0 && ctx->gemm_cfg != 1)          // gemm_cfg 1 = the two-stage K loop (kept for comparison)
+            return launch_gemm8<EPI>(ctx, A, W, bias, C, M_real, N, K, aux);
         return launch_gemm_cfg<EPI, 2, 4, 4, 2>(ctx, A, W, bias, C, M_real, N, K, aux);
     }
     return launch_gemm_cfg<EPI, 4, 2, 2, 3>(ctx, A, W, bias, C, M_real, N, K, aux);
 }
 
+// fp8 operands ("fp8 blocks"): A8 = e4m3 planes [K / 64][M_pad][64] with scale dwords a_scale [K / 256][M_pad], W8 = e4m3 [N][K], one scale
+template <int EPI>
+static int launch_gemm_f8(d2r_ctx *ctx, const uint8_t *A8, const uint8_t *a_scale, const uint8_t *W8, float w_scale, const float *bias, void *C,
+                          uint32_t M_real, uint32_t N, uint32_t K, EpiAux aux)
+{
+    static_assert(EPI_IS_F8(EPI), "fp8 epilogues only");
+    const uint64_t M_pad = round_up(M_real, BM);
+    if (N % 256 || K % 256) return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "fp8 GEMM needs N and K to be multiples of 256");
+    if (M_pad * N >= (1ull << 32) || M_pad * 64 * 4 >= (1ull << 32) || (uint64_t)N * K >= (1ull << 32))
+        return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "fp8 GEMM operand too large for 32-bit indexing");
+    if (EPI_IS_STATS(EPI) && (M_pad * N * 2 >= (1ull << 32) || aux.hm_rows != M_pad))
+        return d2r_fail(ctx, D2R_ERR_INVALID, "residual + statistics epilogues write tile-major planes of M_pad rows (< 4 GiB)");
+    if (EPI == EPI_F8_BIAS_GELU_Q8 && (aux.hm_rows != M_pad || !aux.q8 || !aux.q8_scale))
+        return d2r_fail(ctx, D2R_ERR_INVALID, "fp8 output planes have M_pad rows");
+    aux.a_scale = (const uint32_t *)a_scale;
+    aux.w_scale = w_scale;
+    return launch_gemm8<EPI>(ctx, (const uint16_t *)A8, (const uint16_t *)W8, bias, C, M_real, N, K, aux);
+}
+
 // vision tower: streamed attention, one workgroup per (image, head, group of eight query tiles)
 static void launch_attention_vision(d2r_ctx *ctx, const uint16_t *QKV, uint16_t *AO, uint32_t T, uint32_t d, uint32_t M_pad,
-                                    uint32_t n_heads, uint32_t n)
+                                    uint32_t n_heads, uint32_t n, uint8_t *q8_scales = nullptr)
 {
     // n_qt = 8 g + r query tiles: g full groups on the eight-wave kernel; a short remainder (r <= 4) on workgroups of
     // r (rounded up to 1 / 2 / 4) waves, r >= 5 as one more eight-wave group
     const uint32_t n_qt = (T + 31) / 32, r = n_qt % 8, g = r == 0 || r > (uint32_t)ctx->attn_rem ? (n_qt + 7) / 8 : n_qt / 8;
     const uint32_t lds = ATS_STAGES * ATS_SLOT;
-    if (g) hipLaunchKernelGGL((k_attention_s<8>), dim3(n_heads, n, g), dim3(512), lds, ctx->stream, QKV, AO, T, d, M_pad, 0u);
+    uint8_t *const no_scales = nullptr;
+    if (q8_scales) {              // "fp8 blocks": e4m3 output + scale bytes
+        if (g) hipLaunchKernelGGL((k_attention_s<8, true>), dim3(n_heads, n, g), dim3(512), lds, ctx->stream, QKV, AO, T, d, M_pad, 0u, q8_scales);
+        if (g * 8 < n_qt) {
+            if (r == 1) hipLaunchKernelGGL((k_attention_s<1, true>), dim3(n_heads, n, 1), dim3(64), lds, ctx->stream, QKV, AO, T, d, M_pad, g * 8, q8_scales);
+            else if (r == 2) hipLaunchKernelGGL((k_attention_s<2, true>), dim3(n_heads, n, 1), dim3(128), lds, ctx->stream, QKV, AO, T, d, M_pad, g * 8, q8_scales);
+            else hipLaunchKernelGGL((k_attention_s<4, true>), dim3(n_heads, n, 1), dim3(256), lds, ctx->stream, QKV, AO, T, d, M_pad, g * 8, q8_scales);
+        }
+        return;
+    }
+    if (g) hipLaunchKernelGGL((k_attention_s<8>), dim3(n_heads, n, g), dim3(512), lds, ctx->stream, QKV, AO, T, d, M_pad, 0u, no_scales);
     if (g * 8 < n_qt) {
-        if (r == 1) hipLaunchKernelGGL((k_attention_s<1>), dim3(n_heads, n, 1), dim3(64), lds, ctx->stream, QKV, AO, T, d, M_pad, g * 8);
-        else if (r == 2) hipLaunchKernelGGL((k_attention_s<2>), dim3(n_heads, n, 1), dim3(128), lds, ctx->stream, QKV, AO, T, d, M_pad, g * 8);
-        else hipLaunchKernelGGL((k_attention_s<4>), dim3(n_heads, n, 1), dim3(256), lds, ctx->stream, QKV, AO, T, d, M_pad, g * 8);
+        if (r == 1) hipLaunchKernelGGL((k_attention_s<1>), dim3(n_heads, n, 1), dim3(64), lds, ctx->stream, QKV, AO, T, d, M_pad, g * 8, no_scales);
+        else if (r == 2) hipLaunchKernelGGL((k_attention_s<2>), dim3(n_heads, n, 1), dim3(128), lds, ctx->stream, QKV, AO, T, d, M_pad, g * 8, no_scales);
+        else hipLaunchKernelGGL((k_attention_s<4>), dim3(n_heads, n, 1), dim3(256), lds, ctx->stream, QKV, AO, T, d, M_pad, g * 8, no_scales);
     }
 }
 
@@ -2502,6 +2989,54 @@ int d2r_clip_layer0_background(d2r_ctx *ctx, const d2r_clip *clip, const uint16_
     out->bg_ab = ab;
     out->bg_qkv = qkv;
     out->bg_rows = R;
+    return D2R_OK;
+}
+
+// "fp8 blocks": the e4m3 copies of the Linear weights (from the bf16 operand copies: what the bf16 path multiplies with), on first use
+static int ensure_f8_weights(d2r_ctx *ctx, d2r_clip *clip)
+{
+    std::lock_guard<std::mutex> lock(clip->f8_mu);
+    if (!clip->f8.empty()) return D2R_OK;
+    const d2r_clip_desc &D = clip->desc;
+    const size_t d = D.hidden_size, mlp = D.mlp_size, nl = D.num_layers;
+    const size_t sizes[4] = {3 * d * d, d * d, mlp * d, d * mlp};
+    const size_t per_layer = sizes[0] + sizes[1] + sizes[2] + sizes[3];
+    uint8_t *w8 = nullptr;
+    uint32_t *amax = nullptr;
+    if (hipMalloc(&w8, per_layer * nl) != hipSuccess || hipMalloc(&amax, nl * 4 * 4) != hipSuccess) {
+        if (w8) (void)hipFree(w8);
+        return d2r_fail(ctx, D2R_ERR_MEMORY, "hipMalloc failed for the fp8 weight copies");
+    }
+    clip->allocs.push_back(w8);
+    clip->allocs.push_back(amax);
+    D2R_HIP(ctx, hipMemsetAsync(amax, 0, nl * 16, ctx->stream));
+    std::vector<d2r_clip::F8Layer> f8(nl);
+    for (size_t l = 0; l < nl; l++) {
+        const ClipWeights::Layer &L = clip->layers[l];
+        const uint16_t *src[4] = {L.w_qkv, L.w_o, L.w_fc1, L.w_fc2};
+        uint8_t *dst = w8 + l * per_layer;
+        const uint8_t *out[4];
+        for (int i = 0; i < 4; i++) {
+            hipLaunchKernelGGL(k_amax_bf16, dim3(1024), dim3(256), 0, ctx->stream, src[i], sizes[i], amax + l * 4 + i);
+            hipLaunchKernelGGL(k_quant_w8, dim3(1024), dim3(256), 0, ctx->stream, src[i], sizes[i], (const uint32_t *)(amax + l * 4 + i), dst);
+            out[i] = dst;
+            dst += sizes[i];
+        }
+        f8[l].w_qkv = out[0]; f8[l].w_o = out[1]; f8[l].w_fc1 = out[2]; f8[l].w_fc2 = out[3];
+    }
+    std::vector<uint32_t> bits(nl * 4);
+    D2R_HIP(ctx, hipMemcpyAsync(bits.data(), amax, nl * 16, hipMemcpyDeviceToHost, ctx->stream));
+    D2R_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    auto scale_of = [](uint32_t b) {             // q8_scale_byte on the host
+        const int e = (int)((b + 0x200000u) >> 23);
+        const int byte = std::min(std::max(e - 8, 1), 253);
+        return std::ldexp(1.0f, byte - 127);
+    };
+    for (size_t l = 0; l < nl; l++) {
+        f8[l].s_qkv = scale_of(bits[l * 4 + 0]); f8[l].s_o = scale_of(bits[l * 4 + 1]);
+        f8[l].s_fc1 = scale_of(bits[l * 4 + 2]); f8[l].s_fc2 = scale_of(bits[l * 4 + 3]);
+    }
+    clip->f8 = std::move(f8);
     return D2R_OK;
 }
 
@@ -2619,6 +3154,27 @@ int d2r_clip_forward(d2r_ctx *ctx, const d2r_clip *clip, const uint16_t *patches
     st.part = part;
     st.xlo = Xlo;
     const float inv_d = 1.0f / (float)d;
+    // "fp8 blocks" (option vit_fp8, hi + lo-byte residual only): every block but the first when its rows are reused from the background
+    // (that reuse is exact only in the arithmetic the background's rows were computed in) and the class-token-only last one
+    uint32_t f8_first = D.num_layers, f8_end = D.num_layers;
+    uint8_t *A8 = nullptr, *SA8 = nullptr, *AOS8 = nullptr, *H8 = nullptr, *SH8 = nullptr;
+    uint32_t q8_grid = 0;
+    if (ctx->vit_fp8 && split8 && d % 256 == 0 && mlp % 256 == 0 && mlp >= 2 * d) {
+        f8_first = l0 ? 1u : 0u;
+        f8_end = cls_last ? D.num_layers - 1 : D.num_layers;
+        if (f8_first < f8_end) {
+            if ((rc = ensure_f8_weights(ctx, (d2r_clip *)clip))) return rc;
+            // AO's workspace (2 d bytes per row) holds the attention output's bytes + scales; H's (2 mlp per row) fc1's bytes + scales, then
+            // the LayerNorm operand's bytes + scales
+            const size_t rp = rows_pad;
+            AOS8 = (uint8_t *)AO + rp * d;
+            H8 = (uint8_t *)H;
+            SH8 = H8 + rp * mlp;
+            A8 = SH8 + rp * (mlp / 64);
+            SA8 = A8 + rp * d;
+            q8_grid = (uint32_t)ctx->n_cu * 8u;
+        }
+    }
     for (uint32_t l = 0; l < D.num_layers; l++) {
         const ClipWeights::Layer &L = clip->layers[l];
         ln.cs = L.cs_qkv;
@@ -2640,6 +3196,24 @@ int d2r_clip_forward(d2r_ctx *ctx, const d2r_clip *clip, const uint16_t *patches
             // (the gather reads the residual rows out of Xn / Xlo before Xn's first rows are reused for the LayerNorm output)
             if ((rc = last_block_cls(ctx, D, L, n, T, rows_pad, QKV, Qc, X, xf32 ? nullptr : Xn, Xlo, patch_out, AO, Xn, H, lo8))) return rc;
             break;
+        }
+        if (f8_first <= l && l < f8_end) {
+            // "fp8 blocks": LayerNorm -> e4m3 operand; the four products on the fp8 MFMA; q / k / v, the residual stream and its statistics as ever
+            const d2r_clip::F8Layer &F = clip->f8[l];
+            hipLaunchKernelGGL(k_ln_q8, dim3(q8_grid), dim3(256), 0, ctx->stream, Xn, AB, L.ln1_w, L.ln1_b, rows_pad, d, A8, SA8);
+            if ((rc = launch_gemm_f8<EPI_F8_BIAS_BF16>(ctx, A8, SA8, F.w_qkv, F.s_qkv, L.b_qkv, QKV, rows, 3 * d, d, out_tm))) return rc;
+            launch_attention_vision(ctx, QKV, AO, T, d, rows_pad, D.num_heads, n, AOS8);
+            if ((rc = launch_gemm_f8<EPI_F8_RESID_STATS_SPLIT8>(ctx, (const uint8_t *)AO, AOS8, F.w_o, F.s_o, L.b_o, Xn, rows, d, d, st))) return rc;
+            hipLaunchKernelGGL(k_rowstats, dim3((rows_pad + 255) / 256), dim3(256), 0, ctx->stream, part, np, rows_pad, inv_d, AB);
+            hipLaunchKernelGGL(k_ln_q8, dim3(q8_grid), dim3(256), 0, ctx->stream, Xn, AB, L.ln2_w, L.ln2_b, rows_pad, d, A8, SA8);
+            EpiAux hq = out_tm;
+            hq.q8 = H8;
+            hq.q8_scale = SH8;
+            if ((rc = launch_gemm_f8<EPI_F8_BIAS_GELU_Q8>(ctx, A8, SA8, F.w_fc1, F.s_fc1, L.b_fc1, nullptr, rows, mlp, d, hq))) return rc;
+            if ((rc = launch_gemm_f8<EPI_F8_RESID_STATS_SPLIT8>(ctx, H8, SH8, F.w_fc2, F.s_fc2, L.b_fc2, Xn, rows, d, mlp, st))) return rc;
+            if (l + 1 < D.num_layers)
+                hipLaunchKernelGGL(k_rowstats, dim3((rows_pad + 255) / 256), dim3(256), 0, ctx->stream, part, np, rows_pad, inv_d, AB);
+            continue;
         }
         if (l0 && l == 0) {
             // layer 0: the background's q / k / v rows everywhere, then the touched tokens' own (a product over the compact list)
@@ -2973,3 +3547,94 @@ extern "C" int d2r_text_encode(d2r_ctx *ctx, const d2r_text *tt, const int32_t *
 
 uint32_t d2r_clip_image_size(const d2r_clip *c) { return c->desc.image_size; }
 uint32_t d2r_clip_proj_dim(const d2r_clip *c) { return c->desc.proj_dim; }
+
+// ------------------------------------------------------------ parity hook: one fp8 product ("fp8 blocks")
+//
+// C = q8(A) q8(W)^T * s_w + bias through the product path's own kernels: k_quant_rows_q8 (the activation format), k_amax_bf16 +
+// k_quant_w8 on the bf16-rounded weights (the weight format), k_gemm8f with EPI_F8_BIAS_BF16 (kind 0: bf16 result) or
+// EPI_F8_BIAS_GELU_Q8 (kind 1: quick_gelu, e4m3 result returned dequantised).  Host arrays in and out; a_q8 / a_scales (optional)
+// return the quantised A as [M][K] bytes and [M][K / 64] scale bytes, out_q8 / out_scales (kind 1, optional) the raw result.
+extern "C" int d2r_debug_gemm_fp8(d2r_ctx *ctx, const float *A, const float *W, const float *bias, uint32_t M, uint32_t N, uint32_t K, int kind,
+                                  float *out, uint8_t *a_q8, uint8_t *a_scales, float *w_scale_out, uint8_t *out_q8, uint8_t *out_scales)
+{
+    if (!ctx || !A || !W || !bias || !out) return d2r_fail(ctx, D2R_ERR_INVALID, "null argument");
+    if (!M || N % 256 || K % 256 || kind < 0 || kind > 1) return d2r_fail(ctx, D2R_ERR_INVALID, "d2r_debug_gemm_fp8: N and K must be multiples of 256, kind 0 or 1");
+    hipSetDevice(ctx->device);
+    const size_t Mp = round_up(M, BM);
+    const size_t b_a = (size_t)M * K * 4, b_w = (size_t)N * K * 4, b_wb = (size_t)N * K * 2, b_w8 = (size_t)N * K, b_a8 = Mp * K, b_sa = Mp * (K / 64),
+                 b_c = Mp * N * 2, b_sc = Mp * (N / 64), b_bias = (size_t)N * 4;
+    auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+    const size_t total = al(b_a) + al(b_w) + al(b_wb) + al(b_w8) + al(b_a8) + al(b_sa) + al(b_c) + al(b_sc) + al(b_bias) + 256;
+    int rc;
+    // (its own allocation: the context's workspaces carry invariants — zero padding columns of the patch matrix — that scratch data would break)
+    uint8_t *p = nullptr;
+    if (hipMalloc(&p, total) != hipSuccess) return d2r_fail(ctx, D2R_ERR_MEMORY, "hipMalloc failed in d2r_debug_gemm_fp8");
+    struct Free { void *q; ~Free() { (void)hipFree(q); } } free_p{p};
+    auto take = [&](size_t n) { uint8_t *q = p; p += al(n); return q; };
+    float *dA = (float *)take(b_a), *dW = (float *)take(b_w);
+    uint16_t *dWb = (uint16_t *)take(b_wb);
+    uint8_t *dW8 = take(b_w8), *dA8 = take(b_a8), *dSA = take(b_sa), *dC = take(b_c), *dSC = take(b_sc);
+    float *dBias = (float *)take(b_bias);
+    uint32_t *dAmax = (uint32_t *)take(4);
+    D2R_HIP(ctx, hipMemcpyAsync(dA, A, b_a, hipMemcpyHostToDevice, ctx->stream));
+    D2R_HIP(ctx, hipMemcpyAsync(dW, W, b_w, hipMemcpyHostToDevice, ctx->stream));
+    D2R_HIP(ctx, hipMemcpyAsync(dBias, bias, b_bias, hipMemcpyHostToDevice, ctx->stream));
+    D2R_HIP(ctx, hipMemsetAsync(dAmax, 0, 4, ctx->stream));
+    D2R_HIP(ctx, hipMemsetAsync(dSC, 0, b_sc, ctx->stream));
+    const size_t nw = (size_t)N * K;
+    hipLaunchKernelGGL(k_convert_bf16, dim3((uint32_t)((nw + 255) / 256)), dim3(256), 0, ctx->stream, dW, dWb, N, K, K);
+    hipLaunchKernelGGL(k_amax_bf16, dim3(1024), dim3(256), 0, ctx->stream, dWb, nw, dAmax);
+    hipLaunchKernelGGL(k_quant_w8, dim3(1024), dim3(256), 0, ctx->stream, dWb, nw, (const uint32_t *)dAmax, dW8);
+    const size_t nt = Mp * (K / 8);
+    hipLaunchKernelGGL(k_quant_rows_q8, dim3((uint32_t)((nt + 255) / 256)), dim3(256), 0, ctx->stream, dA, M, K, (uint32_t)Mp, dA8, dSA);
+    uint32_t bits = 0;
+    D2R_HIP(ctx, hipMemcpyAsync(&bits, dAmax, 4, hipMemcpyDeviceToHost, ctx->stream));
+    D2R_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int e = (int)((bits + 0x200000u) >> 23);
+    const float ws = std::ldexp(1.0f, std::min(std::max(e - 8, 1), 253) - 127);
+    if (w_scale_out) *w_scale_out = ws;
+    EpiAux aux{};
+    if (kind == 0) {
+        if ((rc = launch_gemm_f8<EPI_F8_BIAS_BF16>(ctx, dA8, dSA, dW8, ws, dBias, dC, M, N, K, aux))) return rc;      // row-major bf16
+    } else {
+        aux.hm_rows = (uint32_t)Mp;
+        aux.q8 = dC;
+        aux.q8_scale = dSC;
+        if ((rc = launch_gemm_f8<EPI_F8_BIAS_GELU_Q8>(ctx, dA8, dSA, dW8, ws, dBias, nullptr, M, N, K, aux))) return rc;
+    }
+    std::vector<uint8_t> hC(kind == 0 ? b_c : Mp * N), hS(b_sc), hA8(b_a8), hSA(b_sa);
+    D2R_HIP(ctx, hipMemcpyAsync(hC.data(), dC, hC.size(), hipMemcpyDeviceToHost, ctx->stream));
+    D2R_HIP(ctx, hipMemcpyAsync(hS.data(), dSC, b_sc, hipMemcpyDeviceToHost, ctx->stream));
+    D2R_HIP(ctx, hipMemcpyAsync(hA8.data(), dA8, b_a8, hipMemcpyDeviceToHost, ctx->stream));
+    D2R_HIP(ctx, hipMemcpyAsync(hSA.data(), dSA, b_sa, hipMemcpyDeviceToHost, ctx->stream));
+    D2R_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    auto scale_at = [&](const std::vector<uint8_t> &S, size_t row, uint32_t g) {
+        return S[((((size_t)(g >> 1) * (Mp >> 6) + (row >> 6)) * 32 + (row & 31)) << 2) + (((row >> 5) & 1) << 1) + (g & 1u)];
+    };
+    auto e4m3 = [](uint8_t b) {
+        const int s = b >> 7, ex = (b >> 3) & 15, m = b & 7;
+        const float v = ex == 0 ? std::ldexp((float)m, -9) : (ex == 15 && m == 7 ? NAN : std::ldexp(1.0f + m / 8.0f, ex - 7));
+        return s ? -v : v;
+    };
+    for (size_t r = 0; r < M; r++)
+        for (uint32_t c = 0; c < N; c++) {
+            if (kind == 0) {
+                const uint16_t h = ((const uint16_t *)hC.data())[r * N + c];
+                union { uint32_t u; float f; } cv;
+                cv.u = (uint32_t)h << 16;
+                out[r * N + c] = cv.f;
+            } else {
+                const uint8_t q = hC[(((size_t)(c >> 6) * Mp + r) << 6) + (c & 63)], sb = scale_at(hS, r, c >> 6);
+                out[r * N + c] = e4m3(q) * std::ldexp(1.0f, (int)sb - 127);
+                if (out_q8) out_q8[r * N + c] = q;
+                if (out_scales && (c & 63) == 0) out_scales[r * (N / 64) + (c >> 6)] = sb;
+            }
+        }
+    if (a_q8 || a_scales)
+        for (size_t r = 0; r < M; r++)
+            for (uint32_t c = 0; c < K; c++) {
+                if (a_q8) a_q8[r * K + c] = hA8[(((size_t)(c >> 6) * Mp + r) << 6) + (c & 63)];
+                if (a_scales && (c & 63) == 0) a_scales[r * (K / 64) + (c >> 6)] = scale_at(hSA, r, c >> 6);
+            }
+    return D2R_OK;
+}

@@ -19,7 +19,7 @@
 #define D2R_ATTN_ABLATE 0
 #endif
 #ifdef D2R_GEMM_STAMPS
-#define D2R_GEMM_STAMP_KINDS 10          /* EPI_KINDS of clip.hip */
+#define D2R_GEMM_STAMP_KINDS 13          /* EPI_KINDS of clip.hip */
 __device__ unsigned long long d2r_gemm_stamps[D2R_GEMM_STAMP_KINDS][4];
 extern "C" __attribute__((visibility("default"))) int d2r_debug_gemm_stamps(unsigned long long *out, int reset)
 {

@@ -120,6 +120,7 @@ struct d2r_ctx {
     Buf bg_l0, l0_a1, l0_q2, l0_misc;       // layer-0 reuse: the background's rows; gathered patch rows; compact q / k / v; count + list + pairs
     const void *bg_l0_for = nullptr;        // the d2r_clip bg_l0 was computed with (nullptr = stale)
     ClipL0Reuse bg_l0_desc{};               // pointers into bg_l0
+    int64_t vit_fp8 = 0;         // vision tower: the Linear products of the blocks between the first and the last on the MX-scaled fp8 MFMA (clip.hip, "fp8 blocks")
     int64_t l0_reuse = 1;        // d2r_render_score: patch embedding + layer-0 QKV on the touched tokens only
     int64_t prep_reuse = 1;      // k_preprocess copies the background's patch rows for bands a candidate cannot have touched
     uint32_t bg_w = 0, bg_h = 0;

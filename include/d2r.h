@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 #define D2R_API __attribute__((visibility("default")))
-#define D2R_ABI_VERSION 6
+#define D2R_ABI_VERSION 7
 
 typedef enum {
     D2R_OK = 0,
@@ -250,6 +250,19 @@ D2R_API int d2r_clip_preprocess(d2r_ctx *ctx, const d2r_clip *clip, const uint8_
 D2R_API int d2r_clip_embed_pixels(d2r_ctx *ctx, const d2r_clip *clip, const float *pixel_values,
                                   uint32_t n, float *embeds_out);
 
+/*
+ * Parity hook for the vision tower's fp8 mode (option "vit_fp8", below): ONE product C = q(A) q(W)^T s_w + bias through the kernels
+ * the mode uses — activations as OCP e4m3 with one E8M0 scale byte per (row, 64 columns), the bf16-rounded weights as e4m3 with one
+ * power-of-two scale per matrix, fp32 accumulation on v_mfma_scale_f32_32x32x64_f8f6f4 (oracle/clip_fp8.py restates the format).
+ *   A host [M][K], W host [N][K], bias host [N] fp32; N and K multiples of 256
+ *   kind 0: out [M][N] = the bf16 result; kind 1: out = quick_gelu(...) quantised to e4m3 per (row, 64 columns), dequantised
+ *   a_q8 [M][K] / a_scales [M][K/64] (optional): the quantised A;  w_scale_out (optional): s_w
+ *   out_q8 [M][N] / out_scales [M][N/64] (kind 1, optional): the raw bytes of the result
+ */
+D2R_API int d2r_debug_gemm_fp8(d2r_ctx *ctx, const float *A, const float *W, const float *bias, uint32_t M, uint32_t N,
+                               uint32_t K, int kind, float *out, uint8_t *a_q8, uint8_t *a_scales, float *w_scale_out,
+                               uint8_t *out_q8, uint8_t *out_scales);
+
 /* ------------------------------------------------------------- text tower */
 
 typedef struct {
@@ -416,6 +429,12 @@ D2R_API int d2r_get_timing(d2r_ctx *ctx, d2r_timing *out);
  *     and layer-0 q / k / v rows are broadcast from rows computed once per background, and the patch-embedding and layer-0 QKV
  *     products run on the touched tokens only (needs "ln_fold" 4, "prep_reuse" and "raygen_rect" on, at most 1024 patches
  *     per image).  Bit-identical logits; configs[1]: 17 % of the tokens touched, CLIP -2.1 ms per 4096 candidates.
+ * "vit_fp8" (default 0): 1 = the four Linear products of every transformer block except the first (when its rows are reused, "l0_reuse")
+ *     and the class-token-only last one run on the MX-scaled fp8 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4, twice the bf16 MFMA rate):
+ *     activations quantised to OCP e4m3 with one power-of-two scale per (row, 64 columns), weights to e4m3 with one power-of-two scale
+ *     per matrix, fp32 accumulation; residual stream, LayerNorm statistics, q / k / v and attention arithmetic unchanged.  This is the
+ *     "fp8 MFMA ViT" BASELINE.json configs[4] names.  It is NOT within north_star's 1e-3 cosine of the fp32 reference (measured
+ *     in tests/test_fp8.py and DESIGN.md section 7) — which is why it is off unless asked for.  Needs "ln_fold" 4.
  * "timing" (0/1): record HIP events per kernel group for d2r_get_timing.
  * Development builds of the library (make DEV=1) also know experiment switches — schedules that were measured no faster
  * and tile configurations kept for comparison; they are not part of this interface. */

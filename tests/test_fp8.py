@@ -1,0 +1,184 @@
+"""The vision tower's fp8 mode (library option "vit_fp8": BASELINE.json configs[4] names an "fp8 MFMA ViT").
+
+Two questions, kept apart:
+  * does the HIP path implement the quantisation oracle/clip_fp8.py specifies?  Held to the bf16 path's bar: the quantised
+    operands bit for bit, one product within bf16 rounding, whole models within 1e-3 cosine of the restatement.
+  * what does that specification cost against the fp32 reference arithmetic?  MEASURED and printed; fp8 is outside north_star's
+    1e-3 (an e4m3 value has 3 mantissa bits) — the tests only assert that the cost stays where it was measured (< 1.5e-2).
+CPU tests pin the restatement itself (known answers of the e4m3 grid and the scale rule).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from dream2real_amd.clip_model import CLIP_CONFIGS, random_clip_state_dict
+from oracle import clip_fp8, clip_ref
+from tests.parity_utils import cosine
+
+
+# ------------------------------------------------------------------ the restatement (CPU)
+
+def test_e4m3_grid_known_answers():
+    x = np.array([0, 1, 1.0625, 1.125, 1.1875, 448, 447, 3 * 2.0 ** -10, 2.0 ** -9, 2.0 ** -10, -3.3, 17.5, 300, 0.3], np.float32)
+    want = np.array([0, 1, 1, 1.125, 1.25, 448, 448, 2.0 ** -8, 2.0 ** -9, 0, -3.25, 18, 288, 0.3125], np.float32)
+    got = clip_fp8.e4m3_round(x)
+    assert np.array_equal(got, want)          # halves go to the even mantissa; subnormals step 2^-9
+    assert np.array_equal(clip_fp8.e4m3_encode(got), np.array([0, 56, 56, 57, 58, 126, 126, 2, 1, 0, 197, 89, 121, 42], np.uint8))
+    # every byte but the two NaN patterns decodes to a grid point that encodes back to itself
+    b = np.array([v for v in range(256) if v & 0x7F != 0x7F], np.uint8)
+    e, m, s = (b >> 3) & 15, b & 7, b >> 7
+    val = np.where(e == 0, m * 2.0 ** -9, (1 + m / 8.0) * 2.0 ** (e.astype(np.float64) - 7)) * np.where(s == 1, -1.0, 1.0)
+    ok = val != 0                              # (-0 encodes as +0's sign-less pattern only through signbit; skip the two zeros)
+    assert np.array_equal(clip_fp8.e4m3_encode(clip_fp8.e4m3_round(val.astype(np.float32)))[ok], b[ok])
+
+
+def test_scale_rule_known_answers_and_bounds():
+    amax = np.array([448, 447, 1.0, 1.75, 1.7499, 0.0, 1e-30, 500, 3e38], np.float32)
+    assert clip_fp8.scale_byte(amax).tolist() == [128, 127, 119, 120, 119, 1, 19, 128, 247]
+    r = np.random.Generator(np.random.PCG64(1))
+    x = (r.standard_normal((64, 512)) * np.exp(r.uniform(-8, 8, (64, 1)))).astype(np.float32)
+    deq, q, sb = clip_fp8.quant_act(x)
+    assert np.abs(q).max() <= 448 and np.abs(q.reshape(64, 8, 64)).max(-1).min() > 224 - 1e-3      # the top binade is used
+    big = np.abs(x) > np.abs(x).reshape(64, 8, 64).max(-1).repeat(64, -1).reshape(64, 512) * 2.0 ** -8
+    assert (np.abs(deq - x)[big] <= np.abs(x)[big] * 2.0 ** -4 * 1.0001).all()                       # 3 mantissa bits: half an ulp
+
+
+def test_weight_scale_is_one_power_of_two():
+    r = np.random.Generator(np.random.PCG64(2))
+    w = (r.standard_normal((256, 512)) * 0.02).astype(np.float32)
+    wq, s = clip_fp8.quant_weight(w)
+    assert np.log2(s) == np.round(np.log2(s)) and np.abs(wq / s).max() <= 448 and np.abs(wq / s).max() > 224
+    assert np.abs(wq - w).max() <= np.abs(w).max() * 2.0 ** -4
+
+
+# ------------------------------------------------------------------ the HIP path (GPU)
+
+@pytest.fixture(scope="module")
+def gpu():
+    from dream2real_amd import engine
+    ctx = engine.Context(0)
+    yield dict(engine=engine, ctx=ctx)
+    ctx.close()
+
+
+def _gemm(ctx, A, W, bias, kind):
+    from dream2real_amd import _lib
+    M, K = A.shape
+    N = W.shape[0]
+    out = np.empty((M, N), np.float32)
+    aq = np.empty((M, K), np.uint8)
+    asc = np.empty((M, K // 64), np.uint8)
+    oq = np.empty((M, N), np.uint8)
+    osc = np.empty((M, N // 64), np.uint8)
+    ws = C.c_float(0)
+    ctx.check(ctx.lib.d2r_debug_gemm_fp8(ctx.h, _lib.ptr(A), _lib.ptr(W), _lib.ptr(bias), C.c_uint32(M), C.c_uint32(N), C.c_uint32(K),
+                                         C.c_int(kind), _lib.ptr(out), _lib.ptr(aq), _lib.ptr(asc), C.byref(ws), _lib.ptr(oq), _lib.ptr(osc)))
+    return out, aq, asc, float(ws.value), oq, osc
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(300, 512, 768), (1000, 256, 256), (257, 768, 1024), (5000, 1024, 4096)])
+def test_one_fp8_product_is_the_specified_one(gpu, M, N, K):
+    """operand bytes and scales bit for bit; the product (exact in fp32 up to summation order) within bf16 rounding of the output"""
+    ctx = gpu["ctx"]
+    r = np.random.Generator(np.random.PCG64(M + N + K))
+    A = (r.standard_normal((M, K)) * np.exp(r.uniform(-3, 3, (M, 1)))).astype(np.float32)
+    A[:, 64:128] *= 50.0                                  # a group with its own scale
+    A[3, 128:192] = 0.0                                   # an all-zero group
+    W = (r.standard_normal((N, K)) * 0.03).astype(np.float32)
+    bias = r.standard_normal(N).astype(np.float32)
+    out, aq, asc, ws, _, _ = _gemm(ctx, A, W, bias, 0)
+    deq, q, sb = clip_fp8.quant_act(A)
+    assert np.array_equal(asc, sb.astype(np.uint8))
+    assert np.array_equal(aq & 0x7F, clip_fp8.e4m3_encode(q) & 0x7F) and np.array_equal((aq >> 7)[q != 0], (clip_fp8.e4m3_encode(q) >> 7)[q != 0])
+    wq, s = clip_fp8.quant_weight(W)
+    assert ws == float(s)
+    want = deq.astype(np.float64) @ wq.astype(np.float64).T + bias
+    err = np.abs(out - want)
+    # bf16 rounding of the result + the accumulation's own rounding (fp32 accumulators, the hardware's alignment of a 64-element block's
+    # products: measured 2^-16 of the sum of magnitudes whatever K; the operands' own grain is 2^-4)
+    bar = np.abs(want) * 2.0 ** -8 + np.abs(deq).astype(np.float64) @ np.abs(wq).astype(np.float64).T * 2.0 ** -15 + 1e-6
+    print(f"fp8 product {M}x{N}x{K}: max |err| / bar = {float((err / bar).max()):.3f}")
+    assert (err <= bar).all()
+
+
+@pytest.mark.gpu
+def test_fp8_product_with_quantised_gelu_output(gpu):
+    """EPI_F8_BIAS_GELU_Q8: the e4m3 output of fc1 (the operand of fc2).  exp / reciprocal approximations and the summation order move
+    a value across a rounding boundary now and then: nearly every byte equal, no element off by more than one e4m3 step"""
+    ctx = gpu["ctx"]
+    r = np.random.Generator(np.random.PCG64(9))
+    M, N, K = 700, 1024, 768
+    A = r.standard_normal((M, K)).astype(np.float32)
+    W = (r.standard_normal((N, K)) * 0.05).astype(np.float32)
+    bias = (r.standard_normal(N) * 0.5).astype(np.float32)
+    out, _, _, _, oq, osc = _gemm(ctx, A, W, bias, 1)
+    deq, _, _ = clip_fp8.quant_act(A)
+    wq, _ = clip_fp8.quant_weight(W)
+    pre = (deq.astype(np.float64) @ wq.astype(np.float64).T + bias).astype(np.float32)
+    h = clip_ref.quick_gelu(pre)
+    want, q, sb = clip_fp8.quant_act(h)
+    same_scale = osc == sb.astype(np.uint8)
+    print(f"GELU -> e4m3: scale bytes equal {same_scale.mean():.5f}, element bytes equal {(oq == clip_fp8.e4m3_encode(q)).mean():.5f}")
+    assert same_scale.mean() > 0.999
+    step = np.exp2(np.floor(np.log2(np.maximum(np.abs(want), 1e-30))) - 3.0) * 1.0001 + np.exp2(sb.astype(np.float64) - 127 - 9).repeat(64, -1)
+    ok = same_scale.repeat(64, -1)
+    # one step (of the binade above when the value rounds up into it) + what the accumulation's rounding moves the pre-activation by
+    acc = np.abs(deq).astype(np.float64) @ np.abs(wq).astype(np.float64).T * 2.0 ** -15 * 1.2
+    assert (np.abs(out - want)[ok] <= (2 * step + acc)[ok]).all()
+    assert (oq == clip_fp8.e4m3_encode(q))[ok].mean() > 0.99
+
+
+def _embed(engine, ctx, cfg, sd, pv, fp8):
+    ctx.set_option("vit_fp8", 1 if fp8 else 0)
+    try:
+        sc = engine.ClipScorer(ctx, cfg, sd)
+        e = sc.embed_pixels(pv)
+        sc.close()
+    finally:
+        ctx.set_option("vit_fp8", 0)
+    return e
+
+
+FP8_MODELS = {
+    # d = 256 (one K-tile pair in QKV / out-proj / fc1), 17 tokens; four layers -> three fp8 blocks and the class-token last block
+    "d256_x4": (dict(CLIP_CONFIGS["vit_tiny"], hidden_size=256, num_heads=4, mlp=1024, num_layers=4), 24),
+    # ViT-L/14 geometry (257 tokens: the attention's one-wave leftover workgroups), one fp8 block
+    "vit_l14_x2": (CLIP_CONFIGS["vit_l14_x2"], 5),
+    # full ViT-B/16: K = 768 (three K-tile pairs), eleven fp8 blocks
+    "vit_b16": (CLIP_CONFIGS["vit_b16"], 3),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(FP8_MODELS))
+def test_fp8_tower_matches_its_specification_and_reports_its_cost(gpu, name):
+    engine, ctx = gpu["engine"], gpu["ctx"]
+    cfg, n = FP8_MODELS[name]
+    sd = random_clip_state_dict(cfg, seed=11, text=False)
+    r = np.random.Generator(np.random.PCG64(4))
+    pv = r.standard_normal((n, 3, cfg["image_size"], cfg["image_size"]), dtype=np.float32)
+    got8 = _embed(engine, ctx, cfg, sd, pv, True)
+    got16 = _embed(engine, ctx, cfg, sd, pv, False)
+    assert not np.array_equal(got8, got16)                        # the option does something
+    assert np.array_equal(got8, _embed(engine, ctx, cfg, sd, pv, True))
+    layers = clip_fp8.fp8_layers(cfg, l0_reuse=False)
+    spec = clip_fp8.vision_embeds(pv, sd, cfg, layers)
+    ref = clip_ref.vision_embeds(pv, sd, cfg)
+    e_spec = float((1.0 - cosine(got8, spec)).max())
+    e_ref8 = float((1.0 - cosine(got8, ref)).max())
+    e_ref16 = float((1.0 - cosine(got16, ref)).max())
+    e_spec_ref = float((1.0 - cosine(spec, ref)).max())
+    # in logits: |d cos(image, text)| for unit text vectors, the number north_star's 1e-3 is about
+    t = r.standard_normal((16, ref.shape[1]))
+    t /= np.linalg.norm(t, axis=-1, keepdims=True)
+    dl8, dl16, dls = (float(np.abs(x @ t.T - ref @ t.T).max()) for x in (got8, got16, spec))
+    print(f"{name}: fp8 blocks {layers[0]}..{layers[-1]} | 1-cos HIP fp8 vs specification {e_spec:.2e} | against fp32: HIP fp8 {e_ref8:.2e} "
+          f"(specification {e_spec_ref:.2e}), HIP bf16 {e_ref16:.2e} | max |d cos(image, text)|: fp8 {dl8:.2e} (specification {dls:.2e}), bf16 {dl16:.2e}")
+    # Bit-level agreement is what the product tests above establish.  Through a whole tower two implementations of the same format drift
+    # apart by a fraction of the format's own noise (a last-bit difference upstream flips an e4m3 rounding = 6 % of that element), so
+    # here: the HIP path is closer to the restatement than either is to fp32, and costs against fp32 what the restatement costs
+    assert np.isfinite(got8).all()
+    assert e_spec < e_spec_ref and e_ref8 < 1.25 * e_spec_ref + 1e-4
+    assert e_ref8 < 1.5e-2

@@ -70,7 +70,8 @@ def test_k_loop_waits_are_counted_not_drained(clip_isa):
     inside the counted ring."""
     for name, lines in kernels(clip_isa, "k_gemm8"):
         body = [l for b in mfma_blocks(lines) for l in b]
-        assert sum("vmcnt(10)" in l for l in body) >= 8, name
+        # (the fp8 kernel's windows hold one batch of two scale loads each: 12)
+        assert sum(("vmcnt(12)" if "k_gemm8f" in name else "vmcnt(10)") in l for l in body) >= 8, name
         in_asm, compiler_waits = False, []
         for l in body:
             if "#ASMSTART" in l:
@@ -80,3 +81,36 @@ def test_k_loop_waits_are_counted_not_drained(clip_isa):
             elif "vmcnt" in l and not in_asm:
                 compiler_waits.append(l.strip())
         assert not compiler_waits, f"{name}: {compiler_waits[:3]}"
+
+
+def test_fp8_k_loop_owns_its_fragment_registers(clip_isa):
+    """k_gemm8f keeps its MFMA operand fragments in v160-v255 by name (inline asm): between the loop's asm statements the compiler
+    must not touch those registers, must not spill (scratch loads would join the hand-counted vmcnt queue) and must not copy a
+    scale register between its load and the MFMAs that read it (a copy made before the load has landed copies stale data)."""
+    seen = 0
+    for name, lines in kernels(clip_isa, "k_gemm8f"):
+        body = [l for b in mfma_blocks(lines) for l in b]
+        assert sum("v_mfma_scale_f32_32x32x64_f8f6f4" in l for l in body) >= 32, name
+        in_asm, scale_regs, compiler = False, set(), []
+        for l in body:
+            t = l.strip()
+            if "#ASMSTART" in t:
+                in_asm = True
+            elif "#ASMEND" in t:
+                in_asm = False
+            elif in_asm:
+                m = re.match(r"global_load_dword (v\d+),", t)
+                if m:
+                    scale_regs.add(m.group(1))
+            elif t and not t.startswith(";") and not t.startswith("."):
+                compiler.append(t)
+        assert len(scale_regs) >= 4, name
+        for t in compiler:
+            regs = [int(x) for x in re.findall(r"\bv(\d+)\b", t)]
+            for a, b in re.findall(r"v\[(\d+):(\d+)\]", t):
+                regs += list(range(int(a), int(b) + 1))
+            assert not any(r >= 160 for r in regs), f"{name}: compiler instruction on a fragment register: {t}"
+            assert "scratch_" not in t and "v_accvgpr" not in t, f"{name}: {t}"
+            assert not any(re.search(r"\b%s\b" % r, t) for r in scale_regs), f"{name}: compiler instruction on a scale register: {t}"
+        seen += 1
+    assert seen == 3
