@@ -70,6 +70,7 @@ sys.path.insert(0, REPO)
 ALGO_BYTES_PER_SAMPLE = 512          # L*8*F*2 B = 16*8*2*2
 HBM_PEAK_GBPS = 8000.0               # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_BF16_PEAK_TFLOPS = 2500.0       # dense bf16
+MFMA_FP8_PEAK_TFLOPS = 5000.0        # dense fp8 (MX-scaled v_mfma_scale_f32_32x32x64_f8f6f4)
 MLP_FLOP_PER_SAMPLE = 20480
 
 
@@ -89,6 +90,15 @@ def vit_gflop(cfg, executed: bool = False, l0_touched: float = 1.0) -> float:
         # layer-0 reuse: patch embedding and the first block's QKV product run on the touched patch tokens only
         total -= (1.0 - l0_touched) * npatch * (2 * d * 3 * P * P + 2 * d * 3 * d)
     return total / 1e9
+
+
+def vit_fp8_gflop(cfg, l0_reuse: bool) -> float:
+    """FLOPs per image the library issues on the fp8 MFMA with option vit_fp8 (the four Linear products of every block but the
+    first — when its rows are reused — and the class-token-only last one)."""
+    d, mlp, L = cfg["hidden_size"], cfg["mlp"], cfg["num_layers"]
+    T = (cfg["image_size"] // cfg["patch_size"]) ** 2 + 1
+    blocks = max(0, L - 1 - (1 if l0_reuse else 0))
+    return blocks * 2 * T * (4 * d * d + 2 * d * mlp) / 1e9
 
 
 def power_probe(step_fn, device_index: int, seconds: float):
@@ -506,6 +516,9 @@ def main():
     ap.add_argument("--scene", default=None)
     ap.add_argument("--chunk", type=int, default=4096, help="candidates per pass (the library caps it per model/view)")
     ap.add_argument("--opt", action="append", default=[], help="library tunable key=value (repeatable)")
+    ap.add_argument("--vit-fp8", action="store_true",
+                    help="the ViT's Linear products on the fp8 MFMA (library option vit_fp8; configs[4] is worded \"fp8 MFMA ViT\"); NOT within "
+                         "north_star's 1e-3 of the fp32 oracle, hence not the default")
     ap.add_argument("--cpu-sample", type=int, default=32, help="candidates in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--dump", default=None, help="rank 0: write the last step's gathered logits, scores, pose order and grid to this .npz (tests)")
     ap.add_argument("--power-seconds", type=float, default=2.5, help="extra untimed seconds sampled with rocm-smi for the power line (0 = skip)")
@@ -520,6 +533,8 @@ def main():
     ap.add_argument("--dry-collective", action="store_true",
                     help="only rendezvous + communicator init + one 1 MiB all-gather + argmax agreement (diagnoses a failed --gpus N run)")
     args = ap.parse_args()
+    if args.vit_fp8 and "vit_fp8=1" not in args.opt:
+        args.opt.append("vit_fp8=1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args.gpus)
     wd = Watchdog()
@@ -701,6 +716,10 @@ def run_kernel_bench(args, wd):
         l0_frac = stats["l0_touched"] / stats["l0_tokens"] if stats.get("l0_tokens") else 1.0       # of the last step (every step touches the same tokens)
         gflop_exec = vit_gflop(cfg, executed=cls_last, l0_touched=l0_frac) if cls_last else vit_gflop(cfg) - (vit_gflop(cfg, True) - vit_gflop(cfg, True, l0_frac))
         clip_tflops = gflop_exec * 1e9 * n_img / (timing["clip_ms"] * 1e-3) / 1e12 if timing["clip_ms"] > 0 else None
+        # option vit_fp8: part of those flops are issued on the fp8 MFMA (twice the bf16 rate): the ViT's peak is the harmonic blend
+        vit_fp8 = "vit_fp8=1" in args.opt
+        f8_share = min(1.0, vit_fp8_gflop(cfg, bool(stats.get("l0_tokens"))) / gflop_exec) if vit_fp8 else 0.0
+        vit_peak = 1.0 / (f8_share / MFMA_FP8_PEAK_TFLOPS + (1.0 - f8_share) / MFMA_BF16_PEAK_TFLOPS)
         # name the workload from what actually ran: the BASELINE.json config whose scene / grid / size / encoder it is
         per_gpu_res = sample_res[:2] + [1] + sample_res[3:] if scaling == "weak" else sample_res
         match = [k for k, c in BASELINE_CONFIGS.items()
@@ -719,7 +738,8 @@ def run_kernel_bench(args, wd):
             "metric": f"candidate renders scored/sec ({W}x{H})", "value": round(value, 2), "unit": "candidates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": scaling,
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic", "ranks_seen": ranks_seen,
+            "vs_baseline": None, "dtype": "fp8 e4m3 Linear products (fp32 accumulate) in the ViT, bf16 elsewhere" if vit_fp8 else "bf16",
+            "data": "synthetic", "ranks_seen": ranks_seen,
             "config": {"workload": f"{label} — ran: {what}",
                        "baseline_config": match[0] if match else None,
                        "scene": scene_name, "clip": clip_name, "width": W, "height": H,
@@ -751,8 +771,9 @@ def run_kernel_bench(args, wd):
                              "note": "flops the library issues: last block's q, attention output, out-proj and MLP on the class token only (the head reads nothing else); "
                                      "patch embedding and layer-0 QKV on the patch tokens a candidate can have touched only (the others take the background's rows) — both exact",
                              "achieved": round(clip_tflops, 2) if clip_tflops else None,
-                             "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "frac": round(clip_tflops / MFMA_BF16_PEAK_TFLOPS, 5) if clip_tflops else None},
+                             "peak": round(vit_peak, 1), "unit": "TFLOP/s",
+                             "fp8_share_of_flops": round(f8_share, 4),
+                             "frac": round(clip_tflops / vit_peak, 5) if clip_tflops else None},
             "device_ms_per_step": {k.replace("_ms", ""): round(v / args.steps, 3) for k, v in timing.items() if k.endswith("_ms")},
             "render_stats_per_step": stats,
             "argmax_pose": best,
@@ -769,6 +790,9 @@ def run_kernel_bench(args, wd):
             lg_gpu = logits_dev[:K_local].cpu().numpy()[idx]
             out["parity_vs_oracle"] = {"max_cosine_err": float(np.abs(lg_gpu - lg_o).max() / scorer.logit_scale),
                                        "n": int(len(idx))}
+            if vit_fp8:
+                out["parity_vs_oracle"]["note"] = ("option vit_fp8 (BASELINE.json configs[4]'s \"fp8 MFMA ViT\"): e4m3 operands are outside north_star's "
+                                                   "1e-3 cosine of the fp32 oracle by construction (tests/test_fp8.py holds the kernels to the format's restatement)")
         elif world > 1:
             out["cpu_baseline"] = {"value": None, "unit": "candidates/s", "cores": effective_cpus(), "kind": "port",
                                    "sample": "timed on rank 0 at n_gpus = 1 only: see the n_gpus = 1 line of the same --config"}

@@ -182,3 +182,36 @@ def test_fp8_tower_matches_its_specification_and_reports_its_cost(gpu, name):
     assert np.isfinite(got8).all()
     assert e_spec < e_spec_ref and e_ref8 < 1.25 * e_spec_ref + 1e-4
     assert e_ref8 < 1.5e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("clip,W,H,res", [("vit_b16", 640, 360, [8, 5, 1, 1, 1, 1]), ("vit_l14_x4", 336, 336, [4, 3, 1, 1, 1, 1])])
+def test_fp8_tower_in_the_fused_render_and_score_call(clip, W, H, res, tmp_path):
+    """d2r_render_score_host with vit_fp8: with layer-0 reuse the first block stays bf16 (its rows are the background's own), blocks
+    1 .. L-2 run in fp8.  A candidate's logits do not depend on how the batch is cut (chunks, the two-stream pipeline); against the
+    bf16 tower they move by the format's cost, reported."""
+    from dream2real_amd import combined_rendering
+    from dream2real_amd.accio2ngp import converter
+    from dream2real_amd.obj_pose_opt import sample_poses_grid
+    from dream2real_amd.virtual_cam_pose_sample import get_virtual_cam_poses
+    from tests.test_api_path import _setup
+    if clip == "vit_l14_x4":
+        CLIP_CONFIGS["vit_l14_x4"] = dict(CLIP_CONFIGS["vit_l14_x2"], num_layers=4)
+    scene, ctx, fg, bg, sc, task, text = _setup(W, H, clip)
+    poses = converter(sample_poses_grid(task, res, scene.scene_type).reshape(-1, 4, 4))
+    rp = converter(get_virtual_cam_poses(task, [0]))
+    rend = combined_rendering.renderer(str(tmp_path), task, resolution=(W, H))
+    try:
+        base16 = rend.render_score(poses, rp, [0], sc, text, save=False)
+        ctx.set_option("vit_fp8", 1)
+        base8 = rend.render_score(poses, rp, [0], sc, text, save=False)
+        for chunk, overlap in ((16, 0), (16, 1), (7, 0)):
+            ctx.set_option("chunk", chunk)
+            ctx.set_option("overlap", overlap)
+            np.testing.assert_array_equal(rend.render_score(poses, rp, [0], sc, text, save=False), base8, err_msg=f"chunk {chunk} overlap {overlap}")
+        d = float(np.abs(base8 - base16).max() / sc.logit_scale)
+        print(f"{clip} fused call: max |d cos(image, text)| fp8 vs bf16 tower = {d:.2e}; argmax {int(base8[:, 0].argmax())} / {int(base16[:, 0].argmax())}")
+        assert np.isfinite(base8).all() and 0 < d < 1.5e-2
+    finally:
+        ctx.set_option("vit_fp8", 0); ctx.set_option("chunk", 4096); ctx.set_option("overlap", 0)
+        sc.close(); fg.close(); bg.close(); ctx.close()
