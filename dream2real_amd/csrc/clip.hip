@@ -370,6 +370,7 @@ __device__ __forceinline__ uint2 q8_pack8(const float (&f)[8], float inv)
 #else
 #define D2R_GEMM_ABLATE 0
 #define D2R_ATTN_ABLATE 0
+#define D2R_F8_EXP 0
 #define STAMP(var)
 #endif
 #ifndef D2R_GEMM_PRIO
@@ -708,6 +709,17 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], float *ep, u
         // order, so the reads of group g (issued earlier) see group g's data and the writes of group g + 1 land behind
         // them; only the arithmetic waits (lgkmcnt) for its own reads.  Unpipelined, every group paid two LDS round trips
         // back to back (write -> read -> use): 16 groups, ~4 k of a tile's 5 k epilogue cycles.
+        // (EPI_F8_BIAS_GELU_Q8: see the store below; row0 is a multiple of 128, so row >> 6 = row0 >> 6 + half, row & 31 = 8 (j & 3) + rl0,
+        //  (row >> 5) & 1 = j >> 2 for the group 8 half + j: q8_scale_off() with the lane's part separated)
+        uint8_t *q8_base = nullptr, *q8s_base = nullptr;
+        uint32_t q8_lane = 0, q8s_lane = 0, q8_mine = 0;
+        if constexpr (Q8) {
+            static_assert(MT == 4, "the scale-byte gather is written for a 128-row wave tile");
+            q8_base = aux.q8 + (((size_t)(col0 >> 6) * aux.hm_rows + row0) << 6);
+            q8_lane = rl0 * 64u + c8;
+            q8s_base = aux.q8_scale + ((((size_t)(col0 >> 7) * (aux.hm_rows >> 6) + (row0 >> 6)) * 32u) << 2) + ((col0 >> 6) & 1u);
+            q8s_lane = ((8u * (lane & 3u) + rl0) << 2) + (((lane >> 2) & 1u) << 1);
+        }
         constexpr int NG = MT * 4;
         // The buffer reads are issued from inline asm like the writes: hipcc cannot count the LDS operations inside an asm
         // statement, so with compiler-visible reads its own lgkmcnt waits came out too strict (a group's values were
@@ -758,20 +770,23 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], float *ep, u
                 f[0] = u.x + b0.x; f[1] = u.y + b0.y; f[2] = u.z + b0.z; f[3] = u.w + b0.w;
                 f[4] = w.x + b1.x; f[5] = w.y + b1.y; f[6] = w.z + b1.z; f[7] = w.w + b1.w;
             }
-            if (GELU) {
+            if (GELU && !(D2R_F8_EXP & 4)) {
                 // quick_gelu: x * sigmoid(1.702 x) = x / (1 + exp2(-1.702 log2(e) x))
 #pragma unroll
                 for (int e = 0; e < 8; e++)
                     f[e] *= __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930156f * f[e]));
             }
             if constexpr (Q8) {
-                // e4m3 + one scale byte per (row, this wave tile's 64 columns): the 8 lanes of a row agree on the largest magnitude
+                // e4m3 + one scale byte per (row, this wave tile's 64 columns): the 8 lanes of a row agree on the largest magnitude.
+                // Addressing: wave-uniform bases + one lane offset each + immediates (group g is rows 32 (g >> 2) + 8 (g & 3) + rl0 of the
+                // wave tile).  The scale bytes of eight groups are collected across the row's eight lanes — lane j keeps the byte of group
+                // 8 half + j — and leave in ONE all-lanes byte store per half (a predicated store per group is a branch per group).
                 const float am = row8_max(fmaxf(fmaxf(fmaxf(fabsf(f[0]), fabsf(f[1])), fmaxf(fabsf(f[2]), fabsf(f[3]))),
                                                 fmaxf(fmaxf(fabsf(f[4]), fabsf(f[5])), fmaxf(fabsf(f[6]), fabsf(f[7])))));
                 const uint32_t sb = q8_scale_byte(am);
-                const uint32_t row = row0 + (uint32_t)((g >> 2) * 32 + (g & 3) * 8) + rl0;
-                *(uint2 *)(aux.q8 + (((size_t)(col0 >> 6) * aux.hm_rows + row) << 6) + c8) = q8_pack8(f, q8_inv_scale(sb));
-                if ((lane & 7) == 0) aux.q8_scale[q8_scale_off(aux.hm_rows, row, col0 >> 6)] = (uint8_t)sb;
+                if (!(D2R_F8_EXP & 2)) *(uint2 *)(q8_base + (q8_lane + (uint32_t)((g >> 2) * 32 + (g & 3) * 8) * 64u)) = q8_pack8(f, q8_inv_scale(sb));
+                q8_mine = (lane & 7) == (uint32_t)(g & 7) ? sb : q8_mine;
+                if ((g & 7) == 7 && !(D2R_F8_EXP & 1)) q8s_base[q8s_lane + (uint32_t)(g >> 3) * 128u] = (uint8_t)q8_mine;
                 continue;
             }
             const uint4 pk = make_uint4(pack2(f[0], f[1]), pack2(f[2], f[3]), pack2(f[4], f[5]), pack2(f[6], f[7]));
@@ -1364,6 +1379,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm8f(const uint8_t *__restrict__ A
         const bool isA = kind_is_a(kind);
         const uint8_t *base = src[kind];
         src[kind] = base + (isA ? 4 * (size_t)a_plane : (size_t)256);        // two K-tiles on
+        if (D2R_F8_EXP & 32) return;
 #pragma unroll
         for (int qq = 0; qq < 2; qq++)
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
@@ -1378,6 +1394,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm8f(const uint8_t *__restrict__ A
         // dword (64-row block 2 wm + mh, lane li) of a K-tile's array, mh: + 128 bytes; (wm * 64 + li) * 4 from a fragment address (the
         // swizzle term is < 128) rather than one more register held through the loop
         const uint32_t sc_voff = (aoff[0] >> 5) & ~3u;
+        if (D2R_F8_EXP & 8) { sc_src[kt] += 2 * (size_t)sc_kt; return; }
         asm volatile("global_load_dword %0, %2, %3\n\tglobal_load_dword %1, %2, %3 offset:128"
                      : "+v"(sc[kt][0]), "+v"(sc[kt][1]) : "v"(sc_voff), "s"(sc_src[kt]) : "memory", F8_CL_FRAG);
         sc_src[kt] += 2 * (size_t)sc_kt;
@@ -1404,6 +1421,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm8f(const uint8_t *__restrict__ A
         constexpr int h = (KIND == 2 || KIND == 3 || KIND == 5 || KIND == 7) ? 1 : 0;
         constexpr int OFF = (KIND & 3) * (int)SLOT;
         uint32_t add = (isA ? 0u : d_ab) + (KIND >= 4 ? 65536u : 0u);
+        if (D2R_F8_EXP & 64) return;
         if (isA) asm volatile("" : "+v"(add));       // not loop-invariant for the optimiser: four temporaries, not sixteen address registers
         else asm volatile("" : "+s"(add));
         if constexpr (isA && h == 0) f8_read_a0<OFF>(aoff[0] + add, aoff[1] + add, aoff[2] + add, aoff[3] + add);
@@ -1423,6 +1441,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm8f(const uint8_t *__restrict__ A
     float *ep = (float *)(smem + 8 * SLOT) + wave * EP_WAVE_FLOATS;
 
     for (;;) {
+    STAMP(ts0);
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
@@ -1446,6 +1465,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm8f(const uint8_t *__restrict__ A
     read_pos(integral_constant<int, 1>{});
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     bar();
+    STAMP(ts1);
     if (wm == 1) bar();                               // the wave rows run half a phase apart (k_gemm8)
     if (wm == 0) __builtin_amdgcn_s_setprio(1);
 
@@ -1474,7 +1494,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm8f(const uint8_t *__restrict__ A
             constexpr int mh = (P == 2 || P == 3 || P == 6 || P == 7) ? 1 : 0;
             constexpr int nh = (P == 1 || P == 2 || P == 4 || P == 7) ? 1 : 0;
             constexpr int kt = P >= 4 ? 1 : 0;
-            if constexpr (mh == 0 && nh == 0) f8_mfma_00(acc[0][0], acc[1][0], sc[kt][0], b_scale);
+            if (D2R_F8_EXP & 16) {}
+            else if constexpr (mh == 0 && nh == 0) f8_mfma_00(acc[0][0], acc[1][0], sc[kt][0], b_scale);
             else if constexpr (mh == 0) f8_mfma_01(acc[0][1], acc[1][1], sc[kt][0], b_scale);
             else if constexpr (nh == 0) f8_mfma_10(acc[2][0], acc[3][0], sc[kt][1], b_scale);
             else f8_mfma_11(acc[2][1], acc[3][1], sc[kt][1], b_scale);
@@ -1493,6 +1514,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm8f(const uint8_t *__restrict__ A
         phase(integral_constant<int, 7>{});
     }
     if (wm == 0) bar();
+    STAMP(ts2);
     __builtin_amdgcn_s_setprio(0);
     wait_vmcnt<8>();          // every scale request has landed (only the last four phases' staging requests are younger)
     asm volatile("" : : "v"(sc[0][0]), "v"(sc[0][1]), "v"(sc[1][0]), "v"(sc[1][1]));
@@ -1502,6 +1524,17 @@ __global__ __launch_bounds__(512, 2) void k_gemm8f(const uint8_t *__restrict__ A
     uint32_t lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     asm volatile("" : "+v"(lane_e));          // nothing of the epilogue's per-lane addressing is hoisted above the K loop (it has 128 registers)
     gemm_epilogue<EPI, 4>(acc, ep, lane_e, em, en, bias, Cout, N, aux, (const float2 *)nullptr);
+#ifdef D2R_GEMM_STAMPS
+    {
+        const unsigned long long ts3 = __builtin_readcyclecounter();
+        if (threadIdx.x == 0) {
+            atomicAdd(&d2r_gemm_stamps[EPI][0], ts1 - ts0);
+            atomicAdd(&d2r_gemm_stamps[EPI][1], ts2 - ts1);
+            atomicAdd(&d2r_gemm_stamps[EPI][2], ts3 - ts2);
+            atomicAdd(&d2r_gemm_stamps[EPI][3], 1ull);
+        }
+    }
+#endif
     if (!has_next) break;
     t = t_next;
     m0 = m0n;

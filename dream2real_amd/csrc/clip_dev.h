@@ -18,6 +18,11 @@
 #ifndef D2R_ATTN_ABLATE
 #define D2R_ATTN_ABLATE 0
 #endif
+// D2R_F8_EXP (bitmask) — k_gemm8f and the fp8 epilogues: 1 no scale-byte stores, 2 no e4m3 stores, 4 no GELU, 8 no scale loads in the K loop,
+//   16 no MFMA, 32 no LDS-DMA, 64 no fragment reads.  Garbage results; tools/f8_ablate.sh.
+#ifndef D2R_F8_EXP
+#define D2R_F8_EXP 0
+#endif
 #ifdef D2R_GEMM_STAMPS
 #define D2R_GEMM_STAMP_KINDS 13          /* EPI_KINDS of clip.hip */
 __device__ unsigned long long d2r_gemm_stamps[D2R_GEMM_STAMP_KINDS][4];
