@@ -354,12 +354,15 @@ __device__ __forceinline__ size_t q8_scale_off(uint32_t M_pad, size_t row, uint3
 {
     return ((((size_t)(group >> 1) * (M_pad >> 6) + (row >> 6)) * 32 + (row & 31)) << 2) + (((row >> 5) & 1) << 1) + (group & 1u);
 }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint2 q8_pack8(const float (&f)[8], float inv)
 {
-    uint32_t a = __builtin_amdgcn_cvt_pk_fp8_f32(f[0] * inv, f[1] * inv, 0, false);
-    a = __builtin_amdgcn_cvt_pk_fp8_f32(f[2] * inv, f[3] * inv, a, true);
-    uint32_t b = __builtin_amdgcn_cvt_pk_fp8_f32(f[4] * inv, f[5] * inv, 0, false);
-    b = __builtin_amdgcn_cvt_pk_fp8_f32(f[6] * inv, f[7] * inv, b, true);
+    const f32x2 i2 = f32x2{inv, inv};
+    const f32x2 q0 = f32x2{f[0], f[1]} * i2, q1 = f32x2{f[2], f[3]} * i2, q2 = f32x2{f[4], f[5]} * i2, q3 = f32x2{f[6], f[7]} * i2;      // v_pk_mul_f32
+    uint32_t a = __builtin_amdgcn_cvt_pk_fp8_f32(q0[0], q0[1], 0, false);
+    a = __builtin_amdgcn_cvt_pk_fp8_f32(q1[0], q1[1], a, true);
+    uint32_t b = __builtin_amdgcn_cvt_pk_fp8_f32(q2[0], q2[1], 0, false);
+    b = __builtin_amdgcn_cvt_pk_fp8_f32(q3[0], q3[1], b, true);
     return make_uint2(a, b);
 }
 
@@ -713,10 +716,11 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], float *ep, u
         //  (row >> 5) & 1 = j >> 2 for the group 8 half + j: q8_scale_off() with the lane's part separated)
         uint8_t *q8_base = nullptr, *q8s_base = nullptr;
         uint32_t q8_lane = 0, q8s_lane = 0, q8_mine = 0;
+        uint2 q8_prev = make_uint2(0u, 0u);
         if constexpr (Q8) {
             static_assert(MT == 4, "the scale-byte gather is written for a 128-row wave tile");
             q8_base = aux.q8 + (((size_t)(col0 >> 6) * aux.hm_rows + row0) << 6);
-            q8_lane = rl0 * 64u + c8;
+            q8_lane = (lane & 1) ? (rl0 + 8u) * 64u + c8 - 8u : rl0 * 64u + c8;
             q8s_base = aux.q8_scale + ((((size_t)(col0 >> 7) * (aux.hm_rows >> 6) + (row0 >> 6)) * 32u) << 2) + ((col0 >> 6) & 1u);
             q8s_lane = ((8u * (lane & 3u) + rl0) << 2) + (((lane >> 2) & 1u) << 1);
         }
@@ -755,27 +759,35 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], float *ep, u
                 if (g + 1 < NG) asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(ub[cur]), "+v"(wb[cur]), "+v"(abv[cur]) : "n"(FETCH_OPS) : "memory");
                 else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ub[cur]), "+v"(wb[cur]), "+v"(abv[cur]) : : "memory");
             }
-            const float4 u = make_float4(ub[cur][0], ub[cur][1], ub[cur][2], ub[cur][3]), w = make_float4(wb[cur][0], wb[cur][1], wb[cur][2], wb[cur][3]);
-            float f[8];
+            // The arithmetic runs on PAIRS (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two fp32 results per instruction slot; the same
+            // roundings as the scalar instructions) — these epilogues are VALU-bound (fc1: ~1 800 instructions per wave and tile, a wave64
+            // instruction is four cycles, two waves share a SIMD), only exp2 / rcp stay scalar.
+            const f32x2 p_in[4] = {f32x2{ub[cur][0], ub[cur][1]}, f32x2{ub[cur][2], ub[cur][3]}, f32x2{wb[cur][0], wb[cur][1]}, f32x2{wb[cur][2], wb[cur][3]}};
+            const f32x2 bb[4] = {f32x2{b0.x, b0.y}, f32x2{b0.z, b0.w}, f32x2{b1.x, b1.y}, f32x2{b1.z, b1.w}};
+            f32x2 pf[4];
             if (LN) {
-                const float2 ab = make_float2(abv[cur][0], abv[cur][1]);
-                f[0] = fmaf(ab.x, u.x, fmaf(ab.y, s0.x, b0.x)); f[1] = fmaf(ab.x, u.y, fmaf(ab.y, s0.y, b0.y));
-                f[2] = fmaf(ab.x, u.z, fmaf(ab.y, s0.z, b0.z)); f[3] = fmaf(ab.x, u.w, fmaf(ab.y, s0.w, b0.w));
-                f[4] = fmaf(ab.x, w.x, fmaf(ab.y, s1.x, b1.x)); f[5] = fmaf(ab.x, w.y, fmaf(ab.y, s1.y, b1.y));
-                f[6] = fmaf(ab.x, w.z, fmaf(ab.y, s1.z, b1.z)); f[7] = fmaf(ab.x, w.w, fmaf(ab.y, s1.w, b1.w));
+                const f32x2 ax = f32x2{abv[cur][0], abv[cur][0]}, ay = f32x2{abv[cur][1], abv[cur][1]};
+                const f32x2 ss[4] = {f32x2{s0.x, s0.y}, f32x2{s0.z, s0.w}, f32x2{s1.x, s1.y}, f32x2{s1.z, s1.w}};
+#pragma unroll
+                for (int e = 0; e < 4; e++) pf[e] = __builtin_elementwise_fma(ax, p_in[e], __builtin_elementwise_fma(ay, ss[e], bb[e]));
             } else if (EPI_IS_F8(EPI)) {
-                f[0] = fmaf(u.x, ws, b0.x); f[1] = fmaf(u.y, ws, b0.y); f[2] = fmaf(u.z, ws, b0.z); f[3] = fmaf(u.w, ws, b0.w);
-                f[4] = fmaf(w.x, ws, b1.x); f[5] = fmaf(w.y, ws, b1.y); f[6] = fmaf(w.z, ws, b1.z); f[7] = fmaf(w.w, ws, b1.w);
+                const f32x2 w2 = f32x2{ws, ws};
+#pragma unroll
+                for (int e = 0; e < 4; e++) pf[e] = __builtin_elementwise_fma(p_in[e], w2, bb[e]);
             } else {
-                f[0] = u.x + b0.x; f[1] = u.y + b0.y; f[2] = u.z + b0.z; f[3] = u.w + b0.w;
-                f[4] = w.x + b1.x; f[5] = w.y + b1.y; f[6] = w.z + b1.z; f[7] = w.w + b1.w;
+#pragma unroll
+                for (int e = 0; e < 4; e++) pf[e] = p_in[e] + bb[e];
             }
             if (GELU && !(D2R_F8_EXP & 4)) {
                 // quick_gelu: x * sigmoid(1.702 x) = x / (1 + exp2(-1.702 log2(e) x))
 #pragma unroll
-                for (int e = 0; e < 8; e++)
-                    f[e] *= __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930156f * f[e]));
+                for (int e = 0; e < 4; e++) {
+                    const f32x2 t = pf[e] * f32x2{-2.4554669595930156f, -2.4554669595930156f};
+                    const f32x2 d = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + f32x2{1.0f, 1.0f};
+                    pf[e] = pf[e] * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+                }
             }
+            float f[8] = {pf[0][0], pf[0][1], pf[1][0], pf[1][1], pf[2][0], pf[2][1], pf[3][0], pf[3][1]};
             if constexpr (Q8) {
                 // e4m3 + one scale byte per (row, this wave tile's 64 columns): the 8 lanes of a row agree on the largest magnitude.
                 // Addressing: wave-uniform bases + one lane offset each + immediates (group g is rows 32 (g >> 2) + 8 (g & 3) + rl0 of the
@@ -784,7 +796,18 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], float *ep, u
                 const float am = row8_max(fmaxf(fmaxf(fmaxf(fabsf(f[0]), fabsf(f[1])), fmaxf(fabsf(f[2]), fabsf(f[3]))),
                                                 fmaxf(fmaxf(fabsf(f[4]), fabsf(f[5])), fmaxf(fabsf(f[6]), fabsf(f[7])))));
                 const uint32_t sb = q8_scale_byte(am);
-                if (!(D2R_F8_EXP & 2)) *(uint2 *)(q8_base + (q8_lane + (uint32_t)((g >> 2) * 32 + (g & 3) * 8) * 64u)) = q8_pack8(f, q8_inv_scale(sb));
+                // 16-byte stores: groups come in pairs 8 rows apart; neighbouring lanes swap halves so that the even lane holds 16 columns of
+                // the first group's row and the odd lane 16 columns of the second's (half as many store instructions, each 1 KiB)
+                const uint2 pk8 = q8_pack8(f, q8_inv_scale(sb));
+                if ((g & 1) == 0) q8_prev = pk8;
+                else if (!(D2R_F8_EXP & 2)) {
+                    const bool odd = lane & 1;
+                    const uint32_t sx = odd ? q8_prev.x : pk8.x, sy = odd ? q8_prev.y : pk8.y;
+                    const uint32_t rx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sx, 0xB1, 0xf, 0xf, false);       // quad_perm:[1,0,3,2]
+                    const uint32_t ry = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sy, 0xB1, 0xf, 0xf, false);
+                    const uint4 o = odd ? make_uint4(rx, ry, pk8.x, pk8.y) : make_uint4(q8_prev.x, q8_prev.y, rx, ry);
+                    *(uint4 *)(q8_base + (q8_lane + (uint32_t)((g >> 2) * 32 + ((g - 1) & 3) * 8) * 64u)) = o;
+                }
                 q8_mine = (lane & 7) == (uint32_t)(g & 7) ? sb : q8_mine;
                 if ((g & 7) == 7 && !(D2R_F8_EXP & 1)) q8s_base[q8s_lane + (uint32_t)(g >> 3) * 128u] = (uint8_t)q8_mine;
                 continue;
