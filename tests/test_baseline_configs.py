@@ -115,6 +115,20 @@ def test_config4_six_dof_shelf_vit_l14(tmp_path):
     assert np.ptp(lg[:, 0]) > 1e-3                                        # candidates differ
 
 
+def test_config4_as_worded_fp8_vit(tmp_path):
+    """BASELINE.json words configs[4] "fp16 render + fp8 MFMA ViT": `--vit-fp8` runs the transformer blocks' Linear products in e4m3
+    (library option vit_fp8).  Outside north_star's 1e-3 by construction — the line says so and stays where the format was measured
+    (tests/test_fp8.py); everything downstream of the logits (ratio, scatter, smoothing, argmax) is the same code and is re-derived."""
+    out, d = run_bench(tmp_path, "--config", "4", "--slice-of", "64", "--steps", "1", "--warmup", "0", "--cpu-sample", "8", "--vit-fp8")
+    assert out["config"]["baseline_config"] == 4 and "fp8" in out["dtype"] and out["value"] > 0
+    v = out["roofline"]["vit"]
+    assert 0.8 < v["fp8_share_of_flops"] < 1.0 and 2500 < v["peak"] < 5000 and 0 < v["frac"] < 1
+    p = out["parity_vs_oracle"]
+    print("configs[4] with the fp8 ViT: max cosine error vs the fp32 oracle", p["max_cosine_err"])
+    assert p["n"] >= 8 and 1e-4 < p["max_cosine_err"] < 1.5e-2 and "fp8" in p["note"]
+    check_scores(out, d)
+
+
 def test_eight_ranks_give_the_single_rank_scores(tmp_path):
     """The N = 8 code path end to end (rendezvous, shard plan, ragged gather, scatter, smoothing) on whatever GPUs the
     box has — eight ranks time-sharing one GPU here, so the gather goes through torch.distributed (gloo) instead of
