@@ -465,7 +465,8 @@ def run_api(args, wd):
             "metric": f"candidate renders scored/sec ({W}x{H}) through the drop-in API (ImaginationEngine.dream_best_pose)",
             "value": round(n_valid * args.steps / elapsed, 2), "unit": "candidates/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None,
+            "dtype": "fp8 e4m3 Linear products (fp32 accumulate) in the ViT, bf16 elsewhere" if "vit_fp8=1" in args.opt else "bf16", "data": "synthetic",
             "config": {"workload": f"{label} — ran: {scene_name} scene, pose grid {sample_res} = {N} poses sampled, {n_valid} valid after the "
                                    f"physics pre-filter ({'GPU GJK on the mesh files' if use_phys else 'off: every pose valid'}), {W}x{H}, bf16 MLP + {clip_name}, "
                                    f"{'pose-shard x' + str(world) if world > 1 else 'one GPU'}; host arrays in / out, "
