@@ -718,7 +718,9 @@ def run_kernel_bench(args, wd):
         gflop_exec = vit_gflop(cfg, executed=cls_last, l0_touched=l0_frac) if cls_last else vit_gflop(cfg) - (vit_gflop(cfg, True) - vit_gflop(cfg, True, l0_frac))
         clip_tflops = gflop_exec * 1e9 * n_img / (timing["clip_ms"] * 1e-3) / 1e12 if timing["clip_ms"] > 0 else None
         # option vit_fp8: part of those flops are issued on the fp8 MFMA (twice the bf16 rate): the ViT's peak is the harmonic blend
-        vit_fp8 = "vit_fp8=1" in args.opt
+        # (the library runs the fp8 blocks for hidden / MLP sizes that are multiples of 256 with the hi + lo-byte residual, ln_fold 4 — its default)
+        vit_fp8 = ("vit_fp8=1" in args.opt and cfg["hidden_size"] % 256 == 0 and cfg["mlp"] % 256 == 0 and cfg["mlp"] >= 2 * cfg["hidden_size"]
+                   and not any(o.startswith("ln_fold=") and o != "ln_fold=4" for o in args.opt))
         f8_share = min(1.0, vit_fp8_gflop(cfg, bool(stats.get("l0_tokens"))) / gflop_exec) if vit_fp8 else 0.0
         vit_peak = 1.0 / (f8_share / MFMA_FP8_PEAK_TFLOPS + (1.0 - f8_share) / MFMA_BF16_PEAK_TFLOPS)
         # name the workload from what actually ran: the BASELINE.json config whose scene / grid / size / encoder it is

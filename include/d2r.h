@@ -434,7 +434,8 @@ D2R_API int d2r_get_timing(d2r_ctx *ctx, d2r_timing *out);
  *     activations quantised to OCP e4m3 with one power-of-two scale per (row, 64 columns), weights to e4m3 with one power-of-two scale
  *     per matrix, fp32 accumulation; residual stream, LayerNorm statistics, q / k / v and attention arithmetic unchanged.  This is the
  *     "fp8 MFMA ViT" BASELINE.json configs[4] names.  It is NOT within north_star's 1e-3 cosine of the fp32 reference (measured
- *     in tests/test_fp8.py and DESIGN.md section 7) — which is why it is off unless asked for.  Needs "ln_fold" 4.
+ *     in tests/test_fp8.py and DESIGN.md section 7) — which is why it is off unless asked for.  Runs for models whose hidden and MLP sizes are
+ *     multiples of 256 under "ln_fold" 4 (ViT-B/16, ViT-L/14: yes); any other model or residual mode stays in bf16.
  * "timing" (0/1): record HIP events per kernel group for d2r_get_timing.
  * Development builds of the library (make DEV=1) also know experiment switches — schedules that were measured no faster
  * and tile configurations kept for comparison; they are not part of this interface. */
