@@ -3117,7 +3117,6 @@ int d2r_clip_forward(d2r_ctx *ctx, const d2r_clip *clip, const uint16_t *patches
 
     const int fold = (int)ctx->ln_fold;
     // layer-0 reuse (see k_touch_list): needs the hi + lo-byte residual, square images cut into whole patches, a second layer
-    const uint32_t g2 = T - 1;
     const bool l0 = reuse && reuse->rects;
     if (l0 && (!d2r_clip_l0_supported(ctx, clip) || T > reuse->bg_rows))
         return d2r_fail(ctx, D2R_ERR_INVALID, "d2r_clip_forward: layer-0 reuse requested for a model / option set that does not support it");
