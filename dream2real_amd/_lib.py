@@ -137,14 +137,14 @@ def ingp_inspect(data: bytes) -> str:
     return buf.value.decode("utf-8", "replace")
 
 
-def png_write(rgb, path: str, level: int = 1):
+def png_write(rgb, path: str, level: int = -1):
     """d2r_png_write: one uint8 [h,w,3] image -> an RGB PNG file (host only)."""
     a = np.ascontiguousarray(rgb, np.uint8)
     assert a.ndim == 3 and a.shape[2] == 3
     check(load().d2r_png_write(ptr(a), C.c_uint32(a.shape[1]), C.c_uint32(a.shape[0]), os.fsencode(path), C.c_int(level)))
 
 
-def png_write_batch(frames, out_dir: str, first_index: int = 0, threads: int = 0, level: int = 1):
+def png_write_batch(frames, out_dir: str, first_index: int = 0, threads: int = 0, level: int = -1):
     """d2r_png_write_batch: uint8 [n,h,w,3] -> <out_dir>/cb_rgb_%04d.png on a pool of host threads (the GIL is released
     for the duration of the call)."""
     a = np.ascontiguousarray(frames, np.uint8)

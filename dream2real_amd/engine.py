@@ -359,7 +359,7 @@ class TextEncoder:
 
 def render_score_host(ctx: Context, fg: Testbed, scorer: ClipScorer, view: View, obj_pose_now, cam_pose, obj_poses,
                       text_embeds, *, return_frames: bool = False, png_dir: str | None = None, png_first_index: int = 0,
-                      png_threads: int = 0, png_level: int = 1):
+                      png_threads: int = 0, png_level: int = -1):
     """The fused hot path for host arrays (d2r_render_score_host): K candidate poses (NGP convention) -> logits [K,C];
     the frames stay on the GPU unless `return_frames` (-> uint8 [K,h,w,3] as well) or `png_dir` (cb_rgb_%04d.png files,
     written by the library's worker threads while the GPU works on the next chunk).  Needs Context.set_background."""

@@ -324,7 +324,8 @@ typedef struct {
     const char *png_dir;        /* existing directory for cb_rgb_%04d.png; NULL = write no files */
     uint32_t png_first_index;   /* file index of candidate 0 (a pose shard passes its first global render index) */
     int32_t png_threads;        /* encoder threads; 0 = the CPUs the process may use (hardware threads capped by the container's CPU quota), at most 64 */
-    int32_t png_level;          /* zlib level 0..9; negative = 1 (PNG is lossless: the level only trades time for size) */
+    int32_t png_level;          /* negative = the default: Sub-filtered scanlines, zlib run-length strategy, level 1 (cv2.imwrite's defaults);
+                                   0..9 = unfiltered scanlines at that zlib level (PNG is lossless: this only trades time for size) */
 } d2r_frame_sink;
 
 /*
@@ -345,7 +346,8 @@ D2R_API int d2r_render_score_host(d2r_ctx *ctx, const d2r_nerf *fg, const d2r_cl
 
 /* ------------------------------------------------- frame files (host only: no device, no context) */
 
-/* One uint8 RGB image [h][w][3] -> an 8-bit RGB PNG file (best_render.png, reference clip_scoring.py:222-223). */
+/* One uint8 RGB image [h][w][3] -> an 8-bit RGB PNG file (best_render.png, reference clip_scoring.py:222-223).  level: see
+ * d2r_frame_sink.png_level (negative = the default encoding). */
 D2R_API int d2r_png_write(const uint8_t *rgb, uint32_t w, uint32_t h, const char *path, int level);
 /* frames host [n][h][w][3] -> <dir>/cb_rgb_%04d.png for indices first_index .. first_index+n-1, encoded on `threads`
  * host threads (0 = auto): what renderer.render(save=True) leaves behind (combined_rendering.py:157-159). */
