@@ -40,6 +40,122 @@ void chunk(std::vector<uint8_t> &out, const char type[4], const uint8_t *data, s
     put32(out, (uint32_t)crc32(0L, out.data() + at, (uInt)(n + 4)));
 }
 
+// ---- a zlib stream of ONE dynamic-Huffman deflate block with literals only (no matches) ----
+// What zlib's Z_HUFFMAN_ONLY strategy produces, written for speed: a histogram pass, length-limited Huffman codes, and an emit
+// loop on a 64-bit bit buffer (zlib spends its time in per-byte tallying and block bookkeeping: 211 MB/s per thread on Sub-filtered
+// frames, tools/png_strategy_probe.py).  Any inflater reads it.  `out` must hold n + n / 8 + 1024 bytes.
+struct HuffCode { uint16_t code; uint8_t len; };
+
+// code lengths (<= 15) for 257 symbols from their counts: Huffman's algorithm on a two-queue merge of the sorted counts; when the
+// deepest leaf is too deep the counts are halved (rounded up) and the tree is rebuilt — rare (a 16-level tree needs counts that grow
+// like Fibonacci numbers) and costs microseconds
+void huff_lengths(const uint32_t *cnt_in, int n_sym, uint8_t *len)
+{
+    std::vector<uint32_t> cnt(cnt_in, cnt_in + n_sym);
+    for (;;) {
+        struct Node { uint64_t w; int l, r; };
+        std::vector<Node> nodes;
+        std::vector<int> leaves;
+        for (int i = 0; i < n_sym; i++)
+            if (cnt[i]) leaves.push_back(i);
+        for (int i = 0; i < n_sym; i++) len[i] = 0;
+        if (leaves.size() == 1) { len[leaves[0]] = 1; return; }
+        std::sort(leaves.begin(), leaves.end(), [&](int a, int b) { return cnt[a] != cnt[b] ? cnt[a] < cnt[b] : a < b; });
+        nodes.reserve(2 * leaves.size());
+        for (int s : leaves) nodes.push_back({cnt[s], -1 - s, 0});
+        size_t qa = 0, qb = leaves.size(), n_leaf = leaves.size();      // queue a: leaves, queue b: internal nodes (created in order of weight)
+        auto pop = [&]() {
+            const bool from_a = qa < n_leaf && (qb >= nodes.size() || nodes[qa].w <= nodes[qb].w);
+            return (int)(from_a ? qa++ : qb++);
+        };
+        while ((n_leaf - qa) + (nodes.size() - qb) > 1) {
+            const int x = pop(), y = pop();
+            nodes.push_back({nodes[x].w + nodes[y].w, x, y});
+        }
+        // depths from the root down (children precede parents in `nodes`)
+        std::vector<uint8_t> depth(nodes.size(), 0);
+        int deepest = 0;
+        for (size_t i = nodes.size(); i-- > n_leaf;) {
+            depth[nodes[i].l] = depth[nodes[i].r] = (uint8_t)(depth[i] + 1);
+        }
+        for (size_t i = 0; i < n_leaf; i++) {
+            len[-1 - nodes[i].l] = depth[i];
+            deepest = std::max<int>(deepest, depth[i]);
+        }
+        if (deepest <= 15) return;
+        for (int i = 0; i < n_sym; i++)
+            if (cnt[i]) cnt[i] = (cnt[i] + 1) >> 1;
+    }
+}
+
+size_t deflate_huffman_only(const uint8_t *in, size_t n, uint8_t *out)
+{
+    uint32_t h4[4][256];
+    memset(h4, 0, sizeof h4);
+    size_t i = 0;
+    for (; i + 4 <= n; i += 4) {            // four tables: consecutive equal bytes do not wait for one another's increment
+        h4[0][in[i]]++; h4[1][in[i + 1]]++; h4[2][in[i + 2]]++; h4[3][in[i + 3]]++;
+    }
+    for (; i < n; i++) h4[0][in[i]]++;
+    uint32_t cnt[257];
+    for (int s = 0; s < 256; s++) cnt[s] = h4[0][s] + h4[1][s] + h4[2][s] + h4[3][s];
+    cnt[256] = 1;                            // end of block
+    uint8_t len[257];
+    huff_lengths(cnt, 257, len);
+    // canonical codes, bit-reversed (deflate sends Huffman codes most significant bit first into an LSB-first stream)
+    uint16_t next[16] = {0}, bl_count[16] = {0};
+    for (int s = 0; s < 257; s++) bl_count[len[s]]++;
+    bl_count[0] = 0;
+    uint16_t code = 0;
+    for (int b = 1; b <= 15; b++) {
+        code = (uint16_t)((code + bl_count[b - 1]) << 1);
+        next[b] = code;
+    }
+    HuffCode hc[257];
+    for (int s = 0; s < 257; s++) {
+        uint16_t c = len[s] ? next[len[s]]++ : 0, r = 0;
+        for (int b = 0; b < len[s]; b++) r = (uint16_t)((r << 1) | ((c >> b) & 1));
+        hc[s] = {r, len[s]};
+    }
+    uint8_t *o = out;
+    *o++ = 0x78;
+    *o++ = 0x01;
+    uint64_t bits = 0;
+    int nb = 0;
+    auto put = [&](uint32_t v, int k) {
+        bits |= (uint64_t)v << nb;
+        nb += k;
+        if (nb >= 32) {
+            memcpy(o, &bits, 4);             // little-endian hosts (x86-64)
+            o += 4;
+            bits >>= 32;
+            nb -= 32;
+        }
+    };
+    // block header: final, dynamic; 257 literal/length codes, 1 distance code; the code-length alphabet is sent flat — symbols 0..15 in
+    // four bits each (a complete code), 16..18 unused — so a code length costs four bits: 129 bytes per frame
+    put(1, 1);
+    put(2, 2);
+    put(0, 5);                               // HLIT: 257
+    put(0, 5);                               // HDIST: 1
+    put(15, 4);                              // HCLEN: 19
+    static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    for (int k = 0; k < 19; k++) put(order[k] < 16 ? 4 : 0, 3);
+    auto rev4 = [](uint32_t v) { return ((v & 1) << 3) | ((v & 2) << 1) | ((v & 4) >> 1) | ((v & 8) >> 3); };     // canonical 4-bit code of symbol v = v
+    for (int s = 0; s < 257; s++) put(rev4(len[s]), 4);
+    put(rev4(0), 4);                         // the one distance code: length 0 (no distances are used)
+    for (i = 0; i < n; i++) put(hc[in[i]].code, hc[in[i]].len);
+    put(hc[256].code, hc[256].len);
+    while (nb > 0) {
+        *o++ = (uint8_t)bits;
+        bits >>= 8;
+        nb -= 8;
+    }
+    const uint32_t ad = (uint32_t)adler32(adler32(0L, Z_NULL, 0), in, (uInt)n);
+    *o++ = (uint8_t)(ad >> 24); *o++ = (uint8_t)(ad >> 16); *o++ = (uint8_t)(ad >> 8); *o++ = (uint8_t)ad;
+    return (size_t)(o - out);
+}
+
 }  // namespace
 
 // One RGB frame -> PNG bytes: colour type 2, bit depth 8, no interlace (any decoder returns the same pixels: PNG is lossless).
@@ -56,9 +172,10 @@ int d2r_png_encode(const uint8_t *rgb, uint32_t w, uint32_t h, int level, std::v
     thread_local std::vector<uint8_t> raw, z;
     const size_t raw_n = (row + 1) * h;
     if (raw.size() < raw_n) raw.resize(raw_n);
-    // level < 0 (the default): filter type 1 (Sub: each byte minus the same channel of the pixel to its left) + zlib's run-length
-    // strategy at level 1 — what cv2.imwrite's defaults amount to (the reference's writer, combined_rendering.py:157-159), and on
-    // rendered frames both smaller and several times faster to deflate than unfiltered scanlines through the default strategy.
+    // level < 0 (the default): filter type 1 (Sub: each byte minus the same channel of the pixel to its left, cv2.imwrite's filter —
+    // the reference's writer, combined_rendering.py:157-159) + Huffman-only deflate (deflate_huffman_only above).  On rendered frames (tools/png_strategy_probe.py,
+    // 640x360, one thread of the MI355X host) zlib's Huffman-only strategy gives 190 KiB per frame at 211 MB/s, cv2's run-length strategy
+    // the same size at 142 MB/s (textured NeRF backgrounds have no runs to find), unfiltered scanlines at level 1 305 KiB at 109 MB/s.
     // level 0..9: unfiltered scanlines, default strategy, that level.
     const bool fast = level < 0;
     for (uint32_t y = 0; y < h; y++) {
@@ -73,8 +190,10 @@ int d2r_png_encode(const uint8_t *rgb, uint32_t w, uint32_t h, int level, std::v
             memcpy(dst + 1, src, row);
         }
     }
-    uLongf cap = compressBound((uLong)raw_n);
+    uLongf cap = fast ? (uLongf)(raw_n + raw_n / 8 + 1024) : compressBound((uLong)raw_n);
     if (z.size() < cap) z.resize(cap);
+    if (fast) cap = (uLongf)deflate_huffman_only(raw.data(), raw_n, z.data());
+    else {
     // one deflate state per worker thread too (compress2 would allocate and free its quarter megabyte per frame)
     struct Deflater {
         z_stream zs;
@@ -83,11 +202,11 @@ int d2r_png_encode(const uint8_t *rgb, uint32_t w, uint32_t h, int level, std::v
         ~Deflater() { if (live) deflateEnd(&zs); }
     };
     thread_local Deflater df;
-    const int lv = fast ? 100 : std::min(level, 9);             // 100: level 1 with Z_RLE
+    const int lv = std::min(level, 9);
     if (!df.live || df.level != lv) {
         if (df.live) deflateEnd(&df.zs);
         memset(&df.zs, 0, sizeof df.zs);
-        df.live = (fast ? deflateInit2(&df.zs, 1, Z_DEFLATED, 15, 8, Z_RLE) : deflateInit(&df.zs, lv)) == Z_OK;
+        df.live = deflateInit(&df.zs, lv) == Z_OK;
         df.level = lv;
     } else if (deflateReset(&df.zs) != Z_OK) {
         deflateEnd(&df.zs);
@@ -106,6 +225,7 @@ int d2r_png_encode(const uint8_t *rgb, uint32_t w, uint32_t h, int level, std::v
         return D2R_ERR_MEMORY;
     }
     cap = (uLongf)(cap - df.zs.avail_out);
+    }
     out.clear();
     out.reserve(cap + 64);
     static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};

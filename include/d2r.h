@@ -324,7 +324,7 @@ typedef struct {
     const char *png_dir;        /* existing directory for cb_rgb_%04d.png; NULL = write no files */
     uint32_t png_first_index;   /* file index of candidate 0 (a pose shard passes its first global render index) */
     int32_t png_threads;        /* encoder threads; 0 = the CPUs the process may use (hardware threads capped by the container's CPU quota), at most 64 */
-    int32_t png_level;          /* negative = the default: Sub-filtered scanlines, zlib run-length strategy, level 1 (cv2.imwrite's defaults);
+    int32_t png_level;          /* negative = the default: Sub-filtered scanlines (cv2.imwrite's filter), Huffman-only deflate;
                                    0..9 = unfiltered scanlines at that zlib level (PNG is lossless: this only trades time for size) */
 } d2r_frame_sink;
 

@@ -18,6 +18,34 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # ------------------------------------------------------------------ host only
 
+def test_png_default_encoder_is_a_valid_deflate_stream_on_hard_inputs(tmp_path):
+    """The default encoding (Sub filter + the library's own Huffman-only deflate block, pngio.cpp) through a foreign inflater (PIL /
+    zlib): incompressible bytes (codes of 8-9 bits), constant images (a two-symbol code), one pixel, a byte distribution whose Huffman
+    tree is deeper than deflate's 15-bit limit (Fibonacci counts: the length-limiting fallback), and every explicit zlib level."""
+    from PIL import Image
+    r = np.random.default_rng(5)
+    fib = [1, 1]
+    while len(fib) < 27:
+        fib.append(fib[-1] + fib[-2])
+    vals = np.concatenate([np.full(f, i, np.uint8) for i, f in enumerate(fib)])
+    r.shuffle(vals)
+    v = vals[:(vals.size // 3072) * 3072].reshape(-1, 1024, 3).astype(np.int64)
+    cases = {"random": r.integers(0, 256, (90, 160, 3), dtype=np.uint8), "zeros": np.zeros((54, 96, 3), np.uint8),
+             "one pixel": np.full((1, 1, 3), 7, np.uint8), "constant": np.full((3, 5, 3), 255, np.uint8),
+             "deep tree": (np.cumsum(v, axis=1) % 256).astype(np.uint8),            # after the Sub filter the bytes are `vals`
+             "gradient": np.add.outer(np.arange(64), np.arange(200))[..., None].repeat(3, -1).astype(np.uint8)}
+    for name, img in cases.items():
+        for level in (-1, 0, 1, 6):
+            path = str(tmp_path / "t.png")
+            _lib.png_write(img, path, level)
+            np.testing.assert_array_equal(np.asarray(Image.open(path).convert("RGB")), img, err_msg=f"{name} level {level}")
+    path = str(tmp_path / "t.png")
+    _lib.png_write(cases["gradient"], path)
+    small = os.path.getsize(path)
+    _lib.png_write(cases["gradient"], path, 0)
+    assert small * 4 < os.path.getsize(path)                                      # the Sub filter turns a gradient into a constant
+
+
 def test_png_codec_roundtrip_and_foreign_files(tmp_path):
     """d2r_png_write_batch / read_batch against PIL both ways: our files decode to the same pixels in PIL; PIL's files
     (adaptive filters, RGBA, grey) decode to the same pixels here; missing / wrong-size files are named errors."""
