@@ -4,6 +4,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 
 #include "d2r_internal.h"
 #include "pngio.h"
@@ -971,11 +972,20 @@ static int render_score_core(d2r_ctx *ctx, const d2r_nerf *fg, const d2r_clip *c
         }
     }
     if (to_host) {
+        const bool io_debug = getenv("D2R_IO_DEBUG") != nullptr;                  // development aid: where the frame files' time goes
+        const auto t0 = std::chrono::steady_clock::now();
+        auto ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
         if (prev_b >= 0) {
             D2R_HIP(ctx, hipEventSynchronize(ctx->ev_copy[prev_b]));
+            if (io_debug) fprintf(stderr, "[d2r io] last chunk's frames on the host after %.1f ms\n", ms());
             dispatch_frames(ctx, prev_b, prev_c0, prev_nc, V.W, V.H, frames_out, sink);
         }
+        if (io_debug) {
+            D2R_HIP(ctx, hipStreamSynchronize(main));
+            fprintf(stderr, "[d2r io] device work done after %.1f ms\n", ms());
+        }
         ctx->pool->wait(-1);
+        if (io_debug) fprintf(stderr, "[d2r io] %u frames in %u chunks: files written %.1f ms after the last launch (%d threads)\n", K, nchunks, ms(), ctx->pool->size());
         std::string err;
         int prc = ctx->pool->take_error(err);
         D2R_HIP(ctx, hipStreamSynchronize(main));

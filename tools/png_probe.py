@@ -4,15 +4,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from dream2real_amd import _lib
 lib = _lib.load()
-n, w, h = 4096, 336, 336
+n, w, h = 2048, 640, 360
 r = np.random.default_rng(0)
 base = r.integers(0, 256, (64, h, w, 3), dtype=np.uint8)
 base[:, :, :200] = (base[:, :, :200] // 32) * 32          # partly compressible, like a render
 frames = np.concatenate([base] * (n // 64))
 print("cores", os.cpu_count(), "frames", n, f"{w}x{h}")
 for root in ("/tmp/png_probe", "/dev/shm/png_probe"):
-    for threads in (16, 64, 128):
-        for level in (1, 0):
+    for threads in (8, 16, 32):
+        for level in (-1, 1, 0):
             shutil.rmtree(root, ignore_errors=True); os.makedirs(root)
             t = time.time()
             _lib.check(lib.d2r_png_write_batch(_lib.ptr(frames), n, w, h, os.fsencode(root), 0, threads, level))
