@@ -161,10 +161,23 @@ class renderer:
                 json.dump(out, f, indent=2)
 
     def _clear_renders(self):
-        # reference :88-92: old renders are deleted first
+        # reference :88-92: old renders are deleted first.  Unlinking 8 129 files one by one is 0.2 s of the reference workload's call:
+        # the old directory is renamed aside (one syscall) and emptied on a thread while the GPU renders; _old_renders_gone() joins it
+        self._old_renders_gone()
         if os.path.exists(self.out_render_path):
-            shutil.rmtree(self.out_render_path)
+            import tempfile
+            import threading
+            aside = tempfile.mkdtemp(prefix=".cb_render_old_", dir=self.root)
+            os.rename(self.out_render_path, os.path.join(aside, "d"))
+            self._rm_thread = threading.Thread(target=shutil.rmtree, args=(aside,), kwargs={"ignore_errors": True}, name="d2r-rm-old-renders")
+            self._rm_thread.start()
         os.makedirs(self.out_render_path)
+
+    def _old_renders_gone(self):
+        t = getattr(self, "_rm_thread", None)
+        if t is not None:
+            t.join()
+            self._rm_thread = None
 
     def _setup_view(self, render_idx, render_poses, render_cam_pose_idx, depths_gt, movable_masks):
         """Background of one render view (reference :95-116): Shade (+ Depth) render of the background model, or the
@@ -228,9 +241,11 @@ class renderer:
         if save and clear:
             self._clear_renders()
         view, cam_matrix = self._setup_view(0, render_poses, render_cam_pose_idx, depths_gt, movable_masks)
-        return render_score_host(fg.ctx, fg, scorer, view, self._T_WO_1(), cam_matrix, np.asarray(valid_poses), text_embeds,
-                                 return_frames=return_frames, png_dir=self.out_render_path if save else None,
-                                 png_first_index=first_index)
+        out = render_score_host(fg.ctx, fg, scorer, view, self._T_WO_1(), cam_matrix, np.asarray(valid_poses), text_embeds,
+                                return_frames=return_frames, png_dir=self.out_render_path if save else None,
+                                png_first_index=first_index)
+        self._old_renders_gone()
+        return out
 
     def render_one(self, pose_ngp):
         """One candidate's frame in the view `render` / `render_score` set up last (uint8 [H,W,3])."""
@@ -255,6 +270,7 @@ class renderer:
 
     def wait_saved(self):
         """Block until the PNGs of the last render(save=True) are on disk."""
+        self._old_renders_gone()
         t = getattr(self, "_writer", None)
         if t is not None:
             t.join()
