@@ -374,6 +374,7 @@ __device__ __forceinline__ uint2 q8_pack8(const float (&f)[8], float inv)
 #define D2R_GEMM_ABLATE 0
 #define D2R_ATTN_ABLATE 0
 #define D2R_F8_EXP 0
+#define D2R_F8_VAR 0
 #define STAMP(var)
 #endif
 #ifndef D2R_GEMM_PRIO
@@ -1490,7 +1491,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm8f(const uint8_t *__restrict__ A
     bar();
     STAMP(ts1);
     if (wm == 1) bar();                               // the wave rows run half a phase apart (k_gemm8)
-    if (wm == 0) __builtin_amdgcn_s_setprio(1);
+    if (wm == 0 && !(D2R_F8_VAR & 3)) __builtin_amdgcn_s_setprio(1);
 
     const uint32_t t_next = t + per_xcd;
     const bool has_next = t_next < t_end;
@@ -1508,20 +1509,28 @@ __global__ __launch_bounds__(512, 2) void k_gemm8f(const uint8_t *__restrict__ A
                 if (last) sc_src[0] = aux.a_scale;    // two requests all the same (the waits count them): valid, never used, and kept
                 load_scales(0);                       // "live" until they have landed (below) so that nothing else is given their registers
             }
+            if (D2R_F8_VAR & 4) {
+                if (last) src[P] = seat(P, m0n, n0n);
+                stage(P);
+                if (!(last && P >= 6)) read_pos(integral_constant<int, (P + 2) & 7>{});
+            } else {
             if (!(last && P >= 6)) read_pos(integral_constant<int, (P + 2) & 7>{});
             if (last) src[P] = seat(P, m0n, n0n);
             stage(P);
+            }
             wait_vmcnt<12>();
             __builtin_amdgcn_sched_barrier(0);
             bar();
             constexpr int mh = (P == 2 || P == 3 || P == 6 || P == 7) ? 1 : 0;
             constexpr int nh = (P == 1 || P == 2 || P == 4 || P == 7) ? 1 : 0;
             constexpr int kt = P >= 4 ? 1 : 0;
+            if (D2R_F8_VAR & 2) __builtin_amdgcn_s_setprio(1);
             if (D2R_F8_EXP & 16) {}
             else if constexpr (mh == 0 && nh == 0) f8_mfma_00(acc[0][0], acc[1][0], sc[kt][0], b_scale);
             else if constexpr (mh == 0) f8_mfma_01(acc[0][1], acc[1][1], sc[kt][0], b_scale);
             else if constexpr (nh == 0) f8_mfma_10(acc[2][0], acc[3][0], sc[kt][1], b_scale);
             else f8_mfma_11(acc[2][1], acc[3][1], sc[kt][1], b_scale);
+            if (D2R_F8_VAR & 2) __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
             wait_vmcnt<12>();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -23,6 +23,11 @@
 #ifndef D2R_F8_EXP
 #define D2R_F8_EXP 0
 #endif
+// D2R_F8_VAR (bitmask) — schedule variants of k_gemm8f's phase: 1 no s_setprio, 2 s_setprio 1 around the MFMA section of every wave (instead of
+//   a static priority for wave row 0), 4 staging requests before the fragment reads.  Same results.
+#ifndef D2R_F8_VAR
+#define D2R_F8_VAR 0
+#endif
 #ifdef D2R_GEMM_STAMPS
 #define D2R_GEMM_STAMP_KINDS 13          /* EPI_KINDS of clip.hip */
 __device__ unsigned long long d2r_gemm_stamps[D2R_GEMM_STAMP_KINDS][4];
