@@ -935,12 +935,6 @@ static int render_score_core(d2r_ctx *ctx, const d2r_nerf *fg, const d2r_clip *c
             // keep this chunk's counters for the stats read-back at the end
             D2R_HIP(ctx, hipMemcpyAsync((uint8_t *)ctx->counters.p + 64 + 32 * (size_t)ci, ctx->counters.p, 32,
                                         hipMemcpyDeviceToDevice, rs));
-            if (to_host) {
-                D2R_HIP(ctx, hipEventRecord(ctx->ev_march[b], rs));
-                D2R_HIP(ctx, hipStreamWaitEvent(xs, ctx->ev_march[b], 0));
-                D2R_HIP(ctx, hipMemcpyAsync(ctx->frame_host[b], frames_dev, (size_t)nc * px * 3, hipMemcpyDeviceToHost, xs));
-                D2R_HIP(ctx, hipEventRecord(ctx->ev_copy[b], xs));
-            }
             if (two && ci >= 2) D2R_HIP(ctx, hipStreamWaitEvent(rs, ctx->ev_clip[pb], 0));      // patch buffer pb: chunk ci-2 is scored
             size_t tp = ctx->timing_begin(D2R_T_PREP);
             // (with layer-0 reuse only the touched patches are produced: nothing downstream reads the others)
@@ -948,6 +942,15 @@ static int render_score_core(d2r_ctx *ctx, const d2r_nerf *fg, const d2r_clip *c
                                             reuse_bg ? (const uint16_t *)ctx->bg_patches.p : nullptr, l0.rects != nullptr)))
                 return rc;
             ctx->timing_end(tp);
+            if (to_host) {
+                // the frames leave the GPU under the ViT, AFTER the preprocess has read them: the runtime copies device -> pinned host with a
+                // blit kernel that holds wave slots at PCIe speed, and a preprocess launched beside it took as long as the copy (10.9 ms
+                // instead of 0.4 for 3 170 frames of 336 x 336, profiles/r04c_api_kernel_stats.md before this order)
+                D2R_HIP(ctx, hipEventRecord(ctx->ev_march[b], rs));
+                D2R_HIP(ctx, hipStreamWaitEvent(xs, ctx->ev_march[b], 0));
+                D2R_HIP(ctx, hipMemcpyAsync(ctx->frame_host[b], frames_dev, (size_t)nc * px * 3, hipMemcpyDeviceToHost, xs));
+                D2R_HIP(ctx, hipEventRecord(ctx->ev_copy[b], xs));
+            }
             if (two) D2R_HIP(ctx, hipEventRecord(ctx->ev_prep[pb], rs));
         }
         if (two) D2R_HIP(ctx, hipStreamWaitEvent(main, ctx->ev_prep[pb], 0));
