@@ -140,6 +140,7 @@ def optimise_pose_grid(renderer, depths_gt, render_cam_pose_idx, task_model, dat
         return te, n_goal
 
     fetch_render = None            # render index -> uint8 [H,W,3] frame, for best_render.png
+    from .dist import process_rank
     rank, world = 0, 1
     if use_cache_renders:
         old = np.loadtxt(os.path.join(data_dir, "pose_scores.txt"))
@@ -177,7 +178,8 @@ def optimise_pose_grid(renderer, depths_gt, render_cam_pose_idx, task_model, dat
         lap("convert_poses_and_text")
         if hasattr(task_model, "free_visual_models"):
             pass    # the reference frees the NeRFs here to make room for CLIP; 288 GB makes that unnecessary
-        fused = hasattr(renderer, "render_score") and hasattr(scorer, "h") and len(render_cam_pose_idx) == 1
+        L = len(render_cam_pose_idx)
+        fused = hasattr(renderer, "render_score") and hasattr(scorer, "h") and L >= 1
         if shard is None and fused:
             from .dist import PoseShard
             shard = PoseShard.from_env(renderer.fg_obj.vis_model.ctx)        # None outside a multi-rank launcher
@@ -193,8 +195,14 @@ def optimise_pose_grid(renderer, depths_gt, render_cam_pose_idx, task_model, dat
             local = renderer.render_score(valid_poses_ngp[lo:hi], render_poses_ngp, render_cam_pose_idx, scorer, te,
                                           depths_gt, masks, save=save_renders, first_index=lo, clear=shard is None)
             lap("render_score")
-            all_logits = local if shard is None else shard.gather(local, K)
+            if shard is None:
+                all_logits = local
+            else:          # view-major [L * (hi - lo), C] per rank -> one gather per view -> view-major [L * K, C], the reference's frame order
+                per_view = np.asarray(local).reshape(L, hi - lo, -1)
+                all_logits = np.concatenate([shard.gather(per_view[v], K) for v in range(L)], 0)
             lap("gather")
+            # (a multi-view call yields L * K logits for K valid poses: the scatter below then fails exactly as the reference's
+            # `pose_scores[valid_idxs] = logits` (clip_scoring.py:205-206) does — every shipped config renders one view)
             fetch_render = lambda j: renderer.render_one(valid_poses_ngp[j])
         else:
             if world > 1:
@@ -216,7 +224,8 @@ def optimise_pose_grid(renderer, depths_gt, render_cam_pose_idx, task_model, dat
     best_pose_idx = int(np.argmax(pose_scores))
     best_pose = valid_poses[render_idxs[best_pose_idx]]
     lap("reduce_scatter_smooth_argmax")
-    if rank == 0:
+    # one writer under a launcher whichever route was taken (the cached-render and two-step routes never set `rank`)
+    if rank == 0 and (shard is not None or process_rank() == 0):
         best_render = np.rot90(fetch_render(int(render_idxs[best_pose_idx])), k=1, axes=(0, 1))
         _lib.png_write(np.ascontiguousarray(best_render), os.path.join(data_dir, "best_render.png"))
         if show:

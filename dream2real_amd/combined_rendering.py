@@ -171,7 +171,7 @@ class renderer:
             os.rename(self.out_render_path, os.path.join(aside, "d"))
             self._rm_thread = threading.Thread(target=shutil.rmtree, args=(aside,), kwargs={"ignore_errors": True}, name="d2r-rm-old-renders")
             self._rm_thread.start()
-        os.makedirs(self.out_render_path)
+        os.makedirs(self.out_render_path, exist_ok=True)     # (another rank's constructor may have recreated it already)
 
     def _old_renders_gone(self):
         t = getattr(self, "_rm_thread", None)
@@ -230,22 +230,34 @@ class renderer:
     def render_score(self, valid_poses, render_poses, render_cam_pose_idx, scorer, text_embeds, depths_gt=None,
                      movable_masks=None, save=True, first_index=0, clear=True, return_frames=False):
         """The fused form of `render` + the CLIP batches of optimise_pose_grid (reference :73-163 and
-        clip_scoring.py:142-185) for one render view: K candidate poses -> logits_per_image [K,C], frames staying on the
-        GPU (d2r_render_score_host).  save: cb_rgb_%04d.png for every candidate, numbered from `first_index`, written by the
-        library while it renders the next chunk (complete on return); `clear`: delete old renders first, as `render` does
-        (a pose shard other than the first passes False).  return_frames: also the uint8 frames [K,H,W,3]."""
+        clip_scoring.py:142-185): K candidate poses x L render views -> logits_per_image [L*K,C] in `render`'s own
+        VIEW-MAJOR frame order (:95,:118), frames staying on the GPU — one d2r_render_score_host call per view, each with
+        its own background, so host memory is bounded by one chunk whatever K*L is.  save: cb_rgb_%04d.png for every
+        candidate, numbered from `first_index`, written by the library while it renders the next chunk (complete on
+        return) — for ONE view only: the reference's `if save and render_idx == 0` (:157) stands behind its view loop, so
+        a multi-view call clears the directory and writes nothing, reproduced here.  `clear`: delete old renders first, as
+        `render` does (a pose shard other than the first passes False).  return_frames: also the uint8 frames [L*K,H,W,3]."""
         from .engine import render_score_host
-        if len(render_cam_pose_idx) != 1:
-            raise ValueError("render_score scores one render view (the reference's score scatter assumes one frame per valid pose)")
+        L = len(render_cam_pose_idx)
+        if L < 1:
+            raise ValueError("render_score needs at least one render view")
         fg = self.fg_obj.vis_model
         if save and clear:
             self._clear_renders()
-        view, cam_matrix = self._setup_view(0, render_poses, render_cam_pose_idx, depths_gt, movable_masks)
-        out = render_score_host(fg.ctx, fg, scorer, view, self._T_WO_1(), cam_matrix, np.asarray(valid_poses), text_embeds,
-                                return_frames=return_frames, png_dir=self.out_render_path if save else None,
-                                png_first_index=first_index)
+        valid_poses = np.asarray(valid_poses)
+        T_WO_1 = self._T_WO_1()
+        outs = []
+        for render_idx in range(L):
+            view, cam_matrix = self._setup_view(render_idx, render_poses, render_cam_pose_idx, depths_gt, movable_masks)
+            outs.append(render_score_host(fg.ctx, fg, scorer, view, T_WO_1, cam_matrix, valid_poses, text_embeds,
+                                          return_frames=return_frames, png_dir=self.out_render_path if save and L == 1 else None,
+                                          png_first_index=first_index))
         self._old_renders_gone()
-        return out
+        if L == 1:
+            return outs[0]
+        if return_frames:
+            return np.concatenate([o[0] for o in outs], 0), np.concatenate([o[1] for o in outs], 0)
+        return np.concatenate(outs, 0)
 
     def render_one(self, pose_ngp):
         """One candidate's frame in the view `render` / `render_score` set up last (uint8 [H,W,3])."""

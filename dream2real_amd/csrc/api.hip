@@ -218,6 +218,8 @@ int d2r_ctx_set_option(d2r_ctx *ctx, const char *key, int64_t value)
         ctx->attn_rem = value;
     } else if (!strcmp(key, "overlap")) {
         ctx->overlap = value != 0;
+    } else if (!strcmp(key, "debug_fail_chunk")) {
+        ctx->debug_fail_chunk = value;          // test hook: d2r_render_score* fails in this chunk (-1 = off)
     } else if (!strcmp(key, "march_blocks")) {
         if (value < 0 || value > 65535) return d2r_fail(ctx, D2R_ERR_INVALID, "march_blocks out of range");
         ctx->march_blocks = value;
@@ -838,7 +840,7 @@ static void dispatch_frames(d2r_ctx *ctx, int b, uint32_t c0, uint32_t nc, uint3
 // pointers ordered on the context's stream.  With frames_out / sink the frames of every chunk are copied to one of two
 // pinned host buffers on a copy stream and handed to the worker pool; the call then returns after the last file is
 // written, otherwise it is asynchronous.
-static int render_score_core(d2r_ctx *ctx, const d2r_nerf *fg, const d2r_clip *clip, const d2r_view *view,
+static int render_score_body(d2r_ctx *ctx, const d2r_nerf *fg, const d2r_clip *clip, const d2r_view *view,
                              const float *obj_pose_now, const float *cam_pose, const float *poses_dev, uint32_t K,
                              uint32_t C, float logit_scale, float *logits_dev, uint8_t *frames_out, const d2r_frame_sink *sink)
 {
@@ -928,6 +930,9 @@ static int render_score_core(d2r_ctx *ctx, const d2r_nerf *fg, const d2r_clip *c
         {
             StreamSwap sw(ctx, rs);
             if (to_host && ci >= 2) D2R_HIP(ctx, hipStreamWaitEvent(rs, ctx->ev_copy[b], 0));   // frames buffer b has left the GPU
+            // half pb of the patch AND rectangle buffers: chunk ci-2 is scored.  The wait stands BEFORE the render because ray
+            // generation overwrites the rectangles that chunk's ViT (k_touch_list on the main stream) reads.
+            if (two && ci >= 2) D2R_HIP(ctx, hipStreamWaitEvent(rs, ctx->ev_clip[pb], 0));
             if ((rc = d2r_launch_cameras_virtual(ctx, V, obj_pose_now, cam_pose, poses_dev + (size_t)c0 * 16, nc, (float *)ctx->cams.p)))
                 return rc;
             if ((rc = d2r_launch_render(ctx, fg, V, (const float *)ctx->cams.p, nc, true, nullptr, nullptr, frames_dev, rects)))
@@ -935,7 +940,8 @@ static int render_score_core(d2r_ctx *ctx, const d2r_nerf *fg, const d2r_clip *c
             // keep this chunk's counters for the stats read-back at the end
             D2R_HIP(ctx, hipMemcpyAsync((uint8_t *)ctx->counters.p + 64 + 32 * (size_t)ci, ctx->counters.p, 32,
                                         hipMemcpyDeviceToDevice, rs));
-            if (two && ci >= 2) D2R_HIP(ctx, hipStreamWaitEvent(rs, ctx->ev_clip[pb], 0));      // patch buffer pb: chunk ci-2 is scored
+            if (ctx->debug_fail_chunk >= 0 && (int64_t)ci == ctx->debug_fail_chunk)          // fault injection (tests): as if a launch of this chunk had failed
+                return d2r_fail(ctx, D2R_ERR_DEVICE, "injected fault in chunk " + std::to_string(ci) + " (option debug_fail_chunk)");
             size_t tp = ctx->timing_begin(D2R_T_PREP);
             // (with layer-0 reuse only the touched patches are produced: nothing downstream reads the others)
             if ((rc = d2r_launch_preprocess(ctx, (d2r_clip *)clip, frames_dev, nc, V.W, V.H, 1, patches, nullptr, rects,
@@ -997,6 +1003,30 @@ static int render_score_core(d2r_ctx *ctx, const d2r_nerf *fg, const d2r_clip *c
     ctx->stats.rays_total = (uint64_t)K * px;
     ctx->stats.l0_tokens = l0.rects ? (uint64_t)K * (d2r_clip_tokens(clip) - 1) : 0;
     return D2R_OK;
+}
+
+// render_score_body leaves at the first failing call, possibly with the render / copy streams forked off the context's stream
+// and frame jobs in the worker pool.  Whatever happened, the context is handed back quiescent: every stream joined, the pool
+// drained (its own error, if any, dropped in favour of the first one), the pipeline events reusable.
+static int render_score_core(d2r_ctx *ctx, const d2r_nerf *fg, const d2r_clip *clip, const d2r_view *view,
+                             const float *obj_pose_now, const float *cam_pose, const float *poses_dev, uint32_t K,
+                             uint32_t C, float logit_scale, float *logits_dev, uint8_t *frames_out, const d2r_frame_sink *sink)
+{
+    const int rc = render_score_body(ctx, fg, clip, view, obj_pose_now, cam_pose, poses_dev, K, C, logit_scale, logits_dev, frames_out, sink);
+    if (rc == D2R_OK) return rc;
+    const std::string first = ctx->err;
+    if (ctx->render_stream) (void)hipStreamSynchronize(ctx->render_stream);
+    if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->pool) {
+        ctx->pool->wait(-1);
+        std::string dropped;
+        (void)ctx->pool->take_error(dropped);
+    }
+    (void)hipGetLastError();          // a sticky launch error must not fail the next, unrelated call
+    ctx->last_chunks = 0;             // the per-chunk counters are incomplete: d2r_collect_render_stats refuses them
+    ctx->err = first;
+    return rc;
 }
 
 static int check_render_score_args(d2r_ctx *ctx, const d2r_nerf *fg, const d2r_clip *clip, const d2r_view *view,

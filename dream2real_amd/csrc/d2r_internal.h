@@ -142,6 +142,7 @@ struct d2r_ctx {
     size_t frame_host_cap[2] = {0, 0};
     D2rJobPool *pool = nullptr;
     int64_t overlap = 0;        // 1: render half of chunk i+1 on render_stream under the ViT of chunk i (measured neutral: both sides fill whole CUs); 0: program order on `stream`
+    int64_t debug_fail_chunk = -1;   // fault injection for the error path of render_score_core (tests/test_api_path.py)
     uint32_t last_chunks = 0;   // chunks of the last d2r_render_score (its per-chunk counters are behind counters+64)
     int64_t chunk = 4096;       // candidates per pass (capped per model/view by pass_size() in api.hip)
     uint32_t last_pass = 0;     // pass size the last d2r_render_score used (for its stats read-back)

@@ -286,13 +286,31 @@ void check_text(Audit &A, const Node *m, const char *section, const char *key, s
     A.fail(std::string("snapshot: ") + section + "." + key + " = '" + got + "' is not implemented (only " + list + ")");
 }
 
-// optional key that must, when present, be a number equal to `want`
+// every scalar leaf of v (a number, a bool, or arrays of those to any depth: instant-ngp writes its ivec2 / vec3 fields as arrays) equals `want`
+bool all_leaves_equal(const Node &v, double want, std::string &text)
+{
+    if (v.number()) {
+        text += (text.empty() ? "" : ", ") + scalar_text_of(v);
+        return v.num() == want;
+    }
+    if (v.kind != Node::ARR || v.arr.empty()) {
+        text += std::string(text.empty() ? "" : ", ") + "<" + kind_name_of(v) + ">";
+        return false;
+    }
+    bool ok = true;
+    for (const Node &e : v.arr) ok = all_leaves_equal(e, want, text) && ok;
+    return ok;
+}
+
+// optional key that must, when present, be a number equal to `want` — or a vector whose elements all are (upstream serialises e.g.
+// NerfDataset::envmap_resolution as an ivec2, [0, 0] in every snapshot without an environment map)
 void check_num(Audit &A, const Node *m, const char *section, const char *key, double want, const char *why)
 {
     const Node *v = m ? m->get(key) : nullptr;
     if (!v) return;
-    if (!v->number() || v->num() != want)
-        A.fail(std::string("snapshot: ") + section + "." + key + " = " + (v->number() ? scalar_text_of(*v) : std::string("<") + kind_name_of(*v) + ">") +
+    std::string text;
+    if (!all_leaves_equal(*v, want, text))
+        A.fail(std::string("snapshot: ") + section + "." + key + " = " + (v->kind == Node::ARR ? "[" + text + "]" : text) +
                " is not implemented (" + why + ")");
 }
 

@@ -107,7 +107,29 @@ __device__ V3 closest_triangle(V3 *s, int &n)
         s[0] = b; s[1] = c; n = 2;                                 // edge bc
         return {fmaf(w, bc.x, b.x), fmaf(w, bc.y, b.y), fmaf(w, bc.z, b.z)};
     }
-    const float den = 1.f / (va + vb + vc), v = vb * den, w = vc * den;
+    const float sum = va + vb + vc;
+    if (!(sum > 0.f) || !(sum < INFINITY)) {
+        // degenerate (collinear / repeated points: flat hulls, duplicate vertices) — the interior formula would divide by zero and a NaN
+        // direction would make every later comparison false.  The closest point then lies on one of the three edges.
+        V3 best_s[2] = {a, b};
+        int best_n = 2;
+        V3 e[2] = {a, b};
+        int en = 2;
+        V3 q = closest_segment(e, en), best = q;
+        best_s[0] = e[0]; best_s[1] = e[1]; best_n = en;
+        float bq = dot(q, q);
+        const V3 cand[2][2] = {{a, c}, {b, c}};
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            e[0] = cand[k][0]; e[1] = cand[k][1]; en = 2;
+            q = closest_segment(e, en);
+            const float qq = dot(q, q);
+            if (qq < bq) { bq = qq; best = q; best_s[0] = e[0]; best_s[1] = e[1]; best_n = en; }
+        }
+        s[0] = best_s[0]; s[1] = best_s[1]; n = best_n;
+        return best;
+    }
+    const float den = 1.f / sum, v = vb * den, w = vc * den;
     return {fmaf(w, ac.x, fmaf(v, ab.x, a.x)), fmaf(w, ac.y, fmaf(v, ab.y, a.y)), fmaf(w, ac.z, fmaf(v, ab.z, a.z))};
 }
 
@@ -174,6 +196,7 @@ __device__ bool gjk_intersect(const float *__restrict__ a, uint32_t na, const fl
     V3 v = s[0];
     for (int it = 0; it < 48; it++) {
         const float vv = dot(v, v);
+        if (!(vv == vv)) return true;                         // a non-finite direction (should not happen): contact, the conservative answer
         if (vv <= m2 || vv < 1e-18f) return true;             // a point of the difference within margin2 of the origin
         const V3 w = support(neg(v));
         const float vw = dot(v, w);

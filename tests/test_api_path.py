@@ -326,3 +326,80 @@ def test_fused_call_edge_cases(tmp_path):
         if name == "off screen":
             assert (frames == frames[0]).all() and (got == got[0]).all()              # the background, six times
     sc.close(); fg.close(); bg.close(); ctx.close()
+
+
+@pytest.mark.gpu
+def test_fused_multi_view_equals_two_step(tmp_path):
+    """more than one render view through the fused route — one d2r_render_score_host per view, each with
+    its own background (sensor depth + mask per view, indexed by the loop counter as the reference does, :107-110), logits in
+    `render`'s view-major frame order (reference combined_rendering.py:95,118) — bit-identical to render + score_frames, with
+    nothing but one chunk of frames ever on the host.  The reference's `if save and render_idx == 0` (:157) stands behind its
+    view loop: a two-view call clears cb_render/ and writes nothing; both routes reproduce that.  optimise_pose_grid then fails
+    at the scatter for L > 1 exactly as the reference does (K * L logits for K poses, clip_scoring.py:205-206)."""
+    from dream2real_amd import clip_scoring, combined_rendering
+    from dream2real_amd.accio2ngp import converter
+    from dream2real_amd.obj_pose_opt import sample_poses_grid
+    from dream2real_amd.virtual_cam_pose_sample import get_virtual_cam_poses
+    scene, ctx, fg, bg, sc, task, text = _setup()
+    poses = converter(sample_poses_grid(task, [7, 6, 1, 1, 1, 1], scene.scene_type).reshape(-1, 4, 4))      # 42
+    idx = [1, 0]
+    rp = converter(get_virtual_cam_poses(task, idx))
+    r = np.random.default_rng(2)
+    depths = [(0.5 + 0.2 * r.random((72, 128))).astype(np.float32) for _ in idx]
+    masks = [np.ones((72, 128), np.uint8) for _ in idx]
+    masks[0][10:40, 30:80] = 0
+    masks[1][30:60, 60:120] = 0
+    rend = combined_rendering.renderer(str(tmp_path), task, resolution=(96, 54))
+    open(os.path.join(rend.out_render_path, "cb_rgb_0000.png"), "wb").write(b"stale")
+    ctx.set_option("chunk", 16)
+    for dg, mk in ((None, None), (depths, masks)):
+        frames_ref = np.stack(rend.render(poses, rp, idx, dg, mk, save=False))
+        assert frames_ref.shape[0] == 2 * len(poses) and (frames_ref[:len(poses)] != frames_ref[len(poses):]).any()
+        logits_ref = sc.score_frames(frames_ref, text, rot90=True)
+        logits, frames = rend.render_score(poses, rp, idx, sc, text, dg, mk, save=False, return_frames=True)
+        np.testing.assert_array_equal(frames, frames_ref)
+        np.testing.assert_array_equal(logits, logits_ref)
+        np.testing.assert_array_equal(rend.render_score(poses, rp, idx, sc, text, dg, mk, save=True), logits_ref)     # scores only
+        assert os.listdir(rend.out_render_path) == []          # cleared, nothing written (reference :87-91,:157)
+    st = ctx.render_stats()
+    assert st["rays_total"] == len(poses) * 96 * 54
+    task.text_embeds = text
+    with pytest.raises(ValueError):                             # numpy's shape mismatch where torch raises RuntimeError in the reference
+        clip_scoring.optimise_pose_grid(rend, None, idx, task, str(tmp_path), sample_res=[7, 6, 1, 1, 1, 1],
+                                        phys_check=lambda pb, tm, v: v, scene_type=scene.scene_type, scorer=sc, save_renders=False)
+    sc.close(); fg.close(); bg.close(); ctx.close()
+
+
+@pytest.mark.gpu
+def test_failure_in_a_later_chunk_leaves_the_context_usable(tmp_path):
+    """render_score_core used to return mid-loop with the render / copy streams forked and PNG jobs in the
+    worker pool.  With `debug_fail_chunk` (fault injection: the pass fails in chunk 1, after chunk 0's frames are on their way to
+    the host and chunk 1's render is queued on the second stream) the call must report the injected error — not a later one —
+    return with every stream joined and the pool drained, and the NEXT call on the same context must give the reference
+    logits, frames and files bit for bit, with overlap on and off."""
+    from dream2real_amd import combined_rendering
+    from dream2real_amd.accio2ngp import converter
+    from dream2real_amd.obj_pose_opt import sample_poses_grid
+    from dream2real_amd.virtual_cam_pose_sample import get_virtual_cam_poses
+    scene, ctx, fg, bg, sc, task, text = _setup()
+    poses = converter(sample_poses_grid(task, [8, 6, 1, 1, 1, 1], scene.scene_type).reshape(-1, 4, 4))      # 48 = 3 chunks of 16
+    rp = converter(get_virtual_cam_poses(task, [0]))
+    rend = combined_rendering.renderer(str(tmp_path), task, resolution=(96, 54))
+    frames_ref = np.stack(rend.render(poses, rp, [0], save=False))
+    logits_ref = sc.score_frames(frames_ref, text, rot90=True)
+    ctx.set_option("chunk", 16)
+    for overlap in (1, 0):
+        ctx.set_option("overlap", overlap)
+        for fail_at in (1, 2, 0):
+            ctx.set_option("debug_fail_chunk", fail_at)
+            with pytest.raises(_lib.D2RError, match=f"injected fault in chunk {fail_at}"):
+                rend.render_score(poses, rp, [0], sc, text, save=True, return_frames=True)
+            with pytest.raises(_lib.D2RError, match="needs a preceding d2r_render_score"):
+                ctx.render_stats(collect_K=len(poses))          # the failed pass's counters are not offered as statistics
+            ctx.set_option("debug_fail_chunk", -1)
+            logits, frames = rend.render_score(poses, rp, [0], sc, text, save=True, return_frames=True)
+            np.testing.assert_array_equal(frames, frames_ref)
+            np.testing.assert_array_equal(logits, logits_ref)
+            assert sorted(os.listdir(rend.out_render_path)) == [f"cb_rgb_{i:04d}.png" for i in range(48)]
+            np.testing.assert_array_equal(_lib.png_read_batch(rend.out_render_path, 48), frames_ref)
+    sc.close(); fg.close(); bg.close(); ctx.close()

@@ -259,6 +259,7 @@ def test_c_loader_names_the_key_it_refuses(tmp_path):
         (put(True, "snapshot", "nerf", "render_with_lens_distortion"), "render_with_lens_distortion"),
         (put(True, "snapshot", "nerf", "dataset", "is_hdr"), "is_hdr"),
         (put(512, "snapshot", "nerf", "dataset", "envmap_resolution"), "envmap_resolution"),
+        (put([0, 512], "snapshot", "nerf", "dataset", "envmap_resolution"), "envmap_resolution = [0, 512]"),
         (put(0.00390625, "snapshot", "nerf", "cone_angle_constant"), "snapshot.nerf.cone_angle_constant"),
         (put(1, "snapshot", "nerf", "rgb_activation"), "snapshot.nerf.rgb_activation"),
         (put(256, "snapshot", "density_grid_size"), "density_grid_size must be 128"),
@@ -276,5 +277,8 @@ def test_c_loader_names_the_key_it_refuses(tmp_path):
                             put("CutlassMLP", "network", "otype")(c), put("Linear", "encoding", "interpolation")(c),
                             put({"otype": "Composite", "nested": [{"n_dims_to_encode": 3, "otype": "SphericalHarmonics", "degree": 4},
                                                                   {"otype": "Identity", "n_bins": 4, "degree": 4}]}, "dir_encoding")(c),
-                            put(3, "snapshot", "nerf", "density_activation")(c), put(0.0, "snapshot", "nerf", "cone_angle_constant")(c)))
+                            put(3, "snapshot", "nerf", "density_activation")(c), put(0.0, "snapshot", "nerf", "cone_angle_constant")(c),
+                            # upstream writes ivec2 / bool fields where this reader once demanded a scalar 0
+                            put([0, 0], "snapshot", "nerf", "dataset", "envmap_resolution")(c), put(False, "snapshot", "nerf", "dataset", "is_hdr")(c),
+                            put(False, "snapshot", "nerf", "dataset", "from_mitsuba")(c), put(False, "snapshot", "nerf", "render_with_lens_distortion")(c)))
     assert _lib.ingp_validate(ok).n_unknown_keys == 0

@@ -291,3 +291,33 @@ def test_gpu_prefilter_with_margins_compound_parts_and_mesh_files(tmp_path):
     assert len(static2) == 3 and len(movable2) == 1
     check2.shapes.close()
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_gpu_prefilter_on_flat_hulls_and_duplicate_vertices():
+    """Degenerate simplices: a movable object that is a flat sheet (every vertex in one plane, each vertex
+    listed twice, collinear points on its edges) against a table and a thin blade — GJK then meets collinear / repeated
+    support points, where the interior-of-triangle formula divides by zero.  The mask must still equal the oracle's
+    (LP / QP on the same point sets) outside the rounding band, and contain no pose that a NaN would have let through."""
+    from dream2real_amd import engine, physics_utils
+    ctx = engine.Context(0)
+    table = box([-1, -1, -0.1], [1, 1, 0.0])
+    blade = np.array([[0.4, -0.2, 0.0], [0.4, 0.2, 0.0], [0.4, 0.2, 0.3], [0.4, -0.2, 0.3],          # a zero-thickness wall, x = 0.4
+                      [0.4, 0.0, 0.0], [0.4, 0.0, 0.3], [0.4, -0.2, 0.15]], np.float64)            # + collinear points on its edges
+    sq = np.array([[-0.05, -0.05, 0.0], [0.05, -0.05, 0.0], [0.05, 0.05, 0.0], [-0.05, 0.05, 0.0],
+                   [0.0, -0.05, 0.0], [0.05, 0.0, 0.0], [0.0, 0.0, 0.0]], np.float64) + [0, 0, 0.005]
+    sheet = np.concatenate([sq, sq])                                                                  # every vertex twice
+    init = np.eye(4, dtype=np.float32)
+    xs, ys, zs = np.linspace(0.2, 0.6, 41) + 0.00037, [0.0003, 0.1003, 0.2603], [0.0, 0.0125, 0.0175, 0.1, -0.5]
+    poses = _grid(xs, ys, zs)
+    res = [len(xs), len(ys), len(zs), 1, 1, 1]
+    v0 = np.ones(len(poses), bool)
+    sh = physics_utils.PhysicsShapes(ctx, sheet, [table, blade])
+    for m in (0.0, 0.001):
+        for stab in (False, True):
+            got = sh.check(poses, v0, res, init, -0.3, margin=m, stability_check=stab)
+            want = assert_equal_away_from_band(got, lambda mm: phys_ref.unsupcol_check(poses, init, sheet, [table, blade], res, v0, -0.3, margin=mm,
+                                                                                   stability_check=stab), m, f"flat hulls, stability={stab}")
+            assert 0 < want.sum() < len(want)
+    sh.close()
+    ctx.close()
