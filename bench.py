@@ -685,6 +685,7 @@ def run_kernel_bench(args, wd):
     timing = ctx.timing()
     ctx.set_option("timing", 0)
     stats = ctx.render_stats(collect_K=K_local)          # counters of the last step
+    brick_config = {"lds_slots": ctx.get_option("march_lds_slots"), "hbm_brick_slots": ctx.get_option("march_hbm_brick_slots")}
 
     launches_per_step = max(1, round(timing["march_launches"] / max(1, args.steps)))
     per_launch = -(-K_local // launches_per_step)          # candidates per k_march launch actually used
@@ -692,7 +693,7 @@ def run_kernel_bench(args, wd):
     def recorded_traffic():
         """HBM-side bytes per k_march launch from the committed PMC passes (bench.py cannot run
         under --pmc itself); only reported when it was measured on this exact workload."""
-        for name in ("r04_march_traffic.json", "r03_march_traffic.json", "r01_march_traffic.json"):
+        for name in ("r05_march_traffic.json", "r04_march_traffic.json", "r03_march_traffic.json", "r01_march_traffic.json"):
             try:
                 t = json.load(open(os.path.join(REPO, "profiles", name)))
             except OSError:
@@ -762,6 +763,8 @@ def run_kernel_bench(args, wd):
                          "algorithmic_bytes_per_launch": int(samples_per_launch * ALGO_BYTES_PER_SAMPLE),
                          "samples_per_launch": int(samples_per_launch),
                          "lane_utilisation": round(stats["samples"] / max(1, 64 * stats["wave_iters"]), 4),
+                         # which k_march instantiation ran: leading slots (level pairs) served from LDS bricks, further slots from dense HBM bricks
+                         "brick_config": brick_config,
                          "avg_launch_ms": round(march_avg_s * 1e3, 4),
                          "mlp_tflops": round(samples_per_launch * MLP_FLOP_PER_SAMPLE / march_avg_s / 1e12, 3) if march_avg_s > 0 else None,
                          # the same kernel priced on the bytes the memory system actually moved (PMC FETCH_SIZE + WRITE_SIZE per

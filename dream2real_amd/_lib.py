@@ -9,7 +9,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libd2r.so")
-ABI_VERSION = 7          # D2R_ABI_VERSION of include/d2r.h this binding was written against
+ABI_VERSION = 8          # D2R_ABI_VERSION of include/d2r.h this binding was written against
 
 EXPORTS = [
     "d2r_abi_version", "d2r_ctx_create", "d2r_ctx_destroy", "d2r_ctx_set_stream", "d2r_ctx_synchronize",
@@ -20,7 +20,7 @@ EXPORTS = [
     "d2r_text_destroy", "d2r_text_encode", "d2r_comm_get_unique_id", "d2r_comm_init", "d2r_comm_destroy",
     "d2r_allgather_scores", "d2r_phys_create", "d2r_phys_destroy", "d2r_phys_check", "d2r_nerf_load_ingp",
     "d2r_rectify_background_depth", "d2r_ingp_inspect", "d2r_render_score_host", "d2r_png_write", "d2r_png_write_batch",
-    "d2r_png_read_batch", "d2r_png_size", "d2r_savetxt", "d2r_ingp_validate", "d2r_debug_gemm_fp8",
+    "d2r_png_read_batch", "d2r_png_size", "d2r_savetxt", "d2r_ingp_validate", "d2r_debug_gemm_fp8", "d2r_ctx_get_option",
 ]
 
 

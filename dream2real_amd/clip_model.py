@@ -92,6 +92,110 @@ def random_clip_state_dict(cfg, seed: int = 6, text: bool = True, logit_scale: f
     return sd
 
 
+def adversarial_clip_state_dict(cfg, seed: int = 6, text: bool = False, *, outlier_gain: float = 150.0, n_outlier: int = 4,
+                                n_marked_patches: int = 4, broad_outlier: float = 12.0, gamma_sigma: float = 0.45,
+                                gamma_spikes: int = 6, common_mode: float = 2.0, sharp_fraction: float = 0.25,
+                                sharp_gain: float = 2.5, info: dict | None = None) -> dict:
+    """`random_clip_state_dict` plus the statistics TRAINED CLIP vision towers are known to carry and Gaussian weights do
+    not — the regime the bf16 / LayerNorm-fold schedules of the library have to survive:
+
+    * massive activations: `n_outlier` residual channels that reach ~`outlier_gain` x the typical magnitude on the class
+      token and `n_marked_patches` patch tokens ("register"-like) from the middle layer on.  Built the way such channels
+      arise: the position embedding of those tokens carries a marker direction, a few fc1 neurons of the middle block
+      fire on it (and on nothing else), and their fc2 columns write the large value into the outlier channels, where the
+      residual stream keeps it to the end; `broad_outlier`: the same channels also carry a moderate offset on EVERY token
+      (fc2 bias of that block), as the outlier dimensions of trained transformers do;
+    * LayerNorm gains with a heavy tail: log-normal (sigma `gamma_sigma`) with `gamma_spikes` entries per LayerNorm at 5-10x;
+    * a per-token common-mode offset of the residual stream (the all-ones direction, which no LayerNorm sees but every
+      folded product carries): out_proj / fc2 get a rank-one component 1 v^T sized so that the offset they add per block
+      has a spread of `common_mode` / sqrt(layers) row sigmas, plus the pre-LayerNorm bias — |mean| / sigma of a token
+      row ends up around `common_mode`;
+    * sharp attention: the q / k rows of a fraction `sharp_fraction` of the heads scaled by `sharp_gain` (logit spread
+      x gain^2), near one-hot softmax rows.
+    `info` (optional dict) receives the channel / token / head choices.  Deterministic (PCG64)."""
+    sd = random_clip_state_dict(cfg, seed, text=text)
+    rng = np.random.Generator(np.random.PCG64(seed + 7919))
+    d, L, H, mlp, T = cfg["hidden_size"], cfg["num_layers"], cfg["num_heads"], cfg["mlp"], n_tokens(cfg)
+    dh = d // H
+    enc = "vision_model.encoder.layers."
+    f32 = np.float32
+
+    # ---- heavy-tailed LayerNorm gains (every LayerNorm of the vision tower)
+    ln_names = ["vision_model.pre_layrnorm", "vision_model.post_layernorm"] + \
+               [f"{enc}{l}.layer_norm{k}" for l in range(L) for k in (1, 2)]
+    for nm in ln_names:
+        g = np.exp(rng.standard_normal(d) * gamma_sigma).astype(f32)
+        spikes = rng.choice(d, size=min(gamma_spikes, d), replace=False)
+        g[spikes] = rng.uniform(5.0, 10.0, size=len(spikes)).astype(f32)
+        g *= rng.choice([-1.0, 1.0], size=d, p=[0.05, 0.95]).astype(f32)          # a few negative gains, as trained models have
+        sd[nm + ".weight"] = g
+        sd[nm + ".bias"] = (rng.standard_normal(d) * 0.1).astype(f32)
+
+    # ---- sharp heads
+    n_sharp = int(round(sharp_fraction * H))
+    sharp = {}
+    for l in range(L):
+        heads = rng.choice(H, size=n_sharp, replace=False)
+        sharp[l] = sorted(int(h) for h in heads)
+        for h in heads:
+            for nm in ("q_proj", "k_proj"):
+                sd[f"{enc}{l}.self_attn.{nm}.weight"][h * dh:(h + 1) * dh] *= f32(sharp_gain)
+
+    # ---- common mode: rank-one 1 v^T in the residual writers, and a mean in the embedding LayerNorm's bias
+    ones = np.ones(d, f32)
+    if common_mode > 0:
+        per_block = common_mode / np.sqrt(2.0 * L)              # 2 L writers whose offsets add up like a random walk
+        for l in range(L):
+            for nm, n_in in ((f"{enc}{l}.self_attn.out_proj", d), (f"{enc}{l}.mlp.fc2", mlp)):
+                W = sd[nm + ".weight"]
+                # the writer's input has rms ~ r_in per element (attention output ~ 1, GELU hidden ~ 0.4): v^T x has spread |v| r_in
+                r_in = 1.0 if n_in == d else 0.45
+                v = rng.standard_normal(n_in).astype(f32)
+                v *= f32(per_block * 1.5 / (np.linalg.norm(v) * r_in))             # x 1.5: rows have sigma ~ 1.5 after a few blocks
+                W += np.outer(ones, v)
+                sd[nm + ".bias"] = sd[nm + ".bias"] + f32(rng.standard_normal() * per_block)
+        sd["vision_model.pre_layrnorm.bias"] = sd["vision_model.pre_layrnorm.bias"] + f32(0.5 * common_mode)
+
+    # ---- massive activations
+    lm = L // 2
+    marker = rng.standard_normal(d).astype(f32)
+    marker -= marker.mean()
+    marker /= np.linalg.norm(marker)
+    patches = rng.choice(np.arange(1, T), size=min(n_marked_patches, T - 1), replace=False)
+    marked = np.concatenate([[0], np.sort(patches)]).astype(int)
+    out_ch = np.sort(rng.choice(d, size=n_outlier, replace=False))
+    pos = sd["vision_model.embeddings.position_embedding.weight"]
+    amp = 1.5 * np.sqrt(d)                                      # pre_layrnorm divides it by the row sigma: ~ 0.8 sqrt(d) / ... in the stream
+    pos[marked] += f32(amp) * marker
+    # the embedding LayerNorm must let the marker through unscaled by its own heavy tail: gain 1 along it is not expressible
+    # per channel, so the neuron below is fitted to what actually arrives (marker o gain_pre) instead
+    g_pre = sd["vision_model.pre_layrnorm.weight"]
+    arrive = marker * g_pre
+    arrive_dir = arrive - arrive.mean()
+    arrive_dir /= np.linalg.norm(arrive_dir)
+    g2, b2 = sd[f"{enc}{lm}.layer_norm2.weight"], sd[f"{enc}{lm}.layer_norm2.bias"]
+    fc1w, fc1b = sd[f"{enc}{lm}.mlp.fc1.weight"], sd[f"{enc}{lm}.mlp.fc1.bias"]
+    fc2w, fc2b = sd[f"{enc}{lm}.mlp.fc2.weight"], sd[f"{enc}{lm}.mlp.fc2.bias"]
+    neurons = rng.choice(mlp, size=2 * n_outlier, replace=False)
+    # LayerNorm output along the arrival direction: (x . dir) / sigma_row, ~ N(0, 1) for ordinary tokens; the marked ones sit
+    # several sigmas out (measured by tests/diag/adversarial_stats.py).  Threshold 4.5, slope 1.
+    w_row = (arrive_dir / g2).astype(f32)                      # (gain o w) = dir
+    for k, j in enumerate(neurons):
+        sgn = f32(1.0 if k % 2 == 0 else -1.0)
+        fc1w[j] = w_row
+        fc1b[j] = f32(-4.5 - float(w_row @ b2))
+        fc2w[:, j] = 0
+        fc2w[out_ch[k // 2], j] = sgn * f32(outlier_gain / 8.0) * f32(1.0 + 0.3 * rng.standard_normal())
+    # two neurons per channel with opposite signs would cancel: the second one is given its own sign pattern per channel
+    for k in range(n_outlier):
+        fc2w[out_ch[k], neurons[2 * k + 1]] = abs(fc2w[out_ch[k], neurons[2 * k + 1]]) * np.sign(fc2w[out_ch[k], neurons[2 * k]])
+    fc2b[out_ch] += (rng.choice([-1.0, 1.0], size=n_outlier) * broad_outlier).astype(f32)
+    if info is not None:
+        info.update(outlier_channels=out_ch.tolist(), marked_tokens=marked.tolist(), outlier_layer=lm, sharp_heads=sharp,
+                    marker_dir=arrive_dir)
+    return sd
+
+
 def vision_blob_order(cfg):
     """(name, shape) of every tensor in the `d2r_clip_create` weight blob, in order."""
     d, P, mlp = cfg["hidden_size"], cfg["patch_size"], cfg["mlp"]

@@ -235,8 +235,17 @@ int d2r_ctx_set_option(d2r_ctx *ctx, const char *key, int64_t value)
         ctx->gemm_stagger = value != 0;
 #endif
     } else if (!strcmp(key, "gbrick_slots")) {
-        if (value < 0 || value > 3) return d2r_fail(ctx, D2R_ERR_INVALID, "gbrick_slots must be in [0, 3]");
+        if (value < 0 || value > 8) return d2r_fail(ctx, D2R_ERR_INVALID, "gbrick_slots must be in [0, 8]");
         ctx->gbrick_slots = value;
+    } else if (!strcmp(key, "brick_slots_total")) {
+        if (value < 0 || value > 8) return d2r_fail(ctx, D2R_ERR_INVALID, "brick_slots_total must be in [0, 8]");
+        ctx->brick_slots_total = value;
+    } else if (!strcmp(key, "lds_slots_max")) {          // read by d2r_nerf_create: set it before creating the model
+        if (value < 0 || value > 5) return d2r_fail(ctx, D2R_ERR_INVALID, "lds_slots_max must be in [0, 5]");
+        ctx->lds_slots_max = value;
+    } else if (!strcmp(key, "gbrick_max_mib")) {         // read by d2r_nerf_create too
+        if (value < 0 || value > 512) return d2r_fail(ctx, D2R_ERR_INVALID, "gbrick_max_mib must be in [0, 512]");
+        ctx->gbrick_max_mib = value;
     } else if (!strcmp(key, "bricks")) {
         ctx->use_bricks = value != 0;
     } else if (!strcmp(key, "raygen_rect")) {
@@ -249,6 +258,24 @@ int d2r_ctx_set_option(d2r_ctx *ctx, const char *key, int64_t value)
         return d2r_fail(ctx, D2R_ERR_INVALID, std::string("unknown option ") + key);
     }
     return D2R_OK;
+}
+
+int d2r_ctx_get_option(d2r_ctx *ctx, const char *key, int64_t *value)
+{
+    if (!ctx || !key || !value) return d2r_fail(ctx, D2R_ERR_INVALID, "null argument");
+    const struct { const char *k; int64_t v; } tab[] = {
+        {"chunk", ctx->chunk}, {"refill_min", ctx->refill_min}, {"ln_fold", ctx->ln_fold}, {"gemm_nsplit", ctx->gemm_nsplit},
+        {"prep_reuse", ctx->prep_reuse}, {"cls_last", ctx->cls_last}, {"vit_fp8", ctx->vit_fp8}, {"l0_reuse", ctx->l0_reuse},
+        {"attn_rem", ctx->attn_rem}, {"overlap", ctx->overlap}, {"march_blocks", ctx->march_blocks}, {"gbrick_slots", ctx->gbrick_slots},
+        {"brick_slots_total", ctx->brick_slots_total}, {"lds_slots_max", ctx->lds_slots_max}, {"gbrick_max_mib", ctx->gbrick_max_mib},
+        {"bricks", ctx->use_bricks}, {"raygen_rect", ctx->raygen_rect}, {"timing", ctx->timing}, {"debug_fail_chunk", ctx->debug_fail_chunk},
+        {"march_lds_slots", (int64_t)ctx->last_march_nb}, {"march_hbm_brick_slots", (int64_t)ctx->last_march_ngb}};
+    for (const auto &e : tab)
+        if (!strcmp(key, e.k)) {
+            *value = e.v;
+            return D2R_OK;
+        }
+    return d2r_fail(ctx, D2R_ERR_INVALID, std::string("unknown option ") + key);
 }
 
 int d2r_get_render_stats(d2r_ctx *ctx, d2r_render_stats *out)
@@ -469,27 +496,31 @@ int d2r_nerf_create(d2r_ctx *ctx, const d2r_nerf_desc *d, d2r_nerf **out)
         return true;
     };
     if (bhi[0] >= blo[0] && P.n_dense >= 0) {
+        // LDS: the longest prefix of slots (at most 5: levels 0-9) whose bricks fit beside the MLP fragments
         const size_t budget_words = (160 * 1024 - (size_t)D2R_N_WFRAG * 64 * 16) / 4;
+        const uint32_t lds_max = (uint32_t)std::min<int64_t>(5, std::max<int64_t>(0, ctx->lds_slots_max));
         std::vector<uint32_t> words;
-        for (uint32_t i = 0; i < n_slots && i < 5; i++) {
+        for (uint32_t i = 0; i < n_slots && i < lds_max; i++) {
             std::vector<uint32_t> trial = words;
             if (!add_level_brick(i, 0, trial, budget_words, 0) || !add_level_brick(i, 1, trial, budget_words, 0)) break;
             words.swap(trial);
-            if (i + 1 == 4 || i + 1 == 5) {                // instantiated kernel variants
-                P.n_brick_slots = i + 1;
-                P.brick_words = (uint32_t)words.size();
-            }
+            P.n_brick_slots = i + 1;
+            P.brick_words = (uint32_t)words.size();
         }
         brick_tab.assign(words.begin(), words.begin() + P.brick_words);
-        // slots 5 and 6 as HBM-resident bricks (spatially coherent, no hash scatter) when small enough
-        if (P.n_brick_slots == 5) {
-            const size_t gbudget = ((size_t)512 << 20) >> 2;    // 512 MiB of words
-            for (uint32_t i = 5; i < 8 && i < n_slots; i++) {
-                std::vector<uint32_t> trial = gbrick_tab;
-                if (!add_level_brick(i, 0, trial, gbudget, 0) || !add_level_brick(i, 1, trial, gbudget, 0)) break;
-                gbrick_tab.swap(trial);
-                P.n_gbrick_slots = i - 4;
-            }
+        // HBM: the slots behind the LDS ones as dense bounding-box bricks too (neighbouring rays touch neighbouring entries,
+        // one 8-byte gather returns both x-corners) while a slot's brick stays below `gbrick_max_mib` (a brick grows with the
+        // cube of the object's size and of the level's resolution, the hashed table it replaces is 4 MiB per slot whatever
+        // the object) and the total below 512 MiB.  Round 5: for ANY number of LDS slots — an object slightly too large for
+        // five LDS slots used to fall to none and to no HBM bricks either.
+        const size_t gbudget = ((size_t)512 << 20) >> 2;        // words
+        const size_t slot_cap = ((size_t)std::max<int64_t>(0, ctx->gbrick_max_mib) << 20) >> 2;
+        for (uint32_t i = P.n_brick_slots; i < n_slots; i++) {
+            std::vector<uint32_t> trial = gbrick_tab;
+            if (!add_level_brick(i, 0, trial, gbudget, 0) || !add_level_brick(i, 1, trial, gbudget, 0)) break;
+            if (trial.size() - gbrick_tab.size() > slot_cap) break;
+            gbrick_tab.swap(trial);
+            P.n_gbrick_slots = i + 1 - P.n_brick_slots;
         }
     }
     // weight fragments

@@ -19,6 +19,9 @@ class D2rJobPool;   // pngio.h
 #define D2R_INV_DT (1.0f / D2R_DT)
 // aabb_scale 2 (oracle/d2r_oracle.c "cone stepping"): t_{k+1} = t_k + max(dt, t_k/256) in closed form
 #define D2R_CONE 0.00390625f
+// D2R_T_LINEAR: the distance at which steps start to grow, dt_min / cone as in the per-step rule dt = max(dt_min, t * cone).  Newer
+// instant-ngp revisions step in an analytic log space and switch at dt_min / log1p(cone) (~256.5 dt_min; lattices agree to ~0.2 % of a
+// step).  The reference's pinned commit is unknown: if a real snapshot ever disagrees, change this line and oracle/d2r_oracle.c's twin.
 #define D2R_T_LINEAR (D2R_DT * 256.0f)
 #define D2R_N_WFRAG 24                 // MLP weight fragments (see nerf.hip)
 
@@ -55,7 +58,7 @@ struct NerfParams {
     int32_t n_dense;           // leading dense HALF-levels (2 per level when F = 4; slot kinds follow from it), -1 = irregular
     SlotMeta slot[D2R_MAX_LEVELS / 2];
     uint32_t refill_min;       // free lanes in a wave before it pulls new rays from the queue
-    uint32_t n_brick_slots;    // leading slots whose levels are de-hashed into LDS bricks (0, 4 or 5)
+    uint32_t n_brick_slots;    // leading slots whose levels are de-hashed into LDS bricks (0 .. 5)
     uint32_t brick_words;      // total words of those bricks
     const uint32_t *brick_tab; // [brick_words] half2 entries, copied to LDS by every workgroup
     uint32_t n_gbrick_slots;   // further slots de-hashed into dense bricks kept in HBM (spatially coherent)
@@ -147,6 +150,7 @@ struct d2r_ctx {
     int64_t chunk = 4096;       // candidates per pass (capped per model/view by pass_size() in api.hip)
     uint32_t last_pass = 0;     // pass size the last d2r_render_score used (for its stats read-back)
     int64_t march_blocks = 0;  // 0 = auto
+    uint32_t last_march_nb = 0, last_march_ngb = 0;   // brick configuration the last march launch ran with (d2r_get_render_stats)
     int64_t refill_min = 64;   // measured on MI355X: a refill (queue + camera loads, ray setup, SH) costs several iterations,
                                // so a wave runs its 64 rays to the end (lane utilisation 0.79) rather than topping up at 16 free lanes (0.90)
     int64_t ln_fold = 4;       // vision tower: 0 LayerNorm kernels + fp32 residual; LayerNorm folded into the GEMMs with 1 a split (hi + lo) bf16 residual, 2 a bf16 residual, 3 an fp32 residual + bf16 copy, 4 bf16 hi + one lo byte
@@ -158,7 +162,10 @@ struct d2r_ctx {
     int64_t gemm_cfg = 0;      // experiment switch for the GEMM tile configuration (0 = default)
     int64_t use_bricks = 1;
     int64_t raygen_rect = 1;   // composite mode: generate rays only inside the projected occupied bbox
-    int64_t gbrick_slots = 2;  // at most this many slots use HBM bricks (0..2)    // serve de-hashed coarse levels from LDS when the model has them
+    int64_t gbrick_slots = 8;  // at most this many slots use HBM bricks
+    int64_t brick_slots_total = 7;   // ... and none at or beyond this slot index: bricking the finest slot (levels 14-15) measured slower (cache misses)
+    int64_t lds_slots_max = 5;       // d2r_nerf_create: at most this many leading slots as LDS bricks (experiments: the marcher's regimes)
+    int64_t gbrick_max_mib = 64;     // d2r_nerf_create: a slot is HBM-bricked only while its brick stays below this size
     // optional per-kernel timing (HIP events on the launch stream), see d2r_get_timing
     int64_t timing = 0;
     std::vector<hipEvent_t> ev_pool;

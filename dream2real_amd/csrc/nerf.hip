@@ -25,6 +25,7 @@
 #include <algorithm>
 
 #include "d2r_internal.h"
+#include <type_traits>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -598,11 +599,79 @@ __device__ __forceinline__ void slot_blend(const uint32_t *raw, const float *w, 
     o1 = a1;
 }
 
-// All 8 slots of one sample in three phases — 64 addresses, then all 64 gathers issued
-// back-to-back (memory-level parallelism is what bounds this kernel), then the blends.
-// f[2*i], f[2*i+1] = features of slot i (this lane's level of the pair).  Matches oracle
-// hashgrid_encode().
-// NB slots from LDS bricks, the next NGB from HBM bricks, the rest from the hashed tables.
+// compile-time loop: f(std::integral_constant<int, B>{}), ..., f(std::integral_constant<int, E - 1>{})
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
+// Global slots [S0, S0 + CNT) of one sample in three phases — all their addresses, then all their gathers issued
+// back-to-back (memory-level parallelism is what bounds this kernel), then `under()` (work that needs no global data: the
+// LDS-brick slots) while those are in flight, then the blends.  Slots below NB + NGB come from dense HBM bricks, where the two
+// x-neighbour corners are adjacent words: ONE 8-byte gather per (y, z) pair halves the lane-gathers (the texture addresser's
+// cost is per lane); the others from the slot tables (dense / hashed / mixed by ND).
+template <int NB, int NGB, int ND, int S0, int CNT, class Under>
+__device__ __forceinline__ void encode_batch(const NerfParams &P, const __amdgpu_buffer_rsrc_t &rs, const __amdgpu_buffer_rsrc_t &rsb,
+                                             bool hi, float x, float y, float z, float *f, Under &&under)
+{
+    uint32_t off[CNT][8];
+    float w[CNT][3];
+    uint32_t raw[CNT][8];
+    static_for<0, CNT>([&](auto j) {
+        constexpr int I = S0 + decltype(j)::value;
+        if constexpr (I < NB + NGB) slot_addr<K_BRICK>(P, I, hi, x, y, z, off[decltype(j)::value], w[decltype(j)::value]);
+        else slot_addr<slot_kind<NB + NGB, ND>(I)>(P, I, hi, x, y, z, off[decltype(j)::value], w[decltype(j)::value]);
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    static_for<0, CNT>([&](auto j) {
+        constexpr int J = decltype(j)::value, I = S0 + J;
+        if constexpr (I < NB + NGB) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsb, off[J][2 * q], 0, 0);
+                raw[J][2 * q] = v[0];
+                raw[J][2 * q + 1] = v[1];
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 8; c++) raw[J][c] = __builtin_amdgcn_raw_buffer_load_b32(rs, off[J][c], P.slot[I].off, 0);
+        }
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    under();
+    static_for<0, CNT>([&](auto j) {
+        constexpr int J = decltype(j)::value, I = S0 + J;
+        slot_blend(raw[J], w[J], f[2 * I], f[2 * I + 1]);
+    });
+}
+
+// global slots S0 .. 7 in batches: at most four slots per batch while they are bricks (4 address registers per slot survive
+// into the load phase: the base and three strides are shared), at most three once table slots (eight independent
+// addresses each, plus the dense / hashed index arithmetic) are among them
+template <int NB, int NGB, int ND, int S0, class Under>
+__device__ __forceinline__ void encode_from(const NerfParams &P, const __amdgpu_buffer_rsrc_t &rs, const __amdgpu_buffer_rsrc_t &rsb,
+                                            bool hi, float x, float y, float z, float *f, Under &&under)
+{
+    constexpr int LEFT = 8 - S0;
+    constexpr int BMAX = (S0 + 4 <= NB + NGB) ? 4 : 3;
+    // split the remainder evenly over the batches it needs (5 -> 3 + 2, 8 -> 3 + 3 + 2 or 4 + 4)
+    constexpr int NBATCH = (LEFT + BMAX - 1) / BMAX;
+    constexpr int CNT = (LEFT + NBATCH - 1) / NBATCH;
+    encode_batch<NB, NGB, ND, S0, CNT>(P, rs, rsb, hi, x, y, z, f, under);
+    if constexpr (LEFT > CNT) encode_from<NB, NGB, ND, S0 + CNT>(P, rs, rsb, hi, x, y, z, f, [] {});
+}
+
+// All 8 slots of one sample.  f[2*i], f[2*i+1] = features of slot i (this lane's level of the pair).  Matches oracle
+// hashgrid_encode().  NB slots from LDS bricks, the next NGB from HBM bricks, the rest from the hashed tables.
+// The 8 - NB global slots go through encode_batch in batches of at most four (encode_from): a batch keeps up to 19
+// registers per slot live (8 offsets, 3 fractions, 8 gathered words) across its three phases, and with 5 .. 8 slots in ONE
+// batch the 168-register budget of three waves per SIMD spilled 6 .. 90 registers inside the march loop (round 5: the
+// generic no-brick kernel had always run like that).
 template <int NB, int NGB, int ND>
 __device__ __forceinline__ void encode_sample(const NerfParams &P, const __amdgpu_buffer_rsrc_t &rs,
                                               const __amdgpu_buffer_rsrc_t &rsb,
@@ -610,53 +679,24 @@ __device__ __forceinline__ void encode_sample(const NerfParams &P, const __amdgp
                                               float z, uint4 &p0, uint4 &p1)
 {
     float f[16];
-    // Global slots: all addresses, then all gathers back-to-back (memory-level parallelism); the
-    // LDS-brick slots are evaluated underneath while those are in flight, then the global blends.
-    // In a dense brick the two x-neighbour corners are adjacent words: ONE 8-byte gather per
-    // (y,z) pair halves the lane-gathers (the texture addresser's cost is per lane).
     constexpr int NG = 8 - NB;          // slots fetched from HBM (bricks first, then tables)
-    uint32_t off[NG > 0 ? NG : 1][8];
-    float w[NG > 0 ? NG : 1][3];
-    uint32_t raw[NG > 0 ? NG : 1][8];
-#define D2R_SLOT(I)                                                                                              \
-    if (NB <= I) {                                                                                               \
-        if (I < NB + NGB) slot_addr<K_BRICK>(P, I, hi, x, y, z, off[NB <= I ? I - NB : 0], w[NB <= I ? I - NB : 0]); \
-        else slot_addr<slot_kind<NB + NGB, ND>(I)>(P, I, hi, x, y, z, off[NB <= I ? I - NB : 0], w[NB <= I ? I - NB : 0]); \
-    }
-    D2R_SLOT(0) D2R_SLOT(1) D2R_SLOT(2) D2R_SLOT(3) D2R_SLOT(4) D2R_SLOT(5) D2R_SLOT(6) D2R_SLOT(7)
-#undef D2R_SLOT
-    __builtin_amdgcn_sched_barrier(0);
-    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    auto lds_slots = [&]() {
 #pragma unroll
-    for (int i = 0; i < NG; i++) {
-        if (i < NGB) {
+        for (int i = 0; i < NB; i++) {
+            uint32_t bo[8], br[8];
+            float bw[3];
+            slot_addr<K_BRICK>(P, i, hi, x, y, z, bo, bw);
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsb, off[i][2 * j], 0, 0);
-                raw[i][2 * j] = v[0];
-                raw[i][2 * j + 1] = v[1];
+                const uint32_t *p = (const uint32_t *)(lds_bricks + bo[2 * j]);
+                br[2 * j] = p[0];
+                br[2 * j + 1] = p[1];
             }
-        } else {
-#pragma unroll
-            for (int c = 0; c < 8; c++) raw[i][c] = __builtin_amdgcn_raw_buffer_load_b32(rs, off[i][c], P.slot[NB + i].off, 0);
+            slot_blend(br, bw, f[2 * i], f[2 * i + 1]);
         }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < NB; i++) {
-        uint32_t bo[8], br[8];
-        float bw[3];
-        slot_addr<K_BRICK>(P, i, hi, x, y, z, bo, bw);
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const uint32_t *p = (const uint32_t *)(lds_bricks + bo[2 * j]);
-            br[2 * j] = p[0];
-            br[2 * j + 1] = p[1];
-        }
-        slot_blend(br, bw, f[2 * i], f[2 * i + 1]);
-    }
-#pragma unroll
-    for (int i = 0; i < NG; i++) slot_blend(raw[i], w[i], f[2 * (NB + i)], f[2 * (NB + i) + 1]);
+    };
+    if constexpr (NG == 0) lds_slots();
+    else encode_from<NB, NGB, ND, NB>(P, rs, rsb, hi, x, y, z, f, lds_slots);
     // straight into the two bf16 B fragments of density layer 1 (k-step 0: slots 0..3, 1: slots 4..7)
     p0.x = pack2(f[0], f[1]); p0.y = pack2(f[2], f[3]); p0.z = pack2(f[4], f[5]); p0.w = pack2(f[6], f[7]);
     p1.x = pack2(f[8], f[9]); p1.y = pack2(f[10], f[11]); p1.z = pack2(f[12], f[13]); p1.w = pack2(f[14], f[15]);
@@ -1134,12 +1174,32 @@ int d2r_launch_render(d2r_ctx *ctx, const d2r_nerf *m, const ViewParams &V, cons
     const float *bgd = (const float *)ctx->bg_depth.p;
     unsigned long long *sc = (unsigned long long *)(cnt + 2);
     const uint2 *q = (const uint2 *)ctx->queue.p;
-    const uint32_t nb = (ctx->use_bricks && m->P.n_dense == 5) ? m->P.n_brick_slots : 0;
+    // Brick configuration (NB leading slots from LDS, the next NGB from HBM bricks, the rest from the tables) -> one of the
+    // instantiated kernels.  The HBM bricks were built for the model's own LDS count, so NB is that count or 0; NGB is
+    // rounded DOWN to an instantiated value (using fewer HBM-brick slots than exist is always valid).
+    const bool bricks_ok = ctx->use_bricks && m->P.n_dense == 5;
+    uint32_t nb = bricks_ok ? m->P.n_brick_slots : 0;
+    uint32_t ngb = 0;
+    if (bricks_ok) {
+        const uint32_t cap_total = (uint32_t)std::max<int64_t>(ctx->brick_slots_total, nb);
+        ngb = std::min<uint32_t>(std::min<uint32_t>((uint32_t)ctx->gbrick_slots, m->P.n_gbrick_slots), cap_total - nb);
+        // instantiated (NB, NGB): NB = 5: 0..3;  4: 0, 2, 3;  3: 3, 4;  2: 4, 5;  1: 5, 6;  0: 0, 6, 7  (HBM bricks through slot 5 or 6)
+        bool none = false;
+        switch (nb) {
+            case 5: ngb = std::min(ngb, 3u); break;
+            case 4: ngb = ngb >= 3 ? 3 : ngb >= 2 ? 2 : 0; break;
+            case 3: case 2: case 1:
+                if (ngb >= 7 - nb) ngb = 7 - nb;
+                else if (ngb >= 6 - nb) ngb = 6 - nb;
+                else none = true;             // LDS bricks alone are not instantiated for 1..3 slots (slots <= 5 always fit the HBM budget)
+                break;
+            default: ngb = ngb >= 7 ? 7 : ngb >= 6 ? 6 : 0; break;
+        }
+        if (none) nb = ngb = 0;
+    }
     NerfParams PP = m->P;
     PP.refill_min = (uint32_t)ctx->refill_min;
     const size_t lds = (size_t)D2R_N_WFRAG * 64 * 16 + (nb ? (size_t)m->P.brick_words * 4 : 0);
-    uint32_t ngb = nb == 5 ? std::min<uint32_t>((uint32_t)ctx->gbrick_slots, m->P.n_gbrick_slots) : 0;
-#define D2R_MARCH(COMP, NB, NGB, ND) D2R_MARCH_C(COMP, NB, NGB, ND, false)
 #define D2R_MARCH_C(COMP, NB, NGB, ND, CONE)                                                                      \
     do {                                                                                                          \
         static PerDeviceOnce attr;                                                                                \
@@ -1150,16 +1210,17 @@ int d2r_launch_render(d2r_ctx *ctx, const d2r_nerf *m, const ViewParams &V, cons
                            cnt, cnt + 1, COMP ? nullptr : rgba_dev, COMP ? nullptr : depth_dev,                   \
                            COMP ? bgd : nullptr, COMP ? frames_dev : nullptr, sc);                                \
     } while (0)
-    // compile-time slot kinds: the usual tables have 5 leading dense levels; small objects get 4 or
-    // 5 LDS-bricked slots (+ up to 3 HBM-bricked); anything else takes the generic instantiation
+    // compile-time slot kinds: the usual tables have 5 leading dense levels; anything else takes the generic instantiation
+#define D2R_MARCH_CASE(COMP, CONE, NB, NGB) else if (nb == NB && ngb == NGB) D2R_MARCH_C(COMP, NB, NGB, 5, CONE);
 #define D2R_MARCH_PICK(COMP, CONE)                                      \
     do {                                                                \
         if (m->P.n_dense != 5) D2R_MARCH_C(COMP, 0, 0, -1, CONE);       \
-        else if (nb == 5 && ngb == 3) D2R_MARCH_C(COMP, 5, 3, 5, CONE); \
-        else if (nb == 5 && ngb == 2) D2R_MARCH_C(COMP, 5, 2, 5, CONE); \
-        else if (nb == 5 && ngb == 1) D2R_MARCH_C(COMP, 5, 1, 5, CONE); \
-        else if (nb == 5) D2R_MARCH_C(COMP, 5, 0, 5, CONE);             \
-        else if (nb == 4) D2R_MARCH_C(COMP, 4, 0, 5, CONE);             \
+        D2R_MARCH_CASE(COMP, CONE, 5, 3) D2R_MARCH_CASE(COMP, CONE, 5, 2) D2R_MARCH_CASE(COMP, CONE, 5, 1) D2R_MARCH_CASE(COMP, CONE, 5, 0) \
+        D2R_MARCH_CASE(COMP, CONE, 4, 3) D2R_MARCH_CASE(COMP, CONE, 4, 2) D2R_MARCH_CASE(COMP, CONE, 4, 0)                                  \
+        D2R_MARCH_CASE(COMP, CONE, 3, 4) D2R_MARCH_CASE(COMP, CONE, 3, 3)                                                                   \
+        D2R_MARCH_CASE(COMP, CONE, 2, 5) D2R_MARCH_CASE(COMP, CONE, 2, 4)                                                                   \
+        D2R_MARCH_CASE(COMP, CONE, 1, 6) D2R_MARCH_CASE(COMP, CONE, 1, 5)                                                                   \
+        D2R_MARCH_CASE(COMP, CONE, 0, 7) D2R_MARCH_CASE(COMP, CONE, 0, 6)                                                                   \
         else D2R_MARCH_C(COMP, 0, 0, 5, CONE);                          \
     } while (0)
     if (cone) {
@@ -1169,8 +1230,10 @@ int d2r_launch_render(d2r_ctx *ctx, const d2r_nerf *m, const ViewParams &V, cons
         if (composite) D2R_MARCH_PICK(true, false);
         else D2R_MARCH_PICK(false, false);
     }
+    ctx->last_march_nb = nb;
+    ctx->last_march_ngb = ngb;
+#undef D2R_MARCH_CASE
 #undef D2R_MARCH_PICK
-#undef D2R_MARCH
 #undef D2R_MARCH_C
     ctx->timing_end(tm);
     D2R_HIP(ctx, hipGetLastError());

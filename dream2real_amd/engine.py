@@ -55,6 +55,11 @@ class Context:
     def set_option(self, key: str, value: int):
         self.check(self.lib.d2r_ctx_set_option(self.h, key.encode(), C.c_int64(value)))
 
+    def get_option(self, key: str) -> int:
+        v = C.c_int64(0)
+        self.check(self.lib.d2r_ctx_get_option(self.h, key.encode(), C.byref(v)))
+        return int(v.value)
+
     def render_stats(self, collect_K: int | None = None) -> dict:
         if collect_K is not None:
             self.check(self.lib.d2r_collect_render_stats(self.h, C.c_uint32(collect_K)))

@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 #define D2R_API __attribute__((visibility("default")))
-#define D2R_ABI_VERSION 7
+#define D2R_ABI_VERSION 8
 
 typedef enum {
     D2R_OK = 0,
@@ -400,9 +400,13 @@ D2R_API int d2r_get_timing(d2r_ctx *ctx, d2r_timing *out);
  * "refill_min" (default 64, 1..64): free lanes a marcher wave accumulates before it takes new rays
  *     from the queue (64 = a wave runs its 64 rays to the end).
  * "bricks" (default 1): serve the de-hashed coarse levels of small models from LDS; 0 forces every
- *     level through the global tables.  "gbrick_slots" (default 2, 0..3): slots served from de-hashed
- *     bricks in HBM.  "raygen_rect" (default 1): composite mode generates rays only inside the projected
- *     occupied bounding box.  Results are bit-identical whatever these three are set to.
+ *     level through the global tables.  Behind the LDS slots, further slots are served from de-hashed dense bricks in HBM:
+ *     "gbrick_slots" (default 8, 0..8) caps how many, "brick_slots_total" (default 7, 0..8) the first slot that is never
+ *     bricked (the finest one measured slower).  "raygen_rect" (default 1): composite mode generates rays only inside the
+ *     projected occupied bounding box.  Results are bit-identical whatever these are set to.
+ *     Read at d2r_nerf_create / d2r_nerf_load_ingp time (set them BEFORE creating the model): "lds_slots_max" (default 5,
+ *     0..5): at most this many leading slots as LDS bricks; "gbrick_max_mib" (default 64, 0..512): a slot gets an HBM brick
+ *     only while that brick stays below this size.
  * "ln_fold" (default 4): schedule of the vision tower.  0: LayerNorm kernels between the GEMMs, fp32 residual
  *     stream.  1-3: LayerNorm folded into the QKV / fc1 GEMMs (LN(x) W^T + b = rstd (x (gamma o W)^T - mean
  *     colsum) + b'), row statistics emitted by the residual GEMMs' epilogues, which also write the bf16 operand
@@ -442,6 +446,9 @@ D2R_API int d2r_get_timing(d2r_ctx *ctx, d2r_timing *out);
  * Development builds of the library (make DEV=1) also know experiment switches — schedules that were measured no faster
  * and tile configurations kept for comparison; they are not part of this interface. */
 D2R_API int d2r_ctx_set_option(d2r_ctx *ctx, const char *key, int64_t value);
+/* Reads a tunable back (the keys of d2r_ctx_set_option), plus read-only facts about the last ray-march launch on this
+ * context: "march_lds_slots" / "march_hbm_brick_slots" = the brick configuration it ran with (ABI 8). */
+D2R_API int d2r_ctx_get_option(d2r_ctx *ctx, const char *key, int64_t *value);
 
 /* ------------------------------------------------------ multi-GPU (one process per GPU) */
 

@@ -298,6 +298,13 @@ static inline int cell_of(float p)
  * t_k >= 256 dt_min), t_k = t_{k1} (1 + 1/256)^(k - k1) after it.  The power is a fixed-order product
  * of the fp32 constants (1+1/256)^(2^i), the same on both sides. */
 #define D2R_CONE 0.00390625f                     /* 1/256 */
+/* THE switch distance between constant and proportional steps.  As restated (the per-step rule dt = max(dt_min, t * cone),
+ * instant-ngp's `calc_dt` / `advance_n_steps` as published with the 2022 paper) it is dt_min / cone = 256 dt_min.  NEWER
+ * instant-ngp revisions march in an analytic "stepping space" (`to_stepping_space` / `from_stepping_space`: linear below
+ * dt_min / log1p(cone) ~ 256.5 dt_min, exponential t ~ exp(n log1p(cone)) above) — the two lattices agree to ~0.2 % of one
+ * step.  The reference's pinned instant-ngp commit is unknown (empty submodule, .gitmodules:4-6); the day a real snapshot +
+ * render pair disagrees, this constant (and the same one in dream2real_amd/csrc/d2r_internal.h) is the one line to change:
+ * D2R_DT / log1pf(D2R_CONE).  Irrelevant for aabb_scale 1 (cone angle 0: every shipped scene but the shelf). */
 #define D2R_T_LINEAR (D2R_DT * 256.0f)           /* below this distance the step is dt_min */
 static const float d2r_cone_pow[12] = {      /* float((1 + 1/256)^(2^i)), i = 0..11 */
     1.00390625f,         1.0078277587890625f, 1.015716791152954f,  1.0316805839538574f,

@@ -51,6 +51,55 @@ def make_synthetic_nerf(occ_zyx: np.ndarray, *, seed_grid: int, seed_mlp: int,
                      pack_bits(occ_zyx), aabb_scale)
 
 
+def make_trained_like_nerf(occ_zyx: np.ndarray, centre_ngp, radii_ngp, *, seed_grid: int, seed_mlp: int,
+                            levels: Optional[GridLevels] = None, peak: float = 12.0, fall_per_metre: float = 2400.0,
+                            table_limit: float = 8.0, mlp_gain: float = 1.6, aabb_scale: int = 1) -> NerfModel:
+    """A field with the statistics of a TRAINED instant-ngp object rather than of a random one:
+    * hash-table values heavy-tailed (Student-t, 3 degrees of freedom) and clipped to +-`table_limit` (a trained table
+      spans several units where initialisation is 1e-4);
+    * MLP weights `mlp_gain` x Xavier;
+    * density pre-activation out0 from +`peak` ON the surface of the ellipsoid (centre / radii in ngp units) down to
+      -`peak` at 1 cm from it and below further away: sigma = exp(out0) spans exp(+-12) = 1.6e5 ... 6e-6 and the
+      opaque region is a SHELL ~ 3 march steps thick (out0 = peak - fall_per_metre * |distance|), carried by a signed
+      distance stored in feature 0 of the finest DENSE level and read by two ReLU units of opposite sign.
+    Same structure and file layout as make_synthetic_nerf; inputs for oracle and library alike."""
+    levels = levels or grid_levels()
+    F = levels.n_features
+    rg = np.random.Generator(np.random.PCG64(seed_grid))
+    grid = np.clip(rg.standard_t(3, size=(levels.n_entries, F)) * 0.7, -table_limit, table_limit).astype(np.float32)
+    grid[levels.offset[0]:levels.offset[0] + levels.size[0], 0] = 0.5
+    dense = np.nonzero(~levels.hashed)[0]
+    ls = int(dense[-1])                                         # the finest level that is indexed densely
+    res, scale = int(levels.res[ls]), float(levels.scale[ls])
+    g = (np.arange(res, dtype=np.float64) - 0.5) / scale        # vertex g of a level sits at x = (g - 0.5) / scale (pos = x * scale + 0.5)
+    gz, gy, gx = np.meshgrid(g, g, g, indexing="ij")
+    c, r = np.asarray(centre_ngp, np.float64), np.asarray(radii_ngp, np.float64)
+    q = np.sqrt(((gx - c[0]) / r[0]) ** 2 + ((gy - c[1]) / r[1]) ** 2 + ((gz - c[2]) / r[2]) ** 2)
+    sdf = (q - 1.0) * r.min()                                   # ~ signed distance to the ellipsoid (exact for a sphere), metres = ngp units
+    G = table_limit / 0.02                                      # the carrier saturates 2 cm from the surface
+    carrier = np.clip(sdf * G, -table_limit, table_limit).astype(np.float32).reshape(-1)     # index x + res * (y + res * z)
+    grid[levels.offset[ls]:levels.offset[ls] + res ** 3, 0] = carrier
+    rm = np.random.Generator(np.random.PCG64(seed_mlp))
+    n_in = levels.n_levels * F
+    dw1 = _xavier(rm, 64, n_in) * mlp_gain
+    dw2 = _xavier(rm, 16, 64) * mlp_gain
+    cw1 = _xavier(rm, 64, 32) * mlp_gain
+    cw2 = _xavier(rm, 64, 64) * mlp_gain
+    cw3 = _xavier(rm, 16, 64) * mlp_gain
+    k = 2.0
+    slope = fall_per_metre / (k * G)
+    dw1[0:3, :] = 0.0
+    dw1[0, 0] = 2.0                     # hidden0 = relu(2 * 0.5) = 1  (constant carrier, as in make_synthetic_nerf)
+    dw1[1, ls * F] = k                  # hidden1 = relu(+k * carrier): outside the surface
+    dw1[2, ls * F] = -k                 # hidden2 = relu(-k * carrier): inside
+    dw2[0, 0] = peak
+    dw2[0, 1] = -slope
+    dw2[0, 2] = -slope
+    f16 = lambda a: a.astype(np.float16)
+    return NerfModel(levels, f16(grid), f16(dw1), f16(dw2), f16(cw1), f16(cw2), f16(cw3),
+                     pack_bits(occ_zyx), aabb_scale)
+
+
 def _cell_centres(cascade: int = 0):
     """ngp-space centres of the 128^3 cells of an occupancy cascade (side 2^cascade about 0.5)."""
     side = float(1 << cascade)
@@ -100,16 +149,24 @@ def make_scene(kind: str = "shopping") -> SyntheticScene:
     """Seeded scenes of SURVEY.md §8(d).  kind: 'shopping' (apple-sized ellipsoid, scene
     type 3), 'pool_triangle' (2.8 cm sphere, scene type 0) or 'shelf' (aabb_scale 2 like
     configs/shelf_demo.json:62: two occupancy cascades, cone stepping; the object sits outside
-    the unit cube and the camera 1.3 m away)."""
+    the unit cube and the camera 1.3 m away).  'shopping_trained': the shopping scene with a foreground
+    field of trained-like statistics (make_trained_like_nerf: thin opaque shell, sigma over exp(+-12),
+    table values to +-8)."""
+    trained = kind.endswith("_trained")
+    if trained:
+        kind = kind[:-len("_trained")]
     if kind == "shelf":
         return _make_shelf_scene()
     if kind == "room":
         return _make_shelf_scene(aabb_scale=4)
     levels = grid_levels()
     scene_centre = np.array([0.5, 0.0, 0.035])          # configs/shopping_demo.json:29
-    if kind == "shopping":
-        scene_type, radii_w = 3, (0.04, 0.04, 0.05)
-        obj_t = scene_centre + np.array([-0.02, -0.05, 0.05])
+    if kind in ("shopping", "shopping_big", "shopping_huge"):
+        # _big / _huge: the same scene with an object 2.2x / 5x the apple's size (bench.py's marcher-regime sweep: the
+        # level bricks of such an object no longer fit five LDS slots / only the coarsest do)
+        k = {"shopping": 1.0, "shopping_big": 2.2, "shopping_huge": 5.0}[kind]
+        scene_type, radii_w = 3, (0.04 * k, 0.04 * k, 0.05 * k)
+        obj_t = scene_centre + np.array([-0.02, -0.05, 0.05 * k])
     elif kind == "pool_triangle":
         scene_type, radii_w = 0, (0.028, 0.028, 0.028)
         obj_t = scene_centre + np.array([-0.03, -0.02, 0.028])
@@ -120,7 +177,10 @@ def make_scene(kind: str = "shopping") -> SyntheticScene:
     # world radii (x,y,z) -> ngp axes (y,z,x)
     radii_ngp = (radii_w[1], radii_w[2], radii_w[0])
     fg_occ = ellipsoid_occupancy(world_to_ngp(obj_t), radii_ngp)
-    fg = make_synthetic_nerf(fg_occ, seed_grid=1, seed_mlp=3, levels=levels)
+    if trained:
+        fg = make_trained_like_nerf(fg_occ, world_to_ngp(obj_t), radii_ngp, seed_grid=1, seed_mlp=3, levels=levels)
+    else:
+        fg = make_synthetic_nerf(fg_occ, seed_grid=1, seed_mlp=3, levels=levels)
     # background: table slab (6 cm under world z=0, i.e. ngp y in [0.44,0.5]) + three blobs
     x, y, z = _cell_centres()
     bg_occ = (y >= 0.44) & (y < 0.5)
@@ -131,7 +191,7 @@ def make_scene(kind: str = "shopping") -> SyntheticScene:
     eye = scene_centre + 0.6 * np.array([-0.35, -0.45, 0.82]) / np.linalg.norm([-0.35, -0.45, 0.82])
     cams = np.stack([look_at_opencv(eye, scene_centre),
                      look_at_opencv(eye + np.array([0.1, 0.0, 0.02]), scene_centre)])
-    return SyntheticScene(kind, scene_type, scene_centre, fg, bg, obj_pose, cams,
+    return SyntheticScene(kind + ("_trained" if trained else ""), scene_type, scene_centre, fg, bg, obj_pose, cams,
                           fg_background=(0.0, 0.0, 0.0, 1.0))
 
 

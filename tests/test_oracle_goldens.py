@@ -1,6 +1,7 @@
 """The oracle (oracle/) pinned against the committed golden vectors that were produced by
 the real reference code / Hugging Face / Pillow (tests/golden/make_goldens.py)."""
 import numpy as np
+import pytest
 
 from oracle import clip_ref, host_ref, render_ref
 from tests.golden.frames import seeded_render_frames
@@ -109,3 +110,30 @@ def test_cone_stepping_lattice_follows_the_step_recurrence():
         assert np.max(np.abs(t - np.array(seq)) / np.maximum(dt, np.array(seq) / 256.0)) < 1.0
     far = render_ref.cone_lattice(0.9, 600).astype(np.float64)
     np.testing.assert_allclose(far[1:] / far[:-1], 1.0 + 1.0 / 256.0, rtol=1e-6)
+
+
+# ---- round 5: tests/golden/hf_clip_r05.npz (generator: tests/golden/make_hf_goldens_r05.py, Hugging Face CLIPModel run in
+# the build container) — full-depth ViT-L/14 and the adversarial-statistics weights
+
+@pytest.mark.parametrize("key,name,weights,n,tol", [("g5adv_vit_tiny", "vit_tiny", "adversarial", 4, 2e-5),
+                                                    ("g5adv_vit_b16", "vit_b16", "adversarial", 2, 3e-5),
+                                                    ("g5_vit_l14", "vit_l14", "gaussian", 2, 2e-5)])
+def test_oracle_vit_against_hf_goldens_round5(key, name, weights, n, tol):
+    """The numpy fp32 tower against Hugging Face's CLIPModel (a) at FULL depth for ViT-L/14 (224) — g5 held the 2-layer model
+    and ViT-B/16 only — and (b) under clip_model.adversarial_clip_state_dict, the regime the round-5 parity tests use the oracle
+    in (massive activations, negative / spiked LayerNorm gains, near one-hot softmax rows): embeddings within `tol`, and the
+    committed file is the one the generator wrote (SHA-256 of the embedding bytes)."""
+    import hashlib
+    import os
+    from dream2real_amd.clip_model import adversarial_clip_state_dict
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hf_clip_r05.npz"))
+    want = g[key + "_image_embeds"]
+    assert hashlib.sha256(want.tobytes()).digest() == g[key + "_sha256"].tobytes()
+    cfg = CLIP_CONFIGS[name]
+    sd = random_clip_state_dict(cfg, 6, text=False) if weights == "gaussian" else adversarial_clip_state_dict(cfg, 6)
+    r = np.random.Generator(np.random.PCG64(77))
+    pv = r.standard_normal((n, 3, cfg["image_size"], cfg["image_size"]), dtype=np.float32)
+    got = clip_ref.vision_embeds(pv, sd, cfg)
+    err = float(np.abs(got - want).max())
+    print(f"[pin] oracle vs HF CLIPModel, {name} ({weights} weights, {cfg['num_layers']} layers): max |d embedding| = {err:.2e} (bar {tol:.0e})")
+    assert want.shape == (n, cfg["proj"]) and err <= tol

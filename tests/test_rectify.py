@@ -100,3 +100,35 @@ def test_product_resize_agrees_with_the_independent_oracle():
     np.testing.assert_array_equal(rectify_mask(mask, (33, 33)), host_ref.rectify_mask_ref(mask, (33, 33)))
     tall = r.random((90, 40), dtype=np.float32)              # h > w: crop rows
     np.testing.assert_allclose(rectify_depth(tall, (17, 17)), host_ref.rectify_depth_ref(tall, (17, 17)), rtol=0, atol=2e-6)
+
+
+def test_cubic_resize_against_torch_bicubic_a_third_party_restatement():
+    """a pin that is free here.  `torch.nn.functional.interpolate(mode="bicubic", align_corners=False)`
+    is an INDEPENDENT implementation of the same convolution — Keys cubic with A = -0.75, half-pixel centres
+    (src = (dst + 0.5) * scale - 0.5), replicated borders, no antialiasing — i.e. of cv2.resize(INTER_CUBIC)'s float path.
+    The oracle's scalar restatement and the product's host mirror agree with it within 2e-4 on [0, 1] data at the path's
+    shapes (the reference's 720^2 -> 336^2, BASELINE's 720-wide crops -> 640x360 / 160x90) and on up-sampling; the residue is
+    float32 rounding of the source coordinate (torch evaluates the fraction in float at coordinates up to 720: ~6e-5 of a
+    pixel), not a different kernel: at a 2:1 ratio, where every fraction is exactly 0.5, the three agree to 1e-6.
+    STILL UNPINNED: OpenCV's own evaluation order in float32 and its 11-bit fixed-point uint8 path (rectify_mask) — cv2 is
+    not installed; those rest on hand-derived vectors (test_oracle_cubic_hand_derived_vectors)."""
+    import torch
+    from oracle import host_ref
+    r = np.random.default_rng(11)
+    worst = 0.0
+    for (sh, sw), (dw, dh) in (((720, 720), (336, 336)), ((720, 720), (160, 90)), ((720, 720), (640, 360)), ((72, 128), (33, 21)),
+                               ((50, 70), (120, 99)), ((64, 64), (32, 32))):
+        img = r.random((sh, sw), dtype=np.float32)
+        img[sh // 3:sh // 2, sw // 4:sw // 2] = 0.0                          # a step edge: overshoot of the cubic kernel included
+        want = torch.nn.functional.interpolate(torch.from_numpy(img)[None, None], size=(dh, dw), mode="bicubic",
+                                               align_corners=False)[0, 0].numpy()
+        got_product = resize_cubic(img, (dw, dh))
+        np.testing.assert_allclose(got_product, want, rtol=0, atol=2e-4, err_msg=f"product {sh}x{sw} -> {dw}x{dh}")
+        if sh * sw <= 72 * 128 or (dw, dh) == (336, 336):                  # the scalar oracle loops per pixel: the big case once
+            got_oracle = host_ref.resize_cubic_ref(img, (dw, dh))
+            np.testing.assert_allclose(got_oracle, want, rtol=0, atol=2e-4, err_msg=f"oracle {sh}x{sw} -> {dw}x{dh}")
+            worst = max(worst, float(np.abs(got_oracle - want).max()))
+        if (sh, sw, dw, dh) == (64, 64, 32, 32):
+            np.testing.assert_allclose(got_product, want, rtol=0, atol=2e-6)
+        worst = max(worst, float(np.abs(got_product - want).max()))
+    print(f"[pin] resize_cubic vs torch bicubic: max |d| = {worst:.2e} on [0, 1] data (bar 2e-4)")
