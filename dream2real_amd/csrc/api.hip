@@ -497,7 +497,7 @@ int d2r_nerf_create(d2r_ctx *ctx, const d2r_nerf_desc *d, d2r_nerf **out)
     };
     if (bhi[0] >= blo[0] && P.n_dense >= 0) {
         // LDS: the longest prefix of slots (at most 5: levels 0-9) whose bricks fit beside the MLP fragments
-        const size_t budget_words = (160 * 1024 - (size_t)D2R_N_WFRAG * 64 * 16) / 4;
+        const size_t budget_words = (160 * 1024 - (size_t)D2R_N_WFRAG * 64 * 16 - 512 /* the cone-stepping tables of the CONE kernels */) / 4;
         const uint32_t lds_max = (uint32_t)std::min<int64_t>(5, std::max<int64_t>(0, ctx->lds_slots_max));
         std::vector<uint32_t> words;
         for (uint32_t i = 0; i < n_slots && i < lds_max; i++) {

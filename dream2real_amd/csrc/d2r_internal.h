@@ -165,7 +165,7 @@ struct d2r_ctx {
     int64_t gbrick_slots = 8;  // at most this many slots use HBM bricks
     int64_t brick_slots_total = 7;   // ... and none at or beyond this slot index: bricking the finest slot (levels 14-15) measured slower (cache misses)
     int64_t lds_slots_max = 5;       // d2r_nerf_create: at most this many leading slots as LDS bricks (experiments: the marcher's regimes)
-    int64_t gbrick_max_mib = 64;     // d2r_nerf_create: a slot is HBM-bricked only while its brick stays below this size
+    int64_t gbrick_max_mib = 512;    // d2r_nerf_create: a slot is HBM-bricked only while its brick stays below this size (512 = only the 512 MiB total bounds them: measured, a 5x apple renders 1.45x faster on its 100+ MiB bricks than on the 4 MiB hashed tables, profiles/r05_march_regimes.md)
     // optional per-kernel timing (HIP events on the launch stream), see d2r_get_timing
     int64_t timing = 0;
     std::vector<hipEvent_t> ev_pool;

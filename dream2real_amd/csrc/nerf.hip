@@ -166,16 +166,39 @@ struct Ray {
 // aabb_scale >= 2 (template parameter CONE): the lattice of a ray is the cone-stepping sequence
 // t_{k+1} = t_k + max(dt, t_k / 256) in closed form -- t0 + k dt up to k1, t1 (1 + 1/256)^(k - k1) after it,
 // the power as the fixed-order product of fp32 constants that oracle/d2r_oracle.c uses (same bits).
+// (1 + 1/256)^n = hi[n >> 6] * lo[n & 63]: lo[i] = float(c^i), hi[j] = float(c^(64 j)), the powers accumulated in double by
+// repeated multiplication — evaluated at COMPILE time here, by the same IEEE operations oracle/d2r_oracle.c runs at start-up
+// (same bits).  The CONE kernels copy the 512 bytes into LDS: one multiply and two LDS reads per lattice point where the fixed-order
+// product of twelve constants cost twelve selects and multiplies (round 5).
+struct ConeTab { float lo[64], hi[64]; };
+constexpr ConeTab make_cone_tab()
+{
+    ConeTab t{};
+    double p = 1.0;
+    for (int i = 0; i < 64; i++) {
+        t.lo[i] = (float)p;
+        p *= 1.00390625;
+    }
+    const double c64 = p;
+    double q = 1.0;
+    for (int j = 0; j < 64; j++) {
+        t.hi[j] = (float)q;
+        q *= c64;
+    }
+    return t;
+}
+__device__ const ConeTab d2r_cone_tab_dev = make_cone_tab();
+__shared__ float d2r_cone_lds[128];          // [0, 64) lo, [64, 128) hi; only the CONE instantiations reference (and allocate) it
+// every CONE kernel calls this once, before its first lattice_t (ends with a barrier)
+__device__ __forceinline__ void cone_tab_to_lds()
+{
+    for (uint32_t i = threadIdx.x; i < 128; i += blockDim.x) d2r_cone_lds[i] = i < 64 ? d2r_cone_tab_dev.lo[i] : d2r_cone_tab_dev.hi[i - 64];
+    __syncthreads();
+}
 __device__ __forceinline__ float cone_pow(uint32_t n)
 {
-    const float P2[12] = {1.00390625f,         1.0078277587890625f, 1.015716791152954f,  1.0316805839538574f,
-                          1.0643649101257324f, 1.1328725814819336f, 1.2834001779556274f, 1.6471161842346191f,
-                          2.712991714477539f,  7.360323429107666f,  54.17436218261719f,  2934.861572265625f};
-    float r = 1.0f;
-#pragma unroll
-    for (int i = 0; i < 12; i++)
-        if ((n >> i) & 1u) r = r * P2[i];
-    return r;
+    n = min(n, 4095u);
+    return d2r_cone_lds[64 + (n >> 6)] * d2r_cone_lds[n & 63u];
 }
 template <bool CONE>
 __device__ __forceinline__ float lattice_t(const Ray &r, uint32_t k)
@@ -352,6 +375,7 @@ __global__ __launch_bounds__(256) void k_raygen(NerfParams P, ViewParams V, cons
                                                 uint2 *__restrict__ queue, uint32_t *__restrict__ qcount,
                                                 float *__restrict__ rgba_out, float *__restrict__ depth_out)
 {
+    if (CONE) cone_tab_to_lds();
     const uint32_t tiles_x = (V.W + 15) / 16;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t px = (blockIdx.x % tiles_x) * 16 + (wave & 1) * 8 + (lane & 7);
@@ -401,6 +425,7 @@ __global__ __launch_bounds__(256) void k_raygen_rect(NerfParams P, ViewParams V,
                                                      uint2 *__restrict__ queue, uint32_t *__restrict__ qcount,
                                                      int4 *__restrict__ rects)
 {
+    if (CONE) cone_tab_to_lds();
     const uint32_t cam_i = blockIdx.x;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float cam[12];
@@ -908,6 +933,7 @@ __global__ __launch_bounds__(D2R_MARCH_THREADS) void k_march(NerfParams P, ViewP
     for (uint32_t i = threadIdx.x; i < D2R_N_WFRAG * 64; i += blockDim.x) sw[i] = P.wfrag[i];
     if (NB > 0)
         for (uint32_t i = threadIdx.x; i < P.brick_words; i += blockDim.x) ((uint32_t *)lds_bricks)[i] = P.brick_tab[i];
+    if (CONE) cone_tab_to_lds();
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t n_q = *qcount;

@@ -405,8 +405,8 @@ D2R_API int d2r_get_timing(d2r_ctx *ctx, d2r_timing *out);
  *     bricked (the finest one measured slower).  "raygen_rect" (default 1): composite mode generates rays only inside the
  *     projected occupied bounding box.  Results are bit-identical whatever these are set to.
  *     Read at d2r_nerf_create / d2r_nerf_load_ingp time (set them BEFORE creating the model): "lds_slots_max" (default 5,
- *     0..5): at most this many leading slots as LDS bricks; "gbrick_max_mib" (default 64, 0..512): a slot gets an HBM brick
- *     only while that brick stays below this size.
+ *     0..5): at most this many leading slots as LDS bricks; "gbrick_max_mib" (default 512, 0..512): a slot gets an HBM brick
+ *     only while that brick stays below this size (the bricks of a model total at most 512 MiB).
  * "ln_fold" (default 4): schedule of the vision tower.  0: LayerNorm kernels between the GEMMs, fp32 residual
  *     stream.  1-3: LayerNorm folded into the QKV / fc1 GEMMs (LN(x) W^T + b = rstd (x (gamma o W)^T - mean
  *     colsum) + b'), row statistics emitted by the residual GEMMs' epilogues, which also write the bf16 operand

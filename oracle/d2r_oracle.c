@@ -306,17 +306,34 @@ static inline int cell_of(float p)
  * render pair disagrees, this constant (and the same one in dream2real_amd/csrc/d2r_internal.h) is the one line to change:
  * D2R_DT / log1pf(D2R_CONE).  Irrelevant for aabb_scale 1 (cone angle 0: every shipped scene but the shelf). */
 #define D2R_T_LINEAR (D2R_DT * 256.0f)           /* below this distance the step is dt_min */
-static const float d2r_cone_pow[12] = {      /* float((1 + 1/256)^(2^i)), i = 0..11 */
-    1.00390625f,         1.0078277587890625f, 1.015716791152954f,  1.0316805839538574f,
-    1.0643649101257324f, 1.1328725814819336f, 1.2834001779556274f, 1.6471161842346191f,
-    2.712991714477539f,  7.360323429107666f,  54.17436218261719f,  2934.861572265625f};
+/* (1 + 1/256)^n as the product of two table entries: n = 64 j + i -> hi[j] * lo[i], lo[i] = float(c^i), hi[j] = float(c^(64 j)),
+ * the powers accumulated in double by repeated multiplication (IEEE: the same bits under any compiler; dream2real_amd/csrc/nerf.hip
+ * builds the same tables at compile time).  Round 5: replaces the fixed-order product of up to twelve fp32 constants — one multiply
+ * and two lookups per lattice point instead of twelve selects and multiplies in the marcher's inner loop; the lattice moved by at
+ * most a few ulp of t, which is what either closed form is: a definition, unpinned against instant-ngp (see D2R_T_LINEAR). */
+static float d2r_cone_lo[64], d2r_cone_hi[64];
+static int d2r_cone_ready = 0;
+static void cone_tables_init(void)
+{
+    if (d2r_cone_ready) return;
+    double p = 1.0;
+    for (int i = 0; i < 64; i++) {
+        d2r_cone_lo[i] = (float)p;
+        p *= 1.00390625;
+    }
+    const double c64 = p;
+    double q = 1.0;
+    for (int j = 0; j < 64; j++) {
+        d2r_cone_hi[j] = (float)q;
+        q *= c64;
+    }
+    d2r_cone_ready = 1;
+}
 
 static inline float cone_pow(uint32_t n)
 {
-    float r = 1.0f;
-    for (int i = 0; i < 12; i++)
-        if ((n >> i) & 1u) r = r * d2r_cone_pow[i];
-    return r;
+    n = n < 4095u ? n : 4095u;
+    return d2r_cone_hi[n >> 6] * d2r_cone_lo[n & 63u];
 }
 
 /* distance of lattice point k of a ray that starts at t0; k1 / t1 from cone_split() */
@@ -335,6 +352,7 @@ D2R_ORACLE_API void d2r_oracle_cone_lattice(float t0, uint32_t n, float *out)
 {
     uint32_t k1;
     float t1;
+    cone_tables_init();
     cone_split(t0, &k1, &t1);
     for (uint32_t k = 0; k < n; k++) out[k] = cone_t(k, t0, k1, t1);
 }
@@ -355,6 +373,7 @@ D2R_ORACLE_API void d2r_oracle_render(const d2r_oracle_nerf *m, const d2r_oracle
     const int W = (int)v->width, H = (int)v->height;
     const float inv_scale = 1.0f / v->scale;
     uint64_t total = 0;
+    cone_tables_init();          /* before the parallel region */
 
 #pragma omp parallel for schedule(dynamic, 4) reduction(+ : total)
     for (int py = 0; py < H; py++) {

@@ -37,7 +37,7 @@ def distinct_candidate_poses(scene, n, grid=None):
 
 
 def measure(engine, ctx, scene, fg, bg, name, W, H, n_frames, *, weights="adversarial", modes=MODES, seed=6, n_text=3,
-            variants=(), oracle_batch=16, gen_kwargs=None, log=print):
+            variants=(), oracle_batch=16, gen_kwargs=None, floor_frames=0, log=print):
     """-> dict: per ln_fold mode (and per named variant = dict of context options, run at the default mode) the max and rms of
     |dlogit| / logit_scale and the max of 1 - cos(embedding) over n_frames composited frames x n_text captions."""
     from tests.parity_utils import cosine, random_unit_text_embeds
@@ -77,6 +77,14 @@ def measure(engine, ctx, scene, fg, bg, name, W, H, n_frames, *, weights="advers
         oemb_parts.append(b)
     olg, oemb = np.concatenate(olg_parts), np.concatenate(oemb_parts)
     out["oracle_seconds"] = round(time.time() - t0, 1)
+    if floor_frames:
+        # the ideal-bf16 tower (oracle/clip_bf16.py) on the first frames: how far ANY bf16-operand implementation is from fp32 here
+        from oracle import clip_bf16, render_ref
+        k = min(floor_frames, n_frames)
+        pv = np.stack([render_ref.clip_preprocess(f, cfg["image_size"], True)[0] for f in frames0[:k]])
+        d = np.abs((clip_bf16.vision_embeds(pv, sd, cfg) - oemb[:k]) @ text.T)
+        out["ideal_bf16_floor"] = {"frames": k, "max": float(d.max()), "rms": float(np.sqrt((d ** 2).mean()))}
+        log(f"[adversarial parity] {name} {weights}: ideal-bf16 floor on the first {k} frames: max {d.max():.2e} rms {np.sqrt((d ** 2).mean()):.2e}")
     out["distinct_frames"] = len({f.tobytes() for f in frames0})
     scale = float(sc.logit_scale)
     for kind, key, logits in results:
@@ -93,6 +101,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--models", default="vit_b16,vit_l14,vit_l14_336")
     ap.add_argument("--n", type=int, default=64)
+    ap.add_argument("--floor-frames", type=int, default=0, help="also run the ideal-bf16 tower (oracle/clip_bf16.py) on this many frames")
     ap.add_argument("--benign", action="store_true", help="also run the Gaussian weights through the same measurement")
     ap.add_argument("--out", default=os.path.join(REPO, "gpurun_out", "r05_adversarial_parity.json"))
     a = ap.parse_args()
@@ -109,7 +118,7 @@ def main():
     for name in a.models.split(","):
         W, H = sizes.get(name, (640, 360))
         for w in (("adversarial", "benign") if a.benign else ("adversarial",)):
-            res.append(measure(engine, ctx, scene, fg, bg, name, W, H, a.n, weights=w, variants=variants))
+            res.append(measure(engine, ctx, scene, fg, bg, name, W, H, a.n, weights=w, variants=variants, floor_frames=a.floor_frames))
             os.makedirs(os.path.dirname(a.out), exist_ok=True)
             json.dump(res, open(a.out, "w"), indent=1)
     md = ["| model | weights | frames | " + " | ".join(f"ln_fold {m}" for m in MODES) + " | " + " | ".join(k for k, _ in variants) + " |",

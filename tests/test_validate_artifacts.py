@@ -114,3 +114,93 @@ def test_full_harness_on_synthetic_stand_ins(tmp_path):
     rc, rep = run_tool("--method-out", d, "--clip", ck, "--goal-caption", "a completely different sentence about shelves",
                        "--norm-caption", task.norm_captions[0], "--sample-res", ",".join(map(str, sample_res)))
     assert rc == 1 and not rep["sections"]["b_clip"]["within_bar"]
+
+
+# ---- bench.py --api --data-dir: the drop-in API on the reference's real artefacts, on stand-ins
+
+def _stand_in_directory(tmp_path, scene, clip="vit_tiny"):
+    """method_out/<scene>/ + a Hugging Face checkpoint directory as a reference installation lays them out, written by this repo's
+    own writers (tests/ingp_writer.py, safetensors) — what install.sh:38-50 downloads, in the believed formats."""
+    import torch
+    from safetensors.torch import save_file
+    from dream2real_amd.clip_model import CLIP_CONFIGS, random_clip_state_dict
+    from dream2real_amd.tokenizer import ClipBpeTokenizer
+    g = os.path.join(REPO, "tests", "golden")
+    d = str(tmp_path / "method_out" / "shopping")
+    os.makedirs(d)
+    save_ingp(os.path.join(d, "fg_base.ingp"), scene.fg, training_views=VIEWS, background_color=scene.fg_background)
+    save_ingp(os.path.join(d, "bg_base.ingp"), scene.bg, training_views=VIEWS)
+    np.save(os.path.join(d, "opt_cam_poses.npy"), np.asarray(scene.cam_poses))
+    np.savetxt(os.path.join(d, "obj_pose.txt"), scene.obj_pose)
+    ck = str(tmp_path / "clip")
+    os.makedirs(ck)
+    shutil.copy(os.path.join(g, "bpe_vocab.json"), os.path.join(ck, "vocab.json"))
+    shutil.copy(os.path.join(g, "bpe_merges.txt"), os.path.join(ck, "merges.txt"))
+    tok = ClipBpeTokenizer.from_files(os.path.join(ck, "vocab.json"), os.path.join(ck, "merges.txt"), context_length=32)
+    cfg = dict(CLIP_CONFIGS[clip], vocab=len(tok.vocab), ctx=32)
+    sd = random_clip_state_dict(cfg, seed=6)
+    save_file({k: torch.from_numpy(np.asarray(v, np.float32).reshape(np.shape(v) or (1,)).copy()) for k, v in sd.items()}, os.path.join(ck, "model.safetensors"))
+    return d, ck, cfg, sd, tok
+
+
+def run_bench(*flags, timeout=900):
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--api", *flags], capture_output=True, text=True, timeout=timeout, cwd=REPO)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert lines, (r.stdout[-1500:], r.stderr[-3000:])
+    return r.returncode, json.loads(lines[-1])
+
+
+def test_bench_data_dir_check_only_names_what_is_there_and_what_is_missing(tmp_path):
+    """`bench.py --api --data-dir ... --check-only`: the host-side half of the real-artefact command — snapshots through the loader's own
+    validation (d2r_ingp_validate), checkpoint through load_clip_safetensors + the tokenizer, captions from the committed LLM-cache pairs,
+    camera and object poses — runs WITHOUT a GPU, so the command cannot rot between now and the day the files exist."""
+    scene = make_scene("shopping")
+    d, ck, cfg, sd, tok = _stand_in_directory(tmp_path, scene)
+    rc, rep = run_bench("--data-dir", d, "--clip-dir", ck, "--check-only")
+    ra = rep["real_artifacts"]
+    assert rc == 0 and ra["runnable"] and not ra["missing"] and not ra["problems"], ra
+    assert ra["found"]["fg_snapshot"]["n_levels"] == 16 and ra["found"]["clip"]["hidden_size"] == cfg["hidden_size"] and ra["found"]["clip"]["vocab"] == len(tok.vocab)
+    assert ra["captions"]["goal_caption"] == "an apple inside a blue and white bowl" and ra["reference_outputs_present"] == []
+    # without the checkpoint / the object pose: not runnable, and every missing input is named
+    os.remove(os.path.join(d, "obj_pose.txt"))
+    rc, rep = run_bench("--data-dir", d, "--check-only")
+    ra = rep["real_artifacts"]
+    assert rc == 2 and not ra["runnable"] and any("--clip-dir" in m for m in ra["missing"]) and any("obj_pose.txt" in m for m in ra["missing"])
+    # a snapshot the loader would refuse is a named problem
+    import msgpack, zlib
+    p = os.path.join(d, "bg_base.ingp")
+    c = msgpack.unpackb(zlib.decompress(open(p, "rb").read()), raw=False)
+    c["encoding"]["interpolation"] = "Smoothstep"
+    open(p, "wb").write(zlib.compress(msgpack.packb(c, use_bin_type=True), 1))
+    rc, rep = run_bench("--data-dir", d, "--clip-dir", ck, "--check-only")
+    assert rc == 2 and any("bg_base.ingp" in m and "Smoothstep" in m for m in rep["real_artifacts"]["problems"])
+
+
+@pytest.mark.gpu
+def test_bench_data_dir_full_run_reproduces_a_reference_run_on_stand_ins(tmp_path):
+    """The whole command on stand-ins: a "reference run" (this library writing pose_scores / pose_batch / goal_pose.txt into method_out/, with
+    two poses invalid as a physics filter would leave them) and then `bench.py --api --data-dir`: snapshots through get_vis_ngps, checkpoint
+    through load_clip_safetensors, captions -> tokenizer -> text tower, the reference run's validity mask as the pre-filter — arg-max pose
+    identical, scores within 1e-5, goal pose identical."""
+    import torch
+    from dream2real_amd import clip_scoring, combined_rendering, engine
+    scene = make_scene("shopping")
+    d, ck, cfg, sd, tok = _stand_in_directory(tmp_path, scene)
+    ctx = engine.Context(0)
+    fg, bg = engine.Testbed.from_snapshot(ctx, os.path.join(d, "fg_base.ingp")), engine.Testbed.from_snapshot(ctx, os.path.join(d, "bg_base.ingp"))
+    sc, enc = engine.ClipScorer(ctx, cfg, sd), engine.TextEncoder(ctx, cfg, sd)
+    task = make_task(scene, fg, bg)
+    W, H, sample_res = 96, 54, [6, 5, 2, 1, 1, 1]
+    rend = combined_rendering.renderer(d, task, resolution=(W, H))
+    phys = lambda p, t, v: v & torch.tensor([i not in (4, 31) for i in range(len(v))])
+    best, pose_batch, scores = clip_scoring.optimise_pose_grid(rend, None, [0], task, d, sample_res=sample_res, phys_check=phys, scene_type=scene.scene_type,
+                                                               smoothing=True, scorer=sc, text_encoder=enc, tokenizer=tok, save_renders=False)
+    clip_scoring.save_pose_outputs(d, best, pose_batch, scores)
+    sc.close(); enc.close(); fg.close(); bg.close(); ctx.close()
+    rc, rep = run_bench("--data-dir", d, "--clip-dir", ck, "--width", str(W), "--height", str(H), "--sample-res", ",".join(map(str, sample_res)),
+                        "--scene-type", str(scene.scene_type), "--scene-centre", ",".join(str(float(x)) for x in scene.scene_centre))
+    ra = rep["real_artifacts"]
+    assert rc == 0 and ra["runnable"], ra
+    c = ra["comparison"]
+    assert c["argmax_identical"] and c["goal_pose_identical"] and c["max_rel_dscore"] < 1e-5 and c["pose_batch_max_abs_diff"] < 1e-6, c
+    assert c["valid_poses_reference"] == 58 and rep["value"] > 0

@@ -8,10 +8,10 @@
 # -> gpurun_out/r05_march_regimes.{jsonl,md}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $ROOT
-OUT=gpurun_out/r05_march_regimes.jsonl
+OUT=gpurun_out/r05_march_regimes${R05_SUFFIX}.jsonl
 : > $OUT
 B="--steps 3 --warmup 1 --cpu-sample 0 --power-seconds 0 --clip vit_tiny"
-run() { tag=$1; shift; echo "== $tag: $*" >&2; line=$(timeout 600 python bench.py $B "$@" 2>/dev/null | tail -1); echo "{\"regime\": \"$tag\", \"args\": \"$*\", \"bench\": $line}" >> $OUT; }
+run() { tag=$1; shift; if [ -n "$R05_ONLY" ] && ! echo " $R05_ONLY " | grep -q " $tag "; then return; fi; echo "== $tag: $*" >&2; line=$(timeout 600 python bench.py $B "$@" 2>/dev/null | tail -1); echo "{\"regime\": \"$tag\", \"args\": \"$*\", \"bench\": $line}" >> $OUT; }
 run cfg1_default
 run cfg1_bricks_off --opt bricks=0
 for n in 4 3 2 1 0; do run cfg1_lds$n --opt lds_slots_max=$n; done
@@ -32,7 +32,7 @@ run cfg4_lds_only --config 4 --slice-of 64 --opt gbrick_slots=0
 # counters: FETCH_SIZE / WRITE_SIZE each in its own pass, TA busy, L2 hit / miss, wave state
 PASSES=("FETCH_SIZE" "WRITE_SIZE" "TA_TA_BUSY_sum GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES")
 P="--steps 1 --warmup 1 --cpu-sample 0 --power-seconds 0 --clip vit_tiny"
-pmc() { tag=$1; shift; PMC_PASS_TIMEOUT=240 bash tools/pmc.sh r05_pmc_$tag "${PASSES[@]}" -- $P "$@" > gpurun_out/r05_pmc_$tag.log 2>&1; }
+pmc() { tag=$1; shift; if [ -n "$R05_ONLY" ] && ! echo " $R05_ONLY " | grep -q " $tag "; then return; fi; PMC_PASS_TIMEOUT=240 bash tools/pmc.sh r05_pmc_$tag "${PASSES[@]}" -- $P "$@" > gpurun_out/r05_pmc_$tag.log 2>&1; }
 if [ "${R05_PMC:-1}" = "1" ]; then
   pmc cfg1_default
   pmc cfg1_bricks_off --opt bricks=0
@@ -42,4 +42,4 @@ if [ "${R05_PMC:-1}" = "1" ]; then
   pmc cfg2_default --config 2 --sample-res 64,64,1,1,1,1
   pmc cfg4_default --config 4 --slice-of 64
 fi
-python tools/r05_march_regimes_report.py
+python tools/r05_march_regimes_report.py $R05_SUFFIX

@@ -3,8 +3,10 @@
 import json
 import os
 import re
+import sys
 
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.getcwd())
+SUFFIX = sys.argv[1] if len(sys.argv) > 1 else ""
 
 
 def pmc_means(tag):
@@ -24,7 +26,7 @@ def pmc_means(tag):
 
 
 def main():
-    rows = [json.loads(l) for l in open(os.path.join(ROOT, "gpurun_out", "r05_march_regimes.jsonl")) if l.strip()]
+    rows = [json.loads(l) for l in open(os.path.join(ROOT, "gpurun_out", f"r05_march_regimes{SUFFIX}.jsonl")) if l.strip()]
     md = ["# The marcher's regimes, round 5 (`tools/r05_march_regimes.sh`, one MI355X; vit_tiny behind the render: only `k_march` is read)", "",
           "`frac` = samples x 512 B / launch time / 8 TB/s (SURVEY.md 8(d): algorithmic bytes); `traffic` = FETCH_SIZE + WRITE_SIZE of the `k_march` launch, each counter in its own",
           "rocprofv3 pass, KB -> bytes, UNCORRECTED (4- and 8-byte gathers: the guide's x2 applies to wide coalesced reads only) -> `traffic_frac` = traffic / launch time / 8 TB/s = the",
@@ -47,7 +49,7 @@ def main():
         md.append(f"| {r['regime']} | `{r['args']}` | {bc.get('lds_slots')}, {bc.get('hbm_brick_slots')} | {b['config']['poses_per_step']} | {rf['samples_per_launch']:.3g} | {ms:.3f} | "
                   f"**{rf['frac']:.3f}** | {rf['lane_utilisation']:.2f} | {cell(tr / 1e9 if tr else None, '%.2f')} | {cell(tr / (ms * 1e-3) / 8e12 if tr else None, '%.3f')} | "
                   f"{cell(ta, '%.3f')} | {cell(l2, '%.2f')} | {iw} | {cell(mf, '%.2f')} |")
-    open(os.path.join(ROOT, "gpurun_out", "r05_march_regimes.md"), "w").write("\n".join(md) + "\n")
+    open(os.path.join(ROOT, "gpurun_out", f"r05_march_regimes{SUFFIX}.md"), "w").write("\n".join(md) + "\n")
     print("\n".join(md))
 
 
