@@ -678,6 +678,11 @@ def main():
                          "the reference's own workload (70 000 poses, 336x336, ViT-L/14-336, physics on)")
     ap.add_argument("--api-save", type=int, default=0, help="--api: 1 = write cb_render/*.png for every valid pose, as the reference does")
     ap.add_argument("--api-phys", type=int, default=1, help="--api: 0 = skip the physics pre-filter (every pose valid)")
+    ap.add_argument("--text", choices=("synthetic", "tower"), default="synthetic",
+                    help="kernel bench: where the C = 2 text embeddings come from.  synthetic (default): seeded unit vectors correlated with the scene's image "
+                         "embedding (a well-conditioned goal / norm ratio).  tower: the task's goal / normalising captions (tests/golden/captions.json) -> the "
+                         "library's BPE tokenizer -> its text tower (random weights of the same checkpoint) — the reference's caption -> score path end to end; "
+                         "random towers have no language prior, so these scores are numerically real and semantically meaningless")
     ap.add_argument("--api-text", choices=("cached", "tower"), default="cached",
                     help="--api: 'tower' = tokenise the task's captions and run the library's text tower inside the timed call")
     ap.add_argument("--api-dir", default=None, help="--api: data_dir root (default: a temporary directory, removed afterwards)")
@@ -793,9 +798,28 @@ def run_kernel_bench(args, wd):
     T1 = converter(np.asarray(scene.obj_pose, np.float32)[None])[0]
     # cached text embeddings (goal, normalising): seeded unit vectors correlated with the embedding
     # of the un-moved scene, standing in for the text tower output of a real caption pair
-    frame0 = fg.render_composite(view, T1, cam_ngp, T1[None])
-    _, e0 = scorer.score_frames(frame0, np.zeros((1, cfg["proj"]), np.float32), return_embeds=True)
-    text = scene_text_embeds(e0[0])
+    text_info = ("2 seeded unit vectors correlated with the scene's image embedding (random-weight "
+                 "towers give uncorrelated text: the goal/norm ratio needs positive logits); "
+                 "throughput does not depend on their values")
+    if args.text == "tower":
+        # captions -> byte-level BPE (the vocabulary committed as data under tests/golden/) -> text tower -> L2-normalised embeddings, once per task
+        # (reference clip_scoring.py:153-163,177-181 redoes this per batch)
+        from dream2real_amd.clip_scoring import build_captions
+        from dream2real_amd.tokenizer import ClipBpeTokenizer
+        g = os.path.join(REPO, "tests", "golden")
+        tok = ClipBpeTokenizer.from_files(os.path.join(g, "bpe_vocab.json"), os.path.join(g, "bpe_merges.txt"), context_length=32)
+        tcfg = dict(cfg, vocab=len(tok.vocab), ctx=32)
+        enc = engine.TextEncoder(ctx, tcfg, random_clip_state_dict(tcfg, seed=6))
+        captions, _ = build_captions(task.goal_caption, task.norm_captions, False)
+        t_tok = time.perf_counter()
+        ids = tok(captions)
+        text = enc.encode(np.asarray(ids[0] if isinstance(ids, tuple) else ids, np.int32))
+        text_info = (f"captions {captions} -> ClipBpeTokenizer -> d2r_text_encode (random-weight text tower, vocabulary of tests/golden/): "
+                     f"{(time.perf_counter() - t_tok) * 1e3:.1f} ms once per task, outside the timed steps as in a real run (cached per task)")
+    else:
+        frame0 = fg.render_composite(view, T1, cam_ngp, T1[None])
+        _, e0 = scorer.score_frames(frame0, np.zeros((1, cfg["proj"]), np.float32), return_embeds=True)
+        text = scene_text_embeds(e0[0])
     # run the library on a torch-owned (non-null) stream so torch copies order after it
     stream = torch.cuda.Stream(dev)
     torch.cuda.set_stream(stream)
@@ -918,9 +942,7 @@ def run_kernel_bench(args, wd):
                                       "d2r_allgather_scores: one ncclAllGather (RCCL) of fp32 logits per step" if c_abi_comm else
                                       f"torch.distributed all_gather ({torch.distributed.get_backend()}): ranks share a GPU, RCCL unavailable"),
                        "rccl_version": rccl,
-                       "text_embeds": "2 seeded unit vectors correlated with the scene's image embedding (random-weight "
-                                      "towers give uncorrelated text: the goal/norm ratio needs positive logits); "
-                                      "throughput does not depend on their values"},
+                       "text_embeds": text_info},
             "roofline": {"bound": "hbm", "kernel": "k_march (hash-grid fetch + fused MLP + compositing)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,

@@ -246,6 +246,8 @@ int d2r_ctx_set_option(d2r_ctx *ctx, const char *key, int64_t value)
     } else if (!strcmp(key, "gbrick_max_mib")) {         // read by d2r_nerf_create too
         if (value < 0 || value > 512) return d2r_fail(ctx, D2R_ERR_INVALID, "gbrick_max_mib must be in [0, 512]");
         ctx->gbrick_max_mib = value;
+    } else if (!strcmp(key, "mlp_f16")) {
+        ctx->mlp_f16 = value != 0;
     } else if (!strcmp(key, "bricks")) {
         ctx->use_bricks = value != 0;
     } else if (!strcmp(key, "raygen_rect")) {
@@ -268,7 +270,7 @@ int d2r_ctx_get_option(d2r_ctx *ctx, const char *key, int64_t *value)
         {"prep_reuse", ctx->prep_reuse}, {"cls_last", ctx->cls_last}, {"vit_fp8", ctx->vit_fp8}, {"l0_reuse", ctx->l0_reuse},
         {"attn_rem", ctx->attn_rem}, {"overlap", ctx->overlap}, {"march_blocks", ctx->march_blocks}, {"gbrick_slots", ctx->gbrick_slots},
         {"brick_slots_total", ctx->brick_slots_total}, {"lds_slots_max", ctx->lds_slots_max}, {"gbrick_max_mib", ctx->gbrick_max_mib},
-        {"bricks", ctx->use_bricks}, {"raygen_rect", ctx->raygen_rect}, {"timing", ctx->timing}, {"debug_fail_chunk", ctx->debug_fail_chunk},
+        {"bricks", ctx->use_bricks}, {"mlp_f16", ctx->mlp_f16}, {"raygen_rect", ctx->raygen_rect}, {"timing", ctx->timing}, {"debug_fail_chunk", ctx->debug_fail_chunk},
         {"march_lds_slots", (int64_t)ctx->last_march_nb}, {"march_hbm_brick_slots", (int64_t)ctx->last_march_ngb}};
     for (const auto &e : tab)
         if (!strcmp(key, e.k)) {
@@ -317,7 +319,8 @@ static uint16_t float_to_bf16(float f)
 //   kind 2: hash-grid features in slot order              col = 2*(2*(4*s + (j>>1)) + hi) + (j&1)
 //   kind 0: k index is a network INPUT in natural order   col = 16*s + 8*hi + j
 //   kind 1: k index comes from a previous layer's C layout col = 16*s + 8*(j>>2) + 4*hi + (j&3)
-static void build_frag(std::vector<uint16_t> &dst, int frag, const uint16_t *w, int n_out, int n_in, int mtile,
+// f16: the fragment holds the snapshot's fp16 bits unrounded (option mlp_f16) instead of their bf16 rounding
+static void build_frag(std::vector<uint16_t> &dst, bool f16, int frag, const uint16_t *w, int n_out, int n_in, int mtile,
                        int s, int kind, int col_base = 0)
 {
     for (int lane = 0; lane < 64; lane++) {
@@ -326,8 +329,9 @@ static void build_frag(std::vector<uint16_t> &dst, int frag, const uint16_t *w, 
             int col = col_base + (kind == 0   ? 16 * s + 8 * hi + j
                                   : kind == 1 ? 16 * s + 8 * (j >> 2) + 4 * hi + (j & 3)
                                               : 2 * (2 * (4 * s + (j >> 1)) + hi) + (j & 1));
-            float v = (row < n_out && col < n_in) ? half_to_float(w[row * n_in + col]) : 0.f;
-            dst[((size_t)frag * 64 + lane) * 8 + j] = float_to_bf16(v);
+            const bool in = row < n_out && col < n_in;
+            float v = in ? half_to_float(w[row * n_in + col]) : 0.f;
+            dst[((size_t)frag * 64 + lane) * 8 + j] = f16 ? (in ? w[row * n_in + col] : (uint16_t)0) : float_to_bf16(v);
         }
     }
 }
@@ -524,18 +528,23 @@ int d2r_nerf_create(d2r_ctx *ctx, const d2r_nerf_desc *d, d2r_nerf **out)
         }
     }
     // weight fragments
-    std::vector<uint16_t> wf((size_t)D2R_N_WFRAG * 64 * 8);
+    // [0, 24): bf16 fragments; [24, 48): the same fragments in fp16 (exact)
+    std::vector<uint16_t> wf((size_t)2 * D2R_N_WFRAG * 64 * 8);
     const int n_in = (int)(d->n_levels * d->n_features);
-    for (int mt = 0; mt < 2; mt++)
-        for (int s = 0; s < 2; s++) build_frag(wf, 0 + mt * 2 + s, d->dw1_fp16, 64, n_in, mt, s, 2);
-    for (int q = 0; q < 4; q++) build_frag(wf, 4 + q, d->dw2_fp16, 16, 64, 0, q, 1);
-    for (int mt = 0; mt < 2; mt++) {
-        build_frag(wf, 8 + mt * 2 + 0, d->cw1_fp16, 64, 32, mt, 0, 1);          // density outputs (C layout)
-        build_frag(wf, 8 + mt * 2 + 1, d->cw1_fp16, 64, 32, mt, 0, 0, 16);      // SH, natural order at col 16
+    for (int pass = 0; pass < 2; pass++) {
+        const bool f16 = pass == 1;
+        const int o = pass * D2R_N_WFRAG;
+        for (int mt = 0; mt < 2; mt++)
+            for (int s = 0; s < 2; s++) build_frag(wf, f16, o + 0 + mt * 2 + s, d->dw1_fp16, 64, n_in, mt, s, 2);
+        for (int q = 0; q < 4; q++) build_frag(wf, f16, o + 4 + q, d->dw2_fp16, 16, 64, 0, q, 1);
+        for (int mt = 0; mt < 2; mt++) {
+            build_frag(wf, f16, o + 8 + mt * 2 + 0, d->cw1_fp16, 64, 32, mt, 0, 1);          // density outputs (C layout)
+            build_frag(wf, f16, o + 8 + mt * 2 + 1, d->cw1_fp16, 64, 32, mt, 0, 0, 16);      // SH, natural order at col 16
+        }
+        for (int mt = 0; mt < 2; mt++)
+            for (int q = 0; q < 4; q++) build_frag(wf, f16, o + 12 + mt * 4 + q, d->cw2_fp16, 64, 64, mt, q, 1);
+        for (int q = 0; q < 4; q++) build_frag(wf, f16, o + 20 + q, d->cw3_fp16, 16, 64, 0, q, 1);
     }
-    for (int mt = 0; mt < 2; mt++)
-        for (int q = 0; q < 4; q++) build_frag(wf, 12 + mt * 4 + q, d->cw2_fp16, 64, 64, mt, q, 1);
-    for (int q = 0; q < 4; q++) build_frag(wf, 20 + q, d->cw3_fp16, 16, 64, 0, q, 1);
 
     const size_t grid_bytes = tab.size() * 4;
     if (grid_bytes >= (1ull << 32)) {
@@ -560,6 +569,7 @@ int d2r_nerf_create(d2r_ctx *ctx, const d2r_nerf_desc *d, d2r_nerf **out)
     P.grid_bytes = (uint32_t)grid_bytes;
     P.bricks = (const uint64_t *)m->d_bricks;
     P.wfrag = (const uint4 *)m->d_wfrag;
+    P.wfrag16 = P.wfrag + (size_t)D2R_N_WFRAG * 64;
     P.brick_tab = (const uint32_t *)m->d_brick_tab;
     P.gbrick_tab = (const uint32_t *)m->d_gbrick_tab;
     P.gbrick_bytes = (uint32_t)(std::max<size_t>(gbrick_tab.size(), 1) * 4);

@@ -68,7 +68,8 @@ struct NerfParams {
     uint32_t aabb_scale;       // 1, or a power of two up to 128: log2 + 1 cascades, cone stepping, positions normalised to the box (k_*<.., CONE>)
     uint32_t n_casc;
     float side, inv_side;      // aabb_scale and its reciprocal as floats
-    const uint4 *wfrag;        // [24][64] MFMA A-operand fragments of the MLPs
+    const uint4 *wfrag;        // [24][64] MFMA A-operand fragments of the MLPs, bf16
+    const uint4 *wfrag16;      // the same fragments holding the snapshot's fp16 weights unrounded (option mlp_f16)
     float bbox_lo[3], bbox_hi[3];  // bounding box of occupied cells (+margin), unit-cube units
     // Testbed.render_aabb clipped to the model's box: in ngp coordinates (ray slab test) and in the unit cube of
     // the box (per-sample containment test); the whole box when none is set
@@ -160,6 +161,7 @@ struct d2r_ctx {
     int64_t attn_rem = 1;          // attention: a remainder of at most this many query tiles (sequence = 8 g + r tiles) runs on workgroups of r waves instead of one more eight-wave group
     int64_t cls_last = 1;          // vision tower: run the last block on the class-token rows only (the head reads nothing else)
     int64_t gemm_cfg = 0;      // experiment switch for the GEMM tile configuration (0 = default)
+    int64_t mlp_f16 = 0;       // 1: the NeRF MLPs on the fp16 MFMA (the reference's own arithmetic; BASELINE.json configs[4]'s "fp16 render"); 0: bf16 (north_star)
     int64_t use_bricks = 1;
     int64_t raygen_rect = 1;   // composite mode: generate rays only inside the projected occupied bbox
     int64_t gbrick_slots = 8;  // at most this many slots use HBM bricks

@@ -30,18 +30,33 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 union Frag {
     bf16x8 v;
+    f16x8 h;
     uint4 u;
 };
 
+// Operand type of the MLPs' MFMAs.  F16 = false: bf16 (north_star: "a small fused MLP as MFMA bf16 tiles"; the default).  F16 = true
+// (option "mlp_f16"): fp16 — the reference's OWN arithmetic (tiny-cuda-nn's fully fused MLPs are fp16, and BASELINE.json configs[4] names an
+// "fp16 render"): the snapshot's fp16 weights enter the MFMA exactly, features and activations keep 11 significant bits instead of 8,
+// v_mfma_f32_32x32x16_f16 runs at the bf16 rate.  Range: activations must stay below 65504, as in the reference.
+template <bool F16>
 __device__ __forceinline__ uint32_t pack2(float a, float b)
 {
-    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-    union { bf16x2 v; uint32_t u; } r;
-    r.v[0] = (__bf16)a;
-    r.v[1] = (__bf16)b;
-    return r.u;
+    if constexpr (F16) {
+        typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+        union { f16x2 v; uint32_t u; } r;
+        r.v[0] = (_Float16)a;         // v_cvt_pk_f16_f32 (round to nearest even)
+        r.v[1] = (_Float16)b;
+        return r.u;
+    } else {
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        union { bf16x2 v; uint32_t u; } r;
+        r.v[0] = (__bf16)a;
+        r.v[1] = (__bf16)b;
+        return r.u;
+    }
 }
 
 __device__ __forceinline__ float srgb_to_linear(float x)
@@ -528,12 +543,14 @@ __global__ __launch_bounds__(256) void k_raygen_rect(NerfParams P, ViewParams V,
 
 // ------------------------------------------------------- field evaluation
 
+template <bool F16>
 __device__ __forceinline__ f32x16 mfma(const uint4 &a, const uint4 &b, f32x16 c)
 {
     Frag fa, fb;
     fa.u = a;
     fb.u = b;
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v, fb.v, c, 0, 0, 0);
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(fa.h, fb.h, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.v, fb.v, c, 0, 0, 0);
 }
 
 enum { K_DENSE = 0, K_HASH = 1, K_MIXED = 2, K_BRICK = 3 };
@@ -697,7 +714,7 @@ __device__ __forceinline__ void encode_from(const NerfParams &P, const __amdgpu_
 // registers per slot live (8 offsets, 3 fractions, 8 gathered words) across its three phases, and with 5 .. 8 slots in ONE
 // batch the 168-register budget of three waves per SIMD spilled 6 .. 90 registers inside the march loop (round 5: the
 // generic no-brick kernel had always run like that).
-template <int NB, int NGB, int ND>
+template <int NB, int NGB, int ND, bool F16>
 __device__ __forceinline__ void encode_sample(const NerfParams &P, const __amdgpu_buffer_rsrc_t &rs,
                                               const __amdgpu_buffer_rsrc_t &rsb,
                                               const uint8_t *__restrict__ lds_bricks, bool hi, float x, float y,
@@ -723,8 +740,8 @@ __device__ __forceinline__ void encode_sample(const NerfParams &P, const __amdgp
     if constexpr (NG == 0) lds_slots();
     else encode_from<NB, NGB, ND, NB>(P, rs, rsb, hi, x, y, z, f, lds_slots);
     // straight into the two bf16 B fragments of density layer 1 (k-step 0: slots 0..3, 1: slots 4..7)
-    p0.x = pack2(f[0], f[1]); p0.y = pack2(f[2], f[3]); p0.z = pack2(f[4], f[5]); p0.w = pack2(f[6], f[7]);
-    p1.x = pack2(f[8], f[9]); p1.y = pack2(f[10], f[11]); p1.z = pack2(f[12], f[13]); p1.w = pack2(f[14], f[15]);
+    p0.x = pack2<F16>(f[0], f[1]); p0.y = pack2<F16>(f[2], f[3]); p0.z = pack2<F16>(f[4], f[5]); p0.w = pack2<F16>(f[6], f[7]);
+    p1.x = pack2<F16>(f[8], f[9]); p1.y = pack2<F16>(f[10], f[11]); p1.z = pack2<F16>(f[12], f[13]); p1.w = pack2<F16>(f[14], f[15]);
 }
 
 __device__ __forceinline__ void sh16(float x, float y, float z, float *o)
@@ -757,14 +774,16 @@ __device__ __forceinline__ float relu_bits(float x)
 }
 
 // relu + pack registers [r0, r0+8) of an accumulator as the next layer's B fragment
+template <bool F16>
 __device__ __forceinline__ uint4 relu_pack(const f32x16 &a, int r0)
 {
     // pack first, then ReLU on the packed pairs (v_pk_max_i16 against 0: a negative bf16 has its sign bit set, i.e. is a
     // negative int16; rounding to bf16 never changes the sign): 96 packed maxes per wave iteration instead of 192 v_max_i32.
     // The conversion stays with the compiler: it reads MFMA results, and hipcc pads the MFMA -> VALU hazard only for
     // instructions it emits itself; the packed max (inline asm) reads an ordinary VALU result.
+    // (fp16 has its sign bit in the same place: the same integer maximum)
     auto pm = [](float lo, float hi) {
-        uint32_t t = pack2(lo, hi), r;
+        uint32_t t = pack2<F16>(lo, hi), r;
         asm("v_pk_max_i16 %0, %1, 0" : "=v"(r) : "v"(t));
         return r;
     };
@@ -780,48 +799,49 @@ __device__ __forceinline__ uint4 relu_pack(const f32x16 &a, int r0)
 // through both MLPs.  Returns raw density-net output 0 and colour-net outputs 0..2 in lanes 0..31.
 // Scheduling fences between the layers keep hipcc from hoisting later layers' LDS weight reads
 // above the current MFMA chain (that inflated the live register set past 3 waves/SIMD).
+template <bool F16>
 __device__ __forceinline__ void mlp_tile(const uint4 *__restrict__ sw, uint32_t lane, const uint4 &a0,
                                          const uint4 &a1, const uint4 &sh, float *out)
 {
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     // density layer 1: 64 x 32
-    f32x16 h0 = mfma(sw[0 * 64 + lane], a0, zero), h1 = mfma(sw[2 * 64 + lane], a0, zero);
-    h0 = mfma(sw[1 * 64 + lane], a1, h0);
-    h1 = mfma(sw[3 * 64 + lane], a1, h1);
-    uint4 p0 = relu_pack(h0, 0), p1 = relu_pack(h0, 8), p2 = relu_pack(h1, 0), p3 = relu_pack(h1, 8);
+    f32x16 h0 = mfma<F16>(sw[0 * 64 + lane], a0, zero), h1 = mfma<F16>(sw[2 * 64 + lane], a0, zero);
+    h0 = mfma<F16>(sw[1 * 64 + lane], a1, h0);
+    h1 = mfma<F16>(sw[3 * 64 + lane], a1, h1);
+    uint4 p0 = relu_pack<F16>(h0, 0), p1 = relu_pack<F16>(h0, 8), p2 = relu_pack<F16>(h1, 0), p3 = relu_pack<F16>(h1, 8);
     __builtin_amdgcn_sched_barrier(0);
     // density layer 2: 16 (padded 32) x 64
-    f32x16 dd = mfma(sw[4 * 64 + lane], p0, zero);
-    dd = mfma(sw[5 * 64 + lane], p1, dd);
-    dd = mfma(sw[6 * 64 + lane], p2, dd);
-    dd = mfma(sw[7 * 64 + lane], p3, dd);
+    f32x16 dd = mfma<F16>(sw[4 * 64 + lane], p0, zero);
+    dd = mfma<F16>(sw[5 * 64 + lane], p1, dd);
+    dd = mfma<F16>(sw[6 * 64 + lane], p2, dd);
+    dd = mfma<F16>(sw[7 * 64 + lane], p3, dd);
     out[0] = dd[0];
     // colour layer 1: 64 x 32, input = [density out (no activation) | SH]
     uint4 cd;
-    cd.x = pack2(dd[0], dd[1]); cd.y = pack2(dd[2], dd[3]); cd.z = pack2(dd[4], dd[5]); cd.w = pack2(dd[6], dd[7]);
+    cd.x = pack2<F16>(dd[0], dd[1]); cd.y = pack2<F16>(dd[2], dd[3]); cd.z = pack2<F16>(dd[4], dd[5]); cd.w = pack2<F16>(dd[6], dd[7]);
     __builtin_amdgcn_sched_barrier(0);
-    h0 = mfma(sw[8 * 64 + lane], cd, zero);
-    h1 = mfma(sw[10 * 64 + lane], cd, zero);
-    h0 = mfma(sw[9 * 64 + lane], sh, h0);
-    h1 = mfma(sw[11 * 64 + lane], sh, h1);
-    p0 = relu_pack(h0, 0); p1 = relu_pack(h0, 8); p2 = relu_pack(h1, 0); p3 = relu_pack(h1, 8);
+    h0 = mfma<F16>(sw[8 * 64 + lane], cd, zero);
+    h1 = mfma<F16>(sw[10 * 64 + lane], cd, zero);
+    h0 = mfma<F16>(sw[9 * 64 + lane], sh, h0);
+    h1 = mfma<F16>(sw[11 * 64 + lane], sh, h1);
+    p0 = relu_pack<F16>(h0, 0); p1 = relu_pack<F16>(h0, 8); p2 = relu_pack<F16>(h1, 0); p3 = relu_pack<F16>(h1, 8);
     __builtin_amdgcn_sched_barrier(0);
     // colour layer 2: 64 x 64
-    h0 = mfma(sw[12 * 64 + lane], p0, zero);
-    h1 = mfma(sw[16 * 64 + lane], p0, zero);
-    h0 = mfma(sw[13 * 64 + lane], p1, h0);
-    h1 = mfma(sw[17 * 64 + lane], p1, h1);
-    h0 = mfma(sw[14 * 64 + lane], p2, h0);
-    h1 = mfma(sw[18 * 64 + lane], p2, h1);
-    h0 = mfma(sw[15 * 64 + lane], p3, h0);
-    h1 = mfma(sw[19 * 64 + lane], p3, h1);
-    p0 = relu_pack(h0, 0); p1 = relu_pack(h0, 8); p2 = relu_pack(h1, 0); p3 = relu_pack(h1, 8);
+    h0 = mfma<F16>(sw[12 * 64 + lane], p0, zero);
+    h1 = mfma<F16>(sw[16 * 64 + lane], p0, zero);
+    h0 = mfma<F16>(sw[13 * 64 + lane], p1, h0);
+    h1 = mfma<F16>(sw[17 * 64 + lane], p1, h1);
+    h0 = mfma<F16>(sw[14 * 64 + lane], p2, h0);
+    h1 = mfma<F16>(sw[18 * 64 + lane], p2, h1);
+    h0 = mfma<F16>(sw[15 * 64 + lane], p3, h0);
+    h1 = mfma<F16>(sw[19 * 64 + lane], p3, h1);
+    p0 = relu_pack<F16>(h0, 0); p1 = relu_pack<F16>(h0, 8); p2 = relu_pack<F16>(h1, 0); p3 = relu_pack<F16>(h1, 8);
     __builtin_amdgcn_sched_barrier(0);
     // colour layer 3: 16 (padded 32) x 64
-    dd = mfma(sw[20 * 64 + lane], p0, zero);
-    dd = mfma(sw[21 * 64 + lane], p1, dd);
-    dd = mfma(sw[22 * 64 + lane], p2, dd);
-    dd = mfma(sw[23 * 64 + lane], p3, dd);
+    dd = mfma<F16>(sw[20 * 64 + lane], p0, zero);
+    dd = mfma<F16>(sw[21 * 64 + lane], p1, dd);
+    dd = mfma<F16>(sw[22 * 64 + lane], p2, dd);
+    dd = mfma<F16>(sw[23 * 64 + lane], p3, dd);
     out[1] = dd[0];
     out[2] = dd[1];
     out[3] = dd[2];
@@ -831,26 +851,27 @@ __device__ __forceinline__ void mlp_tile(const uint4 *__restrict__ sw, uint32_t 
 // SH fragments of the wave's ray directions: the colour net's second B fragment for tile 0
 // (directions of lanes 0..31) and tile 1 (lanes 32..63); this lane holds coefficients
 // 8hi..8hi+7.  Directions are per RAY, so k_march recomputes these only when it refills.
+template <bool F16>
 __device__ __forceinline__ void sh_fragments(uint32_t lane, float dx, float dy, float dz, uint4 &shfA, uint4 &shfB)
 {
     const bool hi = lane >= 32;
     float qdx = __shfl_xor(dx, 32), qdy = __shfl_xor(dy, 32), qdz = __shfl_xor(dz, 32);
     float sa[16];
     sh16(hi ? qdx : dx, hi ? qdy : dy, hi ? qdz : dz, sa);
-    shfA.x = pack2(hi ? sa[8] : sa[0], hi ? sa[9] : sa[1]);
-    shfA.y = pack2(hi ? sa[10] : sa[2], hi ? sa[11] : sa[3]);
-    shfA.z = pack2(hi ? sa[12] : sa[4], hi ? sa[13] : sa[5]);
-    shfA.w = pack2(hi ? sa[14] : sa[6], hi ? sa[15] : sa[7]);
+    shfA.x = pack2<F16>(hi ? sa[8] : sa[0], hi ? sa[9] : sa[1]);
+    shfA.y = pack2<F16>(hi ? sa[10] : sa[2], hi ? sa[11] : sa[3]);
+    shfA.z = pack2<F16>(hi ? sa[12] : sa[4], hi ? sa[13] : sa[5]);
+    shfA.w = pack2<F16>(hi ? sa[14] : sa[6], hi ? sa[15] : sa[7]);
     sh16(hi ? dx : qdx, hi ? dy : qdy, hi ? dz : qdz, sa);
-    shfB.x = pack2(hi ? sa[8] : sa[0], hi ? sa[9] : sa[1]);
-    shfB.y = pack2(hi ? sa[10] : sa[2], hi ? sa[11] : sa[3]);
-    shfB.z = pack2(hi ? sa[12] : sa[4], hi ? sa[13] : sa[5]);
-    shfB.w = pack2(hi ? sa[14] : sa[6], hi ? sa[15] : sa[7]);
+    shfB.x = pack2<F16>(hi ? sa[8] : sa[0], hi ? sa[9] : sa[1]);
+    shfB.y = pack2<F16>(hi ? sa[10] : sa[2], hi ? sa[11] : sa[3]);
+    shfB.z = pack2<F16>(hi ? sa[12] : sa[4], hi ? sa[13] : sa[5]);
+    shfB.w = pack2<F16>(hi ? sa[14] : sa[6], hi ? sa[15] : sa[7]);
 }
 
 // Evaluate the wave's 64 samples (one per lane; `valid` marks lanes that have one).
 // On return every valid lane holds sigma and the network rgb of ITS OWN sample.
-template <int NB, int NGB, int ND>
+template <int NB, int NGB, int ND, bool F16>
 __device__ __forceinline__ void eval_wave(const NerfParams &P, const __amdgpu_buffer_rsrc_t &rs,
                                           const __amdgpu_buffer_rsrc_t &rsb, const uint4 *__restrict__ sw,
                                           const uint8_t *__restrict__ lds_bricks, uint32_t lane, bool valid, float x,
@@ -868,12 +889,12 @@ __device__ __forceinline__ void eval_wave(const NerfParams &P, const __amdgpu_bu
     // this lane's levels: 2i + hi for every slot i (slots 0..3 -> k-step 0, 4..7 -> k-step 1);
     // the features go straight into bf16 fragments (8 registers per sample instead of 16 floats)
     uint4 fa0 = make_uint4(0, 0, 0, 0), fa1 = fa0, fb0 = fa0, fb1 = fa0;
-    if (av) encode_sample<NB, NGB, ND>(P, rs, rsb, lds_bricks, hi, ax, ay, az, fa0, fa1);
-    if (bv) encode_sample<NB, NGB, ND>(P, rs, rsb, lds_bricks, hi, bx, by, bz, fb0, fb1);
+    if (av) encode_sample<NB, NGB, ND, F16>(P, rs, rsb, lds_bricks, hi, ax, ay, az, fa0, fa1);
+    if (bv) encode_sample<NB, NGB, ND, F16>(P, rs, rsb, lds_bricks, hi, bx, by, bz, fb0, fb1);
     float oa[4], ob[4];
     __builtin_amdgcn_sched_barrier(0);
-    mlp_tile(sw, lane, fa0, fa1, shfA, oa);
-    mlp_tile(sw, lane, fb0, fb1, shfB, ob);
+    mlp_tile<F16>(sw, lane, fa0, fa1, shfA, oa);
+    mlp_tile<F16>(sw, lane, fb0, fb1, shfB, ob);
     // tile-1 results live in lanes 0..31; their owners are lanes 32..63
     float ts = __shfl_xor(ob[0], 32), tr = __shfl_xor(ob[1], 32), tg = __shfl_xor(ob[2], 32), tb = __shfl_xor(ob[3], 32);
     // sigma = exp(x), rgb = sigmoid(x) through the hardware exp2 / rcp (1-2 ulp)
@@ -885,13 +906,13 @@ __device__ __forceinline__ void eval_wave(const NerfParams &P, const __amdgpu_bu
 }
 
 // field evaluation at arbitrary points (parity hook used by tests through d2r_eval_points)
-template <int ND>
+template <int ND, bool F16>
 __global__ __launch_bounds__(256) void k_eval_points(NerfParams P, const float *__restrict__ xyz,
                                                      const float *__restrict__ dirs, uint32_t n,
                                                      float *__restrict__ out)
 {
     __shared__ uint4 sw[D2R_N_WFRAG * 64];
-    for (uint32_t i = threadIdx.x; i < D2R_N_WFRAG * 64; i += blockDim.x) sw[i] = P.wfrag[i];
+    for (uint32_t i = threadIdx.x; i < D2R_N_WFRAG * 64; i += blockDim.x) sw[i] = (F16 ? P.wfrag16 : P.wfrag)[i];
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63;
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)P.grid, 0, P.grid_bytes, 0x00020000);
@@ -904,8 +925,8 @@ __global__ __launch_bounds__(256) void k_eval_points(NerfParams P, const float *
     }
     float s, r, g, b;
     uint4 shfA, shfB;
-    sh_fragments(lane, dx, dy, dz, shfA, shfB);
-    eval_wave<0, 0, ND>(P, rs, rs, sw, nullptr, lane, valid, x, y, z, shfA, shfB, s, r, g, b);   // arbitrary points: no bricks
+    sh_fragments<F16>(lane, dx, dy, dz, shfA, shfB);
+    eval_wave<0, 0, ND, F16>(P, rs, rs, sw, nullptr, lane, valid, x, y, z, shfA, shfB, s, r, g, b);   // arbitrary points: no bricks
     if (valid) *(float4 *)(out + 4 * (size_t)i) = make_float4(s, r, g, b);
 }
 
@@ -916,7 +937,7 @@ __global__ __launch_bounds__(256) void k_eval_points(NerfParams P, const float *
 #ifndef D2R_MARCH_THREADS
 #define D2R_MARCH_THREADS 768
 #endif
-template <bool COMPOSITE, int NB, int NGB, int ND, bool CONE = false>
+template <bool COMPOSITE, int NB, int NGB, int ND, bool CONE = false, bool F16 = false>
 __global__ __launch_bounds__(D2R_MARCH_THREADS) void k_march(NerfParams P, ViewParams V, const float *__restrict__ cams,
                                                   const uint2 *__restrict__ queue,
                                                   const uint32_t *__restrict__ qcount,
@@ -930,7 +951,7 @@ __global__ __launch_bounds__(D2R_MARCH_THREADS) void k_march(NerfParams P, ViewP
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint4 *sw = (uint4 *)smem;
     uint8_t *lds_bricks = smem + D2R_N_WFRAG * 64 * 16;
-    for (uint32_t i = threadIdx.x; i < D2R_N_WFRAG * 64; i += blockDim.x) sw[i] = P.wfrag[i];
+    for (uint32_t i = threadIdx.x; i < D2R_N_WFRAG * 64; i += blockDim.x) sw[i] = (F16 ? P.wfrag16 : P.wfrag)[i];
     if (NB > 0)
         for (uint32_t i = threadIdx.x; i < P.brick_words; i += blockDim.x) ((uint32_t *)lds_bricks)[i] = P.brick_tab[i];
     if (CONE) cone_tab_to_lds();
@@ -999,15 +1020,15 @@ __global__ __launch_bounds__(D2R_MARCH_THREADS) void k_march(NerfParams P, ViewP
             }
             // ray directions changed in some lanes: refresh the wave's SH fragments (all lanes
             // take part: a lane's fragment also carries its partner's direction)
-            if (CONE) sh_fragments(lane, ray.dx * P.side, ray.dy * P.side, ray.dz * P.side, shfA, shfB);     // unit direction
-            else sh_fragments(lane, ray.dx, ray.dy, ray.dz, shfA, shfB);
+            if (CONE) sh_fragments<F16>(lane, ray.dx * P.side, ray.dy * P.side, ray.dz * P.side, shfA, shfB);     // unit direction
+            else sh_fragments<F16>(lane, ray.dx, ray.dy, ray.dz, shfA, shfB);
         }
         if (!__any(alive)) break;
         niter++;
 
         // ---- evaluate this wave's samples
         float sigma, cr, cg, cb;
-        eval_wave<NB, NGB, ND>(P, rs, rsb, sw, lds_bricks, lane, alive, px, py, pz, shfA, shfB, sigma, cr, cg, cb);
+        eval_wave<NB, NGB, ND, F16>(P, rs, rsb, sw, lds_bricks, lane, alive, px, py, pz, shfA, shfB, sigma, cr, cg, cb);
 
         // ---- composite + advance
         if (alive) {
@@ -1226,13 +1247,18 @@ int d2r_launch_render(d2r_ctx *ctx, const d2r_nerf *m, const ViewParams &V, cons
     NerfParams PP = m->P;
     PP.refill_min = (uint32_t)ctx->refill_min;
     const size_t lds = (size_t)D2R_N_WFRAG * 64 * 16 + (nb ? (size_t)m->P.brick_words * 4 : 0);
-#define D2R_MARCH_C(COMP, NB, NGB, ND, CONE)                                                                      \
+#define D2R_MARCH_C(COMP, NB, NGB, ND, CONE)                            \
+    do {                                                                \
+        if (ctx->mlp_f16) D2R_MARCH_F(COMP, NB, NGB, ND, CONE, true);   \
+        else D2R_MARCH_F(COMP, NB, NGB, ND, CONE, false);               \
+    } while (0)
+#define D2R_MARCH_F(COMP, NB, NGB, ND, CONE, F16)                                                                 \
     do {                                                                                                          \
         static PerDeviceOnce attr;                                                                                \
         attr.run(ctx->device, [] {                                                                                \
-            (void)hipFuncSetAttribute((const void *)k_march<COMP, NB, NGB, ND, CONE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            (void)hipFuncSetAttribute((const void *)k_march<COMP, NB, NGB, ND, CONE, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (CONE ? 512 : 0)); /* the CONE kernels hold 512 B of static LDS (cone tables): static + dynamic <= 160 KiB */ \
         });                                                                                                       \
-        hipLaunchKernelGGL((k_march<COMP, NB, NGB, ND, CONE>), dim3(blocks), dim3(D2R_MARCH_THREADS), lds, ctx->stream, PP, V, cams_dev, q, \
+        hipLaunchKernelGGL((k_march<COMP, NB, NGB, ND, CONE, F16>), dim3(blocks), dim3(D2R_MARCH_THREADS), lds, ctx->stream, PP, V, cams_dev, q, \
                            cnt, cnt + 1, COMP ? nullptr : rgba_dev, COMP ? nullptr : depth_dev,                   \
                            COMP ? bgd : nullptr, COMP ? frames_dev : nullptr, sc);                                \
     } while (0)
@@ -1261,6 +1287,7 @@ int d2r_launch_render(d2r_ctx *ctx, const d2r_nerf *m, const ViewParams &V, cons
 #undef D2R_MARCH_CASE
 #undef D2R_MARCH_PICK
 #undef D2R_MARCH_C
+#undef D2R_MARCH_F
     ctx->timing_end(tm);
     D2R_HIP(ctx, hipGetLastError());
     return D2R_OK;
@@ -1278,10 +1305,14 @@ int d2r_launch_bg_quantize(d2r_ctx *ctx, uint32_t w, uint32_t h)
 int d2r_launch_eval_points(d2r_ctx *ctx, const d2r_nerf *m, const float *xyz, const float *dirs, uint32_t n,
                            float *out)
 {
-    if (m->P.n_dense == 5)
-        hipLaunchKernelGGL(k_eval_points<5>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, m->P, xyz, dirs, n, out);
-    else
-        hipLaunchKernelGGL(k_eval_points<-1>, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, m->P, xyz, dirs, n, out);
+    const dim3 g((n + 255) / 256), b(256);
+    if (m->P.n_dense == 5) {
+        if (ctx->mlp_f16) hipLaunchKernelGGL((k_eval_points<5, true>), g, b, 0, ctx->stream, m->P, xyz, dirs, n, out);
+        else hipLaunchKernelGGL((k_eval_points<5, false>), g, b, 0, ctx->stream, m->P, xyz, dirs, n, out);
+    } else {
+        if (ctx->mlp_f16) hipLaunchKernelGGL((k_eval_points<-1, true>), g, b, 0, ctx->stream, m->P, xyz, dirs, n, out);
+        else hipLaunchKernelGGL((k_eval_points<-1, false>), g, b, 0, ctx->stream, m->P, xyz, dirs, n, out);
+    }
     D2R_HIP(ctx, hipGetLastError());
     return D2R_OK;
 }

@@ -23,13 +23,24 @@ from oracle import host_ref, render_ref  # noqa: E402
 from oracle.pipeline import OraclePipeline, oracle_logits  # noqa: E402
 
 
-def measure(engine, ctx, kind="shopping_trained", W=160, H=90, grid=(4, 3, 2), clip="vit_b16", clip_weights="benign", log=print):
+def measure(engine, ctx, kind="shopping_trained", W=160, H=90, grid=(4, 3, 2), clip="vit_b16", clip_weights="benign", mlp_f16=0, log=print):
+    from tests.scenes import make_scene
+    from tests.parity_utils import random_unit_text_embeds
+    ctx.set_option("mlp_f16", mlp_f16)
+    try:
+        return _measure(engine, ctx, kind, W, H, grid, clip, clip_weights, mlp_f16, log)
+    finally:
+        ctx.set_option("mlp_f16", 0)
+
+
+def _measure(engine, ctx, kind, W, H, grid, clip, clip_weights, mlp_f16, log):
     from tests.scenes import make_scene
     from tests.parity_utils import random_unit_text_embeds
     scene = make_scene(kind)
     fg = engine.Testbed(ctx, scene.fg)
     fg.background_color = list(scene.fg_background)
-    out = {"scene": kind, "size": [W, H]}
+    out = {"scene": kind, "size": [W, H], "mlp": "fp16" if mlp_f16 else "bf16"}
+    kind = f"{kind} [{out['mlp']} MLP]"
     # ---- field
     r = np.random.Generator(np.random.PCG64(0))
     n = 20000
@@ -99,10 +110,11 @@ if __name__ == "__main__":
     from dream2real_amd import engine
     ctx = engine.Context(0)
     res = []
-    for kind in ("shopping_trained", "shopping"):
-        for w in ("benign", "adversarial"):
-            res.append(measure(engine, ctx, kind, 160, 90, (6, 4, 2), "vit_b16", w))
-    res.append(measure(engine, ctx, "shopping_trained", 640, 360, (3, 2, 1), "vit_b16", "adversarial"))
+    for f16 in (0, 1):
+        for kind in ("shopping_trained", "shopping"):
+            res.append(measure(engine, ctx, kind, 160, 90, (6, 4, 2), "vit_b16", "benign", mlp_f16=f16))
+        res.append(measure(engine, ctx, "shopping_trained", 640, 360, (3, 2, 1), "vit_b16", "benign", mlp_f16=f16))
+    res.append(measure(engine, ctx, "shopping_trained", 160, 90, (6, 4, 2), "vit_b16", "adversarial"))
     out = os.path.join(REPO, "gpurun_out", "r05_trained_field_parity.json")
     os.makedirs(os.path.dirname(out), exist_ok=True)
     json.dump(res, open(out, "w"), indent=1)

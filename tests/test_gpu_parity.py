@@ -289,6 +289,15 @@ def test_composited_frames_match_oracle(gpu, W, H):
     assert (diff > 0).mean() < 0.02
     st = ctx.render_stats()
     assert st["rays_total"] == len(poses) * W * H and st["samples"] > 0
+    # option mlp_f16 (the MLPs on the fp16 MFMA, the reference's own arithmetic): same bar, fewer pixels off
+    ctx.set_option("mlp_f16", 1)
+    try:
+        frames16 = fg.render_composite(view, T1, TC, host_ref.converter(poses.astype(np.float32)))
+    finally:
+        ctx.set_option("mlp_f16", 0)
+    diff16 = np.abs(frames16.astype(int) - want.astype(int)).max(-1)
+    print(f"[parity] composited frames {W}x{H}: pixels off by 1 LSB: bf16 MLP {(diff > 0).mean():.4%}, fp16 MLP {(diff16 > 0).mean():.4%}")
+    assert diff16.max() <= 1 and (diff16 > 0).mean() <= (diff > 0).mean() + 1e-4
 
 
 def test_rect_culled_raygen_is_bit_identical_to_full_frame_raygen(gpu):
@@ -1518,6 +1527,14 @@ def test_trained_like_field_matches_oracle(gpu):
     assert fr["share_off_by_more"] < 0.004 and fr["object_share_off_by_more"] < 0.16 and fr["share_off_by_1"] < 0.03
     assert lg["end_to_end_max"] <= logit_bar(CLIP_CONFIGS["vit_b16"], lg["end_to_end_max"], "trained-like field, end to end, Gaussian ViT-B/16")
     assert lg["render_only_max"] < 3e-4
+    # option mlp_f16: the MLPs on the fp16 MFMA — the reference's own arithmetic (tiny-cuda-nn is fp16) with the snapshot's weights
+    # unrounded: the same field within a fraction of the bf16 numbers above, and never worse
+    o16 = measure(gpu["engine"], gpu["ctx"], "shopping_trained", 160, 90, (6, 4, 2), "vit_b16", "benign", mlp_f16=1)
+    f16, fr16 = o16["field"], o16["frames"]
+    print(f"[parity] trained-like field, fp16 MLP against bf16: |dlog sigma| max {f16['dlog_sigma_max_active']:.4f} vs {f['dlog_sigma_max_active']:.4f}, "
+          f"object pixels off by > 1 LSB {fr16['object_share_off_by_more']:.2%} vs {fr['object_share_off_by_more']:.2%}")
+    assert f16["dlog_sigma_max_active"] <= f["dlog_sigma_max_active"] and f16["drgb_max"] <= f["drgb_max"]
+    assert fr16["object_share_off_by_more"] <= fr["object_share_off_by_more"] and o16["logits"]["end_to_end_max"] <= 1e-3
 
 
 @pytest.mark.parametrize("name,n", [("vit_l14_x2", 40), ("vit_l14_336_x1", 12), ("vit_tiny", 300)])

@@ -11,7 +11,7 @@ cd $ROOT
 OUT=gpurun_out/r05_march_regimes${R05_SUFFIX}.jsonl
 : > $OUT
 B="--steps 3 --warmup 1 --cpu-sample 0 --power-seconds 0 --clip vit_tiny"
-run() { tag=$1; shift; if [ -n "$R05_ONLY" ] && ! echo " $R05_ONLY " | grep -q " $tag "; then return; fi; echo "== $tag: $*" >&2; line=$(timeout 600 python bench.py $B "$@" 2>/dev/null | tail -1); echo "{\"regime\": \"$tag\", \"args\": \"$*\", \"bench\": $line}" >> $OUT; }
+run() { tag=$1; shift; if [ -n "$R05_ONLY" ] && ! echo " $R05_ONLY " | grep -q " $tag "; then return; fi; echo "== $tag: $*" >&2; line=$(timeout 600 python bench.py $B "$@" 2>/dev/null | tail -1); [ -z "$line" ] && line=null; echo "{\"regime\": \"$tag\", \"args\": \"$*\", \"bench\": $line}" >> $OUT; }
 run cfg1_default
 run cfg1_bricks_off --opt bricks=0
 for n in 4 3 2 1 0; do run cfg1_lds$n --opt lds_slots_max=$n; done

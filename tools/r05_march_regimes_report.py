@@ -36,6 +36,9 @@ def main():
           "|---|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
     for r in rows:
         b = r["bench"]
+        if not b:
+            md.append(f"| {r['regime']} | `{r['args']}` | bench failed | | | | | | | | | | | |")
+            continue
         rf = b["roofline"]
         pm = pmc_means(r["regime"])
         ms = rf["avg_launch_ms"]
