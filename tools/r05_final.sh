@@ -14,7 +14,7 @@ python bench.py --config 0 --steps 5 --warmup 2                 2>$OUT/cfg0.err 
 python bench.py --config 2 --steps 3 --warmup 1 --cpu-sample 16 2>$OUT/cfg2.err | line > $OUT/${TAG}_cfg2_bench.json
 python bench.py --config 3 --steps 2 --warmup 1 --cpu-sample 16 2>$OUT/cfg3.err | line > $OUT/${TAG}_cfg3_bench.json
 python bench.py --config 4 --steps 2 --warmup 1 --cpu-sample 8  2>$OUT/cfg4.err | line > $OUT/${TAG}_cfg4_bench.json
-python bench.py --config 4 --steps 2 --warmup 1 --cpu-sample 8 --opt mlp_f16=1 2>$OUT/cfg4f16.err | line > $OUT/${TAG}_cfg4_fp16render_bench.json
+python bench.py --config 4 --steps 2 --warmup 1 --cpu-sample 8 --opt mlp_f16=0 2>$OUT/cfg4bf16.err | line > $OUT/${TAG}_cfg4_bf16render_bench.json
 python bench.py --clip vit_l14_336 --width 336 --height 336 --poses-per-gpu 1024 --steps 3 --warmup 1 --cpu-sample 4 2>$OUT/ref.err | line > $OUT/${TAG}_refshapes_bench.json
 python bench.py --config 1 --steps 5 --warmup 2 --cpu-sample 0 --power-seconds 0 --text tower 2>$OUT/cfg1tt.err | line > $OUT/${TAG}_cfg1_texttower_bench.json
 python bench.py --config 1 --steps 5 --warmup 2 --cpu-sample 32 --power-seconds 0 --opt mlp_f16=1 2>$OUT/cfg1f16.err | line > $OUT/${TAG}_cfg1_fp16render_bench.json
