@@ -52,7 +52,7 @@ SCENE_TYPES = {"shopping": 3, "pool_triangle": 0, "shelf": 1}
 def common(out, k, n_min):
     assert out["config"]["baseline_config"] == k and f"configs[{k}]" in out["config"]["workload"]
     # configs[4] names an "fp16 render": its NeRF MLPs run on the fp16 MFMA (option mlp_f16), the ViT in bf16 like everywhere
-    assert out["dtype"] == ("bf16" if k != 4 else 'bf16 + fp16 NeRF MLPs (mlp_f16: the configuration's "fp16 render")')
+    assert out["dtype"] == ("bf16" if k != 4 else "bf16 + fp16 NeRF MLPs (mlp_f16: the configuration's \"fp16 render\")")
     assert out["data"] == "synthetic" and out["n_gpus"] == 1 and out["value"] > 0
     assert out["roofline"]["bound"] == "hbm" and 0 < out["roofline"]["frac"] < 1.2
     p = out["parity_vs_oracle"]
