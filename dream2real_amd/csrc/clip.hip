@@ -2221,10 +2221,31 @@ __device__ __forceinline__ void ats_softmax(f32x16 &sacc, f32x16 &o0, f32x16 &o1
     l_run += sacc[0];
     o0[0] += sacc[1];
 #else
+#if (D2R_ATTN_VAR & 1)
+    // variant: the maximum as v_max3_f32 on the raw accumulator registers (no canonicalising self-maxes: MFMA results are never signalling NaNs)
+    float tmax;
+    if constexpr (NR == 16) {
+        float a, b;
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(a) : "v"(sacc[0]), "v"(sacc[1]), "v"(sacc[2]));
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(b) : "v"(sacc[3]), "v"(sacc[4]), "v"(sacc[5]));
+        asm("v_max3_f32 %0, %1, %2, %0" : "+v"(a) : "v"(sacc[6]), "v"(sacc[7]));
+        asm("v_max3_f32 %0, %1, %2, %0" : "+v"(b) : "v"(sacc[8]), "v"(sacc[9]));
+        asm("v_max3_f32 %0, %1, %2, %0" : "+v"(a) : "v"(sacc[10]), "v"(sacc[11]));
+        asm("v_max3_f32 %0, %1, %2, %0" : "+v"(b) : "v"(sacc[12]), "v"(sacc[13]));
+        asm("v_max3_f32 %0, %1, %2, %0" : "+v"(a) : "v"(sacc[14]), "v"(sacc[15]));
+        asm("v_max_f32 %0, %1, %2" : "=v"(tmax) : "v"(a), "v"(b));
+    } else {
+        tmax = sacc[0];
+#pragma unroll
+        for (int r = 1; r < NR; r++) tmax = fmaxf(tmax, sacc[r]);
+    }
+    tmax = half_max(tmax) * sm_c;
+#else
     float tmax = sacc[0];
 #pragma unroll
     for (int r = 1; r < NR; r++) tmax = fmaxf(tmax, sacc[r]);
     tmax = half_max(tmax) * sm_c;
+#endif
     if (__builtin_amdgcn_ballot_w64(tmax > m_run + ATS_DEFER) != 0) {       // first tile: m_run = -inf
         const float m_new = fmaxf(m_run, tmax);
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);          // -inf - finite -> 0; equal -> 1
@@ -2240,6 +2261,24 @@ __device__ __forceinline__ void ats_softmax(f32x16 &sacc, f32x16 &o0, f32x16 &o1
         typedef float f32x8 __attribute__((ext_vector_type(8)));
         typedef float f32x4 __attribute__((ext_vector_type(4)));
         typedef float f32x2 __attribute__((ext_vector_type(2)));
+#if (D2R_ATTN_VAR & 1)
+        // variant: scale-subtract as eight v_pk_fma_f32 and the row sum as packed adds on register PAIRS the compiler cannot split
+        // (the empty asm ties each pair to an aligned 64-bit register)
+        f32x2 pr[8];
+        const f32x2 c2 = {sm_c, sm_c}, m2 = {-m_run, -m_run};
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            f32x2 t2 = __builtin_elementwise_fma(f32x2{sacc[2 * q], sacc[2 * q + 1]}, c2, m2);
+            pr[q] = f32x2{__builtin_amdgcn_exp2f(t2.x), __builtin_amdgcn_exp2f(t2.y)};
+            asm volatile("" : "+v"(pr[q]));
+            sacc[2 * q] = pr[q].x;
+            sacc[2 * q + 1] = pr[q].y;
+        }
+        const f32x2 a0 = pr[0] + pr[4], a1 = pr[1] + pr[5], a2 = pr[2] + pr[6], a3 = pr[3] + pr[7];
+        const f32x2 b0 = a0 + a2, b1 = a1 + a3;
+        const f32x2 s2 = b0 + b1;
+        l_run += s2.x + s2.y;
+#else
         const f32x16 cv = sm_c, mv = -m_run;
         const f32x16 t = __builtin_elementwise_fma(sacc, cv, mv);
 #pragma unroll
@@ -2248,6 +2287,7 @@ __device__ __forceinline__ void ats_softmax(f32x16 &sacc, f32x16 &o0, f32x16 &o1
         const f32x4 s4 = s8.lo + s8.hi;
         const f32x2 s2 = s4.lo + s4.hi;
         l_run += s2.x + s2.y;
+#endif
     } else {
 #pragma unroll
         for (int r = 0; r < 4; r++) sacc[r] = __builtin_amdgcn_exp2f(fmaf(sacc[r], sm_c, -m_run));

@@ -20,6 +20,11 @@
 #endif
 // D2R_F8_EXP (bitmask) — k_gemm8f and the fp8 epilogues: 1 no scale-byte stores, 2 no e4m3 stores, 4 no GELU, 8 no scale loads in the K loop,
 //   16 no MFMA, 32 no LDS-DMA, 64 no fragment reads.  Garbage results; tools/f8_ablate.sh.
+// D2R_ATTN_VAR (bitmask) — instruction-level variants of k_attention_s' softmax (round 5): 1 = v_max3 chain on the raw accumulators, eight packed
+//   scale-subtracts, packed row sum.  Same results up to the order of the row sum.
+#ifndef D2R_ATTN_VAR
+#define D2R_ATTN_VAR 0
+#endif
 #ifndef D2R_F8_EXP
 #define D2R_F8_EXP 0
 #endif
