@@ -164,6 +164,9 @@ __global__ void k_cameras_virtual(ViewParams V, Mat16 obj_now, Mat16 cam, const 
     for (int j = 0; j < 12; j++) cams_out[(size_t)i * 12 + j] = o[j];
 }
 
+#ifndef D2R_MARCH_VAR
+#define D2R_MARCH_VAR 0                /* bit 0: LDS-brick addresses formed in fp32 (slot_addr_lds_f) */
+#endif
 #ifndef D2R_MARCH_RESERVE
 #define D2R_MARCH_RESERVE 128          /* queue entries a wave reserves per atomic */
 #endif
@@ -617,6 +620,30 @@ __device__ __forceinline__ void slot_addr(const NerfParams &P, int slot, bool hi
     }
 }
 
+// LDS-brick slot, addresses formed in fp32 (D2R_MARCH_VAR & 1; same bits as slot_addr<K_BRICK>): w = fract(p), floor = p - w (exact),
+// byte offset = fma(gz, 4 nxy, fma(gy, 4 nx, fma(gx, 4, 4 base))) — integers below 2^24 (an LDS brick is < 2^18 bytes, a coordinate
+// < 2^12), so every step is exact — and ONE v_cvt_u32_f32 per (y, z) corner pair: no quarter-rate v_mul_lo_u32, no v_floor + v_cvt
+// per axis.  The strides live in registers as floats INSTEAD of the integers (round 4 kept both and spilled).
+// off4[j] = byte offset of the corner pair (x, x + 1) at (y + (j & 1), z + (j >> 1)).
+__device__ __forceinline__ void slot_addr_lds_f(const NerfParams &P, int slot, bool hi, float x, float y, float z, uint32_t *off4, float *w)
+{
+    const SlotMeta &m = P.slot[slot];
+    const float scale = hi ? m.scale[1] : m.scale[0];
+    const float nx4 = 4.0f * (float)(hi ? m.bnx[1] : m.bnx[0]), nxy4 = 4.0f * (float)(hi ? m.bnxy[1] : m.bnxy[0]);
+    const float base4 = 4.0f * (float)(hi ? m.bbase[1] : m.bbase[0]);
+    const float p0 = fmaf(scale, x, 0.5f), p1 = fmaf(scale, y, 0.5f), p2 = fmaf(scale, z, 0.5f);
+    w[0] = __builtin_amdgcn_fractf(p0);
+    w[1] = __builtin_amdgcn_fractf(p1);
+    w[2] = __builtin_amdgcn_fractf(p2);
+    const float gx = p0 - w[0], gy = p1 - w[1], gz = p2 - w[2];
+    const float b00 = fmaf(gz, nxy4, fmaf(gy, nx4, fmaf(gx, 4.0f, base4)));
+    const float b10 = b00 + nx4, b01 = b00 + nxy4, b11 = b10 + nxy4;
+    off4[0] = (uint32_t)b00;
+    off4[1] = (uint32_t)b10;
+    off4[2] = (uint32_t)b01;
+    off4[3] = (uint32_t)b11;
+}
+
 // trilinear blend of the 8 corner entries, corner weights in the oracle's order ((wx*wy)*wz).
 // v_fma_mix_f32 multiplies the fp32 weight with one half of the packed fp16 pair and accumulates
 // in fp32 directly — no fp16->fp32 converts (hipcc does not form it with fp32 denormals on).
@@ -725,8 +752,19 @@ __device__ __forceinline__ void encode_sample(const NerfParams &P, const __amdgp
     auto lds_slots = [&]() {
 #pragma unroll
         for (int i = 0; i < NB; i++) {
-            uint32_t bo[8], br[8];
+            uint32_t br[8];
             float bw[3];
+#if (D2R_MARCH_VAR & 1)
+            uint32_t bo4[4];
+            slot_addr_lds_f(P, i, hi, x, y, z, bo4, bw);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t *p = (const uint32_t *)(lds_bricks + bo4[j]);
+                br[2 * j] = p[0];
+                br[2 * j + 1] = p[1];
+            }
+#else
+            uint32_t bo[8];
             slot_addr<K_BRICK>(P, i, hi, x, y, z, bo, bw);
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -734,6 +772,7 @@ __device__ __forceinline__ void encode_sample(const NerfParams &P, const __amdgp
                 br[2 * j] = p[0];
                 br[2 * j + 1] = p[1];
             }
+#endif
             slot_blend(br, bw, f[2 * i], f[2 * i + 1]);
         }
     };
