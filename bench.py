@@ -622,7 +622,11 @@ def run_api_real(args, wd):
             return inner(*a, **k)
         clip_scoring.optimise_pose_grid = with_mask
     t0 = time.perf_counter()
-    best, pose_batch, scores = eng.dream_best_pose(task)
+    try:
+        best, pose_batch, scores = eng.dream_best_pose(task)
+    finally:
+        if old_scores is not None and old_scores.shape[0] == int(np.prod(sample_res)):
+            clip_scoring.optimise_pose_grid = inner          # the wrapper that carried the reference run's validity mask
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     sc = scores.numpy()
