@@ -165,7 +165,7 @@ __global__ void k_cameras_virtual(ViewParams V, Mat16 obj_now, Mat16 cam, const 
 }
 
 #ifndef D2R_MARCH_VAR
-#define D2R_MARCH_VAR 0                /* bit 0: LDS-brick addresses formed in fp32 (slot_addr_lds_f) */
+#define D2R_MARCH_VAR 0                /* bit 0: LDS-brick addresses formed in fp32 (slot_addr_lds_f); bit 1: the next lattice point's occupancy word requested before the field evaluation */
 #endif
 #ifndef D2R_MARCH_RESERVE
 #define D2R_MARCH_RESERVE 128          /* queue entries a wave reserves per atomic */
@@ -303,50 +303,88 @@ __device__ __forceinline__ bool make_ray(const NerfParams &P, const ViewParams &
     return true;
 }
 
+// Lattice point k of a ray: its distance, its position in the unit cube of the box, and the occupancy cell it falls into (cascade
+// `mip`, cell (cx, cy, cz), cell size and origin of that cascade in box units).  inside = false: the point lies outside render_aabb.
+struct OccCell {
+    float t, px, py, pz, cell, corg;
+    int mip, cx, cy, cz;
+    bool inside;
+};
+template <bool CONE>
+__device__ __forceinline__ OccCell occ_cell(const NerfParams &P, const Ray &r, uint32_t k)
+{
+    OccCell o;
+    o.t = lattice_t<CONE>(r, k);
+    const float px = fmaf(o.t, r.dx, r.ox), py = fmaf(o.t, r.dy, r.oy), pz = fmaf(o.t, r.dz, r.oz);
+    o.px = px; o.py = py; o.pz = pz;
+    o.inside = !(px < P.rn_lo[0] || px > P.rn_hi[0] || py < P.rn_lo[1] || py > P.rn_hi[1] || pz < P.rn_lo[2] || pz > P.rn_hi[2]);
+    // occupancy cascade (CONE; n_casc = log2(aabb_scale) + 1 of them, cascade c the cube of side 2^c about 0.5 with
+    // cells 2^c / 128): the smallest one that contains the sample, or a coarser one once the step has grown to
+    // its cells (step * 256 >= 2^(c-1)) — instant-ngp's max(mip_from_pos, mip_from_dt) as believed
+    int mip = 0;
+    float qx = px, qy = py, qz = pz, cell = 1.0f / (float)D2R_GRID, corg = 0.f;
+    if (CONE) {
+        const float mxw = fmaxf(fmaxf(fabsf(px - 0.5f), fabsf(py - 0.5f)), fabsf(pz - 0.5f)) * P.side;   // world units
+        const float dt256 = lattice_dt<CONE>(o.t) * 256.0f;
+        const int top = (int)P.n_casc - 1;
+        float half = 0.5f, step = 1.0f;
+        for (int c = 1; c <= top; c++) {
+            if (mxw >= half || dt256 >= step) mip = c;
+            half *= 2.0f;
+            step *= 2.0f;
+        }
+        if (mip != top) {
+            // the sample in the unit cube of cascade `mip`: scale about the centre by aabb_scale / 2^mip
+            const float sc = P.side / (float)(1 << mip);
+            qx = fmaf(px - 0.5f, sc, 0.5f);
+            qy = fmaf(py - 0.5f, sc, 0.5f);
+            qz = fmaf(pz - 0.5f, sc, 0.5f);
+            cell = 1.0f / ((float)D2R_GRID * sc);
+            corg = 0.5f - 0.5f / sc;
+        }
+    }
+    o.mip = mip; o.cell = cell; o.corg = corg;
+    o.cx = min(max((int)(qx * (float)D2R_GRID), 0), D2R_GRID - 1);
+    o.cy = min(max((int)(qy * (float)D2R_GRID), 0), D2R_GRID - 1);
+    o.cz = min(max((int)(qz * (float)D2R_GRID), 0), D2R_GRID - 1);
+    return o;
+}
+__device__ __forceinline__ const uint64_t *occ_word_ptr(const NerfParams &P, const OccCell &o)
+{
+    return P.bricks + ((size_t)o.mip * 32768 + (o.cx >> 2) + 32 * ((o.cy >> 2) + 32 * (o.cz >> 2)));
+}
+// the occupancy word lattice point k will be tested against (D2R_MARCH_VAR & 2: requested one iteration ahead, before the field evaluation
+// of the current sample, so that its latency hides under the gathers and the MLP instead of heading the next iteration)
+template <bool CONE>
+__device__ __forceinline__ uint64_t occ_prefetch(const NerfParams &P, const Ray &r, uint32_t k)
+{
+    if (k > r.k_hi) return 0ull;
+    const OccCell o = occ_cell<CONE>(P, r, k);
+    return o.inside ? *occ_word_ptr(P, o) : 0ull;
+}
+
 // Advance k to the next lattice sample t0+k*dt that lies in an occupied cell.
 // Empty 4^3 bricks / empty cells are skipped conservatively (never past an untested
 // lattice point that could be in another cell).  Returns false when the ray is finished.
+// pre: optional, the occupancy word of lattice point k (occ_prefetch) — saves the first load.
 template <bool CONE>
 __device__ __forceinline__ bool next_sample(const NerfParams &P, const Ray &r, uint32_t &k, float &px,
-                                            float &py, float &pz)
+                                            float &py, float &pz, const uint64_t *pre = nullptr)
 {
     // approximate reciprocals are enough: they only size the conservative skip below
     float ix = __builtin_amdgcn_rcpf(r.dx), iy = __builtin_amdgcn_rcpf(r.dy), iz = __builtin_amdgcn_rcpf(r.dz);
+    bool first = pre != nullptr;
     while (k <= r.k_hi) {
-        float t = lattice_t<CONE>(r, k);
-        px = fmaf(t, r.dx, r.ox);
-        py = fmaf(t, r.dy, r.oy);
-        pz = fmaf(t, r.dz, r.oz);
-        if (px < P.rn_lo[0] || px > P.rn_hi[0] || py < P.rn_lo[1] || py > P.rn_hi[1] || pz < P.rn_lo[2] || pz > P.rn_hi[2]) return false;
-        // occupancy cascade (CONE; n_casc = log2(aabb_scale) + 1 of them, cascade c the cube of side 2^c about 0.5 with
-        // cells 2^c / 128): the smallest one that contains the sample, or a coarser one once the step has grown to
-        // its cells (step * 256 >= 2^(c-1)) — instant-ngp's max(mip_from_pos, mip_from_dt) as believed
-        int mip = 0;
-        float qx = px, qy = py, qz = pz, cell = 1.0f / (float)D2R_GRID, corg = 0.f;
-        if (CONE) {
-            const float mxw = fmaxf(fmaxf(fabsf(px - 0.5f), fabsf(py - 0.5f)), fabsf(pz - 0.5f)) * P.side;   // world units
-            const float dt256 = lattice_dt<CONE>(t) * 256.0f;
-            const int top = (int)P.n_casc - 1;
-            float half = 0.5f, step = 1.0f;
-            for (int c = 1; c <= top; c++) {
-                if (mxw >= half || dt256 >= step) mip = c;
-                half *= 2.0f;
-                step *= 2.0f;
-            }
-            if (mip != top) {
-                // the sample in the unit cube of cascade `mip`: scale about the centre by aabb_scale / 2^mip
-                const float sc = P.side / (float)(1 << mip);
-                qx = fmaf(px - 0.5f, sc, 0.5f);
-                qy = fmaf(py - 0.5f, sc, 0.5f);
-                qz = fmaf(pz - 0.5f, sc, 0.5f);
-                cell = 1.0f / ((float)D2R_GRID * sc);
-                corg = 0.5f - 0.5f / sc;
-            }
-        }
-        int cx = min(max((int)(qx * (float)D2R_GRID), 0), D2R_GRID - 1);
-        int cy = min(max((int)(qy * (float)D2R_GRID), 0), D2R_GRID - 1);
-        int cz = min(max((int)(qz * (float)D2R_GRID), 0), D2R_GRID - 1);
-        uint64_t w = P.bricks[(size_t)mip * 32768 + (cx >> 2) + 32 * ((cy >> 2) + 32 * (cz >> 2))];
+        const OccCell o = occ_cell<CONE>(P, r, k);
+        const float t = o.t;
+        px = o.px; py = o.py; pz = o.pz;
+        if (!o.inside) return false;
+        const int mip = o.mip, cx = o.cx, cy = o.cy, cz = o.cz;
+        const float cell = o.cell, corg = o.corg;
+        uint64_t w;
+        if (first) w = *pre;
+        else w = *occ_word_ptr(P, o);
+        first = false;
         uint32_t bit = (cx & 3) + 4 * (cy & 3) + 16 * (cz & 3);
         if ((w >> bit) & 1ull) return true;
         // skip: to the far face of the empty brick, or of the empty cell (box units: cell size `cell`, origin `corg`)
@@ -1065,6 +1103,10 @@ __global__ __launch_bounds__(D2R_MARCH_THREADS) void k_march(NerfParams P, ViewP
         if (!__any(alive)) break;
         niter++;
 
+#if (D2R_MARCH_VAR & 2)
+        uint64_t occ_next = 0ull;
+        if (alive) occ_next = occ_prefetch<CONE>(P, ray, k + 1);
+#endif
         // ---- evaluate this wave's samples
         float sigma, cr, cg, cb;
         eval_wave<NB, NGB, ND, F16>(P, rs, rsb, sw, lds_bricks, lane, alive, px, py, pz, shfA, shfB, sigma, cr, cg, cb);
@@ -1090,7 +1132,11 @@ __global__ __launch_bounds__(D2R_MARCH_THREADS) void k_march(NerfParams P, ViewP
                 done = true;
             } else {
                 k++;
+#if (D2R_MARCH_VAR & 2)
+                done = !next_sample<CONE>(P, ray, k, px, py, pz, &occ_next);
+#else
                 done = !next_sample<CONE>(P, ray, k, px, py, pz);
+#endif
             }
             if (done) {
                 alive = false;
