@@ -20,7 +20,7 @@ EXPORTS = [
     "d2r_text_destroy", "d2r_text_encode", "d2r_comm_get_unique_id", "d2r_comm_init", "d2r_comm_destroy",
     "d2r_allgather_scores", "d2r_phys_create", "d2r_phys_destroy", "d2r_phys_check", "d2r_nerf_load_ingp",
     "d2r_rectify_background_depth", "d2r_ingp_inspect", "d2r_render_score_host", "d2r_png_write", "d2r_png_write_batch",
-    "d2r_png_read_batch", "d2r_png_size", "d2r_savetxt", "d2r_ingp_validate", "d2r_debug_gemm_fp8", "d2r_ctx_get_option",
+    "d2r_png_read_batch", "d2r_png_size", "d2r_savetxt", "d2r_ingp_validate", "d2r_debug_gemm_fp8", "d2r_ctx_get_option", "d2r_png_write_batch_bg",
 ]
 
 
@@ -151,6 +151,16 @@ def png_write_batch(frames, out_dir: str, first_index: int = 0, threads: int = 0
     assert a.ndim == 4 and a.shape[3] == 3
     check(load().d2r_png_write_batch(ptr(a), C.c_uint32(a.shape[0]), C.c_uint32(a.shape[2]), C.c_uint32(a.shape[1]),
                                      os.fsencode(out_dir), C.c_uint32(first_index), C.c_int(threads), C.c_int(level)))
+
+
+def png_write_batch_bg(frames, background, out_dir: str, first_index: int = 0, threads: int = 0):
+    """d2r_png_write_batch_bg: like png_write_batch for frames that equal `background` [h,w,3] in most scanlines (those are entropy-coded
+    once); same pixels in the files."""
+    a = np.ascontiguousarray(frames, np.uint8)
+    b = np.ascontiguousarray(background, np.uint8)
+    assert a.ndim == 4 and a.shape[3] == 3 and b.shape == a.shape[1:]
+    check(load().d2r_png_write_batch_bg(ptr(a), C.c_uint32(a.shape[0]), C.c_uint32(a.shape[2]), C.c_uint32(a.shape[1]), ptr(b),
+                                        os.fsencode(out_dir), C.c_uint32(first_index), C.c_int(threads)))
 
 
 def png_size(path: str):

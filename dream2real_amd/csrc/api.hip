@@ -684,6 +684,7 @@ int d2r_set_background(d2r_ctx *ctx, const d2r_view *view, const float *bg_rgba,
     ctx->bg_w = view->width;
     ctx->bg_h = view->height;
     ctx->bg_patches_for = nullptr;          // the background's CLIP patches are recomputed on the next d2r_render_score
+    ctx->png_base.reset();                  // ... and so is the frame files' shared background coding
     return D2R_OK;
 }
 
@@ -861,8 +862,12 @@ static void dispatch_frames(d2r_ctx *ctx, int b, uint32_t c0, uint32_t nc, uint3
         const std::string dir(sink->png_dir);
         const uint32_t first = sink->png_first_index + c0;
         const int level = sink->png_level;
-        for (uint32_t i = 0; i < nc; i++)
-            ctx->pool->submit(b, [=](std::string &err) { return d2r_png_write_file(src + fb * i, W, H, level, d2r_png_name(dir, first + i), err); });
+        // default encoding: scanlines a candidate's object did not touch are the background's, coded once per background (pngio.cpp)
+        const std::shared_ptr<const D2rPngBase> base = level < 0 ? ctx->png_base : nullptr;
+        for (uint32_t i = 0; i < nc; i++) {
+            if (base) ctx->pool->submit(b, [=](std::string &err) { return d2r_png_write_file_delta(*base, src + fb * i, d2r_png_name(dir, first + i), err); });
+            else ctx->pool->submit(b, [=](std::string &err) { return d2r_png_write_file(src + fb * i, W, H, level, d2r_png_name(dir, first + i), err); });
+        }
     }
     if (frames_out) {
         const uint32_t step = std::max<uint32_t>(1, (uint32_t)((32u << 20) / fb));
@@ -917,6 +922,12 @@ static int render_score_body(d2r_ctx *ctx, const d2r_nerf *fg, const d2r_clip *c
                     return d2r_fail(ctx, D2R_ERR_MEMORY, "hipHostMalloc(" + std::to_string(hb) + ") failed for the frame staging buffer");
                 ctx->frame_host_cap[b] = hb;
             }
+        // the background frame as the candidates' frames hold it (k_frames_init copies bg_u8), for the PNG files' shared scanline coding
+        if (sink && sink->png_dir && sink->png_level < 0 && !ctx->png_base && ctx->bg_u8.p && ctx->bg_w == V.W && ctx->bg_h == V.H) {
+            std::vector<uint8_t> bg(px * 3);
+            D2R_HIP(ctx, hipMemcpy(bg.data(), ctx->bg_u8.p, px * 3, hipMemcpyDeviceToHost));
+            ctx->png_base = d2r_png_base_build(bg.data(), V.W, V.H);
+        }
         const int want = sink && sink->png_threads > 0 ? sink->png_threads : d2r_default_io_threads();
         if (!ctx->pool || ctx->pool->size() != want) {
             delete ctx->pool;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <memory>
 #include <mutex>
 #include <string>
 #include <utility>
@@ -11,6 +12,7 @@
 #include "../../include/d2r.h"
 
 class D2rJobPool;   // pngio.h
+struct D2rPngBase;  // pngio.h
 
 #define D2R_MAX_LEVELS 16
 #define D2R_MAX_DEVICES 64              // per-device "kernel attribute already set" flags
@@ -145,6 +147,7 @@ struct d2r_ctx {
     void *frame_host[2] = {nullptr, nullptr};
     size_t frame_host_cap[2] = {0, 0};
     D2rJobPool *pool = nullptr;
+    std::shared_ptr<const D2rPngBase> png_base;     // the current background's scanlines, entropy-coded once for the frame files (reset by d2r_set_background)
     int64_t overlap = 0;        // 1: render half of chunk i+1 on render_stream under the ViT of chunk i (measured neutral: both sides fill whole CUs); 0: program order on `stream`
     int64_t debug_fail_chunk = -1;   // fault injection for the error path of render_score_core (tests/test_api_path.py)
     uint32_t last_chunks = 0;   // chunks of the last d2r_render_score (its per-chunk counters are behind counters+64)

@@ -13,6 +13,7 @@
 #include <condition_variable>
 #include <deque>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -157,6 +158,222 @@ size_t deflate_huffman_only(const uint8_t *in, size_t n, uint8_t *out)
 }
 
 }  // namespace
+
+// ---- frames that differ from a known BACKGROUND frame in a few rows (what a render-and-score pass streams out: the candidate's object
+// covers a band of the frame, every other scanline is the background's) ----
+// The background's Sub-filtered scanlines are Huffman-coded ONCE, with one code shared by all frames (the background's histogram, every
+// literal kept alive); a frame is then written as: the shared block header, and per scanline either the background's ready-made bit
+// string appended at the current bit position (a shift-and-copy at ~GB/s) or, where the scanline differs, a fresh filter + emit pass.
+// Adler-32 of the filtered bytes is combined from per-scanline values (adler32_combine), only the CRC-32 of the compressed bytes is
+// computed per frame.  Any inflater reads the result; pixels are identical to d2r_png_encode's (PNG is lossless), files are a few
+// per cent larger where the object's statistics differ from the background's.
+struct D2rPngBase {
+    uint32_t w = 0, h = 0;
+    size_t row = 0;                          // 3 w
+    std::vector<uint8_t> rgb;                // the background frame
+    HuffCode hc[257];
+    std::vector<uint8_t> head;               // zlib header + deflate block header, as a bit string (starts at bit 0)
+    size_t head_bits = 0;
+    std::vector<uint8_t> bits;               // per-scanline bit strings, each starting at a byte boundary
+    std::vector<size_t> row_off;             // byte offset of scanline y in `bits`
+    std::vector<uint32_t> row_nbits;
+    std::vector<uint32_t> row_adler;         // adler32 of the scanline's filtered bytes (filter type byte included), standalone
+};
+
+namespace {
+
+struct BitWriter {
+    uint8_t *o;
+    uint64_t acc = 0;
+    int nb = 0;                              // < 32 between calls
+    explicit BitWriter(uint8_t *out) : o(out) {}
+    inline void put(uint32_t v, int k)       // k <= 32, v < 2^k
+    {
+        acc |= (uint64_t)v << nb;
+        nb += k;
+        if (nb >= 32) {
+            memcpy(o, &acc, 4);              // little-endian hosts (x86-64)
+            o += 4;
+            acc >>= 32;
+            nb -= 32;
+        }
+    }
+    void append(const uint8_t *src, size_t nbits)      // a bit string that starts at bit 0 of src[0]
+    {
+        size_t i = 0;
+        for (; i + 32 <= nbits; i += 32) {
+            uint32_t v;
+            memcpy(&v, src + (i >> 3), 4);
+            put(v, 32);
+        }
+        size_t left = nbits - i;
+        const uint8_t *p = src + (i >> 3);
+        while (left >= 8) {
+            put(*p++, 8);
+            left -= 8;
+        }
+        if (left) put(*p & ((1u << left) - 1u), (int)left);
+    }
+    size_t finish(uint8_t *base)             // pad to a byte, return the byte count
+    {
+        while (nb > 0) {
+            *o++ = (uint8_t)acc;
+            acc >>= 8;
+            nb -= 8;
+        }
+        nb = 0;
+        return (size_t)(o - base);
+    }
+};
+
+inline void sub_filter_row(const uint8_t *src, size_t row, uint8_t *dst)      // dst: row + 1 bytes
+{
+    dst[0] = 1;
+    dst[1] = src[0]; dst[2] = src[1]; dst[3] = src[2];
+    for (size_t i = 3; i < row; i++) dst[1 + i] = (uint8_t)(src[i] - src[i - 3]);
+}
+
+void canonical_codes(const uint8_t *len, HuffCode *hc)
+{
+    uint16_t next[16] = {0}, bl_count[16] = {0};
+    for (int s = 0; s < 257; s++) bl_count[len[s]]++;
+    bl_count[0] = 0;
+    uint16_t code = 0;
+    for (int b = 1; b <= 15; b++) {
+        code = (uint16_t)((code + bl_count[b - 1]) << 1);
+        next[b] = code;
+    }
+    for (int s = 0; s < 257; s++) {
+        uint16_t c = len[s] ? next[len[s]]++ : 0, r = 0;
+        for (int b = 0; b < len[s]; b++) r = (uint16_t)((r << 1) | ((c >> b) & 1));
+        hc[s] = {r, len[s]};
+    }
+}
+
+}  // namespace
+
+std::shared_ptr<const D2rPngBase> d2r_png_base_build(const uint8_t *bg_rgb, uint32_t w, uint32_t h)
+{
+    if (!bg_rgb || w == 0 || h == 0 || w > 32768 || h > 32768) return nullptr;
+    auto B = std::make_shared<D2rPngBase>();
+    B->w = w;
+    B->h = h;
+    B->row = (size_t)w * 3;
+    const size_t row = B->row;
+    B->rgb.assign(bg_rgb, bg_rgb + row * h);
+    std::vector<uint8_t> f((row + 1) * h);
+    uint32_t cnt[257];
+    for (int s2 = 0; s2 < 257; s2++) cnt[s2] = 1;                 // every literal (and the end-of-block symbol) keeps a code: the object's bytes are not known yet
+    for (uint32_t y = 0; y < h; y++) {
+        sub_filter_row(bg_rgb + row * y, row, &f[(row + 1) * y]);
+        for (size_t i = 0; i <= row; i++) cnt[f[(row + 1) * y + i]] += 4;   // (x 4: the floor of 1 stays small beside real counts)
+    }
+    uint8_t len[257];
+    huff_lengths(cnt, 257, len);
+    canonical_codes(len, B->hc);
+    // zlib header + block header, exactly as deflate_huffman_only writes them
+    B->head.assign(256, 0);
+    {
+        BitWriter bw(B->head.data());
+        bw.put(0x78, 8);
+        bw.put(0x01, 8);
+        bw.put(1, 1);
+        bw.put(2, 2);
+        bw.put(0, 5);
+        bw.put(0, 5);
+        bw.put(15, 4);
+        static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+        for (int k = 0; k < 19; k++) bw.put(order[k] < 16 ? 4 : 0, 3);
+        auto rev4 = [](uint32_t v) { return ((v & 1) << 3) | ((v & 2) << 1) | ((v & 4) >> 1) | ((v & 8) >> 3); };
+        for (int s2 = 0; s2 < 257; s2++) bw.put(rev4(len[s2]), 4);
+        bw.put(rev4(0), 4);
+        B->head_bits = 16 + 3 + 5 + 5 + 4 + 19 * 3 + 258 * 4;
+        bw.finish(B->head.data());
+    }
+    // per-scanline bit strings (worst case 15 bits per byte)
+    B->row_off.resize(h);
+    B->row_nbits.resize(h);
+    B->row_adler.resize(h);
+    std::vector<uint8_t> tmp((row + 1) * 2 + 16);
+    for (uint32_t y = 0; y < h; y++) {
+        const uint8_t *fr = &f[(row + 1) * y];
+        std::fill(tmp.begin(), tmp.end(), 0);
+        BitWriter bw(tmp.data());
+        size_t nbits = 0;
+        for (size_t i = 0; i <= row; i++) {
+            bw.put(B->hc[fr[i]].code, B->hc[fr[i]].len);
+            nbits += B->hc[fr[i]].len;
+        }
+        const size_t nbytes = bw.finish(tmp.data());
+        B->row_off[y] = B->bits.size();
+        B->row_nbits[y] = (uint32_t)nbits;
+        B->bits.insert(B->bits.end(), tmp.begin(), tmp.begin() + nbytes);
+        B->bits.insert(B->bits.end(), 4, 0);                     // slack: append() reads whole 32-bit words
+        B->row_adler[y] = (uint32_t)adler32(adler32(0L, Z_NULL, 0), fr, (uInt)(row + 1));
+    }
+    return B;
+}
+
+int d2r_png_encode_delta(const D2rPngBase &B, const uint8_t *rgb, std::vector<uint8_t> &out, std::string &err)
+{
+    if (!rgb) {
+        err = "null frame";
+        return D2R_ERR_INVALID;
+    }
+    const size_t row = B.row;
+    thread_local std::vector<uint8_t> z, frow;
+    const size_t cap = (row + 1) * B.h * 2 + 2048;               // 15-bit codes at worst
+    if (z.size() < cap) z.resize(cap);
+    if (frow.size() < row + 1) frow.resize(row + 1);
+    BitWriter bw(z.data());
+    bw.append(B.head.data(), B.head_bits);
+    uLong ad = adler32(0L, Z_NULL, 0);
+    for (uint32_t y = 0; y < B.h; y++) {
+        const uint8_t *src = rgb + row * y;
+        if (memcmp(src, &B.rgb[row * y], row) == 0) {
+            bw.append(&B.bits[B.row_off[y]], B.row_nbits[y]);
+            ad = adler32_combine(ad, B.row_adler[y], (z_off_t)(row + 1));
+        } else {
+            sub_filter_row(src, row, frow.data());
+            for (size_t i = 0; i <= row; i++) bw.put(B.hc[frow[i]].code, B.hc[frow[i]].len);
+            ad = adler32(ad, frow.data(), (uInt)(row + 1));
+        }
+    }
+    bw.put(B.hc[256].code, B.hc[256].len);
+    size_t n = bw.finish(z.data());
+    z[n++] = (uint8_t)(ad >> 24); z[n++] = (uint8_t)(ad >> 16); z[n++] = (uint8_t)(ad >> 8); z[n++] = (uint8_t)ad;
+    out.clear();
+    out.reserve(n + 64);
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    out.insert(out.end(), sig, sig + 8);
+    std::vector<uint8_t> ihdr;
+    put32(ihdr, B.w);
+    put32(ihdr, B.h);
+    const uint8_t tail[5] = {8, 2, 0, 0, 0};
+    ihdr.insert(ihdr.end(), tail, tail + 5);
+    chunk(out, "IHDR", ihdr.data(), ihdr.size());
+    chunk(out, "IDAT", z.data(), n);
+    chunk(out, "IEND", nullptr, 0);
+    return D2R_OK;
+}
+
+int d2r_png_write_file_delta(const D2rPngBase &B, const uint8_t *rgb, const std::string &path, std::string &err)
+{
+    thread_local std::vector<uint8_t> bytes;
+    int rc = d2r_png_encode_delta(B, rgb, bytes, err);
+    if (rc) return rc;
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f) {
+        err = "cannot open " + path + " for writing";
+        return D2R_ERR_INVALID;
+    }
+    const bool ok = fwrite(bytes.data(), 1, bytes.size(), f) == bytes.size();
+    if (fclose(f) != 0 || !ok) {
+        err = "short write to " + path;
+        return D2R_ERR_INVALID;
+    }
+    return D2R_OK;
+}
 
 // One RGB frame -> PNG bytes: colour type 2, bit depth 8, no interlace (any decoder returns the same pixels: PNG is lossless).
 int d2r_png_encode(const uint8_t *rgb, uint32_t w, uint32_t h, int level, std::vector<uint8_t> &out, std::string &err)
@@ -525,6 +742,24 @@ int d2r_png_write_batch(const uint8_t *frames, uint32_t n, uint32_t w, uint32_t 
     const std::string d(dir);
     for (uint32_t i = 0; i < n; i++)
         pool.submit(0, [=](std::string &err) { return d2r_png_write_file(frames + fb * i, w, h, level, d2r_png_name(d, first_index + i), err); });
+    pool.wait(-1);
+    std::string err;
+    int rc = pool.take_error(err);
+    return rc ? d2r_fail(nullptr, rc, err) : D2R_OK;
+}
+
+int d2r_png_write_batch_bg(const uint8_t *frames, uint32_t n, uint32_t w, uint32_t h, const uint8_t *background, const char *dir,
+                           uint32_t first_index, int threads)
+{
+    if (!frames || !dir || !background) return d2r_fail(nullptr, D2R_ERR_INVALID, "null argument");
+    if (n == 0) return D2R_OK;
+    std::shared_ptr<const D2rPngBase> base = d2r_png_base_build(background, w, h);
+    if (!base) return d2r_fail(nullptr, D2R_ERR_INVALID, "bad image size");
+    const size_t fb = (size_t)w * h * 3;
+    D2rJobPool pool(std::min<int>((int)n, threads > 0 ? threads : d2r_default_io_threads()));
+    const std::string d(dir);
+    for (uint32_t i = 0; i < n; i++)
+        pool.submit(0, [=](std::string &err) { return d2r_png_write_file_delta(*base, frames + fb * i, d2r_png_name(d, first_index + i), err); });
     pool.wait(-1);
     std::string err;
     int rc = pool.take_error(err);

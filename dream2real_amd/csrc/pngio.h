@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include <functional>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -13,6 +14,12 @@ int d2r_png_decode(const uint8_t *bytes, size_t n, uint32_t want_w, uint32_t wan
                    uint32_t *h_out, std::string &err);
 int d2r_png_read_file(const std::string &path, uint32_t want_w, uint32_t want_h, uint8_t *rgb_out, uint32_t *w_out,
                       uint32_t *h_out, std::string &err);
+// Frames that equal a known background frame in most scanlines (the frames of a render-and-score pass): the background's scanlines are
+// entropy-coded once (d2r_png_base_build), a frame re-codes only the scanlines that differ.  Same pixels as d2r_png_encode.
+struct D2rPngBase;
+std::shared_ptr<const D2rPngBase> d2r_png_base_build(const uint8_t *bg_rgb, uint32_t w, uint32_t h);
+int d2r_png_encode_delta(const D2rPngBase &base, const uint8_t *rgb, std::vector<uint8_t> &out, std::string &err);
+int d2r_png_write_file_delta(const D2rPngBase &base, const uint8_t *rgb, const std::string &path, std::string &err);
 std::string d2r_png_name(const std::string &dir, uint32_t index);      // <dir>/cb_rgb_%04d.png
 int d2r_default_io_threads();
 

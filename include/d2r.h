@@ -353,6 +353,11 @@ D2R_API int d2r_png_write(const uint8_t *rgb, uint32_t w, uint32_t h, const char
  * host threads (0 = auto): what renderer.render(save=True) leaves behind (combined_rendering.py:157-159). */
 D2R_API int d2r_png_write_batch(const uint8_t *frames, uint32_t n, uint32_t w, uint32_t h, const char *dir,
                                 uint32_t first_index, int threads, int level);
+/* The same for frames that equal `background` ([h][w][3]) in most scanlines — the frames of a render-and-score pass, where a candidate's
+ * object covers a band of the frame: the background's scanlines are entropy-coded once and a frame re-codes only the scanlines that differ
+ * (default encoding only; identical pixels, files a few per cent larger).  d2r_render_score_host's frame sink writes its files this way. */
+D2R_API int d2r_png_write_batch_bg(const uint8_t *frames, uint32_t n, uint32_t w, uint32_t h, const uint8_t *background, const char *dir,
+                                   uint32_t first_index, int threads);
 /* The reverse, for use_cache_renders (clip_scoring.py:95-104): n files of w x h -> frames_out host [n][h][w][3]; file i is
  * cb_rgb_%04d.png of indices[i], or of first_index + i when indices is NULL.  Reads 8-bit grey / RGB PNGs with or without
  * alpha, every scanline filter (what cv2.imwrite and PIL write); a file of another size, a missing file or an

@@ -84,6 +84,65 @@ def test_png_codec_roundtrip_and_foreign_files(tmp_path):
         _lib.png_read_batch(d, 1, first_index=400, size=(96, 54))
 
 
+def test_png_background_delta_encoder_writes_the_same_pixels(tmp_path):
+    """d2r_png_write_batch_bg (round 5): frames that equal a background frame except in a band of scanlines — what a render-and-score
+    pass streams out — re-code only the scanlines that differ; the background's scanlines are entropy-coded once with one shared Huffman
+    code.  Through a foreign inflater (PIL) every file must hold exactly its frame: no row changed, one pixel changed, a band, every row
+    changed (noise: codes of 8-9 bits with a code built for other statistics), a one-pixel-wide and a one-row image, a constant background
+    (two-symbol statistics, every other literal kept alive by the floor count), and rows whose bit strings end on every bit offset."""
+    import time
+    from PIL import Image
+    r = np.random.default_rng(9)
+
+    def check(bg, frames, tag):
+        d = str(tmp_path / tag)
+        os.makedirs(d)
+        _lib.png_write_batch_bg(frames, bg, d, first_index=7, threads=3)
+        for i, f in enumerate(frames):
+            got = np.asarray(Image.open(os.path.join(d, f"cb_rgb_{i + 7:04d}.png")).convert("RGB"))
+            np.testing.assert_array_equal(got, f, err_msg=f"{tag} frame {i}")
+        np.testing.assert_array_equal(_lib.png_read_batch(d, len(frames), first_index=7), frames)        # and through the library's own reader
+        return d
+
+    H, W = 90, 160
+    yy, xx = np.mgrid[0:H, 0:W]
+    bg = np.stack([(xx * 3 + yy) % 256, (yy * 5) % 256, (xx + 2 * yy) // 3 % 256], -1).astype(np.uint8)
+    bg[40:60] = r.integers(0, 256, (20, W, 3), dtype=np.uint8)             # a noisy stripe: long codes in the background itself
+    frames = np.repeat(bg[None], 7, 0).copy()
+    frames[1, 45, 80, 1] ^= 0x55                                            # one pixel
+    frames[2, 30:55, 50:90] = r.integers(0, 256, (25, 40, 3), dtype=np.uint8)   # a band (the object's rectangle)
+    frames[3] = r.integers(0, 256, (H, W, 3), dtype=np.uint8)               # every row differs
+    frames[4, 0] = 255 - frames[4, 0]                                       # first row
+    frames[5, H - 1] = 0                                                    # last row
+    frames[6, ::2] = frames[6, ::2][:, ::-1]                                # every other row
+    d = check(bg, frames, "band")
+    # the delta file of an untouched frame is no larger than the plain encoder's by more than the floor counts cost
+    _lib.png_write(frames[0], str(tmp_path / "plain.png"))
+    s_delta, s_plain = os.path.getsize(os.path.join(d, "cb_rgb_0007.png")), os.path.getsize(tmp_path / "plain.png")
+    assert s_delta <= s_plain * 1.03 + 64, (s_delta, s_plain)
+    check(np.full((5, 1, 3), 9, np.uint8), np.stack([np.full((5, 1, 3), 9, np.uint8), r.integers(0, 256, (5, 1, 3), dtype=np.uint8)]), "one_wide")
+    check(np.zeros((1, 33, 3), np.uint8), np.stack([np.zeros((1, 33, 3), np.uint8), r.integers(0, 256, (1, 33, 3), dtype=np.uint8)]), "one_row")
+    const = np.full((24, 31, 3), 200, np.uint8)
+    fr = np.repeat(const[None], 3, 0).copy()
+    fr[1, 10:14] = r.integers(0, 256, (4, 31, 3), dtype=np.uint8)
+    fr[2, 5, 5] = (1, 2, 3)
+    check(const, fr, "constant")
+    # speed, for the record (640x360 frames with a 90-row band changed, one thread): delta against plain
+    H, W = 360, 640
+    bgL = r.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    bgL = (bgL // 8 + np.stack([(np.mgrid[0:H, 0:W][1] // 3) % 200] * 3, -1)).astype(np.uint8)          # smooth-ish with texture
+    fl = np.repeat(bgL[None], 24, 0).copy()
+    for i in range(24):
+        fl[i, 100 + i:190 + i, 200:320] = r.integers(0, 256, (90, 120, 3), dtype=np.uint8)
+    dd, dp = str(tmp_path / "speed_delta"), str(tmp_path / "speed_plain")
+    os.makedirs(dd); os.makedirs(dp)
+    t0 = time.perf_counter(); _lib.png_write_batch_bg(fl, bgL, dd, threads=1); t1 = time.perf_counter()
+    _lib.png_write_batch(fl, dp, threads=1); t2 = time.perf_counter()
+    np.testing.assert_array_equal(_lib.png_read_batch(dd, 24), fl)
+    sz = lambda q: sum(os.path.getsize(os.path.join(q, f)) for f in os.listdir(q))
+    print(f"[png] 24 frames 640x360, 90-row band changed, one thread: delta {(t1 - t0) * 1e3:.0f} ms ({sz(dd) // 24} B / file), plain {(t2 - t1) * 1e3:.0f} ms ({sz(dp) // 24} B / file)")
+
+
 def test_cached_renders_are_read_in_sorted_name_order(tmp_path):
     """use_cache_renders reads cb_render/ in SORTED NAME order like the reference (clip_scoring.py:97): index order up
     to 9999, lexical beyond it."""
