@@ -197,6 +197,9 @@ int d2r_ctx_set_option(d2r_ctx *ctx, const char *key, int64_t value)
     if (!strcmp(key, "chunk")) {
         if (value < 1 || value > 16384) return d2r_fail(ctx, D2R_ERR_INVALID, "chunk must be in [1, 16384]");
         ctx->chunk = value;
+    } else if (!strcmp(key, "march_compact")) {
+        if (value < 0 || value > 1) return d2r_fail(ctx, D2R_ERR_INVALID, "march_compact must be 0 or 1");
+        ctx->march_compact = value;
     } else if (!strcmp(key, "refill_min")) {
         if (value < 1 || value > 64) return d2r_fail(ctx, D2R_ERR_INVALID, "refill_min must be in [1, 64]");
         ctx->refill_min = value;
@@ -266,7 +269,7 @@ int d2r_ctx_get_option(d2r_ctx *ctx, const char *key, int64_t *value)
 {
     if (!ctx || !key || !value) return d2r_fail(ctx, D2R_ERR_INVALID, "null argument");
     const struct { const char *k; int64_t v; } tab[] = {
-        {"chunk", ctx->chunk}, {"refill_min", ctx->refill_min}, {"ln_fold", ctx->ln_fold}, {"gemm_nsplit", ctx->gemm_nsplit},
+        {"chunk", ctx->chunk}, {"refill_min", ctx->refill_min}, {"march_compact", ctx->march_compact}, {"ln_fold", ctx->ln_fold}, {"gemm_nsplit", ctx->gemm_nsplit},
         {"prep_reuse", ctx->prep_reuse}, {"cls_last", ctx->cls_last}, {"vit_fp8", ctx->vit_fp8}, {"l0_reuse", ctx->l0_reuse},
         {"attn_rem", ctx->attn_rem}, {"overlap", ctx->overlap}, {"march_blocks", ctx->march_blocks}, {"gbrick_slots", ctx->gbrick_slots},
         {"brick_slots_total", ctx->brick_slots_total}, {"lds_slots_max", ctx->lds_slots_max}, {"gbrick_max_mib", ctx->gbrick_max_mib},

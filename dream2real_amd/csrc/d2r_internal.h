@@ -60,6 +60,7 @@ struct NerfParams {
     int32_t n_dense;           // leading dense HALF-levels (2 per level when F = 4; slot kinds follow from it), -1 = irregular
     SlotMeta slot[D2R_MAX_LEVELS / 2];
     uint32_t refill_min;       // free lanes in a wave before it pulls new rays from the queue
+    uint32_t compact;          // 1: a wave with <= 32 rays left moves them to lanes 0..31 (tile 1 then costs nothing)
     uint32_t n_brick_slots;    // leading slots whose levels are de-hashed into LDS bricks (0 .. 5)
     uint32_t brick_words;      // total words of those bricks
     const uint32_t *brick_tab; // [brick_words] half2 entries, copied to LDS by every workgroup
@@ -157,6 +158,7 @@ struct d2r_ctx {
     uint32_t last_march_nb = 0, last_march_ngb = 0;   // brick configuration the last march launch ran with (d2r_get_render_stats)
     int64_t refill_min = 64;   // measured on MI355X: a refill (queue + camera loads, ray setup, SH) costs several iterations,
                                // so a wave runs its 64 rays to the end (lane utilisation 0.79) rather than topping up at 16 free lanes (0.90)
+    int64_t march_compact = 1; // marcher: compact a wave's last <= 32 rays into one tile (option "march_compact")
     int64_t ln_fold = 4;       // vision tower: 0 LayerNorm kernels + fp32 residual; LayerNorm folded into the GEMMs with 1 a split (hi + lo) bf16 residual, 2 a bf16 residual, 3 an fp32 residual + bf16 copy, 4 bf16 hi + one lo byte
     int64_t gemm_stagger = 0;      // persistent GEMM: stagger the workgroups' first tile over a tile period (epilogues spread in time)
     int64_t gemm_group = 65535;    // persistent GEMM: column tiles per group of the tile order (large = the plain column-fastest order, the default; 0 = the width a simple L2 model picks: a third fewer L2 misses, same time)

@@ -164,6 +164,9 @@ __global__ void k_cameras_virtual(ViewParams V, Mat16 obj_now, Mat16 cam, const 
     for (int j = 0; j < 12; j++) cams_out[(size_t)i * 12 + j] = o[j];
 }
 
+#ifndef D2R_MARCH_PROF
+#define D2R_MARCH_PROF 0              /* development: per-wave cycle stamps of the refill block, printed by a few waves */
+#endif
 #ifndef D2R_MARCH_VAR
 #define D2R_MARCH_VAR 0                /* bit 0: LDS-brick addresses formed in fp32 (slot_addr_lds_f); bit 1: the next lattice point's occupancy word requested before the field evaluation */
 #endif
@@ -968,10 +971,13 @@ __device__ __forceinline__ void eval_wave(const NerfParams &P, const __amdgpu_bu
     uint4 fa0 = make_uint4(0, 0, 0, 0), fa1 = fa0, fb0 = fa0, fb1 = fa0;
     if (av) encode_sample<NB, NGB, ND, F16>(P, rs, rsb, lds_bricks, hi, ax, ay, az, fa0, fa1);
     if (bv) encode_sample<NB, NGB, ND, F16>(P, rs, rsb, lds_bricks, hi, bx, by, bz, fb0, fb1);
-    float oa[4], ob[4];
+    float oa[4] = {0.f, 0.f, 0.f, 0.f}, ob[4] = {0.f, 0.f, 0.f, 0.f};
     __builtin_amdgcn_sched_barrier(0);
-    mlp_tile<F16>(sw, lane, fa0, fa1, shfA, oa);
-    mlp_tile<F16>(sw, lane, fb0, fb1, shfB, ob);
+    // a tile none of whose 32 samples exists (the tail of a wave's rays, compacted into tile 0 by k_march) costs nothing:
+    // its features were skipped above (exec-masked), its MLP passes are skipped here (wave-uniform)
+    const unsigned long long vm = __ballot(valid);
+    if ((uint32_t)vm != 0u) mlp_tile<F16>(sw, lane, fa0, fa1, shfA, oa);
+    if ((uint32_t)(vm >> 32) != 0u) mlp_tile<F16>(sw, lane, fb0, fb1, shfB, ob);
     // tile-1 results live in lanes 0..31; their owners are lanes 32..63
     float ts = __shfl_xor(ob[0], 32), tr = __shfl_xor(ob[1], 32), tg = __shfl_xor(ob[2], 32), tb = __shfl_xor(ob[3], 32);
     // sigma = exp(x), rgb = sigmoid(x) through the hardware exp2 / rcp (1-2 ulp)
@@ -1050,10 +1056,39 @@ __global__ __launch_bounds__(D2R_MARCH_THREADS) void k_march(NerfParams P, ViewP
     uint32_t nsamp = 0, niter = 0;
     uint4 shfA = make_uint4(0, 0, 0, 0), shfB = shfA;
 
+#if D2R_MARCH_PROF
+    long long prof_t0 = clock64(), prof_refill = 0;
+    uint32_t prof_n = 0, prof_le32 = 0, prof_le16 = 0, prof_half = 0, prof_alive = 0;
+#endif
     for (;;) {
+        // ---- compaction (P.compact): once no more than 32 rays are left and some of them sit in lanes 32..63, the wave's rays move
+        // to lanes 0 .. n-1 (ds_permute: a forward permutation, no LDS memory): tile 1 then holds no sample, its gathers and MLP
+        // passes are skipped (eval_wave), and the free lanes are one contiguous block for the next refill.  Per-ray arithmetic
+        // does not depend on the lane a ray sits in: the frames are bit-identical.
+        bool sh_dirty = false;                 // wave-uniform
+        if (P.compact) {
+            const unsigned long long am = __ballot(alive);
+            const uint32_t na = (uint32_t)__popcll(am);
+            if (na != 0u && na <= 32u && (am >> 32) != 0ull) {
+                const unsigned long long below = (1ull << lane) - 1ull;
+                const uint32_t dest = alive ? (uint32_t)__popcll(am & below) : na + (uint32_t)__popcll(~am & below);
+                const int d4 = (int)(dest << 2);
+                auto mv = [&](float &v) { v = __int_as_float(__builtin_amdgcn_ds_permute(d4, __float_as_int(v))); };
+                auto mvu = [&](uint32_t &v) { v = (uint32_t)__builtin_amdgcn_ds_permute(d4, (int)v); };
+                mv(ray.ox); mv(ray.oy); mv(ray.oz); mv(ray.dx); mv(ray.dy); mv(ray.dz); mv(ray.t0); mvu(ray.k_hi);
+                if (CONE) { mvu(ray.k1); mv(ray.t1); }
+                mvu(k); mvu(ray_id); mv(px); mv(py); mv(pz);
+                mv(C0); mv(C1); mv(C2); mv(A); mv(Z); mv(zslope); mv(zbase);
+                alive = lane < na;
+                sh_dirty = true;
+            }
+        }
         // ---- refill free lanes from the ray queue (ballot + prefix popcount, one atomic per wave)
         unsigned long long freem = __ballot(!alive);
         if ((!exhausted || res_lo < res_hi) && freem != 0ull && (__popcll(freem) >= (int)P.refill_min || freem == ~0ull)) {
+#if D2R_MARCH_PROF
+            const long long prof_a = clock64();
+#endif
             const uint32_t nfree = (uint32_t)__popcll(freem);
             if (res_lo == res_hi) {
                 // this wave's reservation is used up: take the next D2R_MARCH_RESERVE queue entries with
@@ -1095,13 +1130,31 @@ __global__ __launch_bounds__(D2R_MARCH_THREADS) void k_march(NerfParams P, ViewP
                     alive = true;
                 }
             }
-            // ray directions changed in some lanes: refresh the wave's SH fragments (all lanes
-            // take part: a lane's fragment also carries its partner's direction)
+            sh_dirty = true;
+#if D2R_MARCH_PROF
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            prof_refill += clock64() - prof_a;
+            prof_n++;
+#endif
+        }
+        if (!__any(alive)) break;
+        if (sh_dirty) {
+            // ray directions changed in some lanes (refill) or moved between lanes (compaction): refresh the wave's SH
+            // fragments (all lanes take part: a lane's fragment also carries its partner's direction)
             if (CONE) sh_fragments<F16>(lane, ray.dx * P.side, ray.dy * P.side, ray.dz * P.side, shfA, shfB);     // unit direction
             else sh_fragments<F16>(lane, ray.dx, ray.dy, ray.dz, shfA, shfB);
         }
-        if (!__any(alive)) break;
         niter++;
+#if D2R_MARCH_PROF
+        {
+            const unsigned long long am = __ballot(alive);
+            const int na = __popcll(am);
+            prof_le32 += na <= 32;
+            prof_le16 += na <= 16;
+            prof_half += (am >> 32) == 0ull || (am & 0xffffffffull) == 0ull;
+            prof_alive += na;
+        }
+#endif
 
 #if (D2R_MARCH_VAR & 2)
         uint64_t occ_next = 0ull;
@@ -1171,6 +1224,10 @@ __global__ __launch_bounds__(D2R_MARCH_THREADS) void k_march(NerfParams P, ViewP
             }
         }
     }
+#if D2R_MARCH_PROF
+    if (lane == 0 && (threadIdx.x >> 6) < 2 && blockIdx.x % 64 == 0)
+        printf("prof block %u wave %u: cycles %lld refill %lld (%u refills) iterations %u alive<=32 %u alive<=16 %u half-dead %u lane-samples %u\n", blockIdx.x, threadIdx.x >> 6, clock64() - prof_t0, prof_refill, prof_n, niter, prof_le32, prof_le16, prof_half, prof_alive);
+#endif
     // per-wave sample count -> global counter
     unsigned long long tot = nsamp;
 #pragma unroll
@@ -1331,6 +1388,7 @@ int d2r_launch_render(d2r_ctx *ctx, const d2r_nerf *m, const ViewParams &V, cons
     }
     NerfParams PP = m->P;
     PP.refill_min = (uint32_t)ctx->refill_min;
+    PP.compact = (uint32_t)ctx->march_compact;
     const size_t lds = (size_t)D2R_N_WFRAG * 64 * 16 + (nb ? (size_t)m->P.brick_words * 4 : 0);
 #define D2R_MARCH_C(COMP, NB, NGB, ND, CONE)                            \
     do {                                                                \

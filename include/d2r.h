@@ -404,6 +404,8 @@ D2R_API int d2r_get_timing(d2r_ctx *ctx, d2r_timing *out);
  *     view so that one pass stays inside the 32-bit indexing of the ray queue and the GEMM outputs.
  * "refill_min" (default 64, 1..64): free lanes a marcher wave accumulates before it takes new rays
  *     from the queue (64 = a wave runs its 64 rays to the end).
+ * "march_compact" (default 1): once a marcher wave has no more than 32 rays left it moves them to its
+ *     lanes 0..31, so that the second 32-sample tile of its iterations costs nothing (same pixels).
  * "bricks" (default 1): serve the de-hashed coarse levels of small models from LDS; 0 forces every
  *     level through the global tables.  Behind the LDS slots, further slots are served from de-hashed dense bricks in HBM:
  *     "gbrick_slots" (default 8, 0..8) caps how many, "brick_slots_total" (default 7, 0..8) the first slot that is never

@@ -418,6 +418,49 @@ def test_every_brick_configuration_is_bit_identical_to_the_tables(kind):
     ctx.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["shopping", "shelf"])
+def test_ray_compaction_and_refill_policies_do_not_change_a_pixel(kind):
+    """`march_compact` (round 5: a wave's last <= 32 rays move to lanes 0..31 by ds_permute so that tile 1 costs nothing) and
+    `refill_min` (how many free lanes a wave collects before it takes new rays) only change WHICH lane marches a ray: frames (fp32
+    RGBA + depth, uint8 composite) and the sample count are bit-identical for every combination, with and without bricks."""
+    from dream2real_amd import engine
+    scene = make_scene(kind)
+    ctx = engine.Context(0)
+    W, H = 160, 90
+    pipe = OraclePipeline(scene, W, H)
+    poses = host_ref.sample_poses_grid(scene.scene_centre, [3, 3, 2, 1, 1, 1] if kind == "shopping" else [2, 2, 2, 2, 1, 1], scene.scene_type).reshape(-1, 4, 4)
+    cams = np.stack([pipe.fg_camera(p) for p in poses])
+    T1 = host_ref.converter(np.asarray(scene.obj_pose, np.float32)[None])[0]
+    TC = host_ref.converter(np.asarray(scene.cam_poses, np.float32))[0]
+    obg = pipe.background()
+    base = None
+    try:
+        for bricks in (1, 0):
+            ctx.set_option("bricks", bricks)
+            tb = engine.Testbed(ctx, scene.fg)
+            tb.background_color = list(scene.fg_background)
+            view = tb.view(W, H)
+            ctx.set_background(view, obg[0], obg[1])
+            for compact in (0, 1):
+                for refill in (64, 33, 32, 7, 1):
+                    ctx.set_option("march_compact", compact)
+                    ctx.set_option("refill_min", refill)
+                    rgba, depth = tb.render_batch(cams, W, H)
+                    got = (rgba, depth, tb.last_samples, tb.render_composite(view, T1, TC, host_ref.converter(poses.astype(np.float32))))
+                    if base is None:
+                        base = got
+                        assert got[2] > 5000
+                    for a, b in zip(got, base):
+                        np.testing.assert_array_equal(a, b, err_msg=f"bricks {bricks}, march_compact {compact}, refill_min {refill}")
+            tb.close()
+    finally:
+        ctx.set_option("bricks", 1)
+        ctx.set_option("march_compact", 1)
+        ctx.set_option("refill_min", 64)
+    ctx.close()
+
+
 @pytest.mark.parametrize("variant", ["small_tables", "bigger_object", "huge_object", "l8f4", "l8f4_small_tables", "render_aabb"])
 def test_other_kernel_instantiations(gpu, variant):
     """The march kernel is instantiated per table/occupancy shape: generic slot kinds for a level
