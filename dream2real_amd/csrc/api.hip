@@ -49,8 +49,8 @@ int d2r_reserve(d2r_ctx *ctx, d2r_ctx::Buf &b, size_t bytes)
 {
     if (bytes <= b.cap) return D2R_OK;
     if (b.p) {
-        hipStreamSynchronize(ctx->stream);
-        hipFree(b.p);
+        D2R_HIP(ctx, hipStreamSynchronize(ctx->stream));     // an asynchronous fault of earlier work surfaces here: keep the old buffer, report it
+        (void)hipFree(b.p);
         b.p = nullptr;
         b.cap = 0;
     }
@@ -60,7 +60,7 @@ int d2r_reserve(d2r_ctx *ctx, d2r_ctx::Buf &b, size_t bytes)
         return d2r_fail(ctx, D2R_ERR_MEMORY, "hipMalloc(" + std::to_string(want) + ") failed");
     }
     b.cap = want - 64;     // kernels may read a few bytes past the last element (k_preprocess: 4-byte pixel loads)
-    hipMemsetAsync(b.p, 0, want, ctx->stream);   // padded rows/columns of GEMM operands must be finite
+    D2R_HIP(ctx, hipMemsetAsync(b.p, 0, want, ctx->stream));   // padded rows/columns of GEMM operands must be finite
     return D2R_OK;
 }
 
@@ -349,7 +349,7 @@ int d2r_nerf_create(d2r_ctx *ctx, const d2r_nerf_desc *d, d2r_nerf **out)
         return d2r_fail(ctx, D2R_ERR_INVALID, "null field in d2r_nerf_desc");
     const uint32_t aabb = d->aabb_scale ? d->aabb_scale : 1u;
     if ((aabb & (aabb - 1u)) || aabb > 128u) return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "aabb_scale must be a power of two <= 128");
-    hipSetDevice(ctx->device);
+    D2R_HIP(ctx, hipSetDevice(ctx->device));
     d2r_nerf *m = new d2r_nerf();
     m->ctx = ctx;
     NerfParams &P = m->P;
@@ -623,7 +623,7 @@ int d2r_render(d2r_ctx *ctx, const d2r_nerf *model, const d2r_view *view, const 
     int rc = check_view(ctx, view);
     if (rc) return rc;
     if (n == 0) return D2R_OK;
-    hipSetDevice(ctx->device);
+    D2R_HIP(ctx, hipSetDevice(ctx->device));
     const ViewParams V = d2r_view_params(view);
     const size_t px = (size_t)V.W * V.H;
     ctx->stats = d2r_render_stats{};
@@ -656,7 +656,7 @@ int d2r_nerf_eval_points(d2r_ctx *ctx, const d2r_nerf *model, const float *xyz, 
 {
     if (!ctx || !model || !xyz || !dirs || !sigma_rgb_out) return d2r_fail(ctx, D2R_ERR_INVALID, "null argument");
     if (n == 0) return D2R_OK;
-    hipSetDevice(ctx->device);
+    D2R_HIP(ctx, hipSetDevice(ctx->device));
     int rc;
     if ((rc = d2r_reserve(ctx, ctx->rgba, (size_t)n * 16))) return rc;
     if ((rc = d2r_reserve(ctx, ctx->depth, (size_t)n * 12))) return rc;
@@ -675,7 +675,7 @@ int d2r_set_background(d2r_ctx *ctx, const d2r_view *view, const float *bg_rgba,
     if (!ctx || !bg_rgba || !bg_depth) return d2r_fail(ctx, D2R_ERR_INVALID, "null argument");
     int rc = check_view(ctx, view);
     if (rc) return rc;
-    hipSetDevice(ctx->device);
+    D2R_HIP(ctx, hipSetDevice(ctx->device));
     const size_t px = (size_t)view->width * view->height;
     if ((rc = d2r_reserve(ctx, ctx->bg_rgba, px * 16))) return rc;
     if ((rc = d2r_reserve(ctx, ctx->bg_depth, px * 4))) return rc;
@@ -698,7 +698,7 @@ int d2r_render_composite(d2r_ctx *ctx, const d2r_nerf *fg, const d2r_view *view,
         return d2r_fail(ctx, D2R_ERR_INVALID, "null argument");
     int rc = check_view(ctx, view);
     if (rc) return rc;
-    hipSetDevice(ctx->device);
+    D2R_HIP(ctx, hipSetDevice(ctx->device));
     const ViewParams V = d2r_view_params(view);
     const size_t px = (size_t)V.W * V.H;
     ctx->stats = d2r_render_stats{};
@@ -752,7 +752,7 @@ int d2r_clip_score_frames(d2r_ctx *ctx, const d2r_clip *clip, const uint8_t *fra
                           float *logits_out, float *embeds_out)
 {
     if (!ctx || !clip || !frames || !logits_out) return d2r_fail(ctx, D2R_ERR_INVALID, "null argument");
-    hipSetDevice(ctx->device);
+    D2R_HIP(ctx, hipSetDevice(ctx->device));
     int rc = upload_text(ctx, clip, text_embeds, C);
     if (rc) return rc;
     const size_t px = (size_t)w * h;
@@ -783,7 +783,7 @@ int d2r_clip_preprocess(d2r_ctx *ctx, const d2r_clip *clip, const uint8_t *frame
                         uint32_t h, int rot90, float *pixel_values_out)
 {
     if (!ctx || !clip || !frames || !pixel_values_out) return d2r_fail(ctx, D2R_ERR_INVALID, "null argument");
-    hipSetDevice(ctx->device);
+    D2R_HIP(ctx, hipSetDevice(ctx->device));
     const size_t px = (size_t)w * h, S = d2r_clip_image_size(clip);
     int rc;
     if ((rc = d2r_reserve(ctx, ctx->frames, (size_t)n * px * 3))) return rc;
@@ -801,7 +801,7 @@ int d2r_clip_embed_pixels(d2r_ctx *ctx, const d2r_clip *clip, const float *pixel
                           float *embeds_out)
 {
     if (!ctx || !clip || !pixel_values || !embeds_out) return d2r_fail(ctx, D2R_ERR_INVALID, "null argument");
-    hipSetDevice(ctx->device);
+    D2R_HIP(ctx, hipSetDevice(ctx->device));
     const size_t S = d2r_clip_image_size(clip);
     const uint32_t D = d2r_clip_proj_dim(clip);
     int rc;
@@ -1101,7 +1101,7 @@ int d2r_render_score(d2r_ctx *ctx, const d2r_nerf *fg, const d2r_clip *clip, con
 {
     int rc = check_render_score_args(ctx, fg, clip, view, obj_pose_now, cam_pose, obj_poses_dev, logits_dev, nullptr);
     if (rc) return rc;
-    hipSetDevice(ctx->device);
+    D2R_HIP(ctx, hipSetDevice(ctx->device));
     if ((rc = upload_text(ctx, clip, text_embeds, C))) return rc;
     return render_score_core(ctx, fg, clip, view, obj_pose_now, cam_pose, obj_poses_dev, K, C, logit_scale, logits_dev,
                              frames_out, nullptr);
@@ -1115,7 +1115,7 @@ int d2r_render_score_host(d2r_ctx *ctx, const d2r_nerf *fg, const d2r_clip *clip
     int rc = check_render_score_args(ctx, fg, clip, view, obj_pose_now, cam_pose, obj_poses, logits_out, sink);
     if (rc) return rc;
     if (K == 0) return D2R_OK;
-    hipSetDevice(ctx->device);
+    D2R_HIP(ctx, hipSetDevice(ctx->device));
     if ((rc = upload_text(ctx, clip, text_embeds, C))) return rc;
     if ((rc = d2r_reserve(ctx, ctx->poses, (size_t)K * 64))) return rc;
     if ((rc = d2r_reserve(ctx, ctx->logits, (size_t)K * C * 4))) return rc;

@@ -3398,7 +3398,7 @@ extern "C" int d2r_clip_create(d2r_ctx *ctx, const d2r_clip_desc *desc, const fl
     const uint32_t d = desc->hidden_size, P = desc->patch_size, S = desc->image_size, mlp = desc->mlp_size;
     if (d % 128 || mlp % 128 || d > 1024 || desc->proj_dim > 1024 || d / desc->num_heads != 64 || S % P)
         return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "unsupported CLIP geometry (need head_dim 64, d,mlp % 128 == 0, d <= 1024)");
-    hipSetDevice(ctx->device);
+    D2R_HIP(ctx, hipSetDevice(ctx->device));
     d2r_clip *c = new d2r_clip();
     c->ctx = ctx;
     c->desc = *desc;
@@ -3663,7 +3663,7 @@ extern "C" int d2r_debug_gemm_fp8(d2r_ctx *ctx, const float *A, const float *W, 
 {
     if (!ctx || !A || !W || !bias || !out) return d2r_fail(ctx, D2R_ERR_INVALID, "null argument");
     if (!M || N % 256 || K % 256 || kind < 0 || kind > 1) return d2r_fail(ctx, D2R_ERR_INVALID, "d2r_debug_gemm_fp8: N and K must be multiples of 256, kind 0 or 1");
-    hipSetDevice(ctx->device);
+    D2R_HIP(ctx, hipSetDevice(ctx->device));
     const size_t Mp = round_up(M, BM);
     const size_t b_a = (size_t)M * K * 4, b_w = (size_t)N * K * 4, b_wb = (size_t)N * K * 2, b_w8 = (size_t)N * K, b_a8 = Mp * K, b_sa = Mp * (K / 64),
                  b_c = Mp * N * 2, b_sc = Mp * (N / 64), b_bias = (size_t)N * 4;

@@ -124,7 +124,7 @@ extern "C" int d2r_rectify_background_depth(d2r_ctx *ctx, const void *depth, int
     if (!src_w || !src_h || !W || !H || W > 16384 || H > 16384 || src_w > 65535 || src_h > 65535)
         return d2r_fail(ctx, D2R_ERR_INVALID, "bad image size");
     if (mask_out && !mask) return d2r_fail(ctx, D2R_ERR_INVALID, "mask_out without a mask");
-    hipSetDevice(ctx->device);
+    D2R_HIP(ctx, hipSetDevice(ctx->device));
     // centre crop to a square (reference :176-184): the longer side loses (long - short) / 2 at its start
     const uint32_t S = std::min(src_w, src_h);
     const uint32_t x0 = src_w > src_h ? (src_w - src_h) / 2 : 0, y0 = src_h > src_w ? (src_h - src_w) / 2 : 0;

@@ -214,3 +214,27 @@ def test_host_only_entries_return_error_codes(tmp_path):
     assert lib.d2r_ingp_validate(bytes(range(64)), 64, None) == -1 and "snapshot" in err()
     with pytest.raises(ValueError):
         _lib.savetxt(str(tmp_path / "z.txt"), np.float64(3.0))                 # 0-d, like np.savetxt
+
+
+def test_public_header_is_strict_c99_and_a_plain_c_program_links_and_runs(tmp_path):
+    """The drop-in boundary is a C ABI (tier rule 2): include/d2r.h compiles as C99 with -pedantic (no C++ types, no torch types), a C
+    program (examples/c_caller.c) links against libd2r.so alone and runs the host-only entry points — ABI version, error convention,
+    PNG writer / reader, np.savetxt-format writer — without a GPU."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("no gcc")
+    libdir = os.path.join(REPO, "dream2real_amd")
+    exe = str(tmp_path / "c_caller")
+    r = subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(REPO, "include"),
+                        os.path.join(REPO, "examples", "c_caller.c"), "-L" + libdir, "-ld2r", "-Wl,-rpath," + libdir, "-o", exe],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = tmp_path / "out"
+    out.mkdir()
+    r = subprocess.run([exe, str(out)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", (r.stdout, r.stderr)
+    assert sorted(os.listdir(out)) == ["cb_rgb_0005.png", "cb_rgb_0006.png", "pose_scores.txt"]
+    import numpy as np
+    assert np.loadtxt(out / "pose_scores.txt").shape == (3, 2)
