@@ -113,14 +113,20 @@ def power_probe(step_fn, device_index: int, seconds: float):
     if not os.path.exists(smi) or seconds <= 0:
         return None
     samples, stop = [], threading.Event()
+    cmd = [smi, "-d", str(device_index), "--showpower", "--showclocks"]
+    try:
+        # the first rocm-smi of a fresh box takes many seconds (the image pages in): pay that before the sampled steps, not during them
+        subprocess.run(cmd, capture_output=True, text=True, timeout=60)
+    except Exception:
+        return None
+    step_fn()                                    # the device is under load when the first sample is taken
 
     def work():
         while not stop.is_set():
             try:
-                txt = subprocess.run([smi, "-d", str(device_index), "--showpower", "--showclocks"], capture_output=True,
-                                     text=True, timeout=5).stdout
+                txt = subprocess.run(cmd, capture_output=True, text=True, timeout=10).stdout
             except Exception:
-                return
+                continue
             w = re.search(r"Power \(W\):\s*([\d.]+)", txt)
             c = re.search(r"sclk clock level:\s*\S+\s*\((\d+)Mhz\)", txt)
             if w and c:
@@ -128,8 +134,9 @@ def power_probe(step_fn, device_index: int, seconds: float):
 
     th = threading.Thread(target=work, daemon=True)
     th.start()
-    t_end = time.perf_counter() + seconds
-    while time.perf_counter() < t_end:
+    t0 = time.perf_counter()
+    # `seconds` of steps, extended (to at most three times that) until there are enough samples to call it an average
+    while time.perf_counter() - t0 < seconds or (len(samples) < 8 and time.perf_counter() - t0 < 3 * seconds):
         step_fn()
     stop.set()
     th.join(timeout=6)
