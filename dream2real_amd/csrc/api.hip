@@ -223,6 +223,12 @@ int d2r_ctx_set_option(d2r_ctx *ctx, const char *key, int64_t value)
         ctx->overlap = value != 0;
     } else if (!strcmp(key, "debug_fail_chunk")) {
         ctx->debug_fail_chunk = value;          // test hook: d2r_render_score* fails in this chunk (-1 = off)
+    } else if (!strcmp(key, "march_threads")) {
+        if (value < 0 || value > 1024 || value % 64) return d2r_fail(ctx, D2R_ERR_INVALID, "march_threads must be 0 (auto) or a multiple of 64 up to 1024");
+        ctx->march_threads = value;
+    } else if (!strcmp(key, "march_threads_auto_mib")) {
+        if (value < 0 || value > 1 << 20) return d2r_fail(ctx, D2R_ERR_INVALID, "march_threads_auto_mib out of range");
+        ctx->march_threads_auto_mib = value;
     } else if (!strcmp(key, "march_blocks")) {
         if (value < 0 || value > 65535) return d2r_fail(ctx, D2R_ERR_INVALID, "march_blocks out of range");
         ctx->march_blocks = value;
@@ -271,10 +277,11 @@ int d2r_ctx_get_option(d2r_ctx *ctx, const char *key, int64_t *value)
     const struct { const char *k; int64_t v; } tab[] = {
         {"chunk", ctx->chunk}, {"refill_min", ctx->refill_min}, {"march_compact", ctx->march_compact}, {"ln_fold", ctx->ln_fold}, {"gemm_nsplit", ctx->gemm_nsplit},
         {"prep_reuse", ctx->prep_reuse}, {"cls_last", ctx->cls_last}, {"vit_fp8", ctx->vit_fp8}, {"l0_reuse", ctx->l0_reuse},
-        {"attn_rem", ctx->attn_rem}, {"overlap", ctx->overlap}, {"march_blocks", ctx->march_blocks}, {"gbrick_slots", ctx->gbrick_slots},
+        {"attn_rem", ctx->attn_rem}, {"overlap", ctx->overlap}, {"march_blocks", ctx->march_blocks}, {"march_threads", ctx->march_threads}, {"march_threads_auto_mib", ctx->march_threads_auto_mib}, {"gbrick_slots", ctx->gbrick_slots},
         {"brick_slots_total", ctx->brick_slots_total}, {"lds_slots_max", ctx->lds_slots_max}, {"gbrick_max_mib", ctx->gbrick_max_mib},
         {"bricks", ctx->use_bricks}, {"mlp_f16", ctx->mlp_f16}, {"raygen_rect", ctx->raygen_rect}, {"timing", ctx->timing}, {"debug_fail_chunk", ctx->debug_fail_chunk},
-        {"march_lds_slots", (int64_t)ctx->last_march_nb}, {"march_hbm_brick_slots", (int64_t)ctx->last_march_ngb}};
+        {"march_lds_slots", (int64_t)ctx->last_march_nb}, {"march_hbm_brick_slots", (int64_t)ctx->last_march_ngb},
+        {"march_hbm_brick_bytes", (int64_t)ctx->last_march_gbrick_bytes}, {"march_threads_used", (int64_t)ctx->last_march_threads}};
     for (const auto &e : tab)
         if (!strcmp(key, e.k)) {
             *value = e.v;

@@ -155,6 +155,9 @@ struct d2r_ctx {
     int64_t chunk = 4096;       // candidates per pass (capped per model/view by pass_size() in api.hip)
     uint32_t last_pass = 0;     // pass size the last d2r_render_score used (for its stats read-back)
     int64_t march_blocks = 0;  // 0 = auto
+    int64_t march_threads = 0; // threads per marcher workgroup: 0 = auto (768, or 512 when the HBM bricks exceed march_threads_auto_mib MiB), else 64 .. 768 in steps of 64
+    int64_t march_threads_auto_mib = 64;   // apple 36 MB (issue-bound: 768 threads are 8 % faster), shelf 112 MB, 2.2x / 5x apple 394 / 89 MB (L2-miss-bound: 512 are 1-5 % faster)
+    uint32_t last_march_threads = 0, last_march_gbrick_bytes = 0;   // and the workgroup size / HBM-brick bytes of that launch
     uint32_t last_march_nb = 0, last_march_ngb = 0;   // brick configuration the last march launch ran with (d2r_get_render_stats)
     int64_t refill_min = 64;   // measured on MI355X: a refill (queue + camera loads, ray setup, SH) costs several iterations,
                                // so a wave runs its 64 rays to the end (lane utilisation 0.79) rather than topping up at 16 free lanes (0.90)

@@ -1390,6 +1390,12 @@ int d2r_launch_render(d2r_ctx *ctx, const d2r_nerf *m, const ViewParams &V, cons
     PP.refill_min = (uint32_t)ctx->refill_min;
     PP.compact = (uint32_t)ctx->march_compact;
     const size_t lds = (size_t)D2R_N_WFRAG * 64 * 16 + (nb ? (size_t)m->P.brick_words * 4 : 0);
+    // waves per workgroup (= per CU): the kernels are compiled for D2R_MARCH_THREADS (three waves per SIMD); a launch may use fewer.
+    // Auto: where the bricks behind the LDS slots are larger than the L2s can hold, the marcher is bound by the L2-miss path, not by
+    // latency — two waves per SIMD are as fast or faster (less thrash), one is 8-17 % slower (round 5, same-box A/B)
+    uint32_t threads = D2R_MARCH_THREADS;
+    if (ctx->march_threads > 0) threads = std::min<uint32_t>((uint32_t)ctx->march_threads, D2R_MARCH_THREADS);
+    else if (ngb && m->P.gbrick_bytes > (size_t)ctx->march_threads_auto_mib << 20) threads = std::min<uint32_t>(512u, D2R_MARCH_THREADS);
 #define D2R_MARCH_C(COMP, NB, NGB, ND, CONE)                            \
     do {                                                                \
         if (ctx->mlp_f16) D2R_MARCH_F(COMP, NB, NGB, ND, CONE, true);   \
@@ -1401,7 +1407,7 @@ int d2r_launch_render(d2r_ctx *ctx, const d2r_nerf *m, const ViewParams &V, cons
         attr.run(ctx->device, [] {                                                                                \
             (void)hipFuncSetAttribute((const void *)k_march<COMP, NB, NGB, ND, CONE, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (CONE ? 512 : 0)); /* the CONE kernels hold 512 B of static LDS (cone tables): static + dynamic <= 160 KiB */ \
         });                                                                                                       \
-        hipLaunchKernelGGL((k_march<COMP, NB, NGB, ND, CONE, F16>), dim3(blocks), dim3(D2R_MARCH_THREADS), lds, ctx->stream, PP, V, cams_dev, q, \
+        hipLaunchKernelGGL((k_march<COMP, NB, NGB, ND, CONE, F16>), dim3(blocks), dim3(threads), lds, ctx->stream, PP, V, cams_dev, q, \
                            cnt, cnt + 1, COMP ? nullptr : rgba_dev, COMP ? nullptr : depth_dev,                   \
                            COMP ? bgd : nullptr, COMP ? frames_dev : nullptr, sc);                                \
     } while (0)
@@ -1427,6 +1433,8 @@ int d2r_launch_render(d2r_ctx *ctx, const d2r_nerf *m, const ViewParams &V, cons
     }
     ctx->last_march_nb = nb;
     ctx->last_march_ngb = ngb;
+    ctx->last_march_threads = threads;
+    ctx->last_march_gbrick_bytes = ngb ? m->P.gbrick_bytes : 0;
 #undef D2R_MARCH_CASE
 #undef D2R_MARCH_PICK
 #undef D2R_MARCH_C
