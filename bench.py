@@ -975,6 +975,12 @@ def run_kernel_bench(args, wd):
                          # the same kernel priced on the bytes the memory system actually moved (PMC FETCH_SIZE + WRITE_SIZE per
                          # launch / launch time / peak): 10 of 16 levels are served from LDS bricks, so this is far below `frac`
                          "traffic_frac": round(traffic / march_avg_s / 1e9 / HBM_PEAK_GBPS, 5) if (traffic and march_avg_s > 0) else None,
+                         # `achieved` counts ALL 16 levels' bytes (512 B per sample) although the leading level pairs are read
+                         # from LDS bricks, so it can exceed the HBM peak; the same figure on the levels that do go through L2 / the fabric:
+                         "beyond_lds": (lambda lv: {"levels": lv, "bytes_per_sample": lv * 32, "achieved": round(achieved * lv / 16, 2),
+                                                    "frac": round(achieved * lv / 16 / HBM_PEAK_GBPS, 5)})(16 - 2 * int((brick_config or {}).get("lds_slots", 0))),
+                         "note": "frac = algorithmic bytes (16 levels x 8 corners x 4 B per sample) / launch time / 8 TB/s; levels served from LDS bricks are "
+                                 "counted, so frac > 1 is possible: `beyond_lds` prices only the levels fetched through L2, `traffic_frac` the fabric bytes counted by PMC",
                          "vit": None},
             "roofline_vit": {"bound": "mfma", "gflop_per_image": round(gflop_exec, 2),
                              "gflop_per_image_architecture": round(vit_gflop(cfg), 2),

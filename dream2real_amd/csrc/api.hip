@@ -152,7 +152,7 @@ void d2r_ctx_destroy(d2r_ctx *c)
     if (c->render_stream) hipStreamSynchronize(c->render_stream);
     if (c->copy_stream) hipStreamSynchronize(c->copy_stream);
     delete c->pool;
-    d2r_ctx::Buf *bufs[] = {&c->cams, &c->queue, &c->counters, &c->frames, &c->rgba, &c->depth, &c->poses,
+    d2r_ctx::Buf *bufs[] = {&c->cams, &c->queue, &c->queue2, &c->sort_counts, &c->counters, &c->frames, &c->rgba, &c->depth, &c->poses,
                             &c->text, &c->logits, &c->pix, &c->bg_rgba, &c->bg_depth, &c->bg_u8, &c->rects, &c->bg_patches, &c->rect_ws,
                             &c->patches2, &c->frames2, &c->bg_l0, &c->l0_a1, &c->l0_q2, &c->l0_misc};
     for (auto *b : bufs)
@@ -223,6 +223,12 @@ int d2r_ctx_set_option(d2r_ctx *ctx, const char *key, int64_t value)
         ctx->overlap = value != 0;
     } else if (!strcmp(key, "debug_fail_chunk")) {
         ctx->debug_fail_chunk = value;          // test hook: d2r_render_score* fails in this chunk (-1 = off)
+    } else if (!strcmp(key, "ray_sort")) {
+        if (value < 0 || value > 1) return d2r_fail(ctx, D2R_ERR_INVALID, "ray_sort must be 0 or 1");
+        ctx->ray_sort = value;
+    } else if (!strcmp(key, "ray_sort_log2")) {
+        if (value < 1 || value > 4) return d2r_fail(ctx, D2R_ERR_INVALID, "ray_sort_log2 must be 1 .. 4");
+        ctx->ray_sort_log2 = value;
     } else if (!strcmp(key, "march_threads")) {
         if (value < 0 || value > 1024 || value % 64) return d2r_fail(ctx, D2R_ERR_INVALID, "march_threads must be 0 (auto) or a multiple of 64 up to 1024");
         ctx->march_threads = value;
@@ -277,7 +283,7 @@ int d2r_ctx_get_option(d2r_ctx *ctx, const char *key, int64_t *value)
     const struct { const char *k; int64_t v; } tab[] = {
         {"chunk", ctx->chunk}, {"refill_min", ctx->refill_min}, {"march_compact", ctx->march_compact}, {"ln_fold", ctx->ln_fold}, {"gemm_nsplit", ctx->gemm_nsplit},
         {"prep_reuse", ctx->prep_reuse}, {"cls_last", ctx->cls_last}, {"vit_fp8", ctx->vit_fp8}, {"l0_reuse", ctx->l0_reuse},
-        {"attn_rem", ctx->attn_rem}, {"overlap", ctx->overlap}, {"march_blocks", ctx->march_blocks}, {"march_threads", ctx->march_threads}, {"march_threads_auto_mib", ctx->march_threads_auto_mib}, {"gbrick_slots", ctx->gbrick_slots},
+        {"attn_rem", ctx->attn_rem}, {"overlap", ctx->overlap}, {"march_blocks", ctx->march_blocks}, {"march_threads", ctx->march_threads}, {"ray_sort", ctx->ray_sort}, {"ray_sort_log2", ctx->ray_sort_log2}, {"march_threads_auto_mib", ctx->march_threads_auto_mib}, {"gbrick_slots", ctx->gbrick_slots},
         {"brick_slots_total", ctx->brick_slots_total}, {"lds_slots_max", ctx->lds_slots_max}, {"gbrick_max_mib", ctx->gbrick_max_mib},
         {"bricks", ctx->use_bricks}, {"mlp_f16", ctx->mlp_f16}, {"raygen_rect", ctx->raygen_rect}, {"timing", ctx->timing}, {"debug_fail_chunk", ctx->debug_fail_chunk},
         {"march_lds_slots", (int64_t)ctx->last_march_nb}, {"march_hbm_brick_slots", (int64_t)ctx->last_march_ngb},

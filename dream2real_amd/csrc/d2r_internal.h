@@ -61,6 +61,7 @@ struct NerfParams {
     SlotMeta slot[D2R_MAX_LEVELS / 2];
     uint32_t refill_min;       // free lanes in a wave before it pulls new rays from the queue
     uint32_t compact;          // 1: a wave with <= 32 rays left moves them to lanes 0..31 (tile 1 then costs nothing)
+    uint32_t sort_log2;        // ray sort: 0 off, else log2 of the bins per axis of the occupied box (2: 4x4x4 ... 4: 16x16x16); the bin of a ray's first sample rides in bits 20.. of its queue entry's k
     uint32_t n_brick_slots;    // leading slots whose levels are de-hashed into LDS bricks (0 .. 5)
     uint32_t brick_words;      // total words of those bricks
     const uint32_t *brick_tab; // [brick_words] half2 entries, copied to LDS by every workgroup
@@ -110,6 +111,7 @@ struct d2r_ctx {
     std::string err;
     // growable device workspaces (one per role so sizes are independent)
     struct Buf { void *p = nullptr; size_t cap = 0; };
+    Buf queue2, sort_counts;   // ray sort: the sorted queue, per-chunk bin counts / offsets
     Buf cams, queue, counters, frames, rgba, depth, poses, clipws[8], text, logits, pix;
     // host -> device uploads of small caller buffers on asynchronous entry points (text embeddings of d2r_render_score)
     // go through two library-owned pinned slots, so the caller's memory is consumed before the call returns whatever
@@ -155,6 +157,8 @@ struct d2r_ctx {
     int64_t chunk = 4096;       // candidates per pass (capped per model/view by pass_size() in api.hip)
     uint32_t last_pass = 0;     // pass size the last d2r_render_score used (for its stats read-back)
     int64_t march_blocks = 0;  // 0 = auto
+    int64_t ray_sort = 1;      // 1: the ray queue is sorted by the object region (Morton cell of the occupied box) a ray's first sample lies in before it is marched; 0: marched in generation order
+    int64_t ray_sort_log2 = 4; // cells per axis = 2^this (1..4); measured 8^3 -> 16^3: another 6 %
     int64_t march_threads = 0; // threads per marcher workgroup: 0 = auto (768, or 512 when the HBM bricks exceed march_threads_auto_mib MiB), else 64 .. 768 in steps of 64
     int64_t march_threads_auto_mib = 64;   // apple 36 MB (issue-bound: 768 threads are 8 % faster), shelf 112 MB, 2.2x / 5x apple 394 / 89 MB (L2-miss-bound: 512 are 1-5 % faster)
     uint32_t last_march_threads = 0, last_march_gbrick_bytes = 0;   // and the workgroup size / HBM-brick bytes of that launch

@@ -419,6 +419,26 @@ __device__ __forceinline__ bool next_sample(const NerfParams &P, const Ray &r, u
     return false;
 }
 
+// ray sort: the bin (Morton order over 2^L x 2^L x 2^L cells of the occupied box) of a ray's first sample, as bits 20.. of the queue
+// entry's k (k < 2^20: a ray has at most a few thousand lattice points)
+#define D2R_SORT_SHIFT 20
+__device__ __forceinline__ uint32_t sort_tag(const NerfParams &P, float x, float y, float z)
+{
+    if (P.sort_log2 == 0) return 0u;
+    const uint32_t n1 = 1u << P.sort_log2;
+    uint32_t c[3];
+    const float p[3] = {x, y, z};
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const float u = (p[a] - P.bbox_lo[a]) / (P.bbox_hi[a] - P.bbox_lo[a]) * (float)n1;
+        c[a] = min((uint32_t)fmaxf(u, 0.f), n1 - 1u);
+    }
+    uint32_t bin = 0;
+#pragma unroll
+    for (int b = 0; b < 4; b++) bin |= (((c[0] >> b) & 1u) << (3 * b)) | (((c[1] >> b) & 1u) << (3 * b + 1)) | (((c[2] >> b) & 1u) << (3 * b + 2));
+    return bin << D2R_SORT_SHIFT;
+}
+
 __device__ __forceinline__ void empty_pixel(const ViewParams &V, float *rgba)
 {
     // no sample: C = 0, A = 0 -> background blend only
@@ -451,6 +471,7 @@ __global__ __launch_bounds__(256) void k_raygen(NerfParams P, ViewParams V, cons
         if (make_ray<CONE>(P, V, cam, px, py, r, k)) {
             float x, y, z;
             alive = next_sample<CONE>(P, r, k, x, y, z);
+            if (alive) k |= sort_tag(P, x, y, z);
         }
     }
     const uint32_t ray_id = cam_i * (V.W * V.H) + py * V.W + px;
@@ -568,6 +589,7 @@ __global__ __launch_bounds__(256) void k_raygen_rect(NerfParams P, ViewParams V,
             if (make_ray<CONE>(P, V, cam, px, py, r, k)) {
                 float x, y, z;
                 alive = next_sample<CONE>(P, r, k, x, y, z);
+                if (alive) k |= sort_tag(P, x, y, z);
             }
         }
         const uint32_t ray_id = cam_i * (V.W * V.H) + py * V.W + px;
@@ -583,6 +605,97 @@ __global__ __launch_bounds__(256) void k_raygen_rect(NerfParams P, ViewParams V,
         }
     }
     flush();
+}
+
+// --------------------------------------------------------------- ray sort
+//
+// Where the bricks behind the LDS slots outgrow the L2s the marcher is bound by the L2-miss path: at any moment its ~3000 waves march
+// rays of ~50 candidates through every part of the object.  All candidates render the SAME object, so the rays are marched in the
+// order of the object region their first sample lies in (a stable counting sort of the queue on the tag k_raygen* left in the
+// entries): the waves running at one time then read the bricks of a few neighbouring regions.  Three small passes over the queue
+// (8 bytes per ray each): per-chunk bin counts, a scan per bin over the chunks + a scan over the bins, the scatter.  The order of
+// the entries of one bin within a chunk is whatever the LDS atomics give: the frames do not depend on the order rays are marched in.
+#define D2R_SORT_CHUNK 8192u
+#define D2R_SORT_BINS 4096u          /* 16 x 16 x 16 at most (ray_sort_log2 = 4) */
+__global__ __launch_bounds__(256) void k_sort_count(const uint2 *__restrict__ queue, const uint32_t *__restrict__ qcount, uint32_t *__restrict__ counts)
+{
+    __shared__ uint32_t hist[D2R_SORT_BINS];
+    const uint32_t n = *qcount, nchunks = (n + D2R_SORT_CHUNK - 1) / D2R_SORT_CHUNK;
+    for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        for (uint32_t i = threadIdx.x; i < D2R_SORT_BINS; i += 256) hist[i] = 0;
+        __syncthreads();
+        for (uint32_t i = c * D2R_SORT_CHUNK + threadIdx.x; i < min(n, (c + 1) * D2R_SORT_CHUNK); i += 256) atomicAdd(&hist[queue[i].y >> D2R_SORT_SHIFT], 1u);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < D2R_SORT_BINS; i += 256) counts[(size_t)i * nchunks + c] = hist[i];     // bin-major: the scan below reads rows
+        __syncthreads();
+    }
+}
+// one block per bin: exclusive scan of its row of chunk counts, the row's total to bin_total
+__global__ __launch_bounds__(256) void k_sort_scan_rows(const uint32_t *__restrict__ qcount, uint32_t *__restrict__ counts, uint32_t *__restrict__ bin_total)
+{
+    __shared__ uint32_t part[256];
+    const uint32_t n = *qcount, nchunks = (n + D2R_SORT_CHUNK - 1) / D2R_SORT_CHUNK;
+    uint32_t *row = counts + (size_t)blockIdx.x * nchunks;
+    const uint32_t per = (nchunks + 255) / 256, lo = min(nchunks, threadIdx.x * per), hi = min(nchunks, lo + per);
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; i++) sum += row[i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int i = 0; i < 256; i++) {
+            const uint32_t v = part[i];
+            part[i] = run;
+            run += v;
+        }
+        bin_total[blockIdx.x] = run;
+    }
+    __syncthreads();
+    uint32_t run = part[threadIdx.x];
+    for (uint32_t i = lo; i < hi; i++) {
+        const uint32_t v = row[i];
+        row[i] = run;
+        run += v;
+    }
+}
+// exclusive scan of the bin totals (one block)
+__global__ __launch_bounds__(256) void k_sort_scan_bins(const uint32_t *__restrict__ bin_total, uint32_t *__restrict__ bin_base)
+{
+    __shared__ uint32_t part[256];
+    constexpr uint32_t PER = D2R_SORT_BINS / 256;
+    uint32_t sum = 0;
+    for (uint32_t i = 0; i < PER; i++) sum += bin_total[threadIdx.x * PER + i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int i = 0; i < 256; i++) {
+            const uint32_t v = part[i];
+            part[i] = run;
+            run += v;
+        }
+    }
+    __syncthreads();
+    uint32_t run = part[threadIdx.x];
+    for (uint32_t i = 0; i < PER; i++) {
+        bin_base[threadIdx.x * PER + i] = run;
+        run += bin_total[threadIdx.x * PER + i];
+    }
+}
+__global__ __launch_bounds__(256) void k_sort_scatter(const uint2 *__restrict__ queue, const uint32_t *__restrict__ qcount, const uint32_t *__restrict__ counts,
+                                                      const uint32_t *__restrict__ bin_base, uint2 *__restrict__ sorted)
+{
+    __shared__ uint32_t cursor[D2R_SORT_BINS];
+    const uint32_t n = *qcount, nchunks = (n + D2R_SORT_CHUNK - 1) / D2R_SORT_CHUNK;
+    for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        for (uint32_t i = threadIdx.x; i < D2R_SORT_BINS; i += 256) cursor[i] = bin_base[i] + counts[(size_t)i * nchunks + c];
+        __syncthreads();
+        for (uint32_t i = c * D2R_SORT_CHUNK + threadIdx.x; i < min(n, (c + 1) * D2R_SORT_CHUNK); i += 256) {
+            const uint2 e = queue[i];
+            sorted[atomicAdd(&cursor[e.y >> D2R_SORT_SHIFT], 1u)] = make_uint2(e.x, e.y & ((1u << D2R_SORT_SHIFT) - 1u));
+        }
+        __syncthreads();
+    }
 }
 
 // ------------------------------------------------------- field evaluation
@@ -1344,25 +1457,42 @@ int d2r_launch_render(d2r_ctx *ctx, const d2r_nerf *m, const ViewParams &V, cons
         }
     }
     const uint32_t tiles = ((V.W + 15) / 16) * ((V.H + 15) / 16);
+    // ray sort (see k_sort_count): rays marched in the order of the object region they enter
+    const uint32_t sort_log2 = ctx->ray_sort ? (uint32_t)ctx->ray_sort_log2 : 0u;
+    NerfParams PR = m->P;
+    PR.sort_log2 = sort_log2;
     size_t tr = ctx->timing_begin(D2R_T_RAYGEN);
     const bool cone = m->P.aabb_scale >= 2;          // occupancy cascades + cone stepping
     if (composite && ctx->raygen_rect) {
-        if (cone) hipLaunchKernelGGL(k_raygen_rect<true>, dim3(n, 4), dim3(256), 0, ctx->stream, m->P, V, cams_dev, (uint2 *)ctx->queue.p, cnt, (int4 *)rects_dev);
-        else hipLaunchKernelGGL(k_raygen_rect<false>, dim3(n, 4), dim3(256), 0, ctx->stream, m->P, V, cams_dev, (uint2 *)ctx->queue.p, cnt, (int4 *)rects_dev);
+        if (cone) hipLaunchKernelGGL(k_raygen_rect<true>, dim3(n, 4), dim3(256), 0, ctx->stream, PR, V, cams_dev, (uint2 *)ctx->queue.p, cnt, (int4 *)rects_dev);
+        else hipLaunchKernelGGL(k_raygen_rect<false>, dim3(n, 4), dim3(256), 0, ctx->stream, PR, V, cams_dev, (uint2 *)ctx->queue.p, cnt, (int4 *)rects_dev);
     } else {
         if (cone)
-            hipLaunchKernelGGL(k_raygen<true>, dim3(tiles, n), dim3(256), 0, ctx->stream, m->P, V, cams_dev, (uint2 *)ctx->queue.p,
+            hipLaunchKernelGGL(k_raygen<true>, dim3(tiles, n), dim3(256), 0, ctx->stream, PR, V, cams_dev, (uint2 *)ctx->queue.p,
                                cnt, composite ? nullptr : rgba_dev, composite ? nullptr : depth_dev);
         else
-            hipLaunchKernelGGL(k_raygen<false>, dim3(tiles, n), dim3(256), 0, ctx->stream, m->P, V, cams_dev, (uint2 *)ctx->queue.p,
+            hipLaunchKernelGGL(k_raygen<false>, dim3(tiles, n), dim3(256), 0, ctx->stream, PR, V, cams_dev, (uint2 *)ctx->queue.p,
                                cnt, composite ? nullptr : rgba_dev, composite ? nullptr : depth_dev);
+    }
+    const uint2 *q = (const uint2 *)ctx->queue.p;
+    if (sort_log2) {
+        // counts: [bins][chunks] + [bins] bin totals + [bins] bin bases, sized for the worst case (every pixel of every candidate a ray)
+        const size_t max_chunks = (rays + D2R_SORT_CHUNK - 1) / D2R_SORT_CHUNK;
+        if ((rc = d2r_reserve(ctx, ctx->queue2, rays * sizeof(uint2)))) return rc;
+        if ((rc = d2r_reserve(ctx, ctx->sort_counts, (max_chunks + 2) * D2R_SORT_BINS * 4))) return rc;
+        uint32_t *counts = (uint32_t *)ctx->sort_counts.p, *bin_total = counts + max_chunks * D2R_SORT_BINS, *bin_base = bin_total + D2R_SORT_BINS;
+        const int sb = (int)std::min<size_t>(max_chunks, 4096);
+        hipLaunchKernelGGL(k_sort_count, dim3(sb), dim3(256), 0, ctx->stream, q, cnt, counts);
+        hipLaunchKernelGGL(k_sort_scan_rows, dim3(D2R_SORT_BINS), dim3(256), 0, ctx->stream, cnt, counts, bin_total);
+        hipLaunchKernelGGL(k_sort_scan_bins, dim3(1), dim3(256), 0, ctx->stream, bin_total, bin_base);
+        hipLaunchKernelGGL(k_sort_scatter, dim3(sb), dim3(256), 0, ctx->stream, q, cnt, counts, bin_base, (uint2 *)ctx->queue2.p);
+        q = (const uint2 *)ctx->queue2.p;
     }
     ctx->timing_end(tr);
     size_t tm = ctx->timing_begin(D2R_T_MARCH);
     int blocks = ctx->march_blocks > 0 ? (int)ctx->march_blocks : ctx->n_cu;     // persistent: one per CU
     const float *bgd = (const float *)ctx->bg_depth.p;
     unsigned long long *sc = (unsigned long long *)(cnt + 2);
-    const uint2 *q = (const uint2 *)ctx->queue.p;
     // Brick configuration (NB leading slots from LDS, the next NGB from HBM bricks, the rest from the tables) -> one of the
     // instantiated kernels.  The HBM bricks were built for the model's own LDS count, so NB is that count or 0; NGB is
     // rounded DOWN to an instantiated value (using fewer HBM-brick slots than exist is always valid).
@@ -1391,11 +1521,11 @@ int d2r_launch_render(d2r_ctx *ctx, const d2r_nerf *m, const ViewParams &V, cons
     PP.compact = (uint32_t)ctx->march_compact;
     const size_t lds = (size_t)D2R_N_WFRAG * 64 * 16 + (nb ? (size_t)m->P.brick_words * 4 : 0);
     // waves per workgroup (= per CU): the kernels are compiled for D2R_MARCH_THREADS (three waves per SIMD); a launch may use fewer.
-    // Auto: where the bricks behind the LDS slots are larger than the L2s can hold, the marcher is bound by the L2-miss path, not by
-    // latency — two waves per SIMD are as fast or faster (less thrash), one is 8-17 % slower (round 5, same-box A/B)
+    // Auto: all of them — except WITHOUT the ray sort where the bricks behind the LDS slots are larger than the L2s can hold: there the
+    // unsorted marcher is bound by the L2-miss path and two waves per SIMD thrash less (1-5 % faster; round 5, same-box A/B)
     uint32_t threads = D2R_MARCH_THREADS;
     if (ctx->march_threads > 0) threads = std::min<uint32_t>((uint32_t)ctx->march_threads, D2R_MARCH_THREADS);
-    else if (ngb && m->P.gbrick_bytes > (size_t)ctx->march_threads_auto_mib << 20) threads = std::min<uint32_t>(512u, D2R_MARCH_THREADS);
+    else if (!sort_log2 && ngb && m->P.gbrick_bytes > (size_t)ctx->march_threads_auto_mib << 20) threads = std::min<uint32_t>(512u, D2R_MARCH_THREADS);
 #define D2R_MARCH_C(COMP, NB, NGB, ND, CONE)                            \
     do {                                                                \
         if (ctx->mlp_f16) D2R_MARCH_F(COMP, NB, NGB, ND, CONE, true);   \

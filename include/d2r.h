@@ -404,10 +404,14 @@ D2R_API int d2r_get_timing(d2r_ctx *ctx, d2r_timing *out);
  *     view so that one pass stays inside the 32-bit indexing of the ray queue and the GEMM outputs.
  * "refill_min" (default 64, 1..64): free lanes a marcher wave accumulates before it takes new rays
  *     from the queue (64 = a wave runs its 64 rays to the end).
+ * "ray_sort" (default 1): before the march the ray queue is sorted (three small counting-sort passes) by the cell of
+ *     the object's occupied box a ray's first sample lies in — 2^"ray_sort_log2" (default 4, 1..4) cells per axis,
+ *     Morton order: every candidate renders the same object, so the waves running at one time then read the same few
+ *     regions of the level tables / bricks.  Same pixels; 0 marches the rays in generation order.
  * "march_threads" (default 0 = auto; else a multiple of 64 up to the compiled 768): threads per marcher
- *     workgroup (one workgroup per CU).  Auto: 768 (three waves per SIMD), or 512 where the HBM bricks exceed
- *     "march_threads_auto_mib" (default 64) MiB — there the marcher is bound by the L2-miss path and fewer waves
- *     thrash less.  Read-only: "march_threads_used", "march_hbm_brick_bytes" (of the last march launch).
+ *     workgroup (one workgroup per CU).  Auto: 768 (three waves per SIMD); with "ray_sort" 0: 512 where the HBM
+ *     bricks exceed "march_threads_auto_mib" (default 64) MiB — the unsorted marcher is bound by the L2-miss path
+ *     there and fewer waves thrash less.  Read-only: "march_threads_used", "march_hbm_brick_bytes" (of the last march launch).
  * "march_compact" (default 1): once a marcher wave has no more than 32 rays left it moves them to its
  *     lanes 0..31, so that the second 32-sample tile of its iterations costs nothing (same pixels).
  * "bricks" (default 1): serve the de-hashed coarse levels of small models from LDS; 0 forces every

@@ -422,7 +422,7 @@ def test_every_brick_configuration_is_bit_identical_to_the_tables(kind):
 @pytest.mark.parametrize("kind", ["shopping", "shelf"])
 def test_ray_compaction_and_refill_policies_do_not_change_a_pixel(kind):
     """`march_compact` (round 5: a wave's last <= 32 rays move to lanes 0..31 by ds_permute so that tile 1 costs nothing) and
-    `refill_min` (how many free lanes a wave collects before it takes new rays) and `march_threads` (waves per workgroup) only change WHICH
+    `refill_min` (how many free lanes a wave collects before it takes new rays) `march_threads` (waves per workgroup) and `ray_sort` (the queue sorted by the object region a ray enters) only change WHICH
     lane of which wave marches a ray: frames (fp32
     RGBA + depth, uint8 composite) and the sample count are bit-identical for every combination, with and without bricks."""
     from dream2real_amd import engine
@@ -443,24 +443,29 @@ def test_ray_compaction_and_refill_policies_do_not_change_a_pixel(kind):
             tb.background_color = list(scene.fg_background)
             view = tb.view(W, H)
             ctx.set_background(view, obg[0], obg[1])
-            for compact, refill, threads in [(c, r, 0) for c in (0, 1) for r in (64, 33, 32, 7, 1)] + [(1, 64, 512), (1, 64, 64), (0, 16, 320)]:
+            for compact, refill, threads, sort in ([(c, r, 0, 0) for c in (0, 1) for r in (64, 33, 32, 7, 1)] + [(1, 64, 512, 0), (1, 64, 64, 0), (0, 16, 320, 0)]
+                                                   + [(1, 64, 0, 1), (1, 64, 0, 2), (1, 64, 0, 3), (1, 64, 0, 4), (0, 16, 512, 3)]):
                 if True:
                     ctx.set_option("march_compact", compact)
                     ctx.set_option("refill_min", refill)
                     ctx.set_option("march_threads", threads)            # waves per workgroup (0 = auto)
+                    ctx.set_option("ray_sort", 1 if sort else 0)        # rays marched in the order of the object region they enter
+                    ctx.set_option("ray_sort_log2", sort or 4)          # 2^sort cells per axis
                     rgba, depth = tb.render_batch(cams, W, H)
                     got = (rgba, depth, tb.last_samples, tb.render_composite(view, T1, TC, host_ref.converter(poses.astype(np.float32))))
                     if base is None:
                         base = got
                         assert got[2] > 5000
                     for a, b in zip(got, base):
-                        np.testing.assert_array_equal(a, b, err_msg=f"bricks {bricks}, march_compact {compact}, refill_min {refill}, march_threads {threads}")
+                        np.testing.assert_array_equal(a, b, err_msg=f"bricks {bricks}, march_compact {compact}, refill_min {refill}, march_threads {threads}, ray_sort_log2 {sort}")
             tb.close()
     finally:
         ctx.set_option("bricks", 1)
         ctx.set_option("march_compact", 1)
         ctx.set_option("refill_min", 64)
         ctx.set_option("march_threads", 0)
+        ctx.set_option("ray_sort", 1)
+        ctx.set_option("ray_sort_log2", 4)
     ctx.close()
 
 
