@@ -420,7 +420,8 @@ __device__ __forceinline__ bool next_sample(const NerfParams &P, const Ray &r, u
 }
 
 // ray sort: the bin (Morton order over 2^L x 2^L x 2^L cells of the occupied box) of a ray's first sample, as bits 20.. of the queue
-// entry's k (k < 2^20: a ray has at most a few thousand lattice points)
+// entry's k (k < 2^20 always: lattice points are at least dt_min = sqrt(3)/1024 apart and a ray crosses at most the box diagonal,
+// sqrt(3) * aabb_scale <= sqrt(3) * 128, i.e. k <= 2^17 even without cone stepping)
 #define D2R_SORT_SHIFT 20
 __device__ __forceinline__ uint32_t sort_tag(const NerfParams &P, float x, float y, float z)
 {
