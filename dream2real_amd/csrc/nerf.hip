@@ -616,7 +616,7 @@ __global__ __launch_bounds__(256) void k_raygen_rect(NerfParams P, ViewParams V,
 // entries): the waves running at one time then read the bricks of a few neighbouring regions.  Three small passes over the queue
 // (8 bytes per ray each): per-chunk bin counts, a scan per bin over the chunks + a scan over the bins, the scatter.  The order of
 // the entries of one bin within a chunk is whatever the LDS atomics give: the frames do not depend on the order rays are marched in.
-#define D2R_SORT_CHUNK 8192u
+#define D2R_SORT_CHUNK 16384u        /* entries per block and pass: [bins][chunks] counters = 1 GB for the worst case of a configs[1] pass (every pixel a ray) */
 #define D2R_SORT_BINS 4096u          /* 16 x 16 x 16 at most (ray_sort_log2 = 4) */
 __global__ __launch_bounds__(256) void k_sort_count(const uint2 *__restrict__ queue, const uint32_t *__restrict__ qcount, uint32_t *__restrict__ counts)
 {
