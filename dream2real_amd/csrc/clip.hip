@@ -2637,91 +2637,127 @@ __global__ void k_gather_cls_operand(const uint16_t *__restrict__ Xhi, const flo
 
 // ------------------------------------------------------------------ head
 
-// one 1024-thread block per image: post_layernorm(X[b*T]) -> proj -> L2 normalise -> logits.
+// one 1024-thread block per HEAD_NI images: post_layernorm(X[b*T]) -> proj -> L2 normalise -> logits.
 // 16 waves and 4 output rows per wave iteration keep ~48 loads per lane in flight: the
-// projection is a latency problem (1.5 MB of fp32 weights per image out of L2), not a flop one.
+// projection is a latency problem (1.5 MB of fp32 weights out of L2), not a flop one — and the images of a block share
+// every weight load (round 5: four images per block, a quarter of the L2 reads; each image's arithmetic and summation order
+// are those of the one-image kernel: the same bits).
 #define HEAD_THREADS 1024
+#define HEAD_NI 4
 __global__ __launch_bounds__(HEAD_THREADS) void k_head(const float *__restrict__ X, const uint16_t *__restrict__ Xb,
                                                        const uint16_t *__restrict__ Xlo, uint32_t M_pad,
                                                        const uint32_t *__restrict__ pool_row, uint32_t T, uint32_t d,
                                                        const float *__restrict__ lw, const float *__restrict__ lb,
                                                        const float *__restrict__ proj, uint32_t D,
                                                        const float *__restrict__ text, uint32_t C, float logit_scale,
-                                                       float *__restrict__ logits, float *__restrict__ embeds, int lo8 = 0)
+                                                       float *__restrict__ logits, float *__restrict__ embeds, uint32_t n_items, int lo8 = 0)
 {
-    __shared__ float xs[1024];
-    __shared__ float es[1024];
-    __shared__ float red[16];
+    __shared__ float xs[HEAD_NI][1024];
+    __shared__ float es[HEAD_NI][1024];
+    __shared__ float red[HEAD_NI][16];
     constexpr uint32_t NW = HEAD_THREADS / 64;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t item0 = blockIdx.x * HEAD_NI;
+    const uint32_t ni = min((uint32_t)HEAD_NI, n_items - item0);              // block-uniform
     // vision: the class token (row 0 of the image); text: the EOS token's row
     // (the residual stream is fp32 X, or bf16 Xb when the tower runs with a bf16 residual stream)
-    const size_t xrow = (size_t)blockIdx.x * T + (pool_row ? pool_row[blockIdx.x] : 0u);
-    float xv = 0.f;                                                                                            // d <= 1024
-    if (tid < d) {
-        const size_t xo = ((size_t)(tid >> 6) * M_pad + xrow) * 64 + (tid & 63);                                // bf16 residual: tile-major
-        xv = Xb ? __uint_as_float((uint32_t)Xb[xo] << 16) : X[xrow * d + tid];
-        if (Xb && Xlo && lo8) xv = split8_value(Xb[xo], ((const int8_t *)Xlo)[lo8_off(M_pad, xrow, tid)]);
-        else if (Xb && Xlo) xv += __uint_as_float((uint32_t)Xlo[xo] << 16);
+    float xv[HEAD_NI];
+#pragma unroll
+    for (uint32_t m = 0; m < HEAD_NI; m++) {
+        xv[m] = 0.f;
+        if (m < ni && tid < d) {                                                                               // d <= 1024
+            const size_t xrow = (size_t)(item0 + m) * T + (pool_row ? pool_row[item0 + m] : 0u);
+            const size_t xo = ((size_t)(tid >> 6) * M_pad + xrow) * 64 + (tid & 63);                            // bf16 residual: tile-major
+            xv[m] = Xb ? __uint_as_float((uint32_t)Xb[xo] << 16) : X[xrow * d + tid];
+            if (Xb && Xlo && lo8) xv[m] = split8_value(Xb[xo], ((const int8_t *)Xlo)[lo8_off(M_pad, xrow, tid)]);
+            else if (Xb && Xlo) xv[m] += __uint_as_float((uint32_t)Xlo[xo] << 16);
+        }
+        const float s = wave_sum(xv[m]);
+        if (lane == 0) red[m][wave] = s;
     }
-    float s = wave_sum(xv);
-    if (lane == 0) red[wave] = s;
     __syncthreads();
-    float tot = 0.f;
+    float mu[HEAD_NI], dv[HEAD_NI];
 #pragma unroll
-    for (uint32_t i = 0; i < NW; i++) tot += red[i];
-    const float mu = tot / (float)d;
-    __syncthreads();
-    const float dv = tid < d ? xv - mu : 0.f;
-    float q = wave_sum(dv * dv);
-    if (lane == 0) red[wave] = q;
-    __syncthreads();
-    tot = 0.f;
+    for (uint32_t m = 0; m < HEAD_NI; m++) {
+        float tot = 0.f;
 #pragma unroll
-    for (uint32_t i = 0; i < NW; i++) tot += red[i];
-    const float rstd = 1.0f / sqrtf(tot / (float)d + 1e-5f);
-    if (tid < d) xs[tid] = dv * rstd * lw[tid] + lb[tid];
+        for (uint32_t i = 0; i < NW; i++) tot += red[m][i];
+        mu[m] = tot / (float)d;
+    }
     __syncthreads();
-    // projection: wave handles rows o, o+NW, ... four at a time
-    float nrm = 0.f;
+#pragma unroll
+    for (uint32_t m = 0; m < HEAD_NI; m++) {
+        dv[m] = tid < d ? xv[m] - mu[m] : 0.f;
+        const float q = wave_sum(dv[m] * dv[m]);
+        if (lane == 0) red[m][wave] = q;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t m = 0; m < HEAD_NI; m++) {
+        float tot = 0.f;
+#pragma unroll
+        for (uint32_t i = 0; i < NW; i++) tot += red[m][i];
+        const float rstd = 1.0f / sqrtf(tot / (float)d + 1e-5f);
+        if (tid < d) xs[m][tid] = dv[m] * rstd * lw[tid] + lb[tid];
+    }
+    __syncthreads();
+    // projection: wave handles rows o, o+NW, ... four at a time, for every image of the block
+    float nrm[HEAD_NI];
+#pragma unroll
+    for (uint32_t m = 0; m < HEAD_NI; m++) nrm[m] = 0.f;
     for (uint32_t o = wave * 4; o < D; o += NW * 4) {
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        float a[HEAD_NI][4];
+#pragma unroll
+        for (uint32_t m = 0; m < HEAD_NI; m++) a[m][0] = a[m][1] = a[m][2] = a[m][3] = 0.f;
         const float *p0 = proj + (size_t)o * d;
         const bool v1 = o + 1 < D, v2 = o + 2 < D, v3 = o + 3 < D;
         for (uint32_t i = lane; i < d; i += 64) {
-            const float xi = xs[i];
-            a0 = fmaf(p0[i], xi, a0);
-            if (v1) a1 = fmaf(p0[d + i], xi, a1);
-            if (v2) a2 = fmaf(p0[2 * d + i], xi, a2);
-            if (v3) a3 = fmaf(p0[3 * d + i], xi, a3);
-        }
-        a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
-        if (lane == 0) {
-            es[o] = a0;
-            if (v1) es[o + 1] = a1;
-            if (v2) es[o + 2] = a2;
-            if (v3) es[o + 3] = a3;
-        }
-        nrm += a0 * a0 + (v1 ? a1 * a1 : 0.f) + (v2 ? a2 * a2 : 0.f) + (v3 ? a3 * a3 : 0.f);
-    }
-    __syncthreads();
-    if (lane == 0) red[wave] = nrm;
-    __syncthreads();
-    tot = 0.f;
+            const float w0 = p0[i], w1 = v1 ? p0[d + i] : 0.f, w2 = v2 ? p0[2 * d + i] : 0.f, w3 = v3 ? p0[3 * d + i] : 0.f;
 #pragma unroll
-    for (uint32_t i = 0; i < NW; i++) tot += red[i];
-    const float inv = 1.0f / sqrtf(tot);
-    if (tid < D) {
-        es[tid] *= inv;
-        if (embeds) embeds[(size_t)blockIdx.x * D + tid] = es[tid];
+            for (uint32_t m = 0; m < HEAD_NI; m++) {
+                const float xi = xs[m][i];
+                a[m][0] = fmaf(w0, xi, a[m][0]);
+                if (v1) a[m][1] = fmaf(w1, xi, a[m][1]);
+                if (v2) a[m][2] = fmaf(w2, xi, a[m][2]);
+                if (v3) a[m][3] = fmaf(w3, xi, a[m][3]);
+            }
+        }
+#pragma unroll
+        for (uint32_t m = 0; m < HEAD_NI; m++) {
+            const float a0 = wave_sum(a[m][0]), a1 = wave_sum(a[m][1]), a2 = wave_sum(a[m][2]), a3 = wave_sum(a[m][3]);
+            if (lane == 0) {
+                es[m][o] = a0;
+                if (v1) es[m][o + 1] = a1;
+                if (v2) es[m][o + 2] = a2;
+                if (v3) es[m][o + 3] = a3;
+            }
+            nrm[m] += a0 * a0 + (v1 ? a1 * a1 : 0.f) + (v2 ? a2 * a2 : 0.f) + (v3 ? a3 * a3 : 0.f);
+        }
     }
     __syncthreads();
-    for (uint32_t c = wave; c < C; c += NW) {
-        float a = 0.f;
-        for (uint32_t i = lane; i < D; i += 64) a = fmaf(es[i], text[(size_t)c * D + i], a);
-        a = wave_sum(a);
-        if (lane == 0 && logits) logits[(size_t)blockIdx.x * C + c] = logit_scale * a;
+#pragma unroll
+    for (uint32_t m = 0; m < HEAD_NI; m++)
+        if (lane == 0) red[m][wave] = nrm[m];
+    __syncthreads();
+#pragma unroll
+    for (uint32_t m = 0; m < HEAD_NI; m++) {
+        float tot = 0.f;
+#pragma unroll
+        for (uint32_t i = 0; i < NW; i++) tot += red[m][i];
+        const float inv = 1.0f / sqrtf(tot);
+        if (m < ni && tid < D) {
+            es[m][tid] *= inv;
+            if (embeds) embeds[(size_t)(item0 + m) * D + tid] = es[m][tid];
+        }
     }
+    __syncthreads();
+    for (uint32_t m = 0; m < ni; m++)
+        for (uint32_t c = wave; c < C; c += NW) {
+            float a = 0.f;
+            for (uint32_t i = lane; i < D; i += 64) a = fmaf(es[m][i], text[(size_t)c * D + i], a);
+            a = wave_sum(a);
+            if (lane == 0 && logits) logits[(size_t)(item0 + m) * C + c] = logit_scale * a;
+        }
 }
 
 // X[c*T + t] = token_embedding[ids[c][t]] + position_embedding[t]; pool_row[c] = argmax_t ids[c][t]
@@ -3223,9 +3259,9 @@ int d2r_clip_forward(d2r_ctx *ctx, const d2r_clip *clip, const uint16_t *patches
             if ((rc = launch_gemm<EPI_BIAS_GELU_BF16>(ctx, Xn, L.w_fc1, L.b_fc1, H, rows, mlp, d, out_tm))) return rc;
             if ((rc = launch_gemm<EPI_BIAS_RESID_F32>(ctx, H, L.w_fc2, L.b_fc2, X, rows, d, mlp, a_tm))) return rc;
         }
-        hipLaunchKernelGGL(k_head, dim3(n), dim3(HEAD_THREADS), 0, ctx->stream, cls_last ? patch_out : X, (const uint16_t *)nullptr, (const uint16_t *)nullptr, rows_pad,
+        hipLaunchKernelGGL(k_head, dim3((n + HEAD_NI - 1) / HEAD_NI), dim3(HEAD_THREADS), 0, ctx->stream, cls_last ? patch_out : X, (const uint16_t *)nullptr, (const uint16_t *)nullptr, rows_pad,
                            (const uint32_t *)nullptr, cls_last ? 1u : T, d,
-                           clip->w.post_w, clip->w.post_b, clip->w.proj, D.proj_dim, text_dev, C, logit_scale, logits_dev, embeds_dev);
+                           clip->w.post_w, clip->w.post_b, clip->w.proj, D.proj_dim, text_dev, C, logit_scale, logits_dev, embeds_dev, n);
         D2R_HIP(ctx, hipGetLastError());
         return D2R_OK;
     }
@@ -3354,13 +3390,13 @@ int d2r_clip_forward(d2r_ctx *ctx, const d2r_clip *clip, const uint16_t *patches
             hipLaunchKernelGGL(k_rowstats, dim3((rows_pad + 255) / 256), dim3(256), 0, ctx->stream, part, np, rows_pad, inv_d, AB);
     }
     if (cls_last)
-        hipLaunchKernelGGL(k_head, dim3(n), dim3(HEAD_THREADS), 0, ctx->stream, patch_out, (const uint16_t *)nullptr, (const uint16_t *)nullptr, rows_pad,
+        hipLaunchKernelGGL(k_head, dim3((n + HEAD_NI - 1) / HEAD_NI), dim3(HEAD_THREADS), 0, ctx->stream, patch_out, (const uint16_t *)nullptr, (const uint16_t *)nullptr, rows_pad,
                            (const uint32_t *)nullptr, 1u, d, clip->w.post_w, clip->w.post_b, clip->w.proj, D.proj_dim, text_dev, C, logit_scale, logits_dev,
-                           embeds_dev);
+                           embeds_dev, n);
     else
-    hipLaunchKernelGGL(k_head, dim3(n), dim3(HEAD_THREADS), 0, ctx->stream, X, xf32 ? (const uint16_t *)nullptr : (const uint16_t *)Xn,
+    hipLaunchKernelGGL(k_head, dim3((n + HEAD_NI - 1) / HEAD_NI), dim3(HEAD_THREADS), 0, ctx->stream, X, xf32 ? (const uint16_t *)nullptr : (const uint16_t *)Xn,
                        (const uint16_t *)Xlo, rows_pad, (const uint32_t *)nullptr, T, d, clip->w.post_w, clip->w.post_b, clip->w.proj, D.proj_dim, text_dev, C,
-                       logit_scale, logits_dev, embeds_dev, lo8);
+                       logit_scale, logits_dev, embeds_dev, n, lo8);
     D2R_HIP(ctx, hipGetLastError());
     return D2R_OK;
 }
@@ -3640,9 +3676,9 @@ extern "C" int d2r_text_encode(d2r_ctx *ctx, const d2r_text *tt, const int32_t *
         if ((rc = launch_gemm<EPI_BIAS_GELU_BF16>(ctx, Xn, L.w_fc1, L.b_fc1, H, rows, mlp, d, out_tm))) return rc;
         if ((rc = launch_gemm<EPI_BIAS_RESID_F32>(ctx, H, L.w_fc2, L.b_fc2, X, rows, d, mlp, a_tm))) return rc;
     }
-    hipLaunchKernelGGL(k_head, dim3(Cn), dim3(HEAD_THREADS), 0, ctx->stream, X, (const uint16_t *)nullptr, (const uint16_t *)nullptr, rows_pad, (const uint32_t *)pool, T, d, tt->fin_w,
+    hipLaunchKernelGGL(k_head, dim3((Cn + HEAD_NI - 1) / HEAD_NI), dim3(HEAD_THREADS), 0, ctx->stream, X, (const uint16_t *)nullptr, (const uint16_t *)nullptr, rows_pad, (const uint32_t *)pool, T, d, tt->fin_w,
                        tt->fin_b, tt->proj, D.proj_dim, (const float *)ctx->text.p, 0u, 1.0f, (float *)nullptr,
-                       (float *)ctx->logits.p);
+                       (float *)ctx->logits.p, Cn);
     D2R_HIP(ctx, hipGetLastError());
     D2R_HIP(ctx, hipMemcpyAsync(embeds_out, ctx->logits.p, (size_t)Cn * D.proj_dim * 4, hipMemcpyDeviceToHost, ctx->stream));
     D2R_HIP(ctx, hipStreamSynchronize(ctx->stream));
