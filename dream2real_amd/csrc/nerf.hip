@@ -167,6 +167,9 @@ __global__ void k_cameras_virtual(ViewParams V, Mat16 obj_now, Mat16 cam, const 
 #ifndef D2R_MARCH_PROF
 #define D2R_MARCH_PROF 0              /* development: per-wave cycle stamps of the refill block, printed by a few waves */
 #endif
+#ifndef D2R_MARCH_ABLATE
+#define D2R_MARCH_ABLATE 0            /* development: 1 no LDS-brick slots, 2 no global slots (HBM bricks / tables), 4 no MLPs, 8 no occupancy walk (fixed 16 samples per ray); wrong pixels, timing only */
+#endif
 #ifndef D2R_MARCH_VAR
 #define D2R_MARCH_VAR 0                /* bit 0: LDS-brick addresses formed in fp32 (slot_addr_lds_f); bit 1: the next lattice point's occupancy word requested before the field evaluation */
 #endif
@@ -931,8 +934,16 @@ __device__ __forceinline__ void encode_sample(const NerfParams &P, const __amdgp
             slot_blend(br, bw, f[2 * i], f[2 * i + 1]);
         }
     };
+#if D2R_MARCH_ABLATE & 3
+#pragma unroll
+    for (int i = 0; i < 16; i++) f[i] = x + (float)i * y;
+    if (!(D2R_MARCH_ABLATE & 1)) lds_slots();
+    if constexpr (NG != 0)
+        if (!(D2R_MARCH_ABLATE & 2)) encode_from<NB, NGB, ND, NB>(P, rs, rsb, hi, x, y, z, f, [] {});
+#else
     if constexpr (NG == 0) lds_slots();
     else encode_from<NB, NGB, ND, NB>(P, rs, rsb, hi, x, y, z, f, lds_slots);
+#endif
     // straight into the two bf16 B fragments of density layer 1 (k-step 0: slots 0..3, 1: slots 4..7)
     p0.x = pack2<F16>(f[0], f[1]); p0.y = pack2<F16>(f[2], f[3]); p0.z = pack2<F16>(f[4], f[5]); p0.w = pack2<F16>(f[6], f[7]);
     p1.x = pack2<F16>(f[8], f[9]); p1.y = pack2<F16>(f[10], f[11]); p1.z = pack2<F16>(f[12], f[13]); p1.w = pack2<F16>(f[14], f[15]);
@@ -1090,8 +1101,13 @@ __device__ __forceinline__ void eval_wave(const NerfParams &P, const __amdgpu_bu
     // a tile none of whose 32 samples exists (the tail of a wave's rays, compacted into tile 0 by k_march) costs nothing:
     // its features were skipped above (exec-masked), its MLP passes are skipped here (wave-uniform)
     const unsigned long long vm = __ballot(valid);
+#if D2R_MARCH_ABLATE & 4
+    oa[0] = __uint_as_float(fa0.x) * 1e-3f; oa[1] = __uint_as_float(fa0.y); oa[2] = __uint_as_float(fa1.x); oa[3] = __uint_as_float(fa1.y);
+    ob[0] = __uint_as_float(fb0.x) * 1e-3f; ob[1] = __uint_as_float(fb0.y); ob[2] = __uint_as_float(fb1.x); ob[3] = __uint_as_float(fb1.y);
+#else
     if ((uint32_t)vm != 0u) mlp_tile<F16>(sw, lane, fa0, fa1, shfA, oa);
     if ((uint32_t)(vm >> 32) != 0u) mlp_tile<F16>(sw, lane, fb0, fb1, shfB, ob);
+#endif
     // tile-1 results live in lanes 0..31; their owners are lanes 32..63
     float ts = __shfl_xor(ob[0], 32), tr = __shfl_xor(ob[1], 32), tg = __shfl_xor(ob[2], 32), tb = __shfl_xor(ob[3], 32);
     // sigma = exp(x), rgb = sigmoid(x) through the hardware exp2 / rcp (1-2 ulp)
