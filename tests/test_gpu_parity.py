@@ -419,7 +419,7 @@ def test_every_brick_configuration_is_bit_identical_to_the_tables(kind):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind", ["shopping", "shelf"])
+@pytest.mark.parametrize("kind", ["shopping", "shelf", "pool_triangle"])
 def test_ray_compaction_and_refill_policies_do_not_change_a_pixel(kind):
     """`march_compact` (round 5: a wave's last <= 32 rays move to lanes 0..31 by ds_permute so that tile 1 costs nothing) and
     `refill_min` (how many free lanes a wave collects before it takes new rays) `march_threads` (waves per workgroup) and `ray_sort` (the queue sorted by the object region a ray enters) only change WHICH
@@ -430,7 +430,7 @@ def test_ray_compaction_and_refill_policies_do_not_change_a_pixel(kind):
     ctx = engine.Context(0)
     W, H = 160, 90
     pipe = OraclePipeline(scene, W, H)
-    poses = host_ref.sample_poses_grid(scene.scene_centre, [3, 3, 2, 1, 1, 1] if kind == "shopping" else [2, 2, 2, 2, 1, 1], scene.scene_type).reshape(-1, 4, 4)
+    poses = host_ref.sample_poses_grid(scene.scene_centre, [2, 2, 2, 2, 1, 1] if kind == "shelf" else [3, 3, 2, 1, 1, 1], scene.scene_type).reshape(-1, 4, 4)
     cams = np.stack([pipe.fg_camera(p) for p in poses])
     T1 = host_ref.converter(np.asarray(scene.obj_pose, np.float32)[None])[0]
     TC = host_ref.converter(np.asarray(scene.cam_poses, np.float32))[0]
@@ -455,7 +455,7 @@ def test_ray_compaction_and_refill_policies_do_not_change_a_pixel(kind):
                     got = (rgba, depth, tb.last_samples, tb.render_composite(view, T1, TC, host_ref.converter(poses.astype(np.float32))))
                     if base is None:
                         base = got
-                        assert got[2] > 5000
+                        assert got[2] > 2000
                     for a, b in zip(got, base):
                         np.testing.assert_array_equal(a, b, err_msg=f"bricks {bricks}, march_compact {compact}, refill_min {refill}, march_threads {threads}, ray_sort_log2 {sort}")
             tb.close()
