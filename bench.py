@@ -980,7 +980,8 @@ def run_kernel_bench(args, wd):
                          "beyond_lds": (lambda lv: {"levels": lv, "bytes_per_sample": lv * 32, "achieved": round(achieved * lv / 16, 2),
                                                     "frac": round(achieved * lv / 16 / HBM_PEAK_GBPS, 5)})(16 - 2 * int((brick_config or {}).get("lds_slots", 0))),
                          "note": "frac = algorithmic bytes (16 levels x 8 corners x 4 B per sample) / launch time / 8 TB/s; levels served from LDS bricks are "
-                                 "counted, so frac > 1 is possible: `beyond_lds` prices only the levels fetched through L2, `traffic_frac` the fabric bytes counted by PMC",
+                                 "counted, so frac > 1 is possible: `beyond_lds` prices only the levels fetched through L2, `traffic_frac` the fabric bytes counted by PMC.  "
+                                 "By time the step's dominant kernel family is the ViT (MFMA-bound): its fraction is `roofline.vit.frac`",
                          "vit": None},
             "roofline_vit": {"bound": "mfma", "gflop_per_image": round(gflop_exec, 2),
                              "gflop_per_image_architecture": round(vit_gflop(cfg), 2),
