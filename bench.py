@@ -101,6 +101,48 @@ def vit_fp8_gflop(cfg, l0_reuse: bool) -> float:
     return blocks * 2 * T * (4 * d * d + 2 * d * mlp) / 1e9
 
 
+def vit_product_table(t, cfg, per_launch, peak_tflops):
+    """roofline.products: per full-size product launch of the vision tower (default schedule), the average event time, the flops of
+    one launch over `per_launch` images, and flops / time / the dense bf16 MFMA peak."""
+    d, mlp = cfg["hidden_size"], cfg["mlp"]
+    T = (cfg["image_size"] // cfg["patch_size"]) ** 2 + 1
+    rows = per_launch * T
+    flops = {"qkv": 2.0 * rows * 3 * d * d, "attn": 4.0 * per_launch * T * T * d, "out": 2.0 * rows * d * d,
+             "fc1": 2.0 * rows * d * mlp, "fc2": 2.0 * rows * d * mlp}
+    out = {}
+    for k, f in flops.items():
+        ms, n = t.get(f"vit_{k}_ms", 0.0), t.get(f"vit_{k}_launches", 0)
+        if not n or ms <= 0:
+            continue
+        avg_ms = ms / n
+        tf = f / (avg_ms * 1e-3) / 1e12
+        out[k] = {"avg_launch_ms": round(avg_ms, 4), "launches": int(n), "gflop_per_launch": round(f / 1e9, 1),
+                  "achieved": round(tf, 1), "frac": round(tf / peak_tflops, 5)}
+    if out:
+        covered = sum(t.get(f"vit_{k}_ms", 0.0) for k in flops)
+        out["other_ms_per_forward"] = round((t["clip_ms"] - covered) / max(1, t["clip_launches"]), 3)
+        out["images_per_launch"] = int(per_launch)
+        out["note"] = ("full-size launches only (layer 0's compact QKV under l0_reuse and the class-token-only last block are in other_ms_per_forward, with row "
+                       "statistics, patch embedding and head); a ragged last chunk lowers a product's average")
+    return out or None
+
+
+def recorded_pmc(scene_name, W, H, per_launch, clip_name):
+    """PMC figures bench.py cannot collect itself (it does not run under rocprofv3 --pmc): read from the committed summary of the
+    same workload (profiles/r06_pmc.json, separate --pmc passes as MI355X_MICROARCH.md prescribes), else null."""
+    for name in ("r06_pmc.json",):
+        try:
+            t = json.load(open(os.path.join(REPO, "profiles", name)))
+        except (OSError, ValueError):
+            continue
+        wl = t.get("workload", {})
+        if (wl.get("scene"), wl.get("width"), wl.get("height"), wl.get("chunk"), wl.get("clip")) != (scene_name, W, H, per_launch, clip_name):
+            continue
+        src = f"profiles/{name}"
+        return t.get("vit_traffic_bytes_per_forward"), src, dict(t.get("march", {}), source=src)
+    return None, None, None
+
+
 def power_probe(step_fn, device_index: int, seconds: float):
     """Socket power and shader clock (rocm-smi) sampled over EXTRA, untimed steps after the timed region: the step
     runs against the package power limit, which is what prices the ViT's MFMA fraction.
@@ -386,7 +428,8 @@ def run_api(args, wd):
     scene_name, clip_name = args.scene or base["scene"], args.clip or base["clip"]
     W, H = args.width or base["width"], args.height or base["height"]
     sample_res = [int(x) for x in args.sample_res.split(",")] if args.sample_res else list(base["sample_res"])
-    scene = make_scene(scene_name)
+    from dream2real_amd.scene import DEMO_LENS
+    scene = make_scene(scene_name, lens=DEMO_LENS if args.lens == "demo" else None)
     cfg = CLIP_CONFIGS[clip_name]
     sd = random_clip_state_dict(cfg, seed=6)
     ctx = engine.Context(local)
@@ -396,8 +439,7 @@ def run_api(args, wd):
     for kv in args.opt:
         k, v = kv.split("=")
         ctx.set_option(k, int(v))
-    fg, bg = engine.Testbed(ctx, scene.fg), engine.Testbed(ctx, scene.bg)
-    fg.background_color = list(scene.fg_background)
+    fg, bg = scene.testbeds(ctx)       # set_camera_to_training_view(0) on both: the view's intrinsics AND its lens
     scorer = engine.ClipScorer(ctx, cfg, sd)
     task = make_task(scene, fg, bg)
     cam_ngp = converter(np.asarray(scene.cam_poses, np.float32))[0]
@@ -678,7 +720,14 @@ def main():
                     help="strong scaling on fewer GPUs than the partition: every rank takes shard `rank` of this many (config 4 "
                          "defaults to 8: one GPU = a 1/8 slice; 1 = the whole grid)")
     ap.add_argument("--clip", default=None)
+    ap.add_argument("--product-steps", type=int, default=2,
+                    help="extra untimed steps after the timed region with an event pair around every product of the vision tower "
+                         "(roofline.products: QKV / attention / out-proj / fc1 / fc2); 0 = skip")
     ap.add_argument("--scene", default=None)
+    ap.add_argument("--lens", choices=("demo", "none"), default="demo",
+                    help="lens of the scene's training views: demo (default) = the OpenCV coefficients the reference's configs carry "
+                         "(configs/shopping_demo.json:51-56) — every frame is rendered through set_camera_to_training_view's lens, as in the reference "
+                         "(reconstruction/combined_rendering.py:98,116); none = pinhole")
     ap.add_argument("--chunk", type=int, default=4096, help="candidates per pass (the library caps it per model/view)")
     ap.add_argument("--opt", action="append", default=[], help="library tunable key=value (repeatable)")
     ap.add_argument("--vit-fp8", action="store_true",
@@ -785,7 +834,8 @@ def run_kernel_bench(args, wd):
     assert partition % world == 0 or partition == world, "--slice-of must be a multiple of --gpus"
 
     # ---------------- setup (untimed): scene, models, background, poses in HBM
-    scene = make_scene(scene_name)
+    from dream2real_amd.scene import DEMO_LENS
+    scene = make_scene(scene_name, lens=DEMO_LENS if args.lens == "demo" else None)
     cfg = CLIP_CONFIGS[clip_name]
     sd = random_clip_state_dict(cfg, seed=6)
     ctx = engine.Context(local)
@@ -796,8 +846,7 @@ def run_kernel_bench(args, wd):
         k, v = kv.split("=")
         ctx.set_option(k, int(v))
     mlp_f16 = bool(ctx.get_option("mlp_f16"))
-    fg, bg = engine.Testbed(ctx, scene.fg), engine.Testbed(ctx, scene.bg)
-    fg.background_color = list(scene.fg_background)
+    fg, bg = scene.testbeds(ctx)       # set_camera_to_training_view(0) on both: the view's intrinsics AND its lens
     scorer = engine.ClipScorer(ctx, cfg, sd)
     task = make_task(scene)
     pose_batch = obj_pose_opt.sample_poses_grid(task, sample_res, scene.scene_type)       # [N,16] world
@@ -891,6 +940,16 @@ def run_kernel_bench(args, wd):
     timing = ctx.timing()
     ctx.set_option("timing", 0)
     stats = ctx.render_stats(collect_K=K_local)          # counters of the last step
+    # per-product device time of the vision tower ("timing" 2: an event pair around every product launch) over EXTRA, untimed
+    # steps after the timed region — the events cost a few tenths of a per cent of a step, so they stay out of `value`
+    vit_products = None
+    if rank == 0 and world == 1 and args.product_steps > 0:
+        ctx.set_option("timing", 2)
+        for _ in range(args.product_steps):
+            step()
+        torch.cuda.synchronize(dev)
+        vit_products = ctx.timing()
+        ctx.set_option("timing", 0)
     brick_config = {"lds_slots": ctx.get_option("march_lds_slots"), "hbm_brick_slots": ctx.get_option("march_hbm_brick_slots")}
 
     launches_per_step = max(1, round(timing["march_launches"] / max(1, args.steps)))
@@ -899,7 +958,7 @@ def run_kernel_bench(args, wd):
     def recorded_traffic():
         """HBM-side bytes per k_march launch from the committed PMC passes (bench.py cannot run
         under --pmc itself); only reported when it was measured on this exact workload."""
-        for name in ("r05_march_traffic.json", "r04_march_traffic.json", "r03_march_traffic.json", "r01_march_traffic.json"):
+        for name in ("r06_march_traffic.json", "r05_march_traffic.json", "r04_march_traffic.json", "r03_march_traffic.json", "r01_march_traffic.json"):
             try:
                 t = json.load(open(os.path.join(REPO, "profiles", name)))
             except OSError:
@@ -930,6 +989,10 @@ def run_kernel_bench(args, wd):
                    and not any(o.startswith("ln_fold=") and o != "ln_fold=4" for o in args.opt))
         f8_share = min(1.0, vit_fp8_gflop(cfg, bool(stats.get("l0_tokens"))) / gflop_exec) if vit_fp8 else 0.0
         vit_peak = 1.0 / (f8_share / MFMA_FP8_PEAK_TFLOPS + (1.0 - f8_share) / MFMA_BF16_PEAK_TFLOPS)
+        mlp_tflops = samples_per_launch * MLP_FLOP_PER_SAMPLE / march_avg_s / 1e12 if march_avg_s > 0 else None
+        sort_avg_s = timing.get("sort_ms", 0.0) / max(1, timing.get("sort_launches", 0) or 1) * 1e-3
+        products = vit_product_table(vit_products, cfg, per_launch, vit_peak) if vit_products else None
+        vit_traffic, vit_traffic_src, march_pmc = recorded_pmc(scene_name, W, H, per_launch, clip_name)
         # name the workload from what actually ran: the BASELINE.json config whose scene / grid / size / encoder it is
         per_gpu_res = sample_res[:2] + [1] + sample_res[3:] if scaling == "weak" else sample_res
         match = [k for k, c in BASELINE_CONFIGS.items()
@@ -960,45 +1023,53 @@ def run_kernel_bench(args, wd):
                                       "d2r_allgather_scores: one ncclAllGather (RCCL) of fp32 logits per step" if c_abi_comm else
                                       f"torch.distributed all_gather ({torch.distributed.get_backend()}): ranks share a GPU, RCCL unavailable"),
                        "rccl_version": rccl,
+                       "lens": (f"OpenCV k1, k2, p1, p2 = {list(scene.lens)} (configs/shopping_demo.json:51-56) on every ray, as set_camera_to_training_view leaves it"
+                                if scene.lens else "none (pinhole)"),
                        "text_embeds": text_info},
-            "roofline": {"bound": "hbm", "kernel": "k_march (hash-grid fetch + fused MLP + compositing)",
-                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
-                         "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": int(samples_per_launch * ALGO_BYTES_PER_SAMPLE),
-                         "samples_per_launch": int(samples_per_launch),
-                         "lane_utilisation": round(stats["samples"] / max(1, 64 * stats["wave_iters"]), 4),
-                         # which k_march instantiation ran: leading slots (level pairs) served from LDS bricks, further slots from dense HBM bricks
-                         "brick_config": brick_config,
-                         "avg_launch_ms": round(march_avg_s * 1e3, 4),
-                         "mlp_tflops": round(samples_per_launch * MLP_FLOP_PER_SAMPLE / march_avg_s / 1e12, 3) if march_avg_s > 0 else None,
-                         # the same kernel priced on the bytes the memory system actually moved (PMC FETCH_SIZE + WRITE_SIZE per
-                         # launch / launch time / peak): 10 of 16 levels are served from LDS bricks, so this is far below `frac`
-                         "traffic_frac": round(traffic / march_avg_s / 1e9 / HBM_PEAK_GBPS, 5) if (traffic and march_avg_s > 0) else None,
-                         # `achieved` counts ALL 16 levels' bytes (512 B per sample) although the leading level pairs are read
-                         # from LDS bricks, so it can exceed the HBM peak; the same figure on the levels that do go through L2 / the fabric:
-                         "beyond_lds": (lambda lv: {"levels": lv, "bytes_per_sample": lv * 32, "achieved": round(achieved * lv / 16, 2),
-                                                    "frac": round(achieved * lv / 16 / HBM_PEAK_GBPS, 5)})(16 - 2 * int((brick_config or {}).get("lds_slots", 0))),
-                         "note": "frac = algorithmic bytes (16 levels x 8 corners x 4 B per sample) / launch time / 8 TB/s; levels served from LDS bricks are "
-                                 "counted, so frac > 1 is possible: `beyond_lds` prices only the levels fetched through L2, `traffic_frac` the fabric bytes counted by PMC.  "
-                                 "By time the step's dominant kernel family is the ViT (MFMA-bound): its fraction is `roofline.vit.frac`",
-                         "vit": None},
-            "roofline_vit": {"bound": "mfma", "gflop_per_image": round(gflop_exec, 2),
-                             "gflop_per_image_architecture": round(vit_gflop(cfg), 2),
-                             "l0_touched_fraction": round(l0_frac, 4),
-                             "note": "flops the library issues: last block's q, attention output, out-proj and MLP on the class token only (the head reads nothing else); "
-                                     "patch embedding and layer-0 QKV on the patch tokens a candidate can have touched only (the others take the background's rows) — both exact",
-                             "achieved": round(clip_tflops, 2) if clip_tflops else None,
-                             "peak": round(vit_peak, 1), "unit": "TFLOP/s",
-                             "fp8_share_of_flops": round(f8_share, 4),
-                             "frac": round(clip_tflops / vit_peak, 5) if clip_tflops else None},
+            # The step's dominant kernel family by time (86 % of the device time at configs[1]) is the vision tower: MFMA-bound by shape
+            # (dense contractions), priced on the flops the library ISSUES against the dense bf16 MFMA peak.  `products` = the same figure
+            # per product, from HIP events around every launch (extra untimed steps).  No field named `frac` here can exceed 1.
+            "roofline": {"bound": "mfma", "kernel": "vision tower (k_gemm8<EPI> QKV / out-proj / fc1 / fc2 + k_attention_s + small kernels)",
+                         "achieved": round(clip_tflops, 2) if clip_tflops else None, "peak": round(vit_peak, 1), "unit": "TFLOP/s",
+                         "frac": round(clip_tflops / vit_peak, 5) if clip_tflops else None,
+                         "traffic": vit_traffic, "traffic_source": vit_traffic_src,
+                         "share_of_device_time": round(timing["clip_ms"] / max(1e-9, sum(timing.get(k, 0.0) for k in ("march_ms", "raygen_ms", "sort_ms", "prep_ms", "clip_ms"))), 4),
+                         "gflop_per_image": round(gflop_exec, 2), "gflop_per_image_architecture": round(vit_gflop(cfg), 2),
+                         "l0_touched_fraction": round(l0_frac, 4), "fp8_share_of_flops": round(f8_share, 4),
+                         "products": products,
+                         "note": "flops the library issues: last block's q, attention output, out-proj and MLP on the class token only (the head reads nothing else); "
+                                 "patch embedding and layer-0 QKV on the patch tokens a candidate can have touched only (the others take the background's rows) — both exact.  "
+                                 "products: per full-size launch of the default schedule, flops / event time / peak"},
+            # k_march is NOT HBM-bound once the ray sort makes its lookups L2-resident (fabric traffic = 0.5 % of the HBM peak): it is bound by
+            # VALU issue and dependent chains.  north_star's "hash-grid fetch" figure (algorithmic bytes / launch time / 8 TB/s, target >= 0.40)
+            # counts the levels served from LDS bricks too and can exceed 1: it is reported under its own name, not as a roofline fraction.
+            "march": {"bound": "valu-issue", "kernel": "k_march (hash-grid fetch + fused MLP + compositing)",
+                      "avg_launch_ms": round(march_avg_s * 1e3, 4),
+                      "sort_ms_per_launch": round(sort_avg_s * 1e3, 4),
+                      "samples_per_launch": int(samples_per_launch),
+                      "lane_utilisation": round(stats["samples"] / max(1, 64 * stats["wave_iters"]), 4),
+                      "brick_config": brick_config,
+                      "mlp_tflops": round(mlp_tflops, 3) if mlp_tflops else None,
+                      "mlp_frac_of_mfma_peak": round(mlp_tflops / MFMA_BF16_PEAK_TFLOPS, 5) if mlp_tflops else None,
+                      "hash_fetch_algorithmic_GBps": round(achieved, 2),
+                      "hash_fetch_algorithmic_bytes_per_launch": int(samples_per_launch * ALGO_BYTES_PER_SAMPLE),
+                      "hash_fetch_algorithmic_ratio": round(achieved / HBM_PEAK_GBPS, 5),
+                      "hash_fetch_algorithmic_ratio_with_sort": round(samples_per_launch * ALGO_BYTES_PER_SAMPLE / (march_avg_s + sort_avg_s) / 1e9 / HBM_PEAK_GBPS, 5) if march_avg_s > 0 else None,
+                      "hash_fetch_target": 0.40,
+                      "levels_beyond_lds": 16 - 2 * int((brick_config or {}).get("lds_slots", 0)),
+                      "hash_fetch_beyond_lds_ratio": round(achieved * (16 - 2 * int((brick_config or {}).get("lds_slots", 0))) / 16 / HBM_PEAK_GBPS, 5),
+                      "fabric_traffic_bytes_per_launch": traffic, "fabric_traffic_source": traffic_src,
+                      "fabric_frac": round(traffic / march_avg_s / 1e9 / HBM_PEAK_GBPS, 5) if (traffic and march_avg_s > 0) else None,
+                      "pmc": march_pmc,
+                      "note": "hash_fetch_algorithmic_ratio = samples x 512 B (16 levels x 8 corners x 4 B, SURVEY.md 8(d)) / k_march launch time / 8 TB/s — north_star's formula, "
+                              "NOT a roofline fraction: 10 of 16 levels come from LDS bricks and the rest hit L2 at 0.99, so it can exceed 1 (the ..._with_sort variant "
+                              "charges the ray sort's passes, timed separately, to the launch).  What bounds the kernel: VALU issue (pmc.valu_busy) with the MLPs at "
+                              "mlp_frac_of_mfma_peak of the bf16 MFMA peak; fabric_frac is what HBM / Infinity Fabric actually carries"},
             "device_ms_per_step": {k.replace("_ms", ""): round(v / args.steps, 3) for k, v in timing.items() if k.endswith("_ms")},
             "render_stats_per_step": stats,
             "argmax_pose": best,
         }
-        # the step's DOMINANT kernel family is the ViT's GEMMs (MFMA-bound by shape): its fraction rides inside `roofline` so
-        # that a record which keeps only that object keeps it (`roofline_vit` stays as the same object for older readers)
-        out["roofline"]["vit"] = out["roofline_vit"]
+        out["roofline_vit"] = out["roofline"]          # the name older readers look for: the same object
         if world == 1:
             out["power"] = power_probe(step, dev.index or 0, args.power_seconds)
         if world == 1 and args.cpu_sample > 0:

@@ -9,7 +9,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libd2r.so")
-ABI_VERSION = 8          # D2R_ABI_VERSION of include/d2r.h this binding was written against
+ABI_VERSION = 9          # D2R_ABI_VERSION of include/d2r.h this binding was written against
 
 EXPORTS = [
     "d2r_abi_version", "d2r_ctx_create", "d2r_ctx_destroy", "d2r_ctx_set_stream", "d2r_ctx_synchronize",
@@ -18,7 +18,7 @@ EXPORTS = [
     "d2r_clip_score_frames", "d2r_clip_preprocess", "d2r_clip_embed_pixels", "d2r_render_score",
     "d2r_get_render_stats", "d2r_collect_render_stats", "d2r_ctx_set_option", "d2r_get_timing", "d2r_text_create",
     "d2r_text_destroy", "d2r_text_encode", "d2r_comm_get_unique_id", "d2r_comm_init", "d2r_comm_destroy",
-    "d2r_allgather_scores", "d2r_phys_create", "d2r_phys_destroy", "d2r_phys_check", "d2r_nerf_load_ingp",
+    "d2r_allgather_scores", "d2r_phys_create", "d2r_phys_destroy", "d2r_phys_check", "d2r_nerf_load_ingp", "d2r_lens_undistort_view",
     "d2r_rectify_background_depth", "d2r_ingp_inspect", "d2r_render_score_host", "d2r_png_write", "d2r_png_write_batch",
     "d2r_png_read_batch", "d2r_png_size", "d2r_savetxt", "d2r_ingp_validate", "d2r_debug_gemm_fp8", "d2r_ctx_get_option", "d2r_png_write_batch_bg",
 ]
@@ -41,7 +41,7 @@ class ViewC(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("focal", C.c_float * 2),
                 ("center", C.c_float * 2), ("scale", C.c_float), ("offset", C.c_float * 3),
                 ("background", C.c_float * 4), ("min_transmittance", C.c_float),
-                ("near_distance", C.c_float)]
+                ("near_distance", C.c_float), ("lens_mode", C.c_uint32), ("lens_params", C.c_float * 4)]
 
 
 class ClipDesc(C.Structure):
@@ -63,14 +63,15 @@ class PhysParams(C.Structure):
 
 
 class IngpView(C.Structure):
-    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("w", C.c_uint32), ("h", C.c_uint32)]
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("w", C.c_uint32), ("h", C.c_uint32),
+                ("lens_mode", C.c_uint32), ("lens_params", C.c_float * 4)]
 
 
 class IngpInfo(C.Structure):
     _fields_ = [("n_levels", C.c_uint32), ("n_features", C.c_uint32), ("aabb_scale", C.c_uint32),
                 ("has_background", C.c_int32), ("dataset_scale", C.c_double), ("dataset_offset", C.c_double * 3),
                 ("background_color", C.c_float * 4), ("n_views", C.c_uint32), ("n_views_written", C.c_uint32),
-                ("n_unknown_keys", C.c_uint32)]
+                ("n_unknown_keys", C.c_uint32), ("render_with_lens_distortion", C.c_int32)]
 
 
 class FrameSink(C.Structure):
@@ -85,7 +86,10 @@ class RenderStats(C.Structure):
 class Timing(C.Structure):
     _fields_ = [("march_ms", C.c_double), ("march_launches", C.c_uint64), ("raygen_ms", C.c_double),
                 ("raygen_launches", C.c_uint64), ("prep_ms", C.c_double), ("prep_launches", C.c_uint64),
-                ("clip_ms", C.c_double), ("clip_launches", C.c_uint64)]
+                ("clip_ms", C.c_double), ("clip_launches", C.c_uint64), ("sort_ms", C.c_double), ("sort_launches", C.c_uint64),
+                ("vit_qkv_ms", C.c_double), ("vit_qkv_launches", C.c_uint64), ("vit_attn_ms", C.c_double), ("vit_attn_launches", C.c_uint64),
+                ("vit_out_ms", C.c_double), ("vit_out_launches", C.c_uint64), ("vit_fc1_ms", C.c_double), ("vit_fc1_launches", C.c_uint64),
+                ("vit_fc2_ms", C.c_double), ("vit_fc2_launches", C.c_uint64)]
 
 
 COMM_ID_BYTES = 128      # D2R_COMM_ID_BYTES
@@ -222,4 +226,4 @@ def ptr(a) -> C.c_void_p:
 def view_c(v) -> ViewC:
     return ViewC(v.width, v.height, (C.c_float * 2)(*v.focal), (C.c_float * 2)(*v.center), v.scale,
                  (C.c_float * 3)(*v.offset), (C.c_float * 4)(*v.background), v.min_transmittance,
-                 v.near_distance)
+                 v.near_distance, int(v.lens_mode), (C.c_float * 4)(*[float(x) for x in v.lens_params]))

@@ -66,7 +66,7 @@ int d2r_reserve(d2r_ctx *ctx, d2r_ctx::Buf &b, size_t bytes)
 
 size_t d2r_ctx::timing_begin(int kind)
 {
-    if (!timing) return (size_t)-1;
+    if (!timing || (kind >= D2R_T_VIT_QKV && timing < 2)) return (size_t)-1;
     while (ev_pool.size() < ev_used + 2) {
         hipEvent_t e;
         if (hipEventCreate(&e) != hipSuccess) return (size_t)-1;
@@ -93,8 +93,8 @@ int d2r_get_timing(d2r_ctx *ctx, d2r_timing *out)
 {
     if (!ctx || !out) return d2r_fail(ctx, D2R_ERR_INVALID, "null argument");
     D2R_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    double ms[D2R_T_KINDS] = {0, 0, 0, 0};
-    uint64_t n[D2R_T_KINDS] = {0, 0, 0, 0};
+    double ms[D2R_T_KINDS] = {};
+    uint64_t n[D2R_T_KINDS] = {};
     for (auto &p : ctx->ev_pairs) {
         float t = 0.f;
         if (hipEventElapsedTime(&t, ctx->ev_pool[p.second.first], ctx->ev_pool[p.second.second]) == hipSuccess) {
@@ -106,6 +106,12 @@ int d2r_get_timing(d2r_ctx *ctx, d2r_timing *out)
     out->raygen_ms = ms[D2R_T_RAYGEN]; out->raygen_launches = n[D2R_T_RAYGEN];
     out->prep_ms = ms[D2R_T_PREP];     out->prep_launches = n[D2R_T_PREP];
     out->clip_ms = ms[D2R_T_CLIP];     out->clip_launches = n[D2R_T_CLIP];
+    out->sort_ms = ms[D2R_T_SORT];     out->sort_launches = n[D2R_T_SORT];
+    out->vit_qkv_ms = ms[D2R_T_VIT_QKV];   out->vit_qkv_launches = n[D2R_T_VIT_QKV];
+    out->vit_attn_ms = ms[D2R_T_VIT_ATTN]; out->vit_attn_launches = n[D2R_T_VIT_ATTN];
+    out->vit_out_ms = ms[D2R_T_VIT_OUT];   out->vit_out_launches = n[D2R_T_VIT_OUT];
+    out->vit_fc1_ms = ms[D2R_T_VIT_FC1];   out->vit_fc1_launches = n[D2R_T_VIT_FC1];
+    out->vit_fc2_ms = ms[D2R_T_VIT_FC2];   out->vit_fc2_launches = n[D2R_T_VIT_FC2];
     ctx->ev_used = 0;
     ctx->ev_pairs.clear();
     return D2R_OK;
@@ -153,7 +159,7 @@ void d2r_ctx_destroy(d2r_ctx *c)
     if (c->copy_stream) hipStreamSynchronize(c->copy_stream);
     delete c->pool;
     d2r_ctx::Buf *bufs[] = {&c->cams, &c->queue, &c->queue2, &c->sort_counts, &c->counters, &c->frames, &c->rgba, &c->depth, &c->poses,
-                            &c->text, &c->logits, &c->pix, &c->bg_rgba, &c->bg_depth, &c->bg_u8, &c->rects, &c->bg_patches, &c->rect_ws,
+                            &c->text, &c->logits, &c->pix, &c->bg_rgba, &c->bg_depth, &c->bg_u8, &c->rects, &c->bg_patches, &c->rect_ws, &c->lens_tab,
                             &c->patches2, &c->frames2, &c->bg_l0, &c->l0_a1, &c->l0_q2, &c->l0_misc};
     for (auto *b : bufs)
         if (b->p) hipFree(b->p);
@@ -222,7 +228,7 @@ int d2r_ctx_set_option(d2r_ctx *ctx, const char *key, int64_t value)
     } else if (!strcmp(key, "overlap")) {
         ctx->overlap = value != 0;
     } else if (!strcmp(key, "debug_fail_chunk")) {
-        ctx->debug_fail_chunk = value;          // test hook: d2r_render_score* fails in this chunk (-1 = off)
+        ctx->debug_fail_chunk = value;          // test hook, ONE-SHOT: the next d2r_render_score* fails in this chunk, then the hook disarms itself (-1 = off)
     } else if (!strcmp(key, "ray_sort")) {
         if (value < 0 || value > 1) return d2r_fail(ctx, D2R_ERR_INVALID, "ray_sort must be 0 or 1");
         ctx->ray_sort = value;
@@ -230,7 +236,8 @@ int d2r_ctx_set_option(d2r_ctx *ctx, const char *key, int64_t value)
         if (value < 1 || value > 4) return d2r_fail(ctx, D2R_ERR_INVALID, "ray_sort_log2 must be 1 .. 4");
         ctx->ray_sort_log2 = value;
     } else if (!strcmp(key, "march_threads")) {
-        if (value < 0 || value > 1024 || value % 64) return d2r_fail(ctx, D2R_ERR_INVALID, "march_threads must be 0 (auto) or a multiple of 64 up to 1024");
+        if (value < 0 || value > D2R_MARCH_THREADS || value % 64)
+            return d2r_fail(ctx, D2R_ERR_INVALID, "march_threads must be 0 (auto) or a multiple of 64 up to " + std::to_string(D2R_MARCH_THREADS) + " (the size the marcher was compiled for)");
         ctx->march_threads = value;
     } else if (!strcmp(key, "march_threads_auto_mib")) {
         if (value < 0 || value > 1 << 20) return d2r_fail(ctx, D2R_ERR_INVALID, "march_threads_auto_mib out of range");
@@ -268,7 +275,8 @@ int d2r_ctx_set_option(d2r_ctx *ctx, const char *key, int64_t value)
     } else if (!strcmp(key, "raygen_rect")) {
         ctx->raygen_rect = value != 0;
     } else if (!strcmp(key, "timing")) {
-        ctx->timing = value != 0;
+        if (value < 0 || value > 2) return d2r_fail(ctx, D2R_ERR_INVALID, "timing must be 0, 1 or 2");
+        ctx->timing = value;
         ctx->ev_used = 0;
         ctx->ev_pairs.clear();
     } else {
@@ -483,11 +491,9 @@ int d2r_nerf_create(d2r_ctx *ctx, const d2r_nerf_desc *d, d2r_nerf **out)
     P.n_brick_slots = 0;
     P.brick_words = 0;
     P.n_gbrick_slots = 0;
-    // appends the brick of level 2i+h to `words`; false when it would exceed `budget_words`
-    auto add_level_brick = [&](uint32_t i, int h, std::vector<uint32_t> &words, size_t budget_words, size_t word0) -> bool {
-        SlotMeta &sm = P.slot[i];
+    // extent of the brick of level 2i+h over the occupied bounding box: first vertex and vertex counts per axis
+    auto level_brick_extent = [&](uint32_t i, int h, int (&g0)[3], int (&n)[3]) -> size_t {
         const LevelMeta &L = half_level(i, h);
-        int g0[3], n[3];
         for (int a = 0; a < 3; a++) {
             // same correctly-rounded fma the kernels use: monotone, so these bound every sample
             float plo = fmaf(L.scale, blo[a], 0.5f);
@@ -495,8 +501,21 @@ int d2r_nerf_create(d2r_ctx *ctx, const d2r_nerf_desc *d, d2r_nerf **out)
             g0[a] = (int)floorf(plo);
             n[a] = (int)floorf(phi) + 1 - g0[a] + 1;
         }
-        const size_t cnt = (size_t)n[0] * n[1] * n[2];
-        if (words.size() + cnt > budget_words) return false;
+        return (size_t)n[0] * n[1] * n[2];
+    };
+    // words a slot's two bricks take (computed from the box and the levels' resolutions alone: the budget tests below run on
+    // this BEFORE anything is built)
+    auto slot_brick_words = [&](uint32_t i) -> size_t {
+        int g0[3], n[3];
+        return level_brick_extent(i, 0, g0, n) + level_brick_extent(i, 1, g0, n);
+    };
+    // appends the brick of level 2i+h to `words` (the caller has checked the budget)
+    auto add_level_brick = [&](uint32_t i, int h, std::vector<uint32_t> &words, size_t word0) {
+        SlotMeta &sm = P.slot[i];
+        const LevelMeta &L = half_level(i, h);
+        int g0[3], n[3];
+        const size_t cnt = level_brick_extent(i, h, g0, n);
+        words.reserve(words.size() + cnt);
         const size_t base = word0 + words.size();
         sm.bnx[h] = (uint32_t)n[0];
         sm.bnxy[h] = (uint32_t)(n[0] * n[1]);
@@ -513,7 +532,6 @@ int d2r_nerf_create(d2r_ctx *ctx, const d2r_nerf_desc *d, d2r_nerf **out)
                         idx = (uint64_t)gx + (uint64_t)gy * L.res + (uint64_t)gz * L.res * L.res;
                     words.push_back(src_word(i, h, (uint32_t)(idx % L.size)));
                 }
-        return true;
     };
     if (bhi[0] >= blo[0] && P.n_dense >= 0) {
         // LDS: the longest prefix of slots (at most 5: levels 0-9) whose bricks fit beside the MLP fragments
@@ -521,9 +539,9 @@ int d2r_nerf_create(d2r_ctx *ctx, const d2r_nerf_desc *d, d2r_nerf **out)
         const uint32_t lds_max = (uint32_t)std::min<int64_t>(5, std::max<int64_t>(0, ctx->lds_slots_max));
         std::vector<uint32_t> words;
         for (uint32_t i = 0; i < n_slots && i < lds_max; i++) {
-            std::vector<uint32_t> trial = words;
-            if (!add_level_brick(i, 0, trial, budget_words, 0) || !add_level_brick(i, 1, trial, budget_words, 0)) break;
-            words.swap(trial);
+            if (words.size() + slot_brick_words(i) > budget_words) break;
+            add_level_brick(i, 0, words, 0);
+            add_level_brick(i, 1, words, 0);
             P.n_brick_slots = i + 1;
             P.brick_words = (uint32_t)words.size();
         }
@@ -536,10 +554,12 @@ int d2r_nerf_create(d2r_ctx *ctx, const d2r_nerf_desc *d, d2r_nerf **out)
         const size_t gbudget = ((size_t)512 << 20) >> 2;        // words
         const size_t slot_cap = ((size_t)std::max<int64_t>(0, ctx->gbrick_max_mib) << 20) >> 2;
         for (uint32_t i = P.n_brick_slots; i < n_slots; i++) {
-            std::vector<uint32_t> trial = gbrick_tab;
-            if (!add_level_brick(i, 0, trial, gbudget, 0) || !add_level_brick(i, 1, trial, gbudget, 0)) break;
-            if (trial.size() - gbrick_tab.size() > slot_cap) break;
-            gbrick_tab.swap(trial);
+            // size first: a slot whose brick would break the per-slot cap or the total is never built, and a slot
+            // that fits is appended in place — no copy of the (up to 512 MiB) table per candidate slot
+            const size_t need = slot_brick_words(i);
+            if (need > slot_cap || gbrick_tab.size() + need > gbudget) break;
+            add_level_brick(i, 0, gbrick_tab, 0);
+            add_level_brick(i, 1, gbrick_tab, 0);
             P.n_gbrick_slots = i + 1 - P.n_brick_slots;
         }
     }
@@ -610,6 +630,12 @@ static int check_view(d2r_ctx *ctx, const d2r_view *v)
     if (v->width == 0 || v->height == 0 || v->width > 8192 || v->height > 8192)
         return d2r_fail(ctx, D2R_ERR_INVALID, "bad view size");
     if (!(v->scale > 0.f)) return d2r_fail(ctx, D2R_ERR_INVALID, "view.scale must be positive");
+    if (v->lens_mode != D2R_LENS_PERSPECTIVE && v->lens_mode != D2R_LENS_OPENCV)
+        return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "view.lens_mode " + std::to_string(v->lens_mode) + " is not implemented (0 = perspective, 1 = OpenCV k1, k2, p1, p2)");
+    if (v->lens_mode == D2R_LENS_OPENCV)
+        for (int i = 0; i < 4; i++)
+            if (!std::isfinite(v->lens_params[i]) || fabsf(v->lens_params[i]) > 16.f)
+                return d2r_fail(ctx, D2R_ERR_INVALID, "view.lens_params must be finite OpenCV coefficients (k1, k2, p1, p2; magnitude at most 16)");
     return D2R_OK;
 }
 
@@ -661,6 +687,20 @@ int d2r_render(d2r_ctx *ctx, const d2r_nerf *model, const d2r_view *view, const 
         if ((rc = fetch_stats(ctx, (uint64_t)nc * px, true))) return rc;
     }
     if (n_samples_out) *n_samples_out = ctx->stats.samples;
+    return D2R_OK;
+}
+
+int d2r_lens_undistort_view(d2r_ctx *ctx, const d2r_view *view, float *dirs_out)
+{
+    if (!ctx || !dirs_out) return d2r_fail(ctx, D2R_ERR_INVALID, "null argument");
+    int rc = check_view(ctx, view);
+    if (rc) return rc;
+    if (view->lens_mode != D2R_LENS_OPENCV) return d2r_fail(ctx, D2R_ERR_INVALID, "d2r_lens_undistort_view: the view has no lens (lens_mode must be D2R_LENS_OPENCV)");
+    D2R_HIP(ctx, hipSetDevice(ctx->device));
+    ViewParams V = d2r_view_params(view);
+    if ((rc = d2r_lens_table(ctx, V))) return rc;
+    D2R_HIP(ctx, hipMemcpyAsync(dirs_out, V.lens_tab, (size_t)V.W * V.H * 8, hipMemcpyDeviceToHost, ctx->stream));
+    D2R_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return D2R_OK;
 }
 
@@ -921,7 +961,7 @@ static int render_score_body(d2r_ctx *ctx, const d2r_nerf *fg, const d2r_clip *c
     // workspaces are sized once for a full chunk so that no allocation happens inside the loop
     const size_t patch_bytes = d2r_clip_patch_bytes(clip, cap);
     if ((rc = d2r_reserve(ctx, ctx->cams, (size_t)cap * 48))) return rc;
-    if ((rc = d2r_reserve(ctx, ctx->queue, (size_t)cap * px * sizeof(uint2)))) return rc;
+    if ((rc = d2r_reserve_render(ctx, (size_t)cap * px))) return rc;          // queue, and the ray sort's second queue + bin counts
     if ((rc = d2r_reserve(ctx, ctx->frames, (size_t)cap * px * 3))) return rc;
     if ((rc = d2r_reserve(ctx, ctx->clipws[6], patch_bytes))) return rc;
     if (two && (rc = d2r_reserve(ctx, ctx->patches2, patch_bytes))) return rc;
@@ -1008,8 +1048,10 @@ static int render_score_body(d2r_ctx *ctx, const d2r_nerf *fg, const d2r_clip *c
             // keep this chunk's counters for the stats read-back at the end
             D2R_HIP(ctx, hipMemcpyAsync((uint8_t *)ctx->counters.p + 64 + 32 * (size_t)ci, ctx->counters.p, 32,
                                         hipMemcpyDeviceToDevice, rs));
-            if (ctx->debug_fail_chunk >= 0 && (int64_t)ci == ctx->debug_fail_chunk)          // fault injection (tests): as if a launch of this chunk had failed
+            if (ctx->debug_fail_chunk >= 0 && (int64_t)ci == ctx->debug_fail_chunk) {        // fault injection (tests): as if a launch of this chunk had failed
+                ctx->debug_fail_chunk = -1;                                                // one-shot: the context is not left failing every later call
                 return d2r_fail(ctx, D2R_ERR_DEVICE, "injected fault in chunk " + std::to_string(ci) + " (option debug_fail_chunk)");
+            }
             size_t tp = ctx->timing_begin(D2R_T_PREP);
             // (with layer-0 reuse only the touched patches are produced: nothing downstream reads the others)
             if ((rc = d2r_launch_preprocess(ctx, (d2r_clip *)clip, frames_dev, nc, V.W, V.H, 1, patches, nullptr, rects,

@@ -3371,21 +3371,33 @@ int d2r_clip_forward(d2r_ctx *ctx, const d2r_clip *clip, const uint16_t *patches
             if ((rc = launch_gemm_cfg<EPI_LN_BIAS_BF16, 4, 2, 2, 3>(ctx, AO, L.wf_qkv, L.bf_qkv, ctx->l0_q2.p, prow, 3 * d, d, l2))) return rc;
             hipLaunchKernelGGL(k_scatter_qkv, dim3(8192), dim3(256), 0, ctx->stream, (const uint16_t *)ctx->l0_q2.p, cap_pad, (const uint32_t *)l0_list,
                                (const uint32_t *)l0_cnt, QKV, rows_pad, T, planes);
-        } else if ((rc = launch_gemm<EPI_LN_BIAS_BF16>(ctx, Xn, L.wf_qkv, L.bf_qkv, QKV, rows, 3 * d, d, ln))) return rc;
+        } else {
+            const size_t tq = ctx->timing_begin(D2R_T_VIT_QKV);
+            if ((rc = launch_gemm<EPI_LN_BIAS_BF16>(ctx, Xn, L.wf_qkv, L.bf_qkv, QKV, rows, 3 * d, d, ln))) return rc;
+            ctx->timing_end(tq);
+        }
+        size_t tk = ctx->timing_begin(D2R_T_VIT_ATTN);
         launch_attention_vision(ctx, QKV, AO, T, d, rows_pad, D.num_heads, n);
+        ctx->timing_end(tk);
+        tk = ctx->timing_begin(D2R_T_VIT_OUT);
         if (xf32) rc = launch_gemm<EPI_RESID_STATS_F32X>(ctx, AO, L.w_o, L.b_o, X, rows, d, d, st);
         else if (split8) rc = launch_gemm<EPI_RESID_STATS_SPLIT8>(ctx, AO, L.w_o, L.b_o, Xn, rows, d, d, st);
         else if (split) rc = launch_gemm<EPI_RESID_STATS_SPLIT>(ctx, AO, L.w_o, L.b_o, Xn, rows, d, d, st);
         else rc = launch_gemm<EPI_RESID_STATS_BF16>(ctx, AO, L.w_o, L.b_o, Xn, rows, d, d, st);
         if (rc) return rc;
+        ctx->timing_end(tk);
         hipLaunchKernelGGL(k_rowstats, dim3((rows_pad + 255) / 256), dim3(256), 0, ctx->stream, part, np, rows_pad, inv_d, AB);
         ln.cs = L.cs_fc1;
+        tk = ctx->timing_begin(D2R_T_VIT_FC1);
         if ((rc = launch_gemm<EPI_LN_BIAS_GELU_BF16>(ctx, Xn, L.wf_fc1, L.bf_fc1, H, rows, mlp, d, ln))) return rc;
+        ctx->timing_end(tk);
+        tk = ctx->timing_begin(D2R_T_VIT_FC2);
         if (xf32) rc = launch_gemm<EPI_RESID_STATS_F32X>(ctx, H, L.w_fc2, L.b_fc2, X, rows, d, mlp, st);
         else if (split8) rc = launch_gemm<EPI_RESID_STATS_SPLIT8>(ctx, H, L.w_fc2, L.b_fc2, Xn, rows, d, mlp, st);
         else if (split) rc = launch_gemm<EPI_RESID_STATS_SPLIT>(ctx, H, L.w_fc2, L.b_fc2, Xn, rows, d, mlp, st);
         else rc = launch_gemm<EPI_RESID_STATS_BF16>(ctx, H, L.w_fc2, L.b_fc2, Xn, rows, d, mlp, st);
         if (rc) return rc;
+        ctx->timing_end(tk);
         if (l + 1 < D.num_layers)
             hipLaunchKernelGGL(k_rowstats, dim3((rows_pad + 255) / 256), dim3(256), 0, ctx->stream, part, np, rows_pad, inv_d, AB);
     }

@@ -87,6 +87,9 @@ struct ViewParams {
     float offset[3];
     float background[4];
     float min_transmittance, near_distance;
+    uint32_t lens_mode;        // D2R_LENS_*: 1 = every ray's camera-space direction is undistorted (lens_undistort, nerf.hip)
+    float lens[4];             // OpenCV k1, k2, p1, p2
+    const float2 *lens_tab;    // [H][W] undistorted (x, y) of the camera-space direction per pixel (k_lens_table), nullptr = perspective
 };
 
 struct ClipParams;   // clip.hip
@@ -122,6 +125,9 @@ struct d2r_ctx {
     uint32_t text_turn = 0;
     // background of the current view
     Buf bg_rgba, bg_depth, bg_u8;
+    Buf lens_tab;                // undistorted camera-space directions of the current view's pixels (nerf.hip lens_table)
+    float lens_key[10] = {};     // ... and the view (size, intrinsics, coefficients) it was computed for
+    bool lens_key_valid = false;
     Buf rect_ws;                 // d2r_rectify_background_depth: source images, tap tables, outputs
     Buf rects;                   // per candidate of a pass: frame rectangle (x0, y0, x1, y1) its rays were generated in
     Buf bg_patches;              // CLIP patches of the background frame itself (one image)
@@ -185,10 +191,13 @@ struct d2r_ctx {
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
     std::vector<std::pair<int, std::pair<size_t, size_t>>> ev_pairs;   // (kind, (begin, end))
-    size_t timing_begin(int kind);          // returns pair index, records the begin event
+    size_t timing_begin(int kind);          // returns pair index, records the begin event (kinds >= D2R_T_VIT_QKV only with "timing" 2)
     void timing_end(size_t pair);
 };
-enum { D2R_T_MARCH = 0, D2R_T_RAYGEN = 1, D2R_T_CLIP = 2, D2R_T_PREP = 3, D2R_T_KINDS = 4 };
+enum { D2R_T_MARCH = 0, D2R_T_RAYGEN = 1, D2R_T_CLIP = 2, D2R_T_PREP = 3, D2R_T_SORT = 4,
+       // "timing" 2: the vision tower's products, one pair of events per launch (full-size launches of the default schedule only:
+       // layer 0's compact QKV under l0_reuse and the class-token-only last block stay inside D2R_T_CLIP's remainder)
+       D2R_T_VIT_QKV = 5, D2R_T_VIT_ATTN = 6, D2R_T_VIT_OUT = 7, D2R_T_VIT_FC1 = 8, D2R_T_VIT_FC2 = 9, D2R_T_KINDS = 10 };
 
 struct d2r_nerf {
     d2r_ctx *ctx;
@@ -226,3 +235,5 @@ int d2r_launch_render(d2r_ctx *, const d2r_nerf *, const ViewParams &, const flo
                       uint8_t *frames_dev, void *rects_dev = nullptr);
 int d2r_launch_bg_quantize(d2r_ctx *, uint32_t w, uint32_t h);
 ViewParams d2r_view_params(const d2r_view *v);
+int d2r_reserve_render(d2r_ctx *, size_t rays);    // ray queue (+ sorted copy and bin counts with the ray sort) for a pass of `rays` rays
+int d2r_lens_table(d2r_ctx *, ViewParams &V);      // attaches the view's undistorted-direction table (built on first use)

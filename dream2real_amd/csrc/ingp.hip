@@ -357,9 +357,54 @@ void audit_render_state(Audit &A, const Node *snap, const Node *nerf, const Node
     // tiny-cuda-nn activation enums as instant-ngp stores them (ENerfActivation: None 0, ReLU 1, Logistic 2, Exponential 3)
     check_num(A, nerf, "snapshot.nerf", "rgb_activation", 2.0, "colour = sigmoid(network output)");
     check_num(A, nerf, "snapshot.nerf", "density_activation", 3.0, "sigma = exp(network output)");
-    const Node *rl = nerf ? nerf->get("render_with_lens_distortion") : nullptr;
-    if (rl && rl->number() && rl->num() != 0.0)
-        A.fail("snapshot: snapshot.nerf.render_with_lens_distortion is set: lens distortion is not implemented (the reference's cached-snapshot path renders without it)");
+}
+
+// metadata[k].lens as instant-ngp's to_json(Lens) writes it (believed): OpenCV = {k1, k2, p1, p2}; fisheye = {k1 .. k4}; f-theta
+// = {ftheta_p0 ..}; {latlong: true}; {equirectangular: true}; a perspective lens writes no key (nil / an empty map).  The path
+// renders every frame through set_camera_to_training_view's lens (reference reconstruction/combined_rendering.py:98,116), so the
+// OpenCV form is READ (configs/shopping_demo.json:51-56 is what the reference's snapshots carry); the other models are not
+// implemented and refuse the snapshot.  Returns false with `why` set on failure.
+bool read_lens(const Node *ln, uint32_t &mode, float (&prm)[4], std::string &why)
+{
+    mode = D2R_LENS_PERSPECTIVE;
+    for (float &p : prm) p = 0.f;
+    if (!ln || ln->kind == Node::NIL || (ln->kind == Node::MAP && ln->map.empty())) return true;
+    if (ln->kind != Node::MAP) { why = "is not a map"; return false; }
+    auto on = [&](const char *k) { const Node *v = ln->get(k); return v && v->number() && v->num() != 0.0; };
+    if (ln->get("k3") || ln->get("k4")) { why = "is an OpenCV fisheye lens (k3 / k4): not implemented"; return false; }
+    for (const char *k : {"ftheta_p0", "ftheta_p1", "ftheta_p2", "ftheta_p3", "ftheta_p4", "w", "h"})
+        if (ln->get(k)) { why = "is an f-theta lens: not implemented"; return false; }
+    if (on("latlong") || on("equirectangular") || on("orthographic")) { why = "is a lat-long / equirectangular / orthographic lens: not implemented"; return false; }
+    if (const Node *md = ln->get("mode")) {                // {mode, params} form: ELensMode Perspective 0, OpenCV 1
+        if (!md->number() || (md->num() != 0.0 && md->num() != 1.0)) { why = "has a mode other than perspective (0) / OpenCV (1): not implemented"; return false; }
+        const Node *pa = ln->get("params");
+        if (md->num() == 1.0) {
+            if (!pa || pa->kind != Node::ARR || pa->arr.size() < 4) { why = "lacks params (k1, k2, p1, p2)"; return false; }
+            mode = D2R_LENS_OPENCV;
+            for (int k = 0; k < 4; k++) prm[k] = (float)pa->arr[k].num();
+        }
+    } else {
+        const char *keys[4] = {"k1", "k2", "p1", "p2"};
+        int have = 0;
+        for (const char *k : keys) have += ln->get(k) ? 1 : 0;
+        if (have == 0) return true;                         // nothing lens-like: perspective
+        if (have != 4) { why = "is an OpenCV lens without all of k1, k2, p1, p2"; return false; }
+        mode = D2R_LENS_OPENCV;
+        for (int k = 0; k < 4; k++) {
+            const Node *v = ln->get(keys[k]);
+            if (!v->number()) { why = std::string(keys[k]) + " is not a number"; return false; }
+            prm[k] = (float)v->num();
+        }
+    }
+    if (mode == D2R_LENS_OPENCV) {
+        bool zero = true;
+        for (float p : prm) {
+            if (!std::isfinite(p) || fabsf(p) > 16.f) { why = "has a coefficient that is not finite or beyond 16"; return false; }
+            zero = zero && p == 0.f;
+        }
+        if (zero) mode = D2R_LENS_PERSPECTIVE;              // an all-zero OpenCV lens is the pinhole: skip the iteration
+    }
+    return true;
 }
 
 void audit_networks(Audit &A, const Node *enc, const Node *net, const Node *rgb, const Node *dir)
@@ -597,7 +642,17 @@ static int load_ingp(d2r_ctx *ctx, const void *bytes, size_t len, d2r_nerf **out
             v.w = rw >= 0 && rw < 4294967296.0 ? (uint32_t)rw : 0; v.h = rh >= 0 && rh < 4294967296.0 ? (uint32_t)rh : 0;
             v.fx = fl->arr[0].num(); v.fy = fl->arr[1].num();
             v.cx = pp->arr[0].num() * v.w; v.cy = pp->arr[1].num() * v.h;
+            std::string why;
+            if (!read_lens(m.get("lens"), v.lens_mode, v.lens_params, why)) {
+                if (ctx) {
+                    d2r_nerf_destroy(*out);
+                    *out = nullptr;
+                }
+                return d2r_fail(ctx, D2R_ERR_UNSUPPORTED, "snapshot: snapshot.nerf.dataset.metadata[" + std::to_string(k) + "].lens " + why +
+                                " (set_camera_to_training_view makes this lens the render lens)");
+            }
         }
+        if (const Node *rl = nerf->get("render_with_lens_distortion")) info->render_with_lens_distortion = rl->number() && rl->num() != 0.0 ? 1 : 0;
     }
     return D2R_OK;
 }
@@ -614,6 +669,9 @@ const char *const kPathsRead[] = {
     "snapshot.render_aabb.max", "snapshot.background_color", "snapshot.nerf.aabb_scale", "snapshot.nerf.dataset.aabb_scale",
     "snapshot.nerf.dataset.scale", "snapshot.nerf.dataset.offset", "snapshot.nerf.dataset.metadata[].resolution",
     "snapshot.nerf.dataset.metadata[].focal_length", "snapshot.nerf.dataset.metadata[].principal_point",
+    "snapshot.nerf.dataset.metadata[].lens", "snapshot.nerf.dataset.metadata[].lens.k1", "snapshot.nerf.dataset.metadata[].lens.k2",
+    "snapshot.nerf.dataset.metadata[].lens.p1", "snapshot.nerf.dataset.metadata[].lens.p2", "snapshot.nerf.dataset.metadata[].lens.mode",
+    "snapshot.nerf.dataset.metadata[].lens.params", "snapshot.nerf.render_with_lens_distortion",
 };
 // paths the loader CHECKS: they change the rendered function, and only one value of each is implemented (an error otherwise)
 const char *const kPathsChecked[] = {
@@ -625,19 +683,21 @@ const char *const kPathsChecked[] = {
     "snapshot.n_params", "snapshot.exposure", "snapshot.render_aabb_to_local", "snapshot.nerf.dataset.render_aabb_to_local",
     "snapshot.nerf.dataset.n_extra_learnable_dims", "snapshot.nerf.n_extra_dims", "snapshot.nerf.dataset.envmap_resolution",
     "snapshot.nerf.dataset.is_hdr", "snapshot.nerf.dataset.from_mitsuba", "snapshot.nerf.rgb_activation",
-    "snapshot.nerf.density_activation", "snapshot.nerf.render_with_lens_distortion", "snapshot.nerf.cone_angle_constant",
+    "snapshot.nerf.density_activation", "snapshot.nerf.cone_angle_constant",
+    // lens models other than perspective / OpenCV refuse the snapshot (read_lens)
+    "snapshot.nerf.dataset.metadata[].lens.k3", "snapshot.nerf.dataset.metadata[].lens.k4", "snapshot.nerf.dataset.metadata[].lens.latlong",
+    "snapshot.nerf.dataset.metadata[].lens.equirectangular", "snapshot.nerf.dataset.metadata[].lens.orthographic",
 };
 // prefixes known NOT to change what d2r renders through the path's entry points: training state, optimiser / loss
 // configuration, the GUI's own camera and lights, bookkeeping.  (dataset.up / up_dir rotate the GUI's orbit and the
 // poses instant-ngp READS from a transforms file; the path hands camera matrices to set_nerf_camera_matrix, which
-// applies scale / offset / axis cycle only.  Per-image lens parameters matter only with render_with_lens_distortion,
-// which is checked.)
+// applies scale / offset / axis cycle only.)
 const char *const kPrefixesIrrelevant[] = {
     "loss", "optimizer", "envmap", "distortion_map", "parent", "snapshot.version", "snapshot.mode", "snapshot.camera", "snapshot.up_dir",
     "snapshot.sun_dir", "snapshot.aabb", "snapshot.bounding_radius", "snapshot.training_step", "snapshot.loss",
     "snapshot.density_grid_ema_step", "snapshot.nerf.dataset.paths", "snapshot.nerf.dataset.xforms", "snapshot.nerf.dataset.n_images",
     "snapshot.nerf.dataset.up", "snapshot.nerf.dataset.wants_importance_sampling", "snapshot.nerf.dataset.has_rays",
-    "snapshot.nerf.dataset.metadata[].lens", "snapshot.nerf.dataset.metadata[].rolling_shutter", "snapshot.nerf.dataset.metadata[].light_dir",
+    "snapshot.nerf.dataset.metadata[].rolling_shutter", "snapshot.nerf.dataset.metadata[].light_dir",
     "snapshot.nerf.dataset.metadata[].depth_scale", "snapshot.nerf.dataset.render_aabb", "snapshot.nerf.cam_", "snapshot.nerf.extra_dims_opt",
     "snapshot.nerf.rgb", "snapshot.nerf.training", "snapshot.nerf.sharpen", "snapshot.nerf.density_grid", "dir_encoding.nested[].n_bins",
     "dir_encoding.nested", "snapshot.nerf.dataset.metadata",

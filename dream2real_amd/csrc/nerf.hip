@@ -23,6 +23,7 @@
 //                 fp32 RGBA + depth; composite mode: depth test against the background,
 //                 un-premultiply, sRGB, uint8, alpha threshold).
 #include <algorithm>
+#include <cstring>
 
 #include "d2r_internal.h"
 #include <type_traits>
@@ -242,6 +243,65 @@ __device__ __forceinline__ float cone_index_of(const Ray &r, float t)
     return (float)r.k1 + __log2f(t / r.t1) * 177.79119873046875f;       // 1 / log2(1 + 1/256)
 }
 
+// The training view's lens (ViewParams.lens_mode == D2R_LENS_OPENCV; reference reconstruction/combined_rendering.py:98,116:
+// set_camera_to_training_view makes the view's OpenCV lens the render lens).  Same float32 operation sequence as
+// oracle/d2r_oracle.c lens_distortion_delta / lens_undistort (the library is built with -ffp-contract=off; the divisions are
+// IEEE divisions): the offset the lens moves a pinhole direction (u, v, 1) by, and instant-ngp's Newton iteration on a
+// central-difference Jacobian that inverts it for a pixel.  Three to four steps for the demo coefficients; the loop is per lane.
+__device__ __forceinline__ void lens_delta(const float (&L)[4], float u, float v, float &du, float &dv)
+{
+    const float u2 = u * u, uv = u * v, v2 = v * v;
+    const float r2 = u2 + v2;
+    const float radial = L[0] * r2 + L[1] * r2 * r2;
+    du = u * radial + 2.0f * L[2] * uv + L[3] * (r2 + 2.0f * u2);
+    dv = v * radial + 2.0f * L[3] * uv + L[2] * (r2 + 2.0f * v2);
+}
+__device__ __forceinline__ void lens_undistort(const float (&L)[4], float &u, float &v)
+{
+    const float eps = 1.1920928955078125e-07f;
+    const float x0 = u, y0 = v;
+    float x = x0, y = y0;
+    for (int it = 0; it < 100; it++) {
+        const float s0 = fmaxf(eps, fabsf(1e-6f * x));
+        const float s1 = fmaxf(eps, fabsf(1e-6f * y));
+        float dx, dy, bx0, by0, fx0, fy0, bx1, by1, fx1, fy1;
+        lens_delta(L, x, y, dx, dy);
+        lens_delta(L, x - s0, y, bx0, by0);
+        lens_delta(L, x + s0, y, fx0, fy0);
+        lens_delta(L, x, y - s1, bx1, by1);
+        lens_delta(L, x, y + s1, fx1, fy1);
+        const float a = 1.0f + (fx0 - bx0) / (2.0f * s0);
+        const float b = (fx1 - bx1) / (2.0f * s1);
+        const float c = (fy0 - by0) / (2.0f * s0);
+        const float d = 1.0f + (fy1 - by1) / (2.0f * s1);
+        const float rx = x + dx - x0, ry = y + dy - y0;
+        const float inv_det = 1.0f / (a * d - b * c);
+        const float sx = (d * rx - b * ry) * inv_det;
+        const float sy = (a * ry - c * rx) * inv_det;
+        x -= sx;
+        y -= sy;
+        if (sx * sx + sy * sy < 1e-10f) break;
+    }
+    u = x;
+    v = y;
+}
+
+// The undistorted direction depends on the pixel and the view only, not on the candidate: it is computed ONCE per view into a
+// [H][W] float2 table (1.8 MB at 640x360, L2-resident) that make_ray reads — in the ray generators and again when the marcher
+// rebuilds a ray at a refill — so the per-ray cost of the lens is one 8-byte load and the marcher's registers are untouched.
+__global__ __launch_bounds__(256) void k_lens_table(ViewParams V, float2 *__restrict__ tab)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= V.W * V.H) return;
+    const uint32_t px = i % V.W, py = i / V.W;
+    float u = ((float)px + 0.5f) / (float)V.W;
+    float v = ((float)py + 0.5f) / (float)V.H;
+    float dcx = (u - V.center[0]) * (float)V.W / V.focal[0];       // exactly make_ray's expressions
+    float dcy = (v - V.center[1]) * (float)V.H / V.focal[1];
+    lens_undistort(V.lens, dcx, dcy);
+    tab[i] = make_float2(dcx, dcy);
+}
+
 // pixel -> ray, lattice origin and the [k_lo, k_hi] window in which occupied cells can lie.
 // Same fma sequence as the oracle (d2r_oracle_render).
 template <bool CONE>
@@ -252,6 +312,11 @@ __device__ __forceinline__ bool make_ray(const NerfParams &P, const ViewParams &
     float v = ((float)py + 0.5f) / (float)V.H;
     float dcx = (u - V.center[0]) * (float)V.W / V.focal[0];
     float dcy = (v - V.center[1]) * (float)V.H / V.focal[1];
+    if (V.lens_tab) {                           // wave-uniform (a kernel argument): the view's undistorted directions, one per pixel (k_lens_table)
+        const float2 t = V.lens_tab[py * V.W + px];
+        dcx = t.x;
+        dcy = t.y;
+    }
     float d[3], o[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
@@ -525,7 +590,9 @@ __global__ __launch_bounds__(256) void k_raygen_rect(NerfParams P, ViewParams V,
                 const float dot = cam[a] * cam[b] + cam[4 + a] * cam[4 + b] + cam[8 + a] * cam[8 + b];
                 ok = ok && fabsf(dot - (a == b ? 1.0f : 0.0f)) < 1e-3f;
             }
-        float pxmin = INFINITY, pxmax = -INFINITY, pymin = INFINITY, pymax = -INFINITY;
+        // the box's corners in the camera's normalised plane (x / z, y / z): with every corner in front of the camera the
+        // box's pinhole projection lies inside their bounding rectangle [u0, u1] x [v0, v1]
+        float u0 = INFINITY, u1 = -INFINITY, v0 = INFINITY, v1 = -INFINITY;
 #pragma unroll
         for (int c = 0; c < 8; c++) {
             // box-unit corner -> world (CONE: the box is the cube of side 2 about 0.5)
@@ -538,17 +605,55 @@ __global__ __launch_bounds__(256) void k_raygen_rect(NerfParams P, ViewParams V,
             const float cy = cam[1] * qx + cam[5] * qy + cam[9] * qz;
             const float cz = cam[2] * qx + cam[6] * qy + cam[10] * qz;
             ok = ok && cz > 1e-3f;                                          // false for NaN too
-            const float fx = V.center[0] * (float)V.W + cx / cz * V.focal[0] - 0.5f;   // pixel whose centre sees the corner
-            const float fy = V.center[1] * (float)V.H + cy / cz * V.focal[1] - 0.5f;
-            pxmin = fminf(pxmin, fx); pxmax = fmaxf(pxmax, fx);
-            pymin = fminf(pymin, fy); pymax = fmaxf(pymax, fy);
+            const float un = cx / cz, vn = cy / cz;
+            u0 = fminf(u0, un); u1 = fmaxf(u1, un);
+            v0 = fminf(v0, vn); v1 = fmaxf(v1, vn);
         }
-        ok = ok && pxmax - pxmin < 1e6f && pymax - pymin < 1e6f;           // finite
+        ok = ok && u1 - u0 < 1e6f && v1 - v0 < 1e6f;                       // finite
+        float margin = 2.f;                                                 // pixels
+        if (ok && V.lens_mode == D2R_LENS_OPENCV) {
+            // A pixel needs a ray when its UNDISTORTED direction falls into that rectangle, i.e. when its own (distorted) sensor
+            // position lies in the image D(rect) of the rectangle under the forward lens map D(x) = x + delta(x).  D is a local
+            // diffeomorphism on the rectangle (checked: det J > 0.1 on the boundary samples), so the outline of D(rect) is the
+            // image of the rectangle's outline: lane l evaluates D at outline point l (16 per edge), the wave reduces the four
+            // extremes, and what the outline can bulge by BETWEEN two samples (h^2 / 8 max|D''| for spacing h) widens the margin.
+            const uint32_t e = lane >> 4;
+            const float s_ = (float)(lane & 15u) * (1.0f / 15.0f);
+            const float bu = e == 0 ? fmaf(s_, u1 - u0, u0) : e == 1 ? u1 : e == 2 ? fmaf(s_, u1 - u0, u0) : u0;
+            const float bv = e == 0 ? v0 : e == 1 ? fmaf(s_, v1 - v0, v0) : e == 2 ? v1 : fmaf(s_, v1 - v0, v0);
+            float du, dv;
+            lens_delta(V.lens, bu, bv, du, dv);
+            float lu0 = bu + du, lu1 = lu0, lv0 = bv + dv, lv1 = lv0;
+            // Jacobian of D at the sample, analytically
+            const float k1 = V.lens[0], k2 = V.lens[1], p1 = V.lens[2], p2 = V.lens[3];
+            const float r2 = bu * bu + bv * bv;
+            const float rad = k1 * r2 + k2 * r2 * r2, drad = 2.f * k1 + 4.f * k2 * r2;            // d rad / d (r^2) * 2
+            const float jxx = 1.f + rad + bu * bu * drad + 2.f * p1 * bv + 6.f * p2 * bu;
+            const float jxy = bu * bv * drad + 2.f * p1 * bu + 2.f * p2 * bv;
+            const float jyy = 1.f + rad + bv * bv * drad + 2.f * p2 * bu + 6.f * p1 * bv;
+            float detmin = jxx * jyy - jxy * jxy;
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+                lu0 = fminf(lu0, __shfl_xor(lu0, m)); lu1 = fmaxf(lu1, __shfl_xor(lu1, m));
+                lv0 = fminf(lv0, __shfl_xor(lv0, m)); lv1 = fmaxf(lv1, __shfl_xor(lv1, m));
+                detmin = fminf(detmin, __shfl_xor(detmin, m));
+            }
+            const float R = sqrtf(fmaxf(u0 * u0, u1 * u1) + fmaxf(v0 * v0, v1 * v1));
+            const float d2max = 6.f * fabsf(k1) * R + 20.f * fabsf(k2) * R * R * R + 6.f * (fabsf(p1) + fabsf(p2));
+            const float h = fmaxf(u1 - u0, v1 - v0) * (1.0f / 15.0f);
+            margin += h * h * 0.125f * d2max * fmaxf(V.focal[0], V.focal[1]);
+            ok = ok && detmin > 0.1f && margin < 1e6f;                      // false for NaN too
+            u0 = lu0; u1 = lu1; v0 = lv0; v1 = lv1;
+        }
         if (ok) {
-            x0 = max(x0, (int)floorf(fmaxf(pxmin, -4.f)) - 2);
-            y0 = max(y0, (int)floorf(fmaxf(pymin, -4.f)) - 2);
-            x1 = min(x1, (int)ceilf(fminf(pxmax, (float)V.W + 4.f)) + 2);
-            y1 = min(y1, (int)ceilf(fminf(pymax, (float)V.H + 4.f)) + 2);
+            // pixel whose centre has the sensor position (u, v): c W + u f - 0.5
+            const float pxmin = fmaf(u0, V.focal[0], V.center[0] * (float)V.W) - 0.5f, pxmax = fmaf(u1, V.focal[0], V.center[0] * (float)V.W) - 0.5f;
+            const float pymin = fmaf(v0, V.focal[1], V.center[1] * (float)V.H) - 0.5f, pymax = fmaf(v1, V.focal[1], V.center[1] * (float)V.H) - 0.5f;
+            const int mg = (int)ceilf(margin);
+            x0 = max(x0, (int)floorf(fmaxf(pxmin, -4.f)) - mg);
+            y0 = max(y0, (int)floorf(fmaxf(pymin, -4.f)) - mg);
+            x1 = min(x1, (int)ceilf(fminf(pxmax, (float)V.W + 4.f)) + mg);
+            y1 = min(y1, (int)ceilf(fminf(pymax, (float)V.H + 4.f)) + mg);
         }
     }
     if (x0 > x1 || y0 > y1) {                                               // the box is off screen
@@ -1423,6 +1528,9 @@ ViewParams d2r_view_params(const d2r_view *v)
     for (int i = 0; i < 4; i++) V.background[i] = v->background[i];
     V.min_transmittance = v->min_transmittance;
     V.near_distance = v->near_distance;
+    V.lens_mode = v->lens_mode;
+    for (int i = 0; i < 4; i++) V.lens[i] = v->lens_mode ? v->lens_params[i] : 0.f;
+    V.lens_tab = nullptr;           // d2r_launch_render attaches the view's table
     return V;
 }
 
@@ -1450,13 +1558,52 @@ int d2r_launch_cameras_virtual(d2r_ctx *ctx, const ViewParams &V, const float *o
 }
 
 // counters layout: [0] queue count, [1] queue head, [2..3] 64-bit sample counter
-int d2r_launch_render(d2r_ctx *ctx, const d2r_nerf *m, const ViewParams &V, const float *cams_dev, uint32_t n,
+// the [H][W] table of undistorted camera-space directions of a view with a lens: rebuilt only when the view's size, intrinsics
+// or coefficients change (once per task in the path), then synchronised so that any stream of the context may read it
+int d2r_lens_table(d2r_ctx *ctx, ViewParams &V)
+{
+    V.lens_tab = nullptr;
+    if (V.lens_mode != D2R_LENS_OPENCV) return D2R_OK;
+    const float key[10] = {(float)V.W, (float)V.H, V.focal[0], V.focal[1], V.center[0], V.center[1], V.lens[0], V.lens[1], V.lens[2], V.lens[3]};
+    const size_t px = (size_t)V.W * V.H;
+    if (!ctx->lens_tab.p || !ctx->lens_key_valid || memcmp(key, ctx->lens_key, sizeof key) != 0) {
+        ctx->lens_key_valid = false;
+        int rc = d2r_reserve(ctx, ctx->lens_tab, px * sizeof(float2));
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_lens_table, dim3((uint32_t)((px + 255) / 256)), dim3(256), 0, ctx->stream, V, (float2 *)ctx->lens_tab.p);
+        D2R_HIP(ctx, hipGetLastError());
+        D2R_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        memcpy(ctx->lens_key, key, sizeof key);
+        ctx->lens_key_valid = true;
+    }
+    V.lens_tab = (const float2 *)ctx->lens_tab.p;
+    return D2R_OK;
+}
+
+// Every workspace a render pass over `rays` rays (worst case: every pixel of every candidate a ray) takes: the ray queue, and with
+// the ray sort its second copy and the per-chunk bin counts.  render_score_core calls this ONCE before its chunk loop (ADVICE r05:
+// a lazy reservation inside the loop ran under the stream swap of the overlapped pipeline), the single-pass entry points per launch.
+int d2r_reserve_render(d2r_ctx *ctx, size_t rays)
+{
+    int rc;
+    if ((rc = d2r_reserve(ctx, ctx->queue, rays * sizeof(uint2)))) return rc;
+    if (ctx->ray_sort) {
+        const size_t max_chunks = (rays + D2R_SORT_CHUNK - 1) / D2R_SORT_CHUNK;
+        if ((rc = d2r_reserve(ctx, ctx->queue2, rays * sizeof(uint2)))) return rc;
+        if ((rc = d2r_reserve(ctx, ctx->sort_counts, (max_chunks + 2) * D2R_SORT_BINS * 4))) return rc;
+    }
+    return D2R_OK;
+}
+
+int d2r_launch_render(d2r_ctx *ctx, const d2r_nerf *m, const ViewParams &V_in, const float *cams_dev, uint32_t n,
                       bool composite, float *rgba_dev, float *depth_dev, uint8_t *frames_dev, void *rects_dev)
 {
+    ViewParams V = V_in;
     const size_t rays = (size_t)n * V.W * V.H;
     if (rays >= (1ull << 32)) return d2r_fail(ctx, D2R_ERR_INVALID, "too many rays in one pass");
     int rc;
-    if ((rc = d2r_reserve(ctx, ctx->queue, rays * sizeof(uint2)))) return rc;
+    if ((rc = d2r_lens_table(ctx, V))) return rc;
+    if ((rc = d2r_reserve_render(ctx, rays))) return rc;      // no-op when the caller sized the pass up front (render_score_core)
     if ((rc = d2r_reserve(ctx, ctx->counters, 64))) return rc;
     uint32_t *cnt = (uint32_t *)ctx->counters.p;
     D2R_HIP(ctx, hipMemsetAsync(cnt, 0, 32, ctx->stream));
@@ -1491,12 +1638,12 @@ int d2r_launch_render(d2r_ctx *ctx, const d2r_nerf *m, const ViewParams &V, cons
             hipLaunchKernelGGL(k_raygen<false>, dim3(tiles, n), dim3(256), 0, ctx->stream, PR, V, cams_dev, (uint2 *)ctx->queue.p,
                                cnt, composite ? nullptr : rgba_dev, composite ? nullptr : depth_dev);
     }
+    ctx->timing_end(tr);
     const uint2 *q = (const uint2 *)ctx->queue.p;
     if (sort_log2) {
+        size_t ts = ctx->timing_begin(D2R_T_SORT);
         // counts: [bins][chunks] + [bins] bin totals + [bins] bin bases, sized for the worst case (every pixel of every candidate a ray)
-        const size_t max_chunks = (rays + D2R_SORT_CHUNK - 1) / D2R_SORT_CHUNK;
-        if ((rc = d2r_reserve(ctx, ctx->queue2, rays * sizeof(uint2)))) return rc;
-        if ((rc = d2r_reserve(ctx, ctx->sort_counts, (max_chunks + 2) * D2R_SORT_BINS * 4))) return rc;
+        const size_t max_chunks = (rays + D2R_SORT_CHUNK - 1) / D2R_SORT_CHUNK;        // (reserved by d2r_reserve_render above)
         uint32_t *counts = (uint32_t *)ctx->sort_counts.p, *bin_total = counts + max_chunks * D2R_SORT_BINS, *bin_base = bin_total + D2R_SORT_BINS;
         const int sb = (int)std::min<size_t>(max_chunks, 4096);
         hipLaunchKernelGGL(k_sort_count, dim3(sb), dim3(256), 0, ctx->stream, q, cnt, counts);
@@ -1504,8 +1651,8 @@ int d2r_launch_render(d2r_ctx *ctx, const d2r_nerf *m, const ViewParams &V, cons
         hipLaunchKernelGGL(k_sort_scan_bins, dim3(1), dim3(256), 0, ctx->stream, bin_total, bin_base);
         hipLaunchKernelGGL(k_sort_scatter, dim3(sb), dim3(256), 0, ctx->stream, q, cnt, counts, bin_base, (uint2 *)ctx->queue2.p);
         q = (const uint2 *)ctx->queue2.p;
+        ctx->timing_end(ts);
     }
-    ctx->timing_end(tr);
     size_t tm = ctx->timing_begin(D2R_T_MARCH);
     int blocks = ctx->march_blocks > 0 ? (int)ctx->march_blocks : ctx->n_cu;     // persistent: one per CU
     const float *bgd = (const float *)ctx->bg_depth.p;

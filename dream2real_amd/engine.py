@@ -16,7 +16,7 @@ import numpy as np
 
 from . import _lib
 from .clip_model import pack_text_weights, pack_vision_weights
-from .scene import NerfModel, View
+from .scene import LENS_OPENCV, LENS_PERSPECTIVE, NerfModel, View
 
 Shade = "Shade"     # pyngp.Shade
 Depth = "Depth"     # pyngp.Depth
@@ -101,6 +101,14 @@ class Context:
         v = _lib.view_c(view)
         self.check(self.lib.d2r_set_background(self.h, C.byref(v), _lib.ptr(a), _lib.ptr(d)))
 
+    def lens_undistort_view(self, view: View) -> np.ndarray:
+        """[h, w, 2]: the undistorted camera-space direction (x, y; z = 1) of every pixel centre of a view with a lens
+        (parity hook, d2r_lens_undistort_view)."""
+        out = np.empty((view.height, view.width, 2), np.float32)
+        v = _lib.view_c(view)
+        self.check(self.lib.d2r_lens_undistort_view(self.h, C.byref(v), _lib.ptr(out)))
+        return out
+
     def rectify_background_depth(self, depth, mask, width: int, height: int, return_mask: bool = False):
         """Sensor depth [sh, sw] (fp16 or fp32 metres) and movable mask [sh, sw] (bool / uint8, or None) of a render
         view -> background depth [height, width] float32: centre crop, cv2.INTER_CUBIC resize, 100 where the resized
@@ -122,17 +130,22 @@ class Context:
 
 
 class _Nerf:
-    """`testbed.nerf` namespace (render_min_transmittance lives there in pyngp)."""
+    """`testbed.nerf` namespace of pyngp: render_min_transmittance, and the render lens — `render_with_lens_distortion`
+    (False on a fresh Testbed; reference reconstruction/train_ngp.py:70 sets it by hand, set_camera_to_training_view sets it
+    for every frame the path renders) and `render_lens` (dict(mode=0 | 1, params=(k1, k2, p1, p2)))."""
 
     def __init__(self):
         self.render_min_transmittance = 0.01
+        self.render_with_lens_distortion = False
+        self.render_lens = dict(mode=LENS_PERSPECTIVE, params=(0.0, 0.0, 0.0, 0.0))
 
 
 class Testbed:
     """The slice of pyngp.Testbed that Dream2Real's render path touches, backed by libd2r.
 
     `training_views` is the per-view metadata a snapshot carries (intrinsics at the training
-    resolution); `dataset_scale` / `dataset_offset` are the values nerf_matrix_to_ngp uses.
+    resolution, and optionally `lens=(k1, k2, p1, p2)`: the OpenCV coefficients of the transforms the
+    model was trained from); `dataset_scale` / `dataset_offset` are the values nerf_matrix_to_ngp uses.
     """
 
     def __init__(self, ctx: Context, model: NerfModel, training_views=None, dataset_scale: float = 1.0,
@@ -188,12 +201,14 @@ class Testbed:
         views = (_lib.IngpView * cap)()
         ctx.check(ctx.lib.d2r_nerf_load_ingp(ctx.h, _lib.ptr(buf), C.c_size_t(buf.size), C.byref(h), C.byref(info), views,
                                              C.c_uint32(cap)))
-        tv = [dict(fx=float(v.fx), fy=float(v.fy), cx=float(v.cx), cy=float(v.cy), w=int(v.w), h=int(v.h))
+        tv = [dict(fx=float(v.fx), fy=float(v.fy), cx=float(v.cx), cy=float(v.cy), w=int(v.w), h=int(v.h),
+                   lens=tuple(float(x) for x in v.lens_params) if v.lens_mode == LENS_OPENCV else None)
               for v in views[: info.n_views_written]]
         tb = cls.__new__(cls)
         tb.ctx, tb.model, tb._keep, tb.h = ctx, None, {}, h
         tb._init_state(tv or None, float(info.dataset_scale), tuple(float(x) for x in info.dataset_offset))
         tb.snapshot_unknown_keys = int(info.n_unknown_keys)
+        tb.nerf.render_with_lens_distortion = bool(info.render_with_lens_distortion)
         if info.n_unknown_keys:
             import warnings
             warnings.warn(f"{path}: {info.n_unknown_keys} key(s) this loader does not know (neither read, checked nor known to be "
@@ -215,17 +230,27 @@ class Testbed:
 
     # --- pyngp.Testbed surface -------------------------------------------------
     def set_camera_to_training_view(self, idx: int):
+        """pyngp semantics (reference call sites reconstruction/combined_rendering.py:98,116): the view's intrinsics become
+        the render intrinsics AND its lens becomes the render lens with `nerf.render_with_lens_distortion` switched on —
+        the reference's frames are rendered through the OpenCV distortion its configs carry (configs/shopping_demo.json:51-56).
+        Setting `nerf.render_with_lens_distortion = False` afterwards renders the same view as a pinhole."""
         self._view_idx = int(idx) % len(self.training_views)
+        lens = self.training_views[self._view_idx].get("lens")
+        self.nerf.render_with_lens_distortion = True
+        self.nerf.render_lens = (dict(mode=LENS_OPENCV, params=tuple(float(x) for x in lens)) if lens is not None and any(lens)
+                                 else dict(mode=LENS_PERSPECTIVE, params=(0.0, 0.0, 0.0, 0.0)))
 
     def set_nerf_camera_matrix(self, m):
         self._cam = np.ascontiguousarray(np.asarray(m, np.float64)[:3, :4], np.float32)
 
     def view(self, width: int, height: int) -> View:
         tv = self.training_views[self._view_idx]
+        lens = self.nerf.render_lens if self.nerf.render_with_lens_distortion else dict(mode=LENS_PERSPECTIVE, params=(0.0,) * 4)
         return View.from_training_view(width, height, tv["fx"], tv["fy"], tv["cx"], tv["cy"], tv["w"], tv["h"],
                                        scale=self.dataset_scale, offset=self.dataset_offset,
                                        background=tuple(self.background_color),
-                                       min_transmittance=self.nerf.render_min_transmittance)
+                                       min_transmittance=self.nerf.render_min_transmittance,
+                                       lens_mode=int(lens["mode"]), lens_params=tuple(lens["params"]))
 
     def render(self, width: int, height: int, spp: int = 1, linear: bool = True) -> np.ndarray:
         """float32 [h,w,4]; Shade -> premultiplied linear RGBA, Depth -> depth in every colour

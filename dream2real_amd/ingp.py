@@ -136,7 +136,9 @@ def load_ingp(path: str):
         w, h = md["resolution"]
         fx, fy = md["focal_length"]
         cx, cy = md["principal_point"]
-        views.append(dict(fx=float(fx), fy=float(fy), cx=float(cx) * w, cy=float(cy) * h, w=int(w), h=int(h)))
+        ln = md.get("lens") or {}
+        lens = tuple(float(ln[k]) for k in ("k1", "k2", "p1", "p2")) if all(k in ln for k in ("k1", "k2", "p1", "p2")) and "k3" not in ln else None
+        views.append(dict(fx=float(fx), fy=float(fy), cx=float(cx) * w, cy=float(cy) * h, w=int(w), h=int(h), lens=lens))
     info = dict(training_views=views, dataset_scale=float(ds.get("scale", 1.0)),
                 dataset_offset=tuple(ds.get("offset", (0.5, 0.5, 0.5))), aabb_scale=aabb_scale,
                 background_color=snap.get("background_color"), training_step=snap.get("training_step"))

@@ -20,6 +20,10 @@ from typing import Optional
 import numpy as np
 
 GRID = 128          # occupancy grid side (instant-ngp NERF_GRIDSIZE)
+LENS_PERSPECTIVE, LENS_OPENCV = 0, 1      # d2r.h D2R_LENS_*
+# the OpenCV coefficients (k1, k2, p1, p2) every demo config of the reference writes into the transforms its NeRFs are
+# trained from (configs/shopping_demo.json:51-56, shelf_demo.json:51-56; reconstruction/train_ngp.py:171-180)
+DEMO_LENS = (0.096692, -0.166479, -0.000194, 0.002049)
 DT = np.float32(math.sqrt(3.0) / 1024.0)   # constant march step at aabb_scale 1
 
 
@@ -110,6 +114,10 @@ class View:
     background: tuple = (0.0, 0.0, 0.0, 1.0)
     min_transmittance: float = 0.01
     near_distance: float = 0.0
+    # the render lens set_camera_to_training_view leaves behind (nerf.render_with_lens_distortion + nerf.render_lens):
+    # 0 = perspective, 1 = OpenCV (k1, k2, p1, p2) — every ray's camera-space direction is undistorted iteratively
+    lens_mode: int = 0
+    lens_params: tuple = (0.0, 0.0, 0.0, 0.0)
 
     @staticmethod
     def from_training_view(width: int, height: int, fx: float = 924.66912, fy: float = 926.49735,

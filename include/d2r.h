@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 #define D2R_API __attribute__((visibility("default")))
-#define D2R_ABI_VERSION 8
+#define D2R_ABI_VERSION 9
 
 typedef enum {
     D2R_OK = 0,
@@ -95,15 +95,27 @@ D2R_API void d2r_nerf_destroy(d2r_nerf *m);
  * reconstruction/ngp_visual_model.py:24-28): zlib/gzip msgpack -> level table, fp16 tables and MLPs, occupancy
  * bitfield (instant-ngp's threshold rule and cascade max-pool), render_aabb -> d2r_nerf_create.  `info` / `views`
  * (optional) receive what a Testbed keeps beside the model: dataset scale/offset for nerf_matrix_to_ngp, the saved
- * background colour, per-training-view intrinsics for set_camera_to_training_view.
+ * background colour, per-training-view intrinsics AND lens for set_camera_to_training_view.
  * The layout is the BELIEVED one (no instant-ngp file or source offline), so nothing is defaulted: every key the loader
  * needs must be there with the right msgpack kind and size (params_binary: fp16, density MLP | colour MLP | hash tables;
  * density_grid_binary: fp16 128^3 per cascade), every key that changes the rendered function must carry the value the
- * kernels implement (activations, interpolation, SH degree, exposure 0, no envmap / extra dims / lens distortion /
- * rotated crop box, cone angle tied to aabb_scale), unknown keys inside encoding / network / rgb_network / dir_encoding
+ * kernels implement (activations, interpolation, SH degree, exposure 0, no envmap / extra dims / rotated crop box, a
+ * perspective or OpenCV lens per view, cone angle tied to aabb_scale), unknown keys inside encoding / network / rgb_network / dir_encoding
  * are refused; each failure returns D2R_ERR_INVALID / D2R_ERR_UNSUPPORTED with a d2r_last_error message naming the key.
  */
-typedef struct { double fx, fy, cx, cy; uint32_t w, h; } d2r_ingp_view;   /* pixels at the training resolution */
+/* Lens of a training view (instant-ngp's Lens {mode, params}) as this path meets it.  The reference renders every frame after
+ * set_camera_to_training_view (reconstruction/combined_rendering.py:98,116), which switches
+ * nerf.render_with_lens_distortion on and makes the view's lens the render lens; its configs carry OpenCV coefficients
+ * (configs/shopping_demo.json:51-56 -> the transforms the NeRFs are trained from, reconstruction/train_ngp.py:171-180,
+ * utils/accio2ngp.py:47-56; train_ngp.py:70 sets the flag as well).  Other lens models (fisheye, f-theta, lat-long,
+ * equirectangular, orthographic) are refused by the loader with D2R_ERR_UNSUPPORTED naming the view. */
+enum { D2R_LENS_PERSPECTIVE = 0, D2R_LENS_OPENCV = 1 };
+typedef struct {
+    double fx, fy, cx, cy;   /* pixels at the training resolution */
+    uint32_t w, h;
+    uint32_t lens_mode;      /* D2R_LENS_*: metadata[].lens (no lens / an empty one = perspective) */
+    float lens_params[4];    /* OpenCV k1, k2, p1, p2 */
+} d2r_ingp_view;
 typedef struct {
     uint32_t n_levels, n_features, aabb_scale;
     int32_t has_background;
@@ -113,6 +125,8 @@ typedef struct {
     uint32_t n_views_written;    /* how many of them went into `views` (at most views_cap) */
     uint32_t n_unknown_keys;     /* keys of the snapshot the loader neither reads, checks nor knows to be irrelevant to
                                   * rendering (d2r_ingp_inspect lists them with a '?') */
+    int32_t render_with_lens_distortion;   /* snapshot.nerf.render_with_lens_distortion when the file carries it (else 0): the
+                                  * Testbed's flag BEFORE the first set_camera_to_training_view, which sets it to 1 (ABI 9) */
 } d2r_ingp_info;
 D2R_API int d2r_nerf_load_ingp(d2r_ctx *ctx, const void *bytes, size_t len, d2r_nerf **out, d2r_ingp_info *info,
                                d2r_ingp_view *views, uint32_t views_cap);
@@ -145,6 +159,13 @@ typedef struct {
     float background[4];     /* Testbed.background_color RGBA */
     float min_transmittance; /* 0.01 */
     float near_distance;     /* 0 */
+    /* ABI 9 — the render lens: what set_camera_to_training_view leaves in nerf.render_lens when
+     * nerf.render_with_lens_distortion is on (D2R_LENS_PERSPECTIVE otherwise).  With D2R_LENS_OPENCV every ray's camera-space
+     * direction (x, y, 1) goes through instant-ngp's iterative OpenCV undistortion (Newton steps on a central-difference
+     * Jacobian, at most 100, |step|^2 < 1e-10) before the camera rotation; the rectangle cull of the composite passes stays
+     * conservative under it (frames are bit-identical with "raygen_rect" 0 and 1). */
+    uint32_t lens_mode;
+    float lens_params[4];    /* k1, k2, p1, p2 */
 } d2r_view;
 
 /*
@@ -158,6 +179,11 @@ typedef struct {
 D2R_API int d2r_render(d2r_ctx *ctx, const d2r_nerf *model, const d2r_view *view,
                        const float *cams_nerf, uint32_t n, float *rgba_out, float *depth_out,
                        uint64_t *n_samples_out);
+
+/* Parity hook for the lens: the camera-space direction (x, y) — z = 1 — of every pixel centre of `view` after the iterative
+ * OpenCV undistortion, i.e. what the ray generators rotate by the camera matrix.  dirs_out: host [h][w][2].  The view must carry
+ * a lens (lens_mode D2R_LENS_OPENCV).  (ABI 9) */
+D2R_API int d2r_lens_undistort_view(d2r_ctx *ctx, const d2r_view *view, float *dirs_out);
 
 /* Field evaluation at arbitrary unit-cube points (parity hook for the hash-grid encode and
  * both MLPs): xyz, dirs host [n][3] (dirs unit length); out host [n][4] = sigma, r, g, b
@@ -396,6 +422,17 @@ typedef struct {
     double raygen_ms;  uint64_t raygen_launches;
     double prep_ms;    uint64_t prep_launches;
     double clip_ms;    uint64_t clip_launches;   /* one "launch" = one forward over a chunk */
+    /* ABI 9 */
+    double sort_ms;    uint64_t sort_launches;   /* the ray sort's passes (k_sort_*), one "launch" = one sort; NOT part of raygen_ms */
+    /* "timing" 2 only (an event pair per kernel launch: a few tenths of a per cent of a step, so not for timed regions): the
+     * vision tower's full-size products of the default schedule — LayerNorm-folded QKV, streamed attention, out-projection,
+     * fc1 (+ quick_gelu), fc2; layer 0's compact QKV under "l0_reuse", the class-token-only last block, row statistics, patch
+     * embedding and head are clip_ms minus these five */
+    double vit_qkv_ms;  uint64_t vit_qkv_launches;
+    double vit_attn_ms; uint64_t vit_attn_launches;
+    double vit_out_ms;  uint64_t vit_out_launches;
+    double vit_fc1_ms;  uint64_t vit_fc1_launches;
+    double vit_fc2_ms;  uint64_t vit_fc2_launches;
 } d2r_timing;
 D2R_API int d2r_get_timing(d2r_ctx *ctx, d2r_timing *out);
 
@@ -408,7 +445,7 @@ D2R_API int d2r_get_timing(d2r_ctx *ctx, d2r_timing *out);
  *     the object's occupied box a ray's first sample lies in — 2^"ray_sort_log2" (default 4, 1..4) cells per axis,
  *     Morton order: every candidate renders the same object, so the waves running at one time then read the same few
  *     regions of the level tables / bricks.  Same pixels; 0 marches the rays in generation order.
- * "march_threads" (default 0 = auto; else a multiple of 64 up to the compiled 768): threads per marcher
+ * "march_threads" (default 0 = auto; else a multiple of 64 up to the compiled 768 — larger values are refused): threads per marcher
  *     workgroup (one workgroup per CU).  Auto: 768 (three waves per SIMD); with "ray_sort" 0: 512 where the HBM
  *     bricks exceed "march_threads_auto_mib" (default 64) MiB — the unsorted marcher is bound by the L2-miss path
  *     there and fewer waves thrash less.  Read-only: "march_threads_used", "march_hbm_brick_bytes" (of the last march launch).
@@ -460,7 +497,10 @@ D2R_API int d2r_get_timing(d2r_ctx *ctx, d2r_timing *out);
  *     "fp8 MFMA ViT" BASELINE.json configs[4] names.  It is NOT within north_star's 1e-3 cosine of the fp32 reference (measured
  *     in tests/test_fp8.py and DESIGN.md section 7) — which is why it is off unless asked for.  Runs for models whose hidden and MLP sizes are
  *     multiples of 256 under "ln_fold" 4 (ViT-B/16, ViT-L/14: yes); any other model or residual mode stays in bf16.
- * "timing" (0/1): record HIP events per kernel group for d2r_get_timing.
+ * "debug_fail_chunk" (default -1 = off): fault injection for the error path of a chunked pass — the NEXT d2r_render_score /
+ *     d2r_render_score_host fails with D2R_ERR_DEVICE when it reaches this chunk index, exactly as if a launch of that chunk had
+ *     failed (streams joined, worker pool drained, context usable afterwards), and the hook disarms itself (one-shot).
+ * "timing" (0/1/2): record HIP events per kernel group for d2r_get_timing; 2 adds an event pair around every product of the vision tower.
  * Development builds of the library (make DEV=1) also know experiment switches — schedules that were measured no faster
  * and tile configurations kept for comparison; they are not part of this interface. */
 D2R_API int d2r_ctx_set_option(d2r_ctx *ctx, const char *key, int64_t value);

@@ -22,6 +22,12 @@
  *     That covers both model kinds: aabb_scale 1 (constant step, one occupancy
  *     grid) and aabb_scale 2 (configs/shelf_demo.json:62: two cascades, cone-angle
  *     stepping, positions normalised to the box).
+ *   - the training view's LENS (OpenCV k1, k2, p1, p2): set_camera_to_training_view (call sites
+ *     combined_rendering.py:98,116) switches nerf.render_with_lens_distortion on and copies the view's lens, and
+ *     every demo config carries non-zero coefficients (configs/shopping_demo.json:51-56, written into the
+ *     transforms the NeRFs are trained from: train_ngp.py:171-180, utils/accio2ngp.py:47-56; train_ngp.py:70).
+ *     instant-ngp's pixel_to_ray then undistorts (d_cam.x, d_cam.y) with a Newton iteration on central
+ *     differences before the camera rotation — restated in lens_undistort() below.  Unpinned like the rest.
  *   - rot90 + CLIP image preprocessing (PIL antialiased bicubic resize in
  *     fixed point, centre crop, rescale, normalise)
  *                                  clip_scoring.py:145,177 (HF CLIPImageProcessor,
@@ -77,7 +83,77 @@ typedef struct {
     float background[4];     /* Testbed.background_color RGBA */
     float min_transmittance; /* nerf.render_min_transmittance (0.01) */
     float near_distance;     /* 0 */
+    uint32_t lens_mode;      /* 0 = perspective (render_with_lens_distortion off, or a view without a lens); 1 = OpenCV */
+    float lens_params[4];    /* k1, k2, p1, p2 */
 } d2r_oracle_view;
+
+/* ------------------------------------------------------------------- lens */
+
+/* OpenCV radial-tangential model, the offset a pinhole direction (u, v, 1) is moved by on the sensor
+ * (instant-ngp opencv_lens_distortion_delta; params = k1, k2, p1, p2).  Every product and sum is its own
+ * float32 operation, left to right as written (the file is built with -ffp-contract=off). */
+static inline void lens_distortion_delta(const float *prm, float u, float v, float *du, float *dv)
+{
+    const float k1 = prm[0], k2 = prm[1], p1 = prm[2], p2 = prm[3];
+    const float u2 = u * u, uv = u * v, v2 = v * v;
+    const float r2 = u2 + v2;
+    const float radial = k1 * r2 + k2 * r2 * r2;
+    *du = u * radial + 2.0f * p1 * uv + p2 * (r2 + 2.0f * u2);
+    *dv = v * radial + 2.0f * p2 * uv + p1 * (r2 + 2.0f * v2);
+}
+
+/* instant-ngp iterative_lens_undistortion: solve x + delta(x) = x0 for the pinhole direction x of the pixel whose
+ * distorted direction is x0 — Newton steps with a central-difference Jacobian (relative step 1e-6, at least
+ * FLT_EPSILON), at most 100 of them, stopping once |step|^2 < 1e-10. */
+static inline void lens_undistort(const float *prm, float *u, float *v)
+{
+    const float eps = 1.1920928955078125e-07f;
+    const float x0 = *u, y0 = *v;
+    float x = x0, y = y0;
+    for (int it = 0; it < 100; it++) {
+        const float s0 = fmaxf(eps, fabsf(1e-6f * x));
+        const float s1 = fmaxf(eps, fabsf(1e-6f * y));
+        float dx, dy, bx0, by0, fx0, fy0, bx1, by1, fx1, fy1;
+        lens_distortion_delta(prm, x, y, &dx, &dy);
+        lens_distortion_delta(prm, x - s0, y, &bx0, &by0);
+        lens_distortion_delta(prm, x + s0, y, &fx0, &fy0);
+        lens_distortion_delta(prm, x, y - s1, &bx1, &by1);
+        lens_distortion_delta(prm, x, y + s1, &fx1, &fy1);
+        const float a = 1.0f + (fx0 - bx0) / (2.0f * s0);      /* d f_x / d x */
+        const float b = (fx1 - bx1) / (2.0f * s1);             /* d f_x / d y */
+        const float c = (fy0 - by0) / (2.0f * s0);             /* d f_y / d x */
+        const float d = 1.0f + (fy1 - by1) / (2.0f * s1);      /* d f_y / d y */
+        const float rx = x + dx - x0, ry = y + dy - y0;
+        const float inv_det = 1.0f / (a * d - b * c);
+        const float sx = (d * rx - b * ry) * inv_det;
+        const float sy = (a * ry - c * rx) * inv_det;
+        x -= sx;
+        y -= sy;
+        if (sx * sx + sy * sy < 1e-10f) break;
+    }
+    *u = x;
+    *v = y;
+}
+
+/* test hooks: n points (u, v) -> the distorted sensor position u + du, v + dv / the undistorted direction */
+D2R_ORACLE_API void d2r_oracle_lens_distort(const float *prm, const float *uv, uint32_t n, float *out)
+{
+    for (uint32_t i = 0; i < n; i++) {
+        float du, dv;
+        lens_distortion_delta(prm, uv[2 * i], uv[2 * i + 1], &du, &dv);
+        out[2 * i] = uv[2 * i] + du;
+        out[2 * i + 1] = uv[2 * i + 1] + dv;
+    }
+}
+D2R_ORACLE_API void d2r_oracle_lens_undistort(const float *prm, const float *uv, uint32_t n, float *out)
+{
+    for (uint32_t i = 0; i < n; i++) {
+        float u = uv[2 * i], v = uv[2 * i + 1];
+        lens_undistort(prm, &u, &v);
+        out[2 * i] = u;
+        out[2 * i + 1] = v;
+    }
+}
 
 /* ------------------------------------------------------------- fp helpers */
 
@@ -384,6 +460,7 @@ D2R_ORACLE_API void d2r_oracle_render(const d2r_oracle_nerf *m, const d2r_oracle
             float vv = ((float)py + 0.5f) / (float)H;
             float dc[3] = {(u - v->center[0]) * (float)W / v->focal[0],
                            (vv - v->center[1]) * (float)H / v->focal[1], 1.0f};
+            if (v->lens_mode == 1u) lens_undistort(v->lens_params, &dc[0], &dc[1]);
             float d[3], o[3];
             for (int i = 0; i < 3; i++) {
                 d[i] = fmaf(cam[i * 4 + 2], dc[2],

@@ -36,7 +36,7 @@ class _View(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("focal", C.c_float * 2),
                 ("center", C.c_float * 2), ("scale", C.c_float), ("offset", C.c_float * 3),
                 ("background", C.c_float * 4), ("min_transmittance", C.c_float),
-                ("near_distance", C.c_float)]
+                ("near_distance", C.c_float), ("lens_mode", C.c_uint32), ("lens_params", C.c_float * 4)]
 
 
 _lib = None
@@ -76,7 +76,8 @@ class OracleNerf:
 def _cview(view) -> _View:
     return _View(view.width, view.height, (C.c_float * 2)(*view.focal),
                  (C.c_float * 2)(*view.center), view.scale, (C.c_float * 3)(*view.offset),
-                 (C.c_float * 4)(*view.background), view.min_transmittance, view.near_distance)
+                 (C.c_float * 4)(*view.background), view.min_transmittance, view.near_distance,
+                 int(getattr(view, "lens_mode", 0)), (C.c_float * 4)(*getattr(view, "lens_params", (0.0,) * 4)))
 
 
 def nerf_matrix_to_ngp(m34, scale, offset) -> np.ndarray:
@@ -99,6 +100,24 @@ def render(model: OracleNerf, view, cam_nerf):
     lib().d2r_oracle_render(C.byref(model.c), C.byref(v), C.c_void_p(_ptr(cam)),
                             C.c_void_p(_ptr(rgba)), C.c_void_p(_ptr(depth)), C.byref(n))
     return rgba, depth, int(n.value)
+
+
+def lens_distort(params, uv) -> np.ndarray:
+    """[n,2] pinhole directions (u, v, 1) -> where the OpenCV lens (k1, k2, p1, p2) puts them on the sensor."""
+    p = np.ascontiguousarray(params, np.float32)
+    a = np.ascontiguousarray(uv, np.float32).reshape(-1, 2)
+    out = np.zeros_like(a)
+    lib().d2r_oracle_lens_distort(C.c_void_p(_ptr(p)), C.c_void_p(_ptr(a)), C.c_uint32(a.shape[0]), C.c_void_p(_ptr(out)))
+    return out
+
+
+def lens_undistort(params, uv) -> np.ndarray:
+    """instant-ngp's iterative undistortion of [n,2] sensor positions (the step pixel_to_ray runs on every ray)."""
+    p = np.ascontiguousarray(params, np.float32)
+    a = np.ascontiguousarray(uv, np.float32).reshape(-1, 2)
+    out = np.zeros_like(a)
+    lib().d2r_oracle_lens_undistort(C.c_void_p(_ptr(p)), C.c_void_p(_ptr(a)), C.c_uint32(a.shape[0]), C.c_void_p(_ptr(out)))
+    return out
 
 
 def cone_lattice(t0: float, n: int) -> np.ndarray:

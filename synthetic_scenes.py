@@ -14,7 +14,7 @@ from typing import Optional
 
 import numpy as np
 
-from dream2real_amd.scene import GRID, GridLevels, NerfModel, View, grid_levels, pack_bits, world_to_ngp
+from dream2real_amd.scene import DEMO_LENS, GRID, LENS_OPENCV, GridLevels, NerfModel, View, grid_levels, pack_bits, world_to_ngp
 
 
 def _xavier(rng: np.random.Generator, n_out: int, n_in: int) -> np.ndarray:
@@ -140,12 +140,39 @@ class SyntheticScene:
     obj_pose: np.ndarray          # T_WO_1, 4x4 world pose of the movable object now
     cam_poses: np.ndarray         # [V,4,4] opt_cam_poses (OpenCV convention)
     fg_background: tuple          # Testbed.background_color of the fg model
+    lens: Optional[tuple] = None  # OpenCV (k1, k2, p1, p2) of the training views (scene.DEMO_LENS = the reference's configs), None = pinhole
 
     def view(self, width: int, height: int) -> View:
+        """The view a Testbed of this scene renders with after set_camera_to_training_view(0)."""
+        if self.lens is not None and any(self.lens):
+            return View.from_training_view(width, height, lens_mode=LENS_OPENCV, lens_params=tuple(float(x) for x in self.lens))
         return View.from_training_view(width, height)
 
+    @property
+    def training_views(self):
+        """`training_views` of engine.Testbed for this scene: the RealSense intrinsics of configs/shopping_demo.json:49-60
+        and the scene's lens."""
+        return [dict(fx=924.66912, fy=926.49735, cx=654.51953, cy=355.18523, w=1280, h=720, lens=self.lens)]
 
-def make_scene(kind: str = "shopping") -> SyntheticScene:
+    def testbeds(self, ctx):
+        """(fg, bg) engine.Testbed of the scene, their camera set to training view 0 as the reference's renderer does before
+        every render (reconstruction/combined_rendering.py:98,116) — which also makes the view's lens the render lens."""
+        from dream2real_amd import engine
+        fg = engine.Testbed(ctx, self.fg, training_views=self.training_views)
+        bg = engine.Testbed(ctx, self.bg, training_views=self.training_views)
+        fg.background_color = list(self.fg_background)
+        for tb in (fg, bg):
+            tb.set_camera_to_training_view(0)
+        return fg, bg
+
+
+def make_scene(kind: str = "shopping", lens=None) -> SyntheticScene:
+    sc = _make_scene(kind)
+    sc.lens = tuple(lens) if lens is not None else None
+    return sc
+
+
+def _make_scene(kind: str = "shopping") -> SyntheticScene:
     """Seeded scenes of SURVEY.md §8(d).  kind: 'shopping' (apple-sized ellipsoid, scene
     type 3), 'pool_triangle' (2.8 cm sphere, scene type 0) or 'shelf' (aabb_scale 2 like
     configs/shelf_demo.json:62: two occupancy cascades, cone stepping; the object sits outside

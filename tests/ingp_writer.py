@@ -40,7 +40,9 @@ def save_ingp(path: str, model: NerfModel, training_views=None, dataset_scale: f
                 "n_images": len(views), "scale": dataset_scale, "offset": list(dataset_offset),
                 "aabb_scale": int(getattr(model, "aabb_scale", 1)),
                 "metadata": [{"resolution": [v["w"], v["h"]], "focal_length": [v["fx"], v["fy"]],
-                              "principal_point": [v["cx"] / v["w"], v["cy"] / v["h"]]} for v in views]}},
+                              "principal_point": [v["cx"] / v["w"], v["cy"] / v["h"]],
+                              "lens": (dict(zip(("k1", "k2", "p1", "p2"), [float(x) for x in v["lens"]])) if v.get("lens") is not None else {})}
+                             for v in views]}},
         },
     }
     with open(path, "wb") as f:

@@ -91,7 +91,7 @@ def test_bad_arguments_return_error_codes():
     assert lib.d2r_ctx_get_option(h, b"march_lds_slots", C.byref(v)) == 0 and v.value == 0      # no march launch on this context yet
     assert lib.d2r_ctx_get_option(h, b"no_such_option", C.byref(v)) == INVALID and "no_such_option" in msg()
     assert lib.d2r_ctx_get_option(h, b"chunk", None) == INVALID and lib.d2r_ctx_get_option(null, b"chunk", C.byref(v)) == INVALID
-    for key, bad in ((b"gbrick_slots", 9), (b"brick_slots_total", -1), (b"lds_slots_max", 6), (b"gbrick_max_mib", 513), (b"march_compact", 2), (b"refill_min", 65), (b"march_threads", 100), (b"march_threads", 2048), (b"ray_sort", 2), (b"ray_sort_log2", 5)):
+    for key, bad in ((b"gbrick_slots", 9), (b"brick_slots_total", -1), (b"lds_slots_max", 6), (b"gbrick_max_mib", 513), (b"march_compact", 2), (b"refill_min", 65), (b"march_threads", 100), (b"march_threads", 832), (b"march_threads", 2048), (b"ray_sort", 2), (b"ray_sort_log2", 5)):
         assert lib.d2r_ctx_set_option(h, key, C.c_int64(bad)) == INVALID, key
     # model creation: null descriptor, unsupported layout, bad aabb_scale
     assert lib.d2r_nerf_create(h, None, C.byref(out)) < 0

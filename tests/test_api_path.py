@@ -455,7 +455,7 @@ def test_failure_in_a_later_chunk_leaves_the_context_usable(tmp_path):
                 rend.render_score(poses, rp, [0], sc, text, save=True, return_frames=True)
             with pytest.raises(_lib.D2RError, match="needs a preceding d2r_render_score"):
                 ctx.render_stats(collect_K=len(poses))          # the failed pass's counters are not offered as statistics
-            ctx.set_option("debug_fail_chunk", -1)
+            assert ctx.get_option("debug_fail_chunk") == -1      # one-shot: the hook disarmed itself when it fired
             logits, frames = rend.render_score(poses, rp, [0], sc, text, save=True, return_frames=True)
             np.testing.assert_array_equal(frames, frames_ref)
             np.testing.assert_array_equal(logits, logits_ref)

@@ -215,7 +215,7 @@ def test_c_loader_names_the_key_it_refuses(tmp_path):
     def put(value, *keys):
         def fn(c):
             for k in keys[:-1]:
-                c = c.setdefault(k, {})
+                c = c[k] if isinstance(c, list) else c.setdefault(k, {})
             c[keys[-1]] = value
         return fn
 
@@ -256,7 +256,13 @@ def test_c_loader_names_the_key_it_refuses(tmp_path):
              "dir_encoding"), "dir_encoding.nested[1]"),
         (put([[0, 1, 0], [-1, 0, 0], [0, 0, 1]], "snapshot", "render_aabb_to_local"), "snapshot.render_aabb_to_local is not the identity"),
         (put(1.5, "snapshot", "exposure"), "snapshot.exposure = 1.5"),
-        (put(True, "snapshot", "nerf", "render_with_lens_distortion"), "render_with_lens_distortion"),
+        # lens models the path does not implement refuse the snapshot, naming the view (perspective and OpenCV are read)
+        (put({"k1": 0.1, "k2": 0.0, "k3": 0.01, "k4": 0.0}, "snapshot", "nerf", "dataset", "metadata", 0, "lens"), "metadata[0].lens is an OpenCV fisheye lens"),
+        (put({"latlong": True}, "snapshot", "nerf", "dataset", "metadata", 0, "lens"), "metadata[0].lens is a lat-long"),
+        (put({"ftheta_p0": 1.0, "w": 10, "h": 10}, "snapshot", "nerf", "dataset", "metadata", 0, "lens"), "metadata[0].lens is an f-theta lens"),
+        (put({"k1": 0.1, "k2": 0.0}, "snapshot", "nerf", "dataset", "metadata", 0, "lens"), "without all of k1, k2, p1, p2"),
+        (put({"k1": float("nan"), "k2": 0.0, "p1": 0.0, "p2": 0.0}, "snapshot", "nerf", "dataset", "metadata", 0, "lens"), "not finite"),
+        (put({"mode": 3, "params": [0.0] * 7}, "snapshot", "nerf", "dataset", "metadata", 0, "lens"), "mode other than perspective"),
         (put(True, "snapshot", "nerf", "dataset", "is_hdr"), "is_hdr"),
         (put(512, "snapshot", "nerf", "dataset", "envmap_resolution"), "envmap_resolution"),
         (put([0, 512], "snapshot", "nerf", "dataset", "envmap_resolution"), "envmap_resolution = [0, 512]"),
@@ -281,4 +287,11 @@ def test_c_loader_names_the_key_it_refuses(tmp_path):
                             # upstream writes ivec2 / bool fields where this reader once demanded a scalar 0
                             put([0, 0], "snapshot", "nerf", "dataset", "envmap_resolution")(c), put(False, "snapshot", "nerf", "dataset", "is_hdr")(c),
                             put(False, "snapshot", "nerf", "dataset", "from_mitsuba")(c), put(False, "snapshot", "nerf", "render_with_lens_distortion")(c)))
-    assert _lib.ingp_validate(ok).n_unknown_keys == 0
+    info = _lib.ingp_validate(ok)
+    assert info.n_unknown_keys == 0 and info.render_with_lens_distortion == 0
+    # the flag is read, not refused (round 6): the reference sets it (reconstruction/train_ngp.py:70) and every render goes through
+    # set_camera_to_training_view, which sets it anyway
+    on = mutated(lambda c: (put(True, "snapshot", "nerf", "render_with_lens_distortion")(c),
+                            put({"k1": 0.096692, "k2": -0.166479, "p1": -0.000194, "p2": 0.002049}, "snapshot", "nerf", "dataset", "metadata", 0, "lens")(c)))
+    info = _lib.ingp_validate(on)
+    assert info.n_unknown_keys == 0 and info.render_with_lens_distortion == 1
