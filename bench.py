@@ -58,9 +58,20 @@ def effective_cpus() -> int:
     return n
 
 
-# the CPU-baseline leg (oracle: OpenMP render + BLAS ViT) gets the CPUs the box really grants, unless the caller chose
+_ENV_AT_START = set(os.environ)       # thread-count variables the CALLER set are respected, the defaults below are not inherited by child ranks
+
+
+def rank_cpu_share() -> int:
+    """This rank's share of those CPUs when several ranks run on the node (one process per GPU): quota // LOCAL_WORLD_SIZE.  The
+    library's PNG / text workers size themselves the same way (csrc/pngio.cpp d2r_default_io_threads reads LOCAL_WORLD_SIZE)."""
+    lws = int(os.environ.get("D2R_LOCAL_WORLD_SIZE") or os.environ.get("LOCAL_WORLD_SIZE") or 1)
+    return max(1, effective_cpus() // max(1, lws))
+
+
+# the CPU-baseline leg (oracle: OpenMP render + BLAS ViT) gets the CPUs the box really grants — a rank of an N-GPU run its share of
+# them — unless the caller chose
 for _k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
-    os.environ.setdefault(_k, str(effective_cpus()))
+    os.environ.setdefault(_k, str(rank_cpu_share()))
 
 import numpy as np
 
@@ -240,7 +251,8 @@ def self_launch(n: int):
     # buffer registration fails with `hipIpcGetMemHandle: invalid argument`.  The image exports it already — this only
     # fills it in for an environment that was built without it, and never overrides a value the caller set.
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("OMP_NUM_THREADS", "8")
+    for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):       # each rank: its share of the CPU quota (set at import for n = 1)
+        env[k] = str(max(1, effective_cpus() // n)) if k not in _ENV_AT_START else env[k]
     if torch.cuda.device_count() < n:
         # fewer GPUs than ranks (a 1-GPU box): ranks share GPUs, which RCCL refuses -> gloo process group and
         # the torch fallback of the gather; the JSON line says so ("collective")
@@ -263,8 +275,8 @@ BASELINE_CONFIGS = {
             name="pool_triangle scene, 16384 candidate poses per GPU, 640x360 (hash-grid HBM-bound stress)"),
     3: dict(scene="shopping", sample_res=[128, 128, 8, 1, 1, 1], width=640, height=360, clip="vit_b16", scaling="strong",
             name="shopping scene, pose-shard over the GPUs, 131072 candidates, all-gather of scores"),
-    4: dict(scene="shelf", sample_res=[16, 16, 16, 4, 4, 4], width=640, height=360, clip="vit_l14", scaling="strong", partition=8, opts={"mlp_f16": 1},
-            name="shelf_demo 6-DoF, 262144 candidates, ViT-L/14 encoder, fp16 render as BASELINE words it (NeRF MLPs on the fp16 MFMA: option mlp_f16); "
+    4: dict(scene="shelf", sample_res=[16, 16, 16, 4, 4, 4], width=640, height=360, clip="vit_l14", scaling="strong", partition=8,
+            name="shelf_demo 6-DoF, 262144 candidates, ViT-L/14 encoder, fp16 render as BASELINE words it (NeRF MLPs on the fp16 MFMA: the library's default); "
                  "BASELINE's fp8 ViT is --vit-fp8 — outside the 1e-3 parity bar, so the tower runs in bf16 by default"),
 }
 
@@ -334,6 +346,88 @@ def report_failure(stage, err, device_index, code=1):
     print(txt, flush=True)
     print(txt, file=sys.stderr, flush=True)
     os._exit(code)
+
+
+def resolve_workload(args, world: int) -> dict:
+    """The workload `--config` / the individual flags name at `world` GPUs: scene, encoder, frame size, pose grid, scaling, partition."""
+    base = dict(BASELINE_CONFIGS[1 if args.config is None else args.config])
+    scaling = args.scaling or base["scaling"]
+    sample_res = list(base["sample_res"])
+    if args.sample_res:
+        sample_res = [int(x) for x in args.sample_res.split(",")]
+        assert len(sample_res) == 6, "--sample-res takes six numbers"
+    elif args.poses_total is not None or (args.scaling == "strong" and args.config is None):
+        total = args.poses_total or 131072
+        side = int(round(np.sqrt(total / 8)))
+        assert side * side * 8 == total, "--poses-total must be x*x*8"
+        sample_res, scaling = [side, side, 8, 1, 1, 1], "strong"
+    elif args.poses_per_gpu is not None:
+        side = int(round(np.sqrt(args.poses_per_gpu)))
+        assert side * side == args.poses_per_gpu, "--poses-per-gpu must be a square"
+        sample_res = [side, side, 1, 1, 1, 1]
+    if scaling == "weak":
+        assert sample_res[2] == 1, "weak scaling stacks one [x,y] sheet per GPU along z"
+        sample_res[2] = world
+    partition = max(world, args.slice_of if args.slice_of is not None else base.get("partition", 1)) if scaling == "strong" else world
+    assert partition % world == 0 or partition == world, "--slice-of must be a multiple of --gpus"
+    return dict(base=base, scene=args.scene or base["scene"], clip=args.clip or base["clip"], width=args.width or base["width"],
+                height=args.height or base["height"], scaling=scaling, sample_res=sample_res, partition=partition)
+
+
+def device_workspace_estimate(chunk: int, W: int, H: int, cfg: dict, ray_sort: bool = True) -> dict:
+    """HBM a rank's passes take beyond models and weights, from the sizes the library reserves (api.hip render_score_core, nerf.hip
+    d2r_reserve_render, clip.hip): worst-case ray queue(s), frames, patches, and the vision tower's activations.  An ESTIMATE for
+    planning (the measured figure of a real run is `hbm_footprint` in its line); everything scales with the pass size, nothing
+    with the number of ranks — a rank of an 8-GPU run holds exactly what the 1-GPU run holds."""
+    px, P, d, mlp = W * H, cfg["patch_size"], cfg["hidden_size"], cfg["mlp"]
+    T = (cfg["image_size"] // P) ** 2 + 1
+    rows = -(-chunk * T // 256) * 256
+    rays = chunk * px
+    queue = rays * 8
+    out = {"ray_queue": queue, "ray_queue_sorted": queue if ray_sort else 0,
+           "sort_counts": ((-(-rays // 16384)) + 2) * 4096 * 4 if ray_sort else 0,
+           "frames_u8": chunk * px * 3, "patches_bf16": chunk * (T - 1) * (-(-3 * P * P // 64) * 64) * 2,
+           # residual hi + lo byte + operand copy, q / k / v, attention output, the MLP's hidden activations, fp32 patch embedding, row statistics
+           "vit_activations": rows * (d * 2 + d + d * 2 + 3 * d * 2 + d * 2 + mlp * 2 + d * 4 + 64)}
+    out["total"] = int(sum(out.values()))
+    return out
+
+
+def run_plan(args, wd):
+    """--plan: what every rank of this run WOULD do, worked out without touching a GPU (runs on a CPU box under gloo): the device
+    it would take (LOCAL_RANK, as run_kernel_bench does), its contiguous pose shard, passes per step, device workspaces, CPU threads.
+    Rank 0 prints the gathered plan as one JSON line."""
+    import torch
+    from dream2real_amd import dist as d2r_dist
+    from dream2real_amd.clip_model import CLIP_CONFIGS
+    wd.stage("rendezvous (torch.distributed.init_process_group)", 300)
+    rank, world, local = d2r_dist.init_from_env("gloo" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    wl = resolve_workload(args, world)
+    plan = shard_plan(wl["sample_res"], world, wl["partition"])
+    mine = plan["shards"][rank]
+    n_dev = torch.cuda.device_count()
+    chunk = min(args.chunk, max(1, len(mine)))
+    cfg = CLIP_CONFIGS[wl["clip"]]
+    ws = device_workspace_estimate(chunk, wl["width"], wl["height"], cfg)
+    entry = {"rank": rank, "local_rank": local, "device": local % n_dev if n_dev else local, "devices_visible": n_dev,
+             "poses": int(len(mine)), "first_pose": int(mine[0]) if len(mine) else None, "last_pose": int(mine[-1]) if len(mine) else None,
+             "passes_per_step": -(-len(mine) // chunk), "chunk": chunk, "workspace_bytes": ws,
+             "cpu_threads": {"omp": int(os.environ.get("OMP_NUM_THREADS", "0")), "share_of_quota": rank_cpu_share(), "quota": effective_cpus(),
+                             "local_world": int(os.environ.get("LOCAL_WORLD_SIZE", "1"))},
+             "collective": "none" if world == 1 else f"one all-gather of {plan['n_run']} x 2 fp32 logits = {plan['n_run'] * 8} bytes per step (d2r_allgather_scores)"}
+    entries = [entry]
+    if world > 1:
+        entries = [None] * world
+        torch.distributed.all_gather_object(entries, entry)
+    wd.done()
+    if rank == 0:
+        print(json.dumps({"plan": entries, "n_gpus": world, "scaling": wl["scaling"], "sample_res": wl["sample_res"], "poses_total": int(np.prod(wl["sample_res"])),
+                          "poses_per_step": plan["n_run"], "scene": wl["scene"], "clip": wl["clip"], "width": wl["width"], "height": wl["height"],
+                          "partition": wl["partition"]}), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
 
 
 def run_dry_collective(args, wd):
@@ -762,6 +856,9 @@ def main():
     ap.add_argument("--render-view", type=int, default=0, help="--data-dir: render_cam_pose_idx[0]")
     ap.add_argument("--obj-pose", default=None, help="--data-dir: 4x4 txt of the movable object's pose (default <data-dir>/obj_pose.txt)")
     ap.add_argument("--check-only", action="store_true", help="--data-dir: load and validate every input on the host, print what was found, touch no GPU")
+    ap.add_argument("--plan", action="store_true",
+                    help="NO GPU NEEDED: every rank works out what it would do in this run (device it would take, its pose shard, launches per step, "
+                         "device workspaces, CPU threads) and rank 0 prints the gathered plan as one JSON line — the N-GPU run checked on a CPU box")
     ap.add_argument("--dry-collective", action="store_true",
                     help="only rendezvous + communicator init + one 1 MiB all-gather + argmax agreement (diagnoses a failed --gpus N run)")
     args = ap.parse_args()
@@ -771,6 +868,8 @@ def main():
         self_launch(args.gpus)
     wd = Watchdog()
     try:
+        if args.plan:
+            return run_plan(args, wd)
         if args.dry_collective:
             return run_dry_collective(args, wd)
         if args.api and args.data_dir:
@@ -809,35 +908,16 @@ def run_kernel_bench(args, wd):
     dev = torch.device("cuda", local)
 
     # ---------------- which workload
-    base = dict(BASELINE_CONFIGS[1 if args.config is None else args.config])
-    scene_name = args.scene or base["scene"]
-    clip_name = args.clip or base["clip"]
-    W, H = args.width or base["width"], args.height or base["height"]
-    scaling = args.scaling or base["scaling"]
-    sample_res = list(base["sample_res"])
-    if args.sample_res:
-        sample_res = [int(x) for x in args.sample_res.split(",")]
-        assert len(sample_res) == 6, "--sample-res takes six numbers"
-    elif args.poses_total is not None or (args.scaling == "strong" and args.config is None):
-        total = args.poses_total or 131072
-        side = int(round(np.sqrt(total / 8)))
-        assert side * side * 8 == total, "--poses-total must be x*x*8"
-        sample_res, scaling = [side, side, 8, 1, 1, 1], "strong"
-    elif args.poses_per_gpu is not None:
-        side = int(round(np.sqrt(args.poses_per_gpu)))
-        assert side * side == args.poses_per_gpu, "--poses-per-gpu must be a square"
-        sample_res = [side, side, 1, 1, 1, 1]
-    if scaling == "weak":
-        assert sample_res[2] == 1, "weak scaling stacks one [x,y] sheet per GPU along z"
-        sample_res[2] = world
-    partition = max(world, args.slice_of if args.slice_of is not None else base.get("partition", 1)) if scaling == "strong" else world
-    assert partition % world == 0 or partition == world, "--slice-of must be a multiple of --gpus"
+    wl = resolve_workload(args, world)
+    base, scene_name, clip_name, W, H = wl["base"], wl["scene"], wl["clip"], wl["width"], wl["height"]
+    scaling, sample_res, partition = wl["scaling"], wl["sample_res"], wl["partition"]
 
     # ---------------- setup (untimed): scene, models, background, poses in HBM
     from dream2real_amd.scene import DEMO_LENS
     scene = make_scene(scene_name, lens=DEMO_LENS if args.lens == "demo" else None)
     cfg = CLIP_CONFIGS[clip_name]
     sd = random_clip_state_dict(cfg, seed=6)
+    hbm_free0, hbm_total = torch.cuda.mem_get_info(dev)      # before the library allocates anything: the run's HBM footprint is the difference
     ctx = engine.Context(local)
     ctx.set_option("chunk", args.chunk)
     for k, v in base.get("opts", {}).items():          # what the configuration itself names (configs[4]: fp16 render)
@@ -1012,7 +1092,8 @@ def run_kernel_bench(args, wd):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None,
-            "dtype": ("fp8 e4m3 Linear products (fp32 accumulate) in the ViT, bf16 elsewhere" if vit_fp8 else "bf16") + (" + fp16 NeRF MLPs (mlp_f16: the configuration's \"fp16 render\")" if mlp_f16 else ""),
+            "dtype": ("fp8 e4m3 Linear products (fp32 accumulate) in the ViT, bf16 elsewhere" if vit_fp8 else "bf16")
+                     + (" + fp16 NeRF MLP operands (fp32 accumulate; the library's default: the reference's tiny-cuda-nn operand type, same MFMA rate; --opt mlp_f16=0 = bf16 operands)" if mlp_f16 else " (NeRF MLPs too: --opt mlp_f16=0)"),
             "data": "synthetic", "ranks_seen": ranks_seen,
             "config": {"workload": f"{label} — ran: {what}",
                        "baseline_config": match[0] if match else None,
@@ -1065,9 +1146,13 @@ def run_kernel_bench(args, wd):
                               "NOT a roofline fraction: 10 of 16 levels come from LDS bricks and the rest hit L2 at 0.99, so it can exceed 1 (the ..._with_sort variant "
                               "charges the ray sort's passes, timed separately, to the launch).  What bounds the kernel: VALU issue (pmc.valu_busy) with the MLPs at "
                               "mlp_frac_of_mfma_peak of the bf16 MFMA peak; fabric_frac is what HBM / Infinity Fabric actually carries"},
-            "device_ms_per_step": {k.replace("_ms", ""): round(v / args.steps, 3) for k, v in timing.items() if k.endswith("_ms")},
+            "device_ms_per_step": {k.replace("_ms", ""): round(v / args.steps, 3) for k, v in timing.items() if k.endswith("_ms") and not k.startswith("vit_")},
             "render_stats_per_step": stats,
             "argmax_pose": best,
+            # what this rank holds in HBM after the timed steps (models, weights, every workspace; torch's own context included): the same on
+            # every rank of an N-GPU run, whose per-GPU work is this run's (`bench.py --plan` lists the terms)
+            "hbm_footprint": {"bytes": int(hbm_free0 - torch.cuda.mem_get_info(dev)[0]), "of": int(hbm_total),
+                              "workspace_estimate": device_workspace_estimate(per_launch, W, H, cfg, bool(ctx.get_option("ray_sort")))},
         }
         out["roofline_vit"] = out["roofline"]          # the name older readers look for: the same object
         if world == 1:

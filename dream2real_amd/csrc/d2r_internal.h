@@ -179,7 +179,7 @@ struct d2r_ctx {
     int64_t attn_rem = 1;          // attention: a remainder of at most this many query tiles (sequence = 8 g + r tiles) runs on workgroups of r waves instead of one more eight-wave group
     int64_t cls_last = 1;          // vision tower: run the last block on the class-token rows only (the head reads nothing else)
     int64_t gemm_cfg = 0;      // experiment switch for the GEMM tile configuration (0 = default)
-    int64_t mlp_f16 = 0;       // 1: the NeRF MLPs on the fp16 MFMA (the reference's own arithmetic; BASELINE.json configs[4]'s "fp16 render"); 0: bf16 (north_star)
+    int64_t mlp_f16 = 1;       // operand type of the NeRF MLPs' MFMAs: 1 (default since round 6) fp16 — the reference's operand type (tiny-cuda-nn), the snapshot's weights unrounded; 0 bf16 (north_star's wording).  Same MFMA rate; chosen by the distance table of tests/test_gpu_parity.py::test_render_distances_to_the_fp16_accumulation_emulation
     int64_t use_bricks = 1;
     int64_t raygen_rect = 1;   // composite mode: generate rays only inside the projected occupied bbox
     int64_t gbrick_slots = 8;  // at most this many slots use HBM bricks

@@ -38,10 +38,11 @@ union Frag {
     uint4 u;
 };
 
-// Operand type of the MLPs' MFMAs.  F16 = false: bf16 (north_star: "a small fused MLP as MFMA bf16 tiles"; the default).  F16 = true
-// (option "mlp_f16"): fp16 — the reference's OWN arithmetic (tiny-cuda-nn's fully fused MLPs are fp16, and BASELINE.json configs[4] names an
-// "fp16 render"): the snapshot's fp16 weights enter the MFMA exactly, features and activations keep 11 significant bits instead of 8,
-// v_mfma_f32_32x32x16_f16 runs at the bf16 rate.  Range: activations must stay below 65504, as in the reference.
+// Operand type of the MLPs' MFMAs, fp32 accumulation either way.  F16 = true (option "mlp_f16" 1, the default since round 6): fp16 — the
+// reference's OPERAND type (tiny-cuda-nn's fully fused MLPs hold weights and activations in __half; it also ACCUMULATES in half, which
+// nothing here does): the snapshot's fp16 weights enter the MFMA exactly, features and activations keep 11 significant bits,
+// v_mfma_f32_32x32x16_f16 runs at the bf16 rate.  Range: activations must stay below 65504, as in the reference.  F16 = false: bf16
+// operands (north_star: "a small fused MLP as MFMA bf16 tiles"), 8 significant bits.
 template <bool F16>
 __device__ __forceinline__ uint32_t pack2(float a, float b)
 {

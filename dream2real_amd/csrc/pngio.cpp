@@ -717,6 +717,14 @@ int d2r_default_io_threads()
         long long per = 0, dummy = 0;
         if (read2("/sys/fs/cgroup/cpu/cpu.cfs_period_us", per, dummy) && per > 0) n = std::min<unsigned>(n, (unsigned)std::max<long long>(1, q / per));
     }
+    // one process per GPU: the ranks of a node share those CPUs (torch.distributed.run exports LOCAL_WORLD_SIZE; D2R_LOCAL_WORLD_SIZE
+    // overrides it for other launchers) — eight ranks that each started the whole quota's worth of workers would throttle one another
+    for (const char *key : {"D2R_LOCAL_WORLD_SIZE", "LOCAL_WORLD_SIZE"})
+        if (const char *v = getenv(key)) {
+            const long long lws = atoll(v);
+            if (lws > 1) n = (unsigned)std::max<long long>(1, (long long)n / lws);
+            break;
+        }
     return (int)std::min(64u, std::max(1u, n));
 }
 

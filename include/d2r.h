@@ -459,9 +459,13 @@ D2R_API int d2r_get_timing(d2r_ctx *ctx, d2r_timing *out);
  *     Read at d2r_nerf_create / d2r_nerf_load_ingp time (set them BEFORE creating the model): "lds_slots_max" (default 5,
  *     0..5): at most this many leading slots as LDS bricks; "gbrick_max_mib" (default 512, 0..512): a slot gets an HBM brick
  *     only while that brick stays below this size (the bricks of a model total at most 512 MiB).
- * "mlp_f16" (default 0): operand type of the NeRF MLPs' MFMAs.  0 = bf16 (north_star).  1 = fp16: the reference's own arithmetic (tiny-cuda-nn's fully fused
- *     MLPs are fp16; BASELINE.json configs[4] names an "fp16 render") — the snapshot's fp16 weights enter the MFMA unrounded, features and activations keep
- *     11 significant bits instead of 8, same MFMA rate; activations must stay below 65504, as in the reference.
+ * "mlp_f16" (default 1 since round 6): operand type of the NeRF MLPs' MFMAs, fp32 accumulation either way, same MFMA rate.  1 = fp16: the
+ *     reference's operand type (tiny-cuda-nn's fully fused MLPs are __half; BASELINE.json configs[4] names an "fp16 render") — the
+ *     snapshot's fp16 weights enter the MFMA unrounded, features and activations keep 11 significant bits; activations must stay below
+ *     65504, as in the reference.  0 = bf16 (north_star's wording: 8 significant bits).  The default follows the measurement: against an
+ *     emulation of tiny-cuda-nn's half-accumulating arithmetic on a trained-like field the fp16-operand marcher sits where the fp32
+ *     specification sits (|dlog sigma| 0.032 vs 0.030, no object pixel off by more than one LSB), the bf16-operand one twice as far
+ *     (0.064, 9 % of the object's pixels) — DESIGN.md section 5.
  * "ln_fold" (default 4): schedule of the vision tower.  0: LayerNorm kernels between the GEMMs, fp32 residual
  *     stream.  1-3: LayerNorm folded into the QKV / fc1 GEMMs (LN(x) W^T + b = rstd (x (gamma o W)^T - mean
  *     colsum) + b'), row statistics emitted by the residual GEMMs' epilogues, which also write the bf16 operand

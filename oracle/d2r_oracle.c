@@ -183,6 +183,43 @@ static float half_to_float(uint16_t h)
     return f;
 }
 
+/* float -> IEEE half, round to nearest even (what a __half conversion / a half-precision result does), back as a float */
+static uint16_t float_to_half_bits(float f)
+{
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | (x > 0x7f800000u ? 0x200u : 0u));   /* inf / NaN */
+    if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);                                     /* rounds past 65504: inf */
+    if (x < 0x33000001u) return (uint16_t)sign;                                                  /* below half the smallest subnormal: 0 */
+    int e = (int)(x >> 23) - 127;
+    uint32_t man = (x & 0x7fffffu) | 0x800000u;
+    int shift = e < -14 ? 13 + (-14 - e) : 13;          /* bits dropped (subnormal halves drop more) */
+    uint32_t kept = man >> shift, rem = man & ((1u << shift) - 1u), half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (kept & 1u))) kept++;
+    uint32_t h = e < -14 ? kept : ((uint32_t)(e + 15) << 10) + (kept - 0x400u);   /* a mantissa carry runs into the exponent */
+    return (uint16_t)(sign | h);
+}
+static inline float rn16(float f) { return half_to_float(float_to_half_bits(f)); }
+
+/*
+ * Arithmetic of the field evaluation (d2r_oracle_set_arith):
+ *   0  the specification the HIP kernels are held to: fp16 parameters, everything else fp32.
+ *   1  an EMULATION of what tiny-cuda-nn's binary computes (requirements.txt:274 pins it; its fully fused MLPs and grid run in
+ *      __half): hash-grid corners accumulated in half (each (T)(w v) rounded, each add rounded), encodings stored as half, the
+ *      MLPs' products accumulated in a HALF accumulator (the wmma accumulator fragment is __half: one 16-wide k-step's sum of
+ *      exact products is added to it and rounded), activations rounded to half between layers, half network outputs.
+ *   2  the same with the grid's newer form: half fma(half(w), v, acc) per corner.
+ * Modes 1 / 2 are not a specification (NVIDIA's tensor cores do not document their internal summation order): they bound,
+ * from the noisier side, how far the real binary can sit from mode 0 — used only by the distance table of
+ * tests (test_render_distances_to_the_fp16_accumulation_emulation).
+ */
+static int d2r_oracle_arith = 0;
+D2R_ORACLE_API void d2r_oracle_set_arith(int mode) { d2r_oracle_arith = mode; }
+D2R_ORACLE_API int d2r_oracle_get_arith(void) { return d2r_oracle_arith; }
+D2R_ORACLE_API float d2r_oracle_round_half(float f) { return rn16(f); }
+
 static float srgb_to_linear(float x)
 {
     return x <= 0.04045f ? x / 12.92f : powf((x + 0.055f) / 1.055f, 2.4f);
@@ -266,8 +303,12 @@ static void hashgrid_encode(const d2r_oracle_nerf *m, const float x[3], float *o
                 }
             }
             uint32_t idx = grid_index(size, res, gc[0], gc[1], gc[2]);
-            for (uint32_t f = 0; f < F; f++)
-                acc[f] = fmaf(weight, half_to_float(tab[(size_t)idx * F + f]), acc[f]);
+            for (uint32_t f = 0; f < F; f++) {
+                const float val = half_to_float(tab[(size_t)idx * F + f]);
+                if (d2r_oracle_arith == 1) acc[f] = rn16(acc[f] + rn16(weight * val));          /* result += (T)(weight * val), T = __half */
+                else if (d2r_oracle_arith == 2) acc[f] = rn16(fmaf(rn16(weight), val, acc[f])); /* result = fma((T)weight, val, result) */
+                else acc[f] = fmaf(weight, val, acc[f]);
+            }
         }
         for (uint32_t f = 0; f < F; f++) out[l * F + f] = acc[f];
     }
@@ -306,6 +347,21 @@ static void matvec_f16(const uint16_t *w, int n_out, int n_in, const float *in, 
     }
 }
 
+/* the same product with a HALF accumulator (arith modes 1 / 2): per 16-wide k-step the exact products are summed (fp32 here) onto
+ * the accumulator and the sum is rounded to half; inputs are halves already, the activation is applied to the half result */
+static void matvec_f16_halfacc(const uint16_t *w, int n_out, int n_in, const float *in, float *out, int relu)
+{
+    for (int o = 0; o < n_out; o++) {
+        float acc = 0.f;
+        for (int k0 = 0; k0 < n_in; k0 += 16) {
+            float part = 0.f;
+            for (int i = k0; i < k0 + 16 && i < n_in; i++) part = fmaf(half_to_float(w[o * n_in + i]), in[i], part);
+            acc = rn16(acc + part);
+        }
+        out[o] = relu ? (acc > 0.f ? acc : 0.f) : acc;
+    }
+}
+
 /* sigma and rgb (network's sRGB-space prediction) at one sample */
 static void nerf_eval(const d2r_oracle_nerf *m, const float x[3], const float dir[3],
                       float *sigma, float rgb[3])
@@ -314,6 +370,19 @@ static void nerf_eval(const d2r_oracle_nerf *m, const float x[3], const float di
     float h[64], dout[16], cin[32], h2[64], cout[16];
     hashgrid_encode(m, x, feat);
     const int n_in = (int)(m->n_levels * m->n_features); /* 32 */
+    if (d2r_oracle_arith) {
+        matvec_f16_halfacc(m->dw1, 64, n_in, feat, h, 1);           /* feat: halves out of the grid already */
+        matvec_f16_halfacc(m->dw2, 16, 64, h, dout, 0);
+        *sigma = expf(dout[0]);
+        for (int i = 0; i < 16; i++) cin[i] = dout[i];
+        sh_encode4(dir, cin + 16);
+        for (int i = 16; i < 32; i++) cin[i] = rn16(cin[i]);
+        matvec_f16_halfacc(m->cw1, 64, 32, cin, h, 1);
+        matvec_f16_halfacc(m->cw2, 64, 64, h, h2, 1);
+        matvec_f16_halfacc(m->cw3, 16, 64, h2, cout, 0);
+        for (int i = 0; i < 3; i++) rgb[i] = 1.0f / (1.0f + expf(-cout[i]));
+        return;
+    }
     matvec_f16(m->dw1, 64, n_in, feat, h, 1);
     matvec_f16(m->dw2, 16, 64, h, dout, 0);
     *sigma = expf(dout[0]);

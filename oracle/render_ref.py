@@ -102,6 +102,23 @@ def render(model: OracleNerf, view, cam_nerf):
     return rgba, depth, int(n.value)
 
 
+def set_arith(mode: int) -> int:
+    """0: the specification (fp16 parameters, fp32 arithmetic).  1 / 2: emulation of tiny-cuda-nn's half arithmetic (half corner
+    accumulation in the grid — older / newer form —, half accumulators and activations in the MLPs); see d2r_oracle.c.  Returns the
+    previous mode."""
+    lib().d2r_oracle_get_arith.restype = C.c_int
+    old = int(lib().d2r_oracle_get_arith())
+    lib().d2r_oracle_set_arith(C.c_int(int(mode)))
+    return old
+
+
+def round_half(x) -> np.ndarray:
+    """the oracle's float -> half -> float rounding, element-wise (test hook)"""
+    lib().d2r_oracle_round_half.restype = C.c_float
+    a = np.asarray(x, np.float32)
+    return np.array([lib().d2r_oracle_round_half(C.c_float(float(v))) for v in a.reshape(-1)], np.float32).reshape(a.shape)
+
+
 def lens_distort(params, uv) -> np.ndarray:
     """[n,2] pinhole directions (u, v, 1) -> where the OpenCV lens (k1, k2, p1, p2) puts them on the sensor."""
     p = np.ascontiguousarray(params, np.float32)

@@ -26,11 +26,12 @@ from oracle.pipeline import OraclePipeline, oracle_logits  # noqa: E402
 def measure(engine, ctx, kind="shopping_trained", W=160, H=90, grid=(4, 3, 2), clip="vit_b16", clip_weights="benign", mlp_f16=0, log=print):
     from tests.scenes import make_scene
     from tests.parity_utils import random_unit_text_embeds
+    was = ctx.get_option("mlp_f16")
     ctx.set_option("mlp_f16", mlp_f16)
     try:
         return _measure(engine, ctx, kind, W, H, grid, clip, clip_weights, mlp_f16, log)
     finally:
-        ctx.set_option("mlp_f16", 0)
+        ctx.set_option("mlp_f16", was)
 
 
 def _measure(engine, ctx, kind, W, H, grid, clip, clip_weights, mlp_f16, log):
@@ -99,6 +100,77 @@ def _measure(engine, ctx, kind, W, H, grid, clip, clip_weights, mlp_f16, log):
     return out
 
 
+def measure_distances(engine, ctx, kind="shopping_trained", W=160, H=90, grid=(6, 4, 1), clip="vit_b16", log=print):
+    """how far each arithmetic sits from an EMULATION of tiny-cuda-nn's half arithmetic (oracle arith mode 1: half
+    corner accumulation in the grid, half accumulators and half inter-layer activations in both MLPs; mode 2 = the grid's newer
+    fma form) on the trained-like field — the fp32 specification (oracle mode 0), the HIP marcher with bf16 MLP operands (north_star)
+    and with fp16 operands (option mlp_f16), all with fp32 accumulation.  Per contender: field (|dlog sigma|, |drgb|), composited
+    frames (pixels off by 1 / more LSB, share of the object's pixels) and logits through the SAME fp32 tower (so only the render
+    differs).  Returns {"emulation": .., "rows": {name: {...}}}."""
+    from tests.scenes import make_scene
+    from tests.parity_utils import random_unit_text_embeds
+    scene = make_scene(kind)
+    fg = engine.Testbed(ctx, scene.fg)
+    fg.background_color = list(scene.fg_background)
+    r = np.random.Generator(np.random.PCG64(0))
+    n = 20000
+    occ = np.argwhere(scene.fg.occupancy_bool())
+    cells = occ[r.integers(0, len(occ), n)]
+    xyz = ((cells[:, ::-1] + r.random((n, 3))) / 128.0).astype(np.float32)
+    d = r.standard_normal((n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    om = render_ref.OracleNerf(scene.fg)
+    pipe = OraclePipeline(scene, W, H)
+    poses = host_ref.sample_poses_grid(scene.scene_centre, list(grid) + [1, 1, 1], scene.scene_type).reshape(-1, 4, 4)
+    obg = pipe.background()                                  # one background for every contender (an input of the composite)
+    view = fg.view(W, H)
+    ctx.set_background(view, obg[0], obg[1])
+    T1 = host_ref.converter(np.asarray(scene.obj_pose, np.float32)[None])[0]
+    TC = host_ref.converter(np.asarray(scene.cam_poses, np.float32))[0]
+    pn = host_ref.converter(poses.astype(np.float32))
+    cfg = CLIP_CONFIGS[clip]
+    sd = random_clip_state_dict(cfg, 6, text=False)
+    text = random_unit_text_embeds(cfg["proj"], 3)
+    field, frames = {}, {}
+    for name, mode in (("emulation", 1), ("emulation_fma_grid", 2), ("fp32 specification (oracle)", 0)):
+        old = render_ref.set_arith(mode)
+        try:
+            field[name] = render_ref.eval_points(om, xyz, d)
+            frames[name] = pipe.frames(poses, bg=obg)
+        finally:
+            render_ref.set_arith(old)
+    was = ctx.get_option("mlp_f16")
+    for name, f16 in (("HIP, bf16 MLP operands", 0), ("HIP, fp16 MLP operands (mlp_f16)", 1)):
+        ctx.set_option("mlp_f16", f16)
+        try:
+            field[name] = fg.eval_points(xyz, d)
+            frames[name] = fg.render_composite(view, T1, TC, pn)
+        finally:
+            ctx.set_option("mlp_f16", was)
+    ref_f, ref_fr = field["emulation"], frames["emulation"]
+    hit = (ref_fr != np.broadcast_to(_bg_u8(pipe, obg), ref_fr.shape)).any(-1)
+    act = (ref_f[:, 0] * 0.0016914558 > 1e-4) & (ref_f[:, 0] * 0.0016914558 < 30.0)
+    scale = float(np.exp(np.float32(sd.get("logit_scale", 4.6052))))
+    lg_ref, _ = oracle_logits(ref_fr, cfg, sd, text)
+    rows = {}
+    for name in field:
+        if name == "emulation":
+            continue
+        dls = np.abs(np.log(np.maximum(field[name][:, 0], 1e-30)) - np.log(np.maximum(ref_f[:, 0], 1e-30)))
+        diff = np.abs(frames[name].astype(int) - ref_fr.astype(int)).max(-1)
+        lg, _ = oracle_logits(frames[name], cfg, sd, text)
+        rows[name] = {"dlog_sigma_max": float(dls[act].max()), "dlog_sigma_rms": float(np.sqrt((dls[act] ** 2).mean())),
+                      "drgb_max": float(np.abs(field[name][:, 1:] - ref_f[:, 1:]).max()),
+                      "pixels_off_by_1": float((diff == 1).mean()), "pixels_off_by_more": float((diff > 1).mean()),
+                      "object_pixels_off_by_more": float((diff[hit] > 1).mean()) if hit.any() else 0.0,
+                      "logit_max": float(np.abs(lg - lg_ref).max() / scale)}
+        log(f"[fp16-accumulation emulation] {name:36s}: |dlog sigma| max {rows[name]['dlog_sigma_max']:.4f} rms {rows[name]['dlog_sigma_rms']:.4f}  |drgb| {rows[name]['drgb_max']:.4f}  "
+            f"pixels off by 1 {rows[name]['pixels_off_by_1']:.3%} by more {rows[name]['pixels_off_by_more']:.3%} ({rows[name]['object_pixels_off_by_more']:.2%} of the object's)  "
+            f"|dlogit|/scale {rows[name]['logit_max']:.2e}")
+    fg.close()
+    return {"scene": kind, "size": [W, H], "frames": int(len(poses)), "object_pixels": int(hit.sum()), "clip": clip, "rows": rows}
+
+
 def _bg_u8(pipe, obg):
     """the oracle's composite of an EMPTY foreground over the background = the background frame in uint8"""
     z = np.zeros_like(obg[0])
@@ -115,7 +187,9 @@ if __name__ == "__main__":
             res.append(measure(engine, ctx, kind, 160, 90, (6, 4, 2), "vit_b16", "benign", mlp_f16=f16))
         res.append(measure(engine, ctx, "shopping_trained", 640, 360, (3, 2, 1), "vit_b16", "benign", mlp_f16=f16))
     res.append(measure(engine, ctx, "shopping_trained", 160, 90, (6, 4, 2), "vit_b16", "adversarial"))
-    out = os.path.join(REPO, "gpurun_out", "r05_trained_field_parity.json")
+    res.append({"distances_to_fp16_accumulation_emulation": [measure_distances(engine, ctx, "shopping_trained", 160, 90, (6, 4, 1)),
+                                                              measure_distances(engine, ctx, "shopping", 160, 90, (6, 4, 1))]})
+    out = os.path.join(REPO, "gpurun_out", "r06_trained_field_parity.json")
     os.makedirs(os.path.dirname(out), exist_ok=True)
     json.dump(res, open(out, "w"), indent=1)
     ctx.close()

@@ -85,7 +85,7 @@ def test_bad_arguments_return_error_codes():
     v = C.c_int64(-7)
     assert lib.d2r_ctx_get_option(h, b"chunk", C.byref(v)) == 0 and v.value == 4096             # ABI 8: tunables read back
     assert lib.d2r_ctx_set_option(h, b"mlp_f16", C.c_int64(5)) == 0 and lib.d2r_ctx_get_option(h, b"mlp_f16", C.byref(v)) == 0 and v.value == 1
-    assert lib.d2r_ctx_set_option(h, b"mlp_f16", C.c_int64(0)) == 0
+    assert lib.d2r_ctx_set_option(h, b"mlp_f16", C.c_int64(1)) == 0
     assert lib.d2r_ctx_get_option(h, b"march_compact", C.byref(v)) == 0 and v.value == 1
     assert lib.d2r_ctx_get_option(h, b"ray_sort", C.byref(v)) == 0 and v.value == 1 and lib.d2r_ctx_get_option(h, b"ray_sort_log2", C.byref(v)) == 0 and v.value == 4
     assert lib.d2r_ctx_get_option(h, b"march_lds_slots", C.byref(v)) == 0 and v.value == 0      # no march launch on this context yet

@@ -59,3 +59,45 @@ def test_ragged_partitions_gather_in_rank_order():
     assert [shard_range(8, r, 2) for r in range(2)] == [(0, 4), (4, 8)]
     plan = bench.shard_plan([5, 2, 1, 1, 1, 1], 3, 3)       # 10 over 3: 4, 3, 3
     assert [len(s) for s in plan["shards"]] == [4, 3, 3]
+
+
+def _plan(*flags):
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE"):
+        env.pop(k, None)
+    env["D2R_WATCHDOG_SCALE"] = "4"
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--plan", *flags], capture_output=True, text=True, timeout=600, env=env, cwd=REPO)
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{"plan"')]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    return json.loads(lines[0])
+
+
+def test_eight_rank_plan_on_a_cpu_box():
+    """`bench.py --gpus 8 --plan`: the 8-GPU scaling run worked out without a GPU (self-launch under torch.distributed.run,
+    gloo): rank r takes device r (LOCAL_RANK), the shards are the eight (x, y) sheets of the weak-scaling grid, every rank holds
+    the 1-GPU run's workspaces and nothing more, each rank's OpenMP / PNG workers get an eighth of the CPU quota, and the only
+    data-path collective is the one all-gather of logits."""
+    one, eight = _plan(), _plan("--gpus", "8")
+    assert one["n_gpus"] == 1 and eight["n_gpus"] == 8 and eight["scaling"] == "weak" and eight["sample_res"] == [64, 64, 8, 1, 1, 1]
+    assert eight["poses_per_step"] == eight["poses_total"] == 8 * 4096
+    ranks = eight["plan"]
+    assert [e["rank"] for e in ranks] == list(range(8)) and [e["device"] for e in ranks] == [e["local_rank"] for e in ranks] == list(range(8))
+    assert all(e["poses"] == 4096 and e["passes_per_step"] == 1 and e["chunk"] == 4096 for e in ranks)
+    w1 = one["plan"][0]["workspace_bytes"]
+    assert all(e["workspace_bytes"] == w1 for e in ranks)                       # per-rank footprint does not depend on the rank count
+    assert w1["ray_queue"] == w1["ray_queue_sorted"] == 4096 * 640 * 360 * 8 and 30e9 < w1["total"] < 40e9 < 288e9
+    quota = ranks[0]["cpu_threads"]["quota"]
+    assert all(e["cpu_threads"]["local_world"] == 8 and e["cpu_threads"]["omp"] == e["cpu_threads"]["share_of_quota"] == max(1, quota // 8) for e in ranks)
+    assert "one all-gather of 32768 x 2 fp32 logits = 262144 bytes" in ranks[0]["collective"]
+    assert one["plan"][0]["cpu_threads"]["omp"] == quota
+
+
+def test_strong_scaling_plan_splits_config3_and_config4():
+    p3 = _plan("--gpus", "4", "--config", "3")
+    assert p3["scaling"] == "strong" and p3["poses_total"] == 131072 and [e["poses"] for e in p3["plan"]] == [32768] * 4
+    assert all(e["passes_per_step"] == 8 for e in p3["plan"])
+    p4 = _plan("--gpus", "2", "--config", "4")                                   # two GPUs of the 8-way partition: shards 0 and 1
+    assert p4["partition"] == 8 and p4["poses_per_step"] == 2 * 32768 and p4["clip"] == "vit_l14"
+    assert [(e["first_pose"], e["last_pose"]) for e in p4["plan"]] == [(0, 32767), (32768, 65535)]

@@ -137,3 +137,40 @@ def test_oracle_vit_against_hf_goldens_round5(key, name, weights, n, tol):
     err = float(np.abs(got - want).max())
     print(f"[pin] oracle vs HF CLIPModel, {name} ({weights} weights, {cfg['num_layers']} layers): max |d embedding| = {err:.2e} (bar {tol:.0e})")
     assert want.shape == (n, cfg["proj"]) and err <= tol
+
+
+def test_half_arithmetic_emulation_of_the_oracle():
+    """oracle arith modes 1 / 2 (the emulation of tiny-cuda-nn's half arithmetic, used only for the distance table of the GPU suite):
+    the float -> half rounding is numpy's, bit for bit incl. subnormals, ties and overflow; mode 0 is untouched by the switch; the
+    emulated field differs from the specification by half-precision noise and no more."""
+    from oracle import render_ref
+    from tests.scenes import make_scene
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.standard_normal(3000) * 10.0 ** rng.uniform(-9, 5, 3000),
+                        [0, -0.0, 65504, 65519.9, 65520, 70000, 6e-8, 2.98e-8, 2.99e-8, 5.96e-8, 6.1e-5, 6.0e-5, 1.0009765625, 1.00048828125,
+                         1.00146484375, -3.5e-8, np.inf, -np.inf]]).astype(np.float32)
+    with np.errstate(over="ignore"):
+        want = x.astype(np.float16).astype(np.float32)
+    np.testing.assert_array_equal(render_ref.round_half(x), want)
+    scene = make_scene("shopping_trained")
+    m = render_ref.OracleNerf(scene.fg)
+    occ = np.argwhere(scene.fg.occupancy_bool())
+    cells = occ[rng.integers(0, len(occ), 2000)]
+    xyz = ((cells[:, ::-1] + rng.random((2000, 3))) / 128.0).astype(np.float32)
+    d = rng.standard_normal((2000, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    a = render_ref.eval_points(m, xyz, d)
+    assert render_ref.set_arith(1) == 0
+    try:
+        b = render_ref.eval_points(m, xyz, d)
+        feats = render_ref.encode_points(m, xyz[:64])
+        np.testing.assert_array_equal(feats, render_ref.round_half(feats))          # the grid's outputs are halves
+        render_ref.set_arith(2)
+        c = render_ref.eval_points(m, xyz, d)
+    finally:
+        render_ref.set_arith(0)
+    np.testing.assert_array_equal(render_ref.eval_points(m, xyz, d), a)
+    act = (a[:, 0] * 0.0016914558 > 1e-4) & (a[:, 0] * 0.0016914558 < 30.0)
+    for v in (b, c):
+        dl = np.abs(np.log(np.maximum(v[:, 0], 1e-30)) - np.log(np.maximum(a[:, 0], 1e-30)))[act]
+        assert 1e-4 < dl.max() < 0.06 and np.abs(v[:, 1:] - a[:, 1:]).max() < 0.02
