@@ -2244,7 +2244,7 @@ __device__ __forceinline__ void ats_softmax(f32x16 &sacc, f32x16 &o0, f32x16 &o1
     float tmax = sacc[0];
 #pragma unroll
     for (int r = 1; r < NR; r++) tmax = fmaxf(tmax, sacc[r]);
-    tmax = half_max(tmax) * sm_c;
+    tmax = (D2R_ATTN_ABLATE & 1024) ? half_max(tmax) : half_max(tmax) * sm_c;
 #endif
     if (__builtin_amdgcn_ballot_w64(tmax > m_run + ATS_DEFER) != 0) {       // first tile: m_run = -inf
         const float m_new = fmaxf(m_run, tmax);
@@ -2279,10 +2279,17 @@ __device__ __forceinline__ void ats_softmax(f32x16 &sacc, f32x16 &o0, f32x16 &o1
         const f32x2 s2 = b0 + b1;
         l_run += s2.x + s2.y;
 #else
+#if (D2R_ATTN_ABLATE & 1024)
+        // ablation (garbage values, timing only): the scores as they would leave an accumulator initialised with -m_run from a q already
+        // scaled by log2(e) / 8 — no scale-subtract between the MFMA and the exponential
+#pragma unroll
+        for (int r = 0; r < 16; r++) sacc[r] = __builtin_amdgcn_exp2f(sacc[r]);
+#else
         const f32x16 cv = sm_c, mv = -m_run;
         const f32x16 t = __builtin_elementwise_fma(sacc, cv, mv);
 #pragma unroll
         for (int r = 0; r < 16; r++) sacc[r] = __builtin_amdgcn_exp2f(t[r]);
+#endif
         const f32x8 s8 = sacc.lo + sacc.hi;
         const f32x4 s4 = s8.lo + s8.hi;
         const f32x2 s2 = s4.lo + s4.hi;
@@ -2324,7 +2331,11 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void k_attention_s(const 
     const uint32_t H = d >> 6;
     const uint32_t n_kt = (T + 31) / 32;
     const uint32_t qt = qt0 + blockIdx.z * NW + wave;
+#if (D2R_ATTN_ABLATE & 512)
+    const bool active = qt < n_kt && (qt + 1) * 32 <= T;  // ablation: the partial last query tile (5 of 32 queries at 197 tokens) computes nothing — the upper bound of what a cheaper tail tile can return
+#else
     const bool active = qt < n_kt;                        // query tiles = key tiles = ceil(T / 32)
+#endif
     const uint32_t qrow = qt * 32 + li;
     const uint16_t *Qg = QKV + ((size_t)head * M_pad + row_base) * 64;
     // slice c of a key tile (c = 0..3: eight K rows each, 4..7: eight V rows each) is staged by wave c % NW; a lane fetches
@@ -2470,7 +2481,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void k_attention_s(const 
         // no faster and costs ten registers)
         if constexpr (!LAST) {
 #pragma unroll
-            for (int r = 0; r < 16; r++) sacc[r] = (D2R_ATTN_ABLATE & 128) ? __uint_as_float(ka[r & 3].x) : 0.f;
+            for (int r = 0; r < 16; r++) sacc[r] = (D2R_ATTN_ABLATE & 128) ? __uint_as_float(ka[r & 3].x) : (D2R_ATTN_ABLATE & 1024) ? -m_run : 0.f;
 #pragma unroll
             for (int s = 0; s < ((D2R_ATTN_ABLATE & 128) ? 0 : 4); s++) s_mfma(sacc, s);
         }

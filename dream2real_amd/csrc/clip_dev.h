@@ -6,7 +6,8 @@
 // D2R_GEMM_ABLATE (bitmask) — k_gemm8 and the shared epilogue: 1 no LDS-DMA, 2 no fragment ds_reads, 4 no epilogue,
 //   8 no MFMA, 128 no global loads/stores in the epilogue, 256 no LDS transposes in the epilogue.
 // D2R_ATTN_ABLATE (bitmask) — k_attention_s: 16 no DMA requests, 32 no softmax, 64 no PV (V reads + MFMAs), 128 no
-//   S MFMAs, 256 no per-tile barriers.
+//   S MFMAs, 256 no per-tile barriers, 512 the partial last query tile computes nothing (prices a cheaper tail tile), 1024 no
+//   scale-subtract between the S MFMAs and the exponentials (prices the accumulator initialised with -m_run + log2(e)/8 folded into W_q).
 // Results are garbage when a mask is set; tools/gemm_ablate.sh / tools/attn_ablate.sh rebuild with each mask to see
 // what a tile's time is made of.
 // D2R_GEMM_STAMPS — shader-clock cycles wave 0 of every workgroup spends per tile section of k_gemm8, read back with
