@@ -176,6 +176,9 @@ __global__ void k_cameras_virtual(ViewParams V, Mat16 obj_now, Mat16 cam, const 
 #define D2R_MARCH_VAR 0                /* bit 0: LDS-brick addresses formed in fp32 (slot_addr_lds_f); bit 1: the next lattice point's occupancy word requested before the field evaluation */
 #endif
 #ifndef D2R_MARCH_RESERVE
+#ifndef D2R_MARCH_MLP2
+#define D2R_MARCH_MLP2 0               /* 1: both tiles of a wave iteration share every MLP weight fragment read (mlp_tile2) */
+#endif
 #define D2R_MARCH_RESERVE 128          /* queue entries a wave reserves per atomic */
 #endif
 
@@ -1159,6 +1162,67 @@ __device__ __forceinline__ void mlp_tile(const uint4 *__restrict__ sw, uint32_t 
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// Both tiles of a wave iteration through both MLPs at once: every weight fragment is read from LDS ONCE and feeds two
+// independent MFMAs (tile A, tile B), so the 48 KiB of fragment reads per wave iteration become 24 KiB and each layer is
+// two interleaved dependent chains instead of one.  Per-sample arithmetic is mlp_tile's, operation by operation.
+template <bool F16>
+__device__ __forceinline__ void mlp_tile2(const uint4 *__restrict__ sw, uint32_t lane, const uint4 &a0, const uint4 &a1, const uint4 &shA, float *outA,
+                                          const uint4 &b0, const uint4 &b1, const uint4 &shB, float *outB)
+{
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // one 32-output half of a layer for both tiles: NK weight fragments starting at sw[W0], inputs xa[] / xb[]; the halves run one after
+    // the other with a scheduling fence in between so that ONE accumulator per tile is live beside the packed activations
+    // (both halves at once, four accumulators, pushed 37 registers of ray state to scratch)
+    auto half2 = [&](int W0, int NK, const uint4 *xa, const uint4 *xb, f32x16 &ra, f32x16 &rb) {
+        uint4 w = sw[W0 * 64 + lane];
+        ra = mfma<F16>(w, xa[0], zero);
+        rb = mfma<F16>(w, xb[0], zero);
+#pragma unroll
+        for (int i = 1; i < NK; i++) {
+            w = sw[(W0 + i) * 64 + lane];
+            ra = mfma<F16>(w, xa[i], ra);
+            rb = mfma<F16>(w, xb[i], rb);
+        }
+    };
+    f32x16 g, k;
+    uint4 pa[4], pb[4], xa[4], xb[4];
+    // density layer 1: 64 x 32
+    xa[0] = a0; xa[1] = a1; xb[0] = b0; xb[1] = b1;
+    half2(0, 2, xa, xb, g, k);
+    pa[0] = relu_pack<F16>(g, 0); pa[1] = relu_pack<F16>(g, 8); pb[0] = relu_pack<F16>(k, 0); pb[1] = relu_pack<F16>(k, 8);
+    __builtin_amdgcn_sched_barrier(0);
+    half2(2, 2, xa, xb, g, k);
+    pa[2] = relu_pack<F16>(g, 0); pa[3] = relu_pack<F16>(g, 8); pb[2] = relu_pack<F16>(k, 0); pb[3] = relu_pack<F16>(k, 8);
+    __builtin_amdgcn_sched_barrier(0);
+    // density layer 2: 16 (padded 32) x 64
+    half2(4, 4, pa, pb, g, k);
+    outA[0] = g[0];
+    outB[0] = k[0];
+    // colour layer 1: 64 x 32, input = [density out (no activation) | SH]
+    xa[0].x = pack2<F16>(g[0], g[1]); xa[0].y = pack2<F16>(g[2], g[3]); xa[0].z = pack2<F16>(g[4], g[5]); xa[0].w = pack2<F16>(g[6], g[7]);
+    xb[0].x = pack2<F16>(k[0], k[1]); xb[0].y = pack2<F16>(k[2], k[3]); xb[0].z = pack2<F16>(k[4], k[5]); xb[0].w = pack2<F16>(k[6], k[7]);
+    xa[1] = shA; xb[1] = shB;
+    __builtin_amdgcn_sched_barrier(0);
+    half2(8, 2, xa, xb, g, k);
+    pa[0] = relu_pack<F16>(g, 0); pa[1] = relu_pack<F16>(g, 8); pb[0] = relu_pack<F16>(k, 0); pb[1] = relu_pack<F16>(k, 8);
+    __builtin_amdgcn_sched_barrier(0);
+    half2(10, 2, xa, xb, g, k);
+    pa[2] = relu_pack<F16>(g, 0); pa[3] = relu_pack<F16>(g, 8); pb[2] = relu_pack<F16>(k, 0); pb[3] = relu_pack<F16>(k, 8);
+    __builtin_amdgcn_sched_barrier(0);
+    // colour layer 2: 64 x 64
+    half2(12, 4, pa, pb, g, k);
+    xa[0] = relu_pack<F16>(g, 0); xa[1] = relu_pack<F16>(g, 8); xb[0] = relu_pack<F16>(k, 0); xb[1] = relu_pack<F16>(k, 8);
+    __builtin_amdgcn_sched_barrier(0);
+    half2(16, 4, pa, pb, g, k);
+    xa[2] = relu_pack<F16>(g, 0); xa[3] = relu_pack<F16>(g, 8); xb[2] = relu_pack<F16>(k, 0); xb[3] = relu_pack<F16>(k, 8);
+    __builtin_amdgcn_sched_barrier(0);
+    // colour layer 3: 16 (padded 32) x 64
+    half2(20, 4, xa, xb, g, k);
+    outA[1] = g[0]; outA[2] = g[1]; outA[3] = g[2];
+    outB[1] = k[0]; outB[2] = k[1]; outB[3] = k[2];
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // SH fragments of the wave's ray directions: the colour net's second B fragment for tile 0
 // (directions of lanes 0..31) and tile 1 (lanes 32..63); this lane holds coefficients
 // 8hi..8hi+7.  Directions are per RAY, so k_march recomputes these only when it refills.
@@ -1211,8 +1275,14 @@ __device__ __forceinline__ void eval_wave(const NerfParams &P, const __amdgpu_bu
     oa[0] = __uint_as_float(fa0.x) * 1e-3f; oa[1] = __uint_as_float(fa0.y); oa[2] = __uint_as_float(fa1.x); oa[3] = __uint_as_float(fa1.y);
     ob[0] = __uint_as_float(fb0.x) * 1e-3f; ob[1] = __uint_as_float(fb0.y); ob[2] = __uint_as_float(fb1.x); ob[3] = __uint_as_float(fb1.y);
 #else
+#if D2R_MARCH_MLP2
+    if ((uint32_t)vm != 0u && (uint32_t)(vm >> 32) != 0u) mlp_tile2<F16>(sw, lane, fa0, fa1, shfA, oa, fb0, fb1, shfB, ob);
+    else if ((uint32_t)vm != 0u) mlp_tile<F16>(sw, lane, fa0, fa1, shfA, oa);
+    else if ((uint32_t)(vm >> 32) != 0u) mlp_tile<F16>(sw, lane, fb0, fb1, shfB, ob);
+#else
     if ((uint32_t)vm != 0u) mlp_tile<F16>(sw, lane, fa0, fa1, shfA, oa);
     if ((uint32_t)(vm >> 32) != 0u) mlp_tile<F16>(sw, lane, fb0, fb1, shfB, ob);
+#endif
 #endif
     // tile-1 results live in lanes 0..31; their owners are lanes 32..63
     float ts = __shfl_xor(ob[0], 32), tr = __shfl_xor(ob[1], 32), tg = __shfl_xor(ob[2], 32), tb = __shfl_xor(ob[3], 32);
