@@ -2330,6 +2330,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void k_attention_s(const 
     const size_t row_base = (size_t)img * T;
     const uint32_t H = d >> 6;
     const uint32_t n_kt = (T + 31) / 32;
+    // (wave i of a workgroup does NOT always sit on SIMD i mod 4 — the dispatcher rotates the first SIMD from workgroup to workgroup
+    // (tools/probes/wave_placement_probe.hip), so the idle wave and the 5-query tail wave of a 197-token sequence are spread over the
+    // four SIMDs already; rotating the wave -> query-tile map per workgroup measured neutral, profiles/r06_ab_attention.md)
     const uint32_t qt = qt0 + blockIdx.z * NW + wave;
 #if (D2R_ATTN_ABLATE & 512)
     const bool active = qt < n_kt && (qt + 1) * 32 <= T;  // ablation: the partial last query tile (5 of 32 queries at 197 tokens) computes nothing — the upper bound of what a cheaper tail tile can return

@@ -5,7 +5,7 @@ import numpy as np
 from dream2real_amd import engine
 from dream2real_amd.clip_model import CLIP_CONFIGS, random_clip_state_dict
 ctx = engine.Context(0)
-cfg = dict(CLIP_CONFIGS["vit_b16"], num_layers=2)
+cfg = dict(CLIP_CONFIGS[os.environ.get("ATTN_PROBE_MODEL", "vit_b16")], num_layers=int(os.environ.get("ATTN_PROBE_LAYERS", "2")))
 sc = engine.ClipScorer(ctx, cfg, random_clip_state_dict(cfg, seed=6, text=False))
 pv = np.random.default_rng(0).standard_normal((2048, 3, 224, 224), dtype=np.float32)
 ctx.set_option("chunk", 4096)
