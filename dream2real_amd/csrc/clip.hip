@@ -377,6 +377,9 @@ __device__ __forceinline__ uint2 q8_pack8(const float (&f)[8], float inv)
 #define D2R_F8_VAR 0
 #define STAMP(var)
 #endif
+#ifndef D2R_GEMM_LATE_DRAIN
+#define D2R_GEMM_LATE_DRAIN 1  /* 1 (default since round 6): k_gemm8 does not drain the previous tile's epilogue stores at the top of a tile (see there); 0: the round-5 drain */
+#endif
 #ifndef D2R_GEMM_PRIO
 #define D2R_GEMM_PRIO 2        /* 0: s_setprio 1 around every MFMA section; 1 / 2: static priority for wave row 1 / 0; 3: none */
 #endif
@@ -1178,6 +1181,9 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
     // i.e. for the whole next tile's first K-tile pair)
     const float2 *ab_lds = (const float2 *)(smem + 8 * SLOT + 8 * EP_WAVE_FLOATS * 4) + wave * 128;
 
+#if D2R_GEMM_LATE_DRAIN
+    bool first_tile = true;                           // block-uniform
+#endif
     for (;;) {
     STAMP(ts0);               // (the first bucket of the cycle stamps: accumulator reset + drain + first fragment reads)
 #pragma unroll
@@ -1194,9 +1200,25 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
     // (the builtin, not inline asm: hipcc's own wait-count bookkeeping must also learn that the
     // epilogue's loads and stores have retired, or it protects their registers with a vmcnt(0) of its
     // own inside the K loop)
+#if D2R_GEMM_LATE_DRAIN
+    // No drain (same-box A/B, profiles/r06_ab_gemm.md: CLIP 140.1 -> 138.9 ms per configs[1] step, bit-identical results).  The eight half-tiles this tile starts on were requested BEFORE the previous tile's epilogue, whose first act is
+    // to load and consume bias values: loads retire in order, so those half-tiles had landed before the first epilogue store was even
+    // issued.  What the drain really waits for are the store acknowledgements (2-7 k cycles per tile, profiles/r06_gemm_stamps.txt: the
+    // whole chip writes its tiles at the same moment) — and nothing needs them before the first request of THIS tile is awaited, in
+    // phase 5 of the first K-tile pair (phases 0..4 read positions 3..7).  So: only a workgroup's first tile waits here, and the first
+    // pair's phases 0..4 carry no vmcnt wait (below); the stores get ~1.5 k cycles of MFMA work to retire behind.
+    // (EPI_F32 loads nothing in its epilogue: no such guarantee, it keeps the drain)
+    if (first_tile || EPI == EPI_F32) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        wait_vmcnt<0>();
+    }
+    first_tile = false;
+    bar();
+#else
     __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0), lgkmcnt / expcnt untouched
     wait_vmcnt<0>();
     bar();
+#endif
     read_pos(0);
     read_pos(1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1241,7 +1263,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
             // requests stay in flight.  That barrier is this one for wave row 1 and the one behind the MFMAs for wave row
             // 0 (half a phase apart); both rows wait at both — the second wait of a row finds its count already met, and
             // two unconditional waits are cheaper than a wave-uniform branch around each
-            wait_vmcnt<10>();
+            if (!(D2R_GEMM_LATE_DRAIN && P < 5) || u != 0) wait_vmcnt<10>();
             __builtin_amdgcn_sched_barrier(0);
             bar();
             // MFMA section
@@ -1249,7 +1271,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
             const int nh = (P == 1 || P == 2 || P == 4 || P == 7) ? 1 : 0;
             mfma_quadrant(mh, nh);
             __builtin_amdgcn_sched_barrier(0);
-            wait_vmcnt<10>();
+            if (!(D2R_GEMM_LATE_DRAIN && P < 5) || u != 0) wait_vmcnt<10>();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             bar();
         }
