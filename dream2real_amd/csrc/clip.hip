@@ -826,6 +826,90 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], float *ep, u
     }
 }
 
+// ---- transposed epilogues (k_gemm8, round 6) ----
+//
+// gemm_epilogue above first transposes the fp32 tile through LDS so that a lane owns consecutive columns of a row: 256 KiB written and
+// 256 KiB read back per 256x256 tile at 128 B/clk = ~4 k cycles — the whole QKV epilogue (profiles/r06_gemm_stamps.txt: 4.3 k).
+// k_gemm8 instead computes the TRANSPOSED product for these epilogue kinds — the MFMA's A operand is the W fragment, its B operand the
+// activation fragment (the two fragments have the same lane layout, and a dot product does not care which factor is called A) — so that
+//     acc[i][j][r]  <->  row 32 i + li,  column 32 j + 8 (r >> 2) + 4 hi + (r & 3)      (lane = 32 hi + li)
+// a lane holds 4 consecutive columns of ONE row per register quad: per-row constants (the LayerNorm statistics) are per lane, per-column
+// constants (bias, column sums) are 2 x 4 float4 per lane, the arithmetic is gemm_epilogue's operation by operation (same results), and
+// one v_permlane32_swap per dword pairs the lane halves so that every lane stores 8 consecutive bf16 (16 bytes; the two halves of a row
+// 32 contiguous bytes) — k_attention_s' output idiom.  No LDS traffic at all.
+#ifndef D2R_GEMM_TR
+#define D2R_GEMM_TR 1
+#endif
+#define EPI_HAS_TR(E) (D2R_GEMM_TR && ((E) == EPI_BIAS_BF16 || (E) == EPI_BIAS_GELU_BF16 || EPI_IS_LN(E)))
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue_tr(f32x16 (&acc)[4][2], uint32_t lane, uint32_t row0, uint32_t col0, const float *__restrict__ bias,
+                                                 void *__restrict__ Cout, uint32_t N, const EpiAux &aux, const float2 *ab_lds)
+{
+    constexpr bool LN = EPI_IS_LN(EPI);
+    constexpr bool GELU = EPI == EPI_BIAS_GELU_BF16 || EPI == EPI_LN_BIAS_GELU_BF16;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const uint32_t li = lane & 31, hi = lane >> 5;
+    // this lane's columns: col0 + 32 j + 8 q + 4 hi + (0..3)
+    float4 bq[2][4], sq[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            bq[j][q] = *(const float4 *)(bias + col0 + 32 * j + 8 * q + 4 * hi);
+            if (LN) sq[j][q] = *(const float4 *)(aux.cs + col0 + 32 * j + 8 * q + 4 * hi);
+        }
+    const uint32_t rs = aux.hm_rows ? 128u : N * 2u;                                   // bytes between rows
+    char *const cb = (char *)Cout + (aux.hm_rows ? ((size_t)(col0 >> 6) * aux.hm_rows + row0) * 128u : ((size_t)row0 * N + col0) * 2u);
+    const uint32_t loff = li * rs + hi * 16u;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        f32x2 ax = {1.f, 1.f}, ay = {0.f, 0.f};
+        if (LN) {
+            const float2 ab = ab_lds[32 * i + li];                                     // (rstd, -rstd * mean) of this lane's row
+            ax = f32x2{ab.x, ab.x};
+            ay = f32x2{ab.y, ab.y};
+        }
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            uint32_t pk[8];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                f32x2 pf[2] = {f32x2{acc[i][j][4 * q], acc[i][j][4 * q + 1]}, f32x2{acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]}};
+                const f32x2 bb[2] = {f32x2{bq[j][q].x, bq[j][q].y}, f32x2{bq[j][q].z, bq[j][q].w}};
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    if (LN) {
+                        const f32x2 ss = e ? f32x2{sq[j][q].z, sq[j][q].w} : f32x2{sq[j][q].x, sq[j][q].y};
+                        pf[e] = __builtin_elementwise_fma(ax, pf[e], __builtin_elementwise_fma(ay, ss, bb[e]));
+                    } else {
+                        pf[e] = pf[e] + bb[e];
+                    }
+                    if (GELU) {
+                        // quick_gelu: x * sigmoid(1.702 x) = x / (1 + exp2(-1.702 log2(e) x))
+                        const f32x2 t = pf[e] * f32x2{-2.4554669595930156f, -2.4554669595930156f};
+                        const f32x2 d = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + f32x2{1.0f, 1.0f};
+                        pf[e] = pf[e] * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+                    }
+                    pk[2 * q + e] = pack2(pf[e][0], pf[e][1]);
+                }
+            }
+            // quads q = 2 g (lane half 0 keeps it) and 2 g + 1 (lane half 1): after the swaps lanes 0-31 hold columns 16 g .. 16 g + 7 of their
+            // row and lanes 32-63 columns 16 g + 8 .. 16 g + 15
+#pragma unroll
+            for (int g = 0; g < 2; g++) {
+                const u32x2 x = __builtin_amdgcn_permlane32_swap(pk[4 * g + 0], pk[4 * g + 2], false, false);
+                const u32x2 y = __builtin_amdgcn_permlane32_swap(pk[4 * g + 1], pk[4 * g + 3], false, false);
+#if (D2R_GEMM_ABLATE & 128) && defined(__HIP_DEVICE_COMPILE__)
+                asm volatile("" ::"v"(x[0]), "v"(x[1]), "v"(y[0]), "v"(y[1]));
+                continue;
+#endif
+                *(uint4 *)(cb + (loff + (uint32_t)(32 * i) * rs + (uint32_t)(32 * j + 16 * g) * 2u)) = make_uint4(x[0], y[0], x[1], y[1]);
+            }
+        }
+    }
+}
+
 // C = A[M,K] * W[N,K]^T.  A [M_pad][K] bf16, W [N][K] bf16, K % 64 == 0.  The plain-K-loop GEMM that
 // serves what k_gemm8 below does not (outputs with few 256x256 tiles, K not a multiple of 128).
 // 8 waves as WGM x WGN, each wave MT x 2 MFMA 32x32x16 tiles:
@@ -1145,7 +1229,9 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
 #if (D2R_GEMM_ABLATE & 8) && defined(__HIP_DEVICE_COMPILE__)
                 asm volatile("" ::"v"(a.u.x), "v"(b.u.x));
 #else
-                acc[mh * 2 + mt][nh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc[mh * 2 + mt][nh], 0, 0, 0);
+                // EPI_HAS_TR: the transposed product (W fragment as the MFMA's A operand), see gemm_epilogue_tr
+                acc[mh * 2 + mt][nh] = EPI_HAS_TR(EPI) ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(b.v, a.v, acc[mh * 2 + mt][nh], 0, 0, 0)
+                                                       : __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc[mh * 2 + mt][nh], 0, 0, 0);
 #endif
             }
 #if D2R_GEMM_PRIO == 0
@@ -1292,7 +1378,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
     // a freshly computed lane id (mbcnt) instead of the one derived from threadIdx at kernel entry: that
     // one would stay live across the K loop for the epilogue's sake, and at 250+ registers it gets spilled
     const uint32_t lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    gemm_epilogue<EPI, 4>(acc, ep, lane_e, em, en, bias, Cout, N, aux, ab_lds);
+    if constexpr (EPI_HAS_TR(EPI)) gemm_epilogue_tr<EPI>(acc, lane_e, em, en, bias, Cout, N, aux, ab_lds);
+    else gemm_epilogue<EPI, 4>(acc, ep, lane_e, em, en, bias, Cout, N, aux, ab_lds);
 #endif
 #ifdef D2R_GEMM_STAMPS
     {
@@ -1918,16 +2005,17 @@ __global__ __launch_bounds__(256) void k_scatter_qkv(const uint16_t *__restrict_
 
 // LayerNorm folding of a Linear that follows a LayerNorm (weights prepared once at create):
 //   Wf[n][k] = bf16(W[n][k] * gamma[k]);   cs[n] = sum_k float(Wf[n][k]);   bf[n] = b[n] + sum_k W[n][k] * beta[k]
+// `scale` multiplies the whole output row (weight row before its bf16 rounding, bias): the attention scale of the q rows (ATTN_Q_SCALE)
 __global__ void k_fold_ln_weight(const float *__restrict__ W, const float *__restrict__ gamma, const float *__restrict__ beta,
                                  const float *__restrict__ b, uint16_t *__restrict__ Wf, float *__restrict__ cs,
-                                 float *__restrict__ bf, uint32_t N, uint32_t K)
+                                 float *__restrict__ bf, uint32_t N, uint32_t K, float scale = 1.0f)
 {
     const uint32_t n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (n >= N) return;
     float s = 0.f, t = 0.f;
     for (uint32_t k = lane; k < K; k += 64) {
         const float w = W[(size_t)n * K + k];
-        const uint16_t h = f2bf(w * gamma[k]);
+        const uint16_t h = f2bf(w * gamma[k] * scale);
         Wf[(size_t)n * K + k] = h;
         s += __uint_as_float((uint32_t)h << 16);
         t = fmaf(w, beta[k], t);
@@ -1936,7 +2024,7 @@ __global__ void k_fold_ln_weight(const float *__restrict__ W, const float *__res
     t = wave_sum(t);
     if (lane == 0) {
         cs[n] = s;
-        bf[n] = b[n] + t;
+        bf[n] = (b[n] + t) * scale;
     }
 }
 
@@ -2219,6 +2307,7 @@ __global__ __launch_bounds__(ATTN_THREADS, 4) void k_attention(const uint16_t *_
 // fp32's exponent, so the relative rounding of P is unchanged).  The last key tile of a CLIP sequence holds T mod 32
 // = 5 (197 tokens) or 1 (257, 577) valid keys: when that is <= 8 only accumulator registers 0..3 (keys 0..7 of the
 // tile) go through the softmax and only the first of the two PV k-steps runs.
+#define ATTN_Q_SCALE (0.125f * 1.4426950408889634f)     /* head_dim^-0.5 * log2(e), head_dim = 64: folded into the vision tower's W_q, b_q at create */
 #define ATS_THREADS 512
 #define ATS_STAGES 5
 #define ATS_SLOT 8192u
@@ -2232,94 +2321,51 @@ __device__ __forceinline__ uint2 lds_read_tr16(lds_cptr p)
     return c.u;
 }
 
-// softmax of one key tile's scores: running maximum with deferred rescale, P = exp2(s c - m) packed to bf16 as the B
-// fragments of the two PV k-steps (P regs 8s..8s+7 -> pb[s]).  NR = 16: all of the tile's keys; NR = 4: the tile's first
-// 8 keys only (registers 0..3; the other keys' P is 0).
+// softmax of one key tile's scores.  The scores arrive SHIFTED and in the exp2 domain: sacc = s c - m_run, because (round 6)
+//   * c = head_dim^-0.5 * log2(e) is folded into W_q, b_q once at d2r_clip_create (the product is rounded to bf16 once either way), and
+//   * the S^T accumulator starts at -m_run instead of 0, so the MFMA's own additions do the subtraction:
+// no multiply and no scale-subtract between the MFMAs and the exponentials (ablation D2R_ATTN_ABLATE 1024 of round 5 priced it:
+// -3.7 % of the kernel, profiles/r06_attn_price.txt).  Running maximum with deferred rescale as before: only when some query's tile
+// maximum exceeds its running maximum by more than ATS_DEFER are the accumulators rescaled and the tile's scores shifted again
+// (p <= 2^ATS_DEFER in between).  P = exp2(sacc) packed to bf16 as the B fragments of the two PV k-steps (P regs 8s..8s+7 -> pb[s]).
+// NR = 16: all of the tile's keys; NR = 4: the tile's first 8 keys only (registers 0..3; the other keys' P is 0).
 template <int NR>
 __device__ __forceinline__ void ats_softmax(f32x16 &sacc, f32x16 &o0, f32x16 &o1, float &m_run, float &l_run, uint4 (&pb)[2])
 {
-    const float sm_c = 0.125f * 1.4426950408889634f;   // head_dim^-0.5 * log2(e), head_dim = 64
 #if D2R_ATTN_ABLATE & 32
     l_run += sacc[0];
     o0[0] += sacc[1];
 #else
-#if (D2R_ATTN_VAR & 1)
-    // variant: the maximum as v_max3_f32 on the raw accumulator registers (no canonicalising self-maxes: MFMA results are never signalling NaNs)
-    float tmax;
-    if constexpr (NR == 16) {
-        float a, b;
-        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(a) : "v"(sacc[0]), "v"(sacc[1]), "v"(sacc[2]));
-        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(b) : "v"(sacc[3]), "v"(sacc[4]), "v"(sacc[5]));
-        asm("v_max3_f32 %0, %1, %2, %0" : "+v"(a) : "v"(sacc[6]), "v"(sacc[7]));
-        asm("v_max3_f32 %0, %1, %2, %0" : "+v"(b) : "v"(sacc[8]), "v"(sacc[9]));
-        asm("v_max3_f32 %0, %1, %2, %0" : "+v"(a) : "v"(sacc[10]), "v"(sacc[11]));
-        asm("v_max3_f32 %0, %1, %2, %0" : "+v"(b) : "v"(sacc[12]), "v"(sacc[13]));
-        asm("v_max3_f32 %0, %1, %2, %0" : "+v"(a) : "v"(sacc[14]), "v"(sacc[15]));
-        asm("v_max_f32 %0, %1, %2" : "=v"(tmax) : "v"(a), "v"(b));
-    } else {
-        tmax = sacc[0];
-#pragma unroll
-        for (int r = 1; r < NR; r++) tmax = fmaxf(tmax, sacc[r]);
-    }
-    tmax = half_max(tmax) * sm_c;
-#else
     float tmax = sacc[0];
 #pragma unroll
     for (int r = 1; r < NR; r++) tmax = fmaxf(tmax, sacc[r]);
-    tmax = (D2R_ATTN_ABLATE & 1024) ? half_max(tmax) : half_max(tmax) * sm_c;
-#endif
-    if (__builtin_amdgcn_ballot_w64(tmax > m_run + ATS_DEFER) != 0) {       // first tile: m_run = -inf
-        const float m_new = fmaxf(m_run, tmax);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);          // -inf - finite -> 0; equal -> 1
+    tmax = half_max(tmax);                                                   // this query's tile maximum MINUS its running maximum
+    if (__builtin_amdgcn_ballot_w64(tmax > ATS_DEFER) != 0) {
+        const float dm = fmaxf(tmax, 0.f);                                   // m_new - m_run
+        const float alpha = __builtin_amdgcn_exp2f(-dm);
         l_run *= alpha;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             o0[r] *= alpha;
             o1[r] *= alpha;
         }
-        m_run = m_new;
+#pragma unroll
+        for (int r = 0; r < NR; r++) sacc[r] -= dm;
+        m_run += dm;
     }
     if constexpr (NR == 16) {
         typedef float f32x8 __attribute__((ext_vector_type(8)));
         typedef float f32x4 __attribute__((ext_vector_type(4)));
         typedef float f32x2 __attribute__((ext_vector_type(2)));
-#if (D2R_ATTN_VAR & 1)
-        // variant: scale-subtract as eight v_pk_fma_f32 and the row sum as packed adds on register PAIRS the compiler cannot split
-        // (the empty asm ties each pair to an aligned 64-bit register)
-        f32x2 pr[8];
-        const f32x2 c2 = {sm_c, sm_c}, m2 = {-m_run, -m_run};
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-            f32x2 t2 = __builtin_elementwise_fma(f32x2{sacc[2 * q], sacc[2 * q + 1]}, c2, m2);
-            pr[q] = f32x2{__builtin_amdgcn_exp2f(t2.x), __builtin_amdgcn_exp2f(t2.y)};
-            asm volatile("" : "+v"(pr[q]));
-            sacc[2 * q] = pr[q].x;
-            sacc[2 * q + 1] = pr[q].y;
-        }
-        const f32x2 a0 = pr[0] + pr[4], a1 = pr[1] + pr[5], a2 = pr[2] + pr[6], a3 = pr[3] + pr[7];
-        const f32x2 b0 = a0 + a2, b1 = a1 + a3;
-        const f32x2 s2 = b0 + b1;
-        l_run += s2.x + s2.y;
-#else
-#if (D2R_ATTN_ABLATE & 1024)
-        // ablation (garbage values, timing only): the scores as they would leave an accumulator initialised with -m_run from a q already
-        // scaled by log2(e) / 8 — no scale-subtract between the MFMA and the exponential
 #pragma unroll
         for (int r = 0; r < 16; r++) sacc[r] = __builtin_amdgcn_exp2f(sacc[r]);
-#else
-        const f32x16 cv = sm_c, mv = -m_run;
-        const f32x16 t = __builtin_elementwise_fma(sacc, cv, mv);
-#pragma unroll
-        for (int r = 0; r < 16; r++) sacc[r] = __builtin_amdgcn_exp2f(t[r]);
-#endif
         const f32x8 s8 = sacc.lo + sacc.hi;
         const f32x4 s4 = s8.lo + s8.hi;
         const f32x2 s2 = s4.lo + s4.hi;
         l_run += s2.x + s2.y;
-#endif
     } else {
 #pragma unroll
-        for (int r = 0; r < 4; r++) sacc[r] = __builtin_amdgcn_exp2f(fmaf(sacc[r], sm_c, -m_run));
+        for (int r = 0; r < 4; r++) sacc[r] = __builtin_amdgcn_exp2f(sacc[r]);
         l_run += (sacc[0] + sacc[1]) + (sacc[2] + sacc[3]);
     }
 #endif
@@ -2422,7 +2468,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void k_attention_s(const 
     f32x16 o0, o1;
 #pragma unroll
     for (int r = 0; r < 16; r++) o0[r] = o1[r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
+    float m_run = 0.f, l_run = 0.f;                       // m_run: set from the first key tile below
     // per-lane LDS offsets inside a slot.  K: row li, chunks 2s + hi.  V (transposing read): a 16-lane group g = li >> 4
     // with lane-in-group i reads key row 4hi + (i >> 2) (+ 16s + 8j per read), dims 32t + 16g + 4(i & 3)
     uint32_t koff[4];
@@ -2457,6 +2503,14 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void k_attention_s(const 
         for (int r = 0; r < 16; r++) sacc[r] = 0.f;
 #pragma unroll
         for (int s = 0; s < ((D2R_ATTN_ABLATE & 128) ? 0 : 4); s++) s_mfma(sacc, s);
+        // the first key tile's maximum is the first running maximum (key rows >= T repeat row T-1: a duplicate of a real score
+        // changes no maximum); from here on the scores reach ats_softmax with m_run already subtracted
+        float m0 = sacc[0];
+#pragma unroll
+        for (int r = 1; r < 16; r++) m0 = fmaxf(m0, sacc[r]);
+        m_run = half_max(m0);
+#pragma unroll
+        for (int r = 0; r < 16; r++) sacc[r] -= m_run;
     }
     // One key tile, whose scores are already in sacc.  Unless LAST, first the hand-over to the next tile: wait for
     // this wave's request of tile kt+1 (WAIT younger requests may stay in flight), barrier — tile kt+1 is complete and
@@ -2506,7 +2560,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void k_attention_s(const 
         // no faster and costs ten registers)
         if constexpr (!LAST) {
 #pragma unroll
-            for (int r = 0; r < 16; r++) sacc[r] = (D2R_ATTN_ABLATE & 128) ? __uint_as_float(ka[r & 3].x) : (D2R_ATTN_ABLATE & 1024) ? -m_run : 0.f;
+            for (int r = 0; r < 16; r++) sacc[r] = (D2R_ATTN_ABLATE & 128) ? __uint_as_float(ka[r & 3].x) : -m_run;     // the MFMAs subtract the running maximum
 #pragma unroll
             for (int s = 0; s < ((D2R_ATTN_ABLATE & 128) ? 0 : 4); s++) s_mfma(sacc, s);
         }
@@ -2618,15 +2672,14 @@ __global__ __launch_bounds__(256) void k_attention_cls(const uint16_t *__restric
             a = fmaf(q[8 * c + 4], bf_lo(v.z), a); a = fmaf(q[8 * c + 5], bf_hi(v.z), a);
             a = fmaf(q[8 * c + 6], bf_lo(v.w), a); a = fmaf(q[8 * c + 7], bf_hi(v.w), a);
         }
-        a *= 0.125f;                                              // head_dim^-0.5
-        ps[w][key] = a;
+        ps[w][key] = a;                                           // q carries head_dim^-0.5 * log2(e) (folded into W_q at create): exp2 domain
         mx = fmaxf(mx, a);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
     float sum = 0.f;
     for (uint32_t key = lane; key < T; key += 64) {
-        const float p = __expf(ps[w][key] - mx);
+        const float p = __builtin_amdgcn_exp2f(ps[w][key] - mx);
         ps[w][key] = p;
         sum += p;
     }
@@ -2820,12 +2873,17 @@ __global__ void k_text_embed(const int32_t *__restrict__ ids, const float *__res
 
 // fp32 -> bf16 weight conversion with optional K padding
 __global__ void k_convert_bf16(const float *__restrict__ src, uint16_t *__restrict__ dst, uint32_t rows,
-                               uint32_t K, uint32_t K_pad)
+                               uint32_t K, uint32_t K_pad, float scale = 1.0f)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)rows * K_pad) return;
     uint32_t r = i / K_pad, c = i % K_pad;
-    dst[i] = c < K ? f2bf(src[(size_t)r * K + c]) : (uint16_t)0;
+    dst[i] = c < K ? f2bf(src[(size_t)r * K + c] * scale) : (uint16_t)0;
+}
+__global__ void k_scale_f32(float *__restrict__ p, uint32_t n, float scale)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] *= scale;
 }
 
 // ---------------------------------------------------------------- host side
@@ -3535,12 +3593,15 @@ extern "C" int d2r_clip_create(d2r_ctx *ctx, const d2r_clip_desc *desc, const fl
         if (hipMalloc(&wqkv, (size_t)3 * d * d * 2) != hipSuccess || hipMalloc(&bqkv, (size_t)3 * d * 4) != hipSuccess) { ok = false; break; }
         c->allocs.push_back(wqkv);
         c->allocs.push_back(bqkv);
+        // the q rows (weights, bias) carry the attention scale head_dim^-0.5 * log2(e): k_attention_s / k_attention_cls work in the exp2
+        // domain on scores that need no further scaling (the scaled weight is rounded to bf16 once, like the unscaled one was)
         for (int j = 0; j < 3; j++) {
             const float *wj = f32((size_t)d * d), *bj = f32(d);
             size_t tot = (size_t)d * d;
             hipLaunchKernelGGL(k_convert_bf16, dim3((uint32_t)((tot + 255) / 256)), dim3(256), 0, ctx->stream, wj,
-                               wqkv + (size_t)j * d * d, d, d, d);
+                               wqkv + (size_t)j * d * d, d, d, d, j == 0 ? ATTN_Q_SCALE : 1.0f);
             hipMemcpyAsync(bqkv + (size_t)j * d, bj, (size_t)d * 4, hipMemcpyDeviceToDevice, ctx->stream);
+            if (j == 0) hipLaunchKernelGGL(k_scale_f32, dim3((d + 255) / 256), dim3(256), 0, ctx->stream, bqkv, d, ATTN_Q_SCALE);
         }
         L.w_qkv = wqkv;
         L.b_qkv = bqkv;
@@ -3556,7 +3617,7 @@ extern "C" int d2r_clip_create(d2r_ctx *ctx, const d2r_clip_desc *desc, const fl
             for (int j = 0; j < 3; j++) {
                 const float *wj = q0 + (size_t)j * ((size_t)d * d + d), *bj = wj + (size_t)d * d;
                 hipLaunchKernelGGL(k_fold_ln_weight, dim3((d + 3) / 4), dim3(256), 0, ctx->stream, wj, L.ln1_w, L.ln1_b, bj,
-                                   wfq + (size_t)j * d * d, csq + (size_t)j * d, bfq + (size_t)j * d, d, d);
+                                   wfq + (size_t)j * d * d, csq + (size_t)j * d, bfq + (size_t)j * d, d, d, j == 0 ? ATTN_Q_SCALE : 1.0f);
             }
         }
         L.wf_qkv = wfq; L.cs_qkv = csq; L.bf_qkv = bfq;

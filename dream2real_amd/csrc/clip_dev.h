@@ -6,8 +6,8 @@
 // D2R_GEMM_ABLATE (bitmask) — k_gemm8 and the shared epilogue: 1 no LDS-DMA, 2 no fragment ds_reads, 4 no epilogue,
 //   8 no MFMA, 128 no global loads/stores in the epilogue, 256 no LDS transposes in the epilogue.
 // D2R_ATTN_ABLATE (bitmask) — k_attention_s: 16 no DMA requests, 32 no softmax, 64 no PV (V reads + MFMAs), 128 no
-//   S MFMAs, 256 no per-tile barriers, 512 the partial last query tile computes nothing (prices a cheaper tail tile), 1024 no
-//   scale-subtract between the S MFMAs and the exponentials (prices the accumulator initialised with -m_run + log2(e)/8 folded into W_q).
+//   S MFMAs, 256 no per-tile barriers, 512 the partial last query tile computes nothing (prices a cheaper tail tile: -2.7 % of the kernel at
+//   197 tokens, profiles/r06_attn_price.txt).  (1024, round 6's pricing of the shifted accumulator, is gone: it is what the kernel now does.)
 // Results are garbage when a mask is set; tools/gemm_ablate.sh / tools/attn_ablate.sh rebuild with each mask to see
 // what a tile's time is made of.
 // D2R_GEMM_STAMPS — shader-clock cycles wave 0 of every workgroup spends per tile section of k_gemm8, read back with
@@ -21,11 +21,6 @@
 #endif
 // D2R_F8_EXP (bitmask) — k_gemm8f and the fp8 epilogues: 1 no scale-byte stores, 2 no e4m3 stores, 4 no GELU, 8 no scale loads in the K loop,
 //   16 no MFMA, 32 no LDS-DMA, 64 no fragment reads.  Garbage results; tools/f8_ablate.sh.
-// D2R_ATTN_VAR (bitmask) — instruction-level variants of k_attention_s' softmax (round 5): 1 = v_max3 chain on the raw accumulators, eight packed
-//   scale-subtracts, packed row sum.  Same results up to the order of the row sum.
-#ifndef D2R_ATTN_VAR
-#define D2R_ATTN_VAR 0
-#endif
 #ifndef D2R_F8_EXP
 #define D2R_F8_EXP 0
 #endif
