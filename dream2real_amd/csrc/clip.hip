@@ -838,9 +838,12 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], float *ep, u
 // one v_permlane32_swap per dword pairs the lane halves so that every lane stores 8 consecutive bf16 (16 bytes; the two halves of a row
 // 32 contiguous bytes) — k_attention_s' output idiom.  No LDS traffic at all.
 #ifndef D2R_GEMM_TR
-#define D2R_GEMM_TR 1
+#define D2R_GEMM_TR 0
 #endif
-#define EPI_HAS_TR(E) (D2R_GEMM_TR && ((E) == EPI_BIAS_BF16 || (E) == EPI_BIAS_GELU_BF16 || EPI_IS_LN(E)))
+#ifndef D2R_GEMM_TR_RESID
+#define D2R_GEMM_TR_RESID 0
+#endif
+#define EPI_HAS_TR(E) ((D2R_GEMM_TR && ((E) == EPI_BIAS_BF16 || (E) == EPI_BIAS_GELU_BF16 || EPI_IS_LN(E))) || (D2R_GEMM_TR_RESID && (E) == EPI_RESID_STATS_SPLIT8))
 template <int EPI>
 __device__ __forceinline__ void gemm_epilogue_tr(f32x16 (&acc)[4][2], uint32_t lane, uint32_t row0, uint32_t col0, const float *__restrict__ bias,
                                                  void *__restrict__ Cout, uint32_t N, const EpiAux &aux, const float2 *ab_lds)
@@ -907,6 +910,107 @@ __device__ __forceinline__ void gemm_epilogue_tr(f32x16 (&acc)[4][2], uint32_t l
                 *(uint4 *)(cb + (loff + (uint32_t)(32 * i) * rs + (uint32_t)(32 * j + 16 * g) * 2u)) = make_uint4(x[0], y[0], x[1], y[1]);
             }
         }
+    }
+}
+
+// EPI_RESID_STATS_SPLIT8 in the transposed layout: the residual's hi rows are read and written in the STORE layout above (16 bytes = 8
+// consecutive columns per lane) and pass through the same v_permlane32_swap pairs, inverted on the way in; the lo bytes of the row pair
+// (32 i' + li, + 32) — 8 + 8 contiguous bytes in the lo8_off layout — are read and written one row per lane half and swapped likewise.
+// The row statistics add up in gemm_epilogue's order exactly (per 8 columns ((f0+f1)+(f2+f3)) + ((f4+f5)+(f6+f7)), then the balanced tree
+// over the eight groups), the cross-half terms through swaps instead of DPP: same bits.
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue_tr_resid(f32x16 (&acc)[4][2], uint32_t lane, uint32_t row0, uint32_t col0, const float *__restrict__ bias,
+                                                       const EpiAux &aux)
+{
+    static_assert(EPI == EPI_RESID_STATS_SPLIT8, "hi + lo-byte residual only");
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const uint32_t li = lane & 31, hi = lane >> 5;
+    // 32-bit byte offsets on top of the uniform array bases (arrays < 4 GiB: checked by launch_gemm8)
+    const uint32_t x0 = (((col0 >> 6) * aux.hm_rows + row0 + li) * 64u + 8u * hi) * 2u;
+    const uint32_t p0 = ((col0 >> 6) * aux.hm_rows + row0 + li) * 8u;
+    const uint32_t l0 = (((col0 >> 6) * (aux.hm_rows >> 6) + (row0 >> 6)) << 12) + li * 128u + hi * 8u;
+    char *xb_b = (char *)aux.xb, *xlo_b = (char *)aux.xlo, *part_b = (char *)aux.part;
+    auto swap = [](uint32_t a, uint32_t b) -> u32x2 { return __builtin_amdgcn_permlane32_swap(a, b, false, false); };
+    auto fswap_sum = [&](float a, float b) -> float {       // lanes 0-31: a + partner's a; lanes 32-63: partner's b + b  (partner = lane ^ 32)
+        const u32x2 r = swap(__float_as_uint(a), __float_as_uint(b));
+        return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    };
+#pragma unroll
+    for (int ip = 0; ip < 2; ip++) {
+        float ysum[2][2], ysq[2][2];                       // [row of the pair][n-tile]
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            float4 bq[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) bq[q] = *(const float4 *)(bias + col0 + 32 * j + 8 * q + 4 * hi);
+            uint4 Lh[2][2];
+            uint2 Ll[4];
+#pragma unroll
+            for (int ii = 0; ii < 2; ii++)
+#pragma unroll
+                for (int g = 0; g < 2; g++) Lh[ii][g] = *(const uint4 *)(xb_b + x0 + (uint32_t)(32 * (2 * ip + ii)) * 128u + (uint32_t)(32 * j + 16 * g) * 2u);
+#pragma unroll
+            for (int q = 0; q < 4; q++) Ll[q] = *(const uint2 *)(xlo_b + l0 + (uint32_t)ip * 4096u + (uint32_t)(4 * j + q) * 16u);
+            uint32_t lo_in[2][4], lo_out[2][4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const u32x2 r = swap(Ll[q].x, Ll[q].y);
+                lo_in[0][q] = r[0];
+                lo_in[1][q] = r[1];
+            }
+#pragma unroll
+            for (int ii = 0; ii < 2; ii++) {
+                const int i = 2 * ip + ii;
+                uint32_t hw[4][2], nh[4][2];                 // [q][dword]: bf16 pairs (e = 0, 1), (e = 2, 3) of this lane's columns 8 q + 4 hi + e
+#pragma unroll
+                for (int g = 0; g < 2; g++) {
+                    const u32x2 a = swap(Lh[ii][g].x, Lh[ii][g].z), b = swap(Lh[ii][g].y, Lh[ii][g].w);
+                    hw[2 * g][0] = a[0]; hw[2 * g + 1][0] = a[1];
+                    hw[2 * g][1] = b[0]; hw[2 * g + 1][1] = b[1];
+                }
+                float ps[4], pq[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    float f[4] = {acc[i][j][4 * q] + bq[q].x, acc[i][j][4 * q + 1] + bq[q].y, acc[i][j][4 * q + 2] + bq[q].z, acc[i][j][4 * q + 3] + bq[q].w};
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const uint32_t hb = (e & 1) ? (hw[q][e >> 1] & 0xffff0000u) : (hw[q][e >> 1] << 16);
+                        const int32_t t = __builtin_amdgcn_sbfe((int32_t)lo_in[ii][q], 8 * e, 8);
+                        f[e] += __uint_as_float(hb + (uint32_t)(t << 8));
+                    }
+                    nh[q][0] = pack2(f[0], f[1]);
+                    nh[q][1] = pack2(f[2], f[3]);
+                    int32_t qv[4];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) qv[e] = split8_round(f[e], (e & 1) ? (nh[q][e >> 1] & 0xffff0000u) : (nh[q][e >> 1] << 16));
+                    lo_out[ii][q] = __builtin_amdgcn_perm((uint32_t)qv[1], (uint32_t)qv[0], 0x0c0c0501u) |
+                                    (__builtin_amdgcn_perm((uint32_t)qv[3], (uint32_t)qv[2], 0x0c0c0501u) << 16);
+                    ps[q] = (f[0] + f[1]) + (f[2] + f[3]);
+                    pq[q] = fmaf(f[0], f[0], f[1] * f[1]) + fmaf(f[2], f[2], f[3] * f[3]);
+                }
+#pragma unroll
+                for (int g = 0; g < 2; g++) {
+                    const u32x2 x = swap(nh[2 * g][0], nh[2 * g + 1][0]), y = swap(nh[2 * g][1], nh[2 * g + 1][1]);
+                    *(uint4 *)(xb_b + x0 + (uint32_t)(32 * i) * 128u + (uint32_t)(32 * j + 16 * g) * 2u) = make_uint4(x[0], y[0], x[1], y[1]);
+                }
+                // s_t = A_t + B_t (the two lane halves' quads of 8-column group t = 4 j + q), x = s_t + s_(t^1), y = x + x': lanes 0-31 / 32-63
+                // hold the even / odd member at every level, the last level leaves the sum in both halves
+                const float s01 = fswap_sum(ps[0], ps[1]), s23 = fswap_sum(ps[2], ps[3]);       // lanes lo: s_0 / s_2, lanes hi: s_1 / s_3
+                const float xx = fswap_sum(s01, s23);                                           // lanes lo: s_0 + s_1, lanes hi: s_2 + s_3
+                ysum[ii][j] = fswap_sum(xx, xx);
+                const float q01 = fswap_sum(pq[0], pq[1]), q23 = fswap_sum(pq[2], pq[3]);
+                const float qx = fswap_sum(q01, q23);
+                ysq[ii][j] = fswap_sum(qx, qx);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const u32x2 r = swap(lo_out[0][q], lo_out[1][q]);
+                *(uint2 *)(xlo_b + l0 + (uint32_t)ip * 4096u + (uint32_t)(4 * j + q) * 16u) = make_uint2(r[0], r[1]);
+            }
+        }
+#pragma unroll
+        for (int ii = 0; ii < 2; ii++)          // both lane halves hold (and store) the same pair
+            *(float2 *)(part_b + p0 + (uint32_t)(32 * (2 * ip + ii)) * 8u) = make_float2(ysum[ii][0] + ysum[ii][1], ysq[ii][0] + ysq[ii][1]);
     }
 }
 
@@ -1378,7 +1482,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
     // a freshly computed lane id (mbcnt) instead of the one derived from threadIdx at kernel entry: that
     // one would stay live across the K loop for the epilogue's sake, and at 250+ registers it gets spilled
     const uint32_t lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    if constexpr (EPI_HAS_TR(EPI)) gemm_epilogue_tr<EPI>(acc, lane_e, em, en, bias, Cout, N, aux, ab_lds);
+    if constexpr (EPI_HAS_TR(EPI) && EPI == EPI_RESID_STATS_SPLIT8) gemm_epilogue_tr_resid<EPI>(acc, lane_e, em, en, bias, aux);
+    else if constexpr (EPI_HAS_TR(EPI)) gemm_epilogue_tr<EPI>(acc, lane_e, em, en, bias, Cout, N, aux, ab_lds);
     else gemm_epilogue<EPI, 4>(acc, ep, lane_e, em, en, bias, Cout, N, aux, ab_lds);
 #endif
 #ifdef D2R_GEMM_STAMPS
