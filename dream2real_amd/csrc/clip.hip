@@ -826,194 +826,11 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[MT][2], float *ep, u
     }
 }
 
-// ---- transposed epilogues (k_gemm8, round 6) ----
-//
-// gemm_epilogue above first transposes the fp32 tile through LDS so that a lane owns consecutive columns of a row: 256 KiB written and
-// 256 KiB read back per 256x256 tile at 128 B/clk = ~4 k cycles — the whole QKV epilogue (profiles/r06_gemm_stamps.txt: 4.3 k).
-// k_gemm8 instead computes the TRANSPOSED product for these epilogue kinds — the MFMA's A operand is the W fragment, its B operand the
-// activation fragment (the two fragments have the same lane layout, and a dot product does not care which factor is called A) — so that
-//     acc[i][j][r]  <->  row 32 i + li,  column 32 j + 8 (r >> 2) + 4 hi + (r & 3)      (lane = 32 hi + li)
-// a lane holds 4 consecutive columns of ONE row per register quad: per-row constants (the LayerNorm statistics) are per lane, per-column
-// constants (bias, column sums) are 2 x 4 float4 per lane, the arithmetic is gemm_epilogue's operation by operation (same results), and
-// one v_permlane32_swap per dword pairs the lane halves so that every lane stores 8 consecutive bf16 (16 bytes; the two halves of a row
-// 32 contiguous bytes) — k_attention_s' output idiom.  No LDS traffic at all.
-#ifndef D2R_GEMM_TR
-#define D2R_GEMM_TR 0
-#endif
-#ifndef D2R_GEMM_TR_RESID
-#define D2R_GEMM_TR_RESID 0
-#endif
-#define EPI_HAS_TR(E) ((D2R_GEMM_TR && ((E) == EPI_BIAS_BF16 || (E) == EPI_BIAS_GELU_BF16 || EPI_IS_LN(E))) || (D2R_GEMM_TR_RESID && (E) == EPI_RESID_STATS_SPLIT8))
-template <int EPI>
-__device__ __forceinline__ void gemm_epilogue_tr(f32x16 (&acc)[4][2], uint32_t lane, uint32_t row0, uint32_t col0, const float *__restrict__ bias,
-                                                 void *__restrict__ Cout, uint32_t N, const EpiAux &aux, const float2 *ab_lds)
-{
-    constexpr bool LN = EPI_IS_LN(EPI);
-    constexpr bool GELU = EPI == EPI_BIAS_GELU_BF16 || EPI == EPI_LN_BIAS_GELU_BF16;
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    const uint32_t li = lane & 31, hi = lane >> 5;
-    // this lane's columns: col0 + 32 j + 8 q + 4 hi + (0..3)
-    float4 bq[2][4], sq[2][4];
-#pragma unroll
-    for (int j = 0; j < 2; j++)
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            bq[j][q] = *(const float4 *)(bias + col0 + 32 * j + 8 * q + 4 * hi);
-            if (LN) sq[j][q] = *(const float4 *)(aux.cs + col0 + 32 * j + 8 * q + 4 * hi);
-        }
-    const uint32_t rs = aux.hm_rows ? 128u : N * 2u;                                   // bytes between rows
-    char *const cb = (char *)Cout + (aux.hm_rows ? ((size_t)(col0 >> 6) * aux.hm_rows + row0) * 128u : ((size_t)row0 * N + col0) * 2u);
-    const uint32_t loff = li * rs + hi * 16u;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        f32x2 ax = {1.f, 1.f}, ay = {0.f, 0.f};
-        if (LN) {
-            const float2 ab = ab_lds[32 * i + li];                                     // (rstd, -rstd * mean) of this lane's row
-            ax = f32x2{ab.x, ab.x};
-            ay = f32x2{ab.y, ab.y};
-        }
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            uint32_t pk[8];
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                f32x2 pf[2] = {f32x2{acc[i][j][4 * q], acc[i][j][4 * q + 1]}, f32x2{acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]}};
-                const f32x2 bb[2] = {f32x2{bq[j][q].x, bq[j][q].y}, f32x2{bq[j][q].z, bq[j][q].w}};
-#pragma unroll
-                for (int e = 0; e < 2; e++) {
-                    if (LN) {
-                        const f32x2 ss = e ? f32x2{sq[j][q].z, sq[j][q].w} : f32x2{sq[j][q].x, sq[j][q].y};
-                        pf[e] = __builtin_elementwise_fma(ax, pf[e], __builtin_elementwise_fma(ay, ss, bb[e]));
-                    } else {
-                        pf[e] = pf[e] + bb[e];
-                    }
-                    if (GELU) {
-                        // quick_gelu: x * sigmoid(1.702 x) = x / (1 + exp2(-1.702 log2(e) x))
-                        const f32x2 t = pf[e] * f32x2{-2.4554669595930156f, -2.4554669595930156f};
-                        const f32x2 d = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + f32x2{1.0f, 1.0f};
-                        pf[e] = pf[e] * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
-                    }
-                    pk[2 * q + e] = pack2(pf[e][0], pf[e][1]);
-                }
-            }
-            // quads q = 2 g (lane half 0 keeps it) and 2 g + 1 (lane half 1): after the swaps lanes 0-31 hold columns 16 g .. 16 g + 7 of their
-            // row and lanes 32-63 columns 16 g + 8 .. 16 g + 15
-#pragma unroll
-            for (int g = 0; g < 2; g++) {
-                const u32x2 x = __builtin_amdgcn_permlane32_swap(pk[4 * g + 0], pk[4 * g + 2], false, false);
-                const u32x2 y = __builtin_amdgcn_permlane32_swap(pk[4 * g + 1], pk[4 * g + 3], false, false);
-#if (D2R_GEMM_ABLATE & 128) && defined(__HIP_DEVICE_COMPILE__)
-                asm volatile("" ::"v"(x[0]), "v"(x[1]), "v"(y[0]), "v"(y[1]));
-                continue;
-#endif
-                *(uint4 *)(cb + (loff + (uint32_t)(32 * i) * rs + (uint32_t)(32 * j + 16 * g) * 2u)) = make_uint4(x[0], y[0], x[1], y[1]);
-            }
-        }
-    }
-}
-
-// EPI_RESID_STATS_SPLIT8 in the transposed layout: the residual's hi rows are read and written in the STORE layout above (16 bytes = 8
-// consecutive columns per lane) and pass through the same v_permlane32_swap pairs, inverted on the way in; the lo bytes of the row pair
-// (32 i' + li, + 32) — 8 + 8 contiguous bytes in the lo8_off layout — are read and written one row per lane half and swapped likewise.
-// The row statistics add up in gemm_epilogue's order exactly (per 8 columns ((f0+f1)+(f2+f3)) + ((f4+f5)+(f6+f7)), then the balanced tree
-// over the eight groups), the cross-half terms through swaps instead of DPP: same bits.
-template <int EPI>
-__device__ __forceinline__ void gemm_epilogue_tr_resid(f32x16 (&acc)[4][2], uint32_t lane, uint32_t row0, uint32_t col0, const float *__restrict__ bias,
-                                                       const EpiAux &aux)
-{
-    static_assert(EPI == EPI_RESID_STATS_SPLIT8, "hi + lo-byte residual only");
-    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    const uint32_t li = lane & 31, hi = lane >> 5;
-    // 32-bit byte offsets on top of the uniform array bases (arrays < 4 GiB: checked by launch_gemm8)
-    const uint32_t x0 = (((col0 >> 6) * aux.hm_rows + row0 + li) * 64u + 8u * hi) * 2u;
-    const uint32_t p0 = ((col0 >> 6) * aux.hm_rows + row0 + li) * 8u;
-    const uint32_t l0 = (((col0 >> 6) * (aux.hm_rows >> 6) + (row0 >> 6)) << 12) + li * 128u + hi * 8u;
-    char *xb_b = (char *)aux.xb, *xlo_b = (char *)aux.xlo, *part_b = (char *)aux.part;
-    auto swap = [](uint32_t a, uint32_t b) -> u32x2 { return __builtin_amdgcn_permlane32_swap(a, b, false, false); };
-    auto fswap_sum = [&](float a, float b) -> float {       // lanes 0-31: a + partner's a; lanes 32-63: partner's b + b  (partner = lane ^ 32)
-        const u32x2 r = swap(__float_as_uint(a), __float_as_uint(b));
-        return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    };
-#pragma unroll
-    for (int ip = 0; ip < 2; ip++) {
-        float ysum[2][2], ysq[2][2];                       // [row of the pair][n-tile]
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            float4 bq[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) bq[q] = *(const float4 *)(bias + col0 + 32 * j + 8 * q + 4 * hi);
-            uint4 Lh[2][2];
-            uint2 Ll[4];
-#pragma unroll
-            for (int ii = 0; ii < 2; ii++)
-#pragma unroll
-                for (int g = 0; g < 2; g++) Lh[ii][g] = *(const uint4 *)(xb_b + x0 + (uint32_t)(32 * (2 * ip + ii)) * 128u + (uint32_t)(32 * j + 16 * g) * 2u);
-#pragma unroll
-            for (int q = 0; q < 4; q++) Ll[q] = *(const uint2 *)(xlo_b + l0 + (uint32_t)ip * 4096u + (uint32_t)(4 * j + q) * 16u);
-            uint32_t lo_in[2][4], lo_out[2][4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const u32x2 r = swap(Ll[q].x, Ll[q].y);
-                lo_in[0][q] = r[0];
-                lo_in[1][q] = r[1];
-            }
-#pragma unroll
-            for (int ii = 0; ii < 2; ii++) {
-                const int i = 2 * ip + ii;
-                uint32_t hw[4][2], nh[4][2];                 // [q][dword]: bf16 pairs (e = 0, 1), (e = 2, 3) of this lane's columns 8 q + 4 hi + e
-#pragma unroll
-                for (int g = 0; g < 2; g++) {
-                    const u32x2 a = swap(Lh[ii][g].x, Lh[ii][g].z), b = swap(Lh[ii][g].y, Lh[ii][g].w);
-                    hw[2 * g][0] = a[0]; hw[2 * g + 1][0] = a[1];
-                    hw[2 * g][1] = b[0]; hw[2 * g + 1][1] = b[1];
-                }
-                float ps[4], pq[4];
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    float f[4] = {acc[i][j][4 * q] + bq[q].x, acc[i][j][4 * q + 1] + bq[q].y, acc[i][j][4 * q + 2] + bq[q].z, acc[i][j][4 * q + 3] + bq[q].w};
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const uint32_t hb = (e & 1) ? (hw[q][e >> 1] & 0xffff0000u) : (hw[q][e >> 1] << 16);
-                        const int32_t t = __builtin_amdgcn_sbfe((int32_t)lo_in[ii][q], 8 * e, 8);
-                        f[e] += __uint_as_float(hb + (uint32_t)(t << 8));
-                    }
-                    nh[q][0] = pack2(f[0], f[1]);
-                    nh[q][1] = pack2(f[2], f[3]);
-                    int32_t qv[4];
-#pragma unroll
-                    for (int e = 0; e < 4; e++) qv[e] = split8_round(f[e], (e & 1) ? (nh[q][e >> 1] & 0xffff0000u) : (nh[q][e >> 1] << 16));
-                    lo_out[ii][q] = __builtin_amdgcn_perm((uint32_t)qv[1], (uint32_t)qv[0], 0x0c0c0501u) |
-                                    (__builtin_amdgcn_perm((uint32_t)qv[3], (uint32_t)qv[2], 0x0c0c0501u) << 16);
-                    ps[q] = (f[0] + f[1]) + (f[2] + f[3]);
-                    pq[q] = fmaf(f[0], f[0], f[1] * f[1]) + fmaf(f[2], f[2], f[3] * f[3]);
-                }
-#pragma unroll
-                for (int g = 0; g < 2; g++) {
-                    const u32x2 x = swap(nh[2 * g][0], nh[2 * g + 1][0]), y = swap(nh[2 * g][1], nh[2 * g + 1][1]);
-                    *(uint4 *)(xb_b + x0 + (uint32_t)(32 * i) * 128u + (uint32_t)(32 * j + 16 * g) * 2u) = make_uint4(x[0], y[0], x[1], y[1]);
-                }
-                // s_t = A_t + B_t (the two lane halves' quads of 8-column group t = 4 j + q), x = s_t + s_(t^1), y = x + x': lanes 0-31 / 32-63
-                // hold the even / odd member at every level, the last level leaves the sum in both halves
-                const float s01 = fswap_sum(ps[0], ps[1]), s23 = fswap_sum(ps[2], ps[3]);       // lanes lo: s_0 / s_2, lanes hi: s_1 / s_3
-                const float xx = fswap_sum(s01, s23);                                           // lanes lo: s_0 + s_1, lanes hi: s_2 + s_3
-                ysum[ii][j] = fswap_sum(xx, xx);
-                const float q01 = fswap_sum(pq[0], pq[1]), q23 = fswap_sum(pq[2], pq[3]);
-                const float qx = fswap_sum(q01, q23);
-                ysq[ii][j] = fswap_sum(qx, qx);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const u32x2 r = swap(lo_out[0][q], lo_out[1][q]);
-                *(uint2 *)(xlo_b + l0 + (uint32_t)ip * 4096u + (uint32_t)(4 * j + q) * 16u) = make_uint2(r[0], r[1]);
-            }
-        }
-#pragma unroll
-        for (int ii = 0; ii < 2; ii++)          // both lane halves hold (and store) the same pair
-            *(float2 *)(part_b + p0 + (uint32_t)(32 * (2 * ip + ii)) * 8u) = make_float2(ysum[ii][0] + ysum[ii][1], ysq[ii][0] + ysq[ii][1]);
-    }
-}
-
+// (Round 6 measured the alternative to the LDS transposes above: the TRANSPOSED product — W fragment as the MFMA's A operand, so that a
+// lane holds 4 consecutive columns of one row, pairs its halves with v_permlane32_swap and stores 16 bytes with no LDS traffic.  Correct
+// and bit-identical, but a store instruction then writes 32 rows x 32 bytes instead of 8 full 128-byte rows, and the write path answers
+// four times the requests slower than the LDS round trip costs: QKV epilogue 4.4 -> 5.5 k cycles, drain 1.6 -> 4.8 k; residual epilogue
+// 16.5 -> 28.3 k.  Commit bdc5381, profiles/r06_gemm_stamps_transposed.txt.)
 // C = A[M,K] * W[N,K]^T.  A [M_pad][K] bf16, W [N][K] bf16, K % 64 == 0.  The plain-K-loop GEMM that
 // serves what k_gemm8 below does not (outputs with few 256x256 tiles, K not a multiple of 128).
 // 8 waves as WGM x WGN, each wave MT x 2 MFMA 32x32x16 tiles:
@@ -1333,9 +1150,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
 #if (D2R_GEMM_ABLATE & 8) && defined(__HIP_DEVICE_COMPILE__)
                 asm volatile("" ::"v"(a.u.x), "v"(b.u.x));
 #else
-                // EPI_HAS_TR: the transposed product (W fragment as the MFMA's A operand), see gemm_epilogue_tr
-                acc[mh * 2 + mt][nh] = EPI_HAS_TR(EPI) ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(b.v, a.v, acc[mh * 2 + mt][nh], 0, 0, 0)
-                                                       : __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc[mh * 2 + mt][nh], 0, 0, 0);
+                acc[mh * 2 + mt][nh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc[mh * 2 + mt][nh], 0, 0, 0);
 #endif
             }
 #if D2R_GEMM_PRIO == 0
@@ -1482,9 +1297,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm8(const uint16_t *__restrict__ A
     // a freshly computed lane id (mbcnt) instead of the one derived from threadIdx at kernel entry: that
     // one would stay live across the K loop for the epilogue's sake, and at 250+ registers it gets spilled
     const uint32_t lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    if constexpr (EPI_HAS_TR(EPI) && EPI == EPI_RESID_STATS_SPLIT8) gemm_epilogue_tr_resid<EPI>(acc, lane_e, em, en, bias, aux);
-    else if constexpr (EPI_HAS_TR(EPI)) gemm_epilogue_tr<EPI>(acc, lane_e, em, en, bias, Cout, N, aux, ab_lds);
-    else gemm_epilogue<EPI, 4>(acc, ep, lane_e, em, en, bias, Cout, N, aux, ab_lds);
+    gemm_epilogue<EPI, 4>(acc, ep, lane_e, em, en, bias, Cout, N, aux, ab_lds);
 #endif
 #ifdef D2R_GEMM_STAMPS
     {
