@@ -28,6 +28,9 @@ except Exception as e:
     print(sys.argv[1], "FAILED", e)
 PY
 done
+# the render's distance to the emulation of tiny-cuda-nn's half arithmetic (+ the round-5 trained-field table on this library) -> gpurun_out/r06_trained_field_parity.json
+timeout 900 python tests/diag/trained_field_parity.py > $OUT/${TAG}_trained_field_parity.log 2>&1
+cp gpurun_out/r06_trained_field_parity.json $OUT/${TAG}_trained_field_parity.json 2>/dev/null
 # API lines
 a() { python bench.py --api --steps 1 --warmup 1 "$@" 2>$OUT/api.err | tail -1; }
 a                                   > $OUT/${TAG}_api_ref_scores.json
