@@ -2254,10 +2254,29 @@ __device__ __forceinline__ void ats_softmax(f32x16 &sacc, f32x16 &o0, f32x16 &o1
     l_run += sacc[0];
     o0[0] += sacc[1];
 #else
-    float tmax = sacc[0];
-#pragma unroll
-    for (int r = 1; r < NR; r++) tmax = fmaxf(tmax, sacc[r]);
-    tmax = half_max(tmax);                                                   // this query's tile maximum MINUS its running maximum
+    float tmax;
+    // v_max3 on the raw accumulator registers and a plain v_max across the lane halves: MFMA results are never signalling NaNs, the
+    // canonicalising self-maxes hipcc puts in front of fmaxf (four per key tile) buy nothing
+    if constexpr (NR == 16) {
+        float a, b;
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(a) : "v"(sacc[0]), "v"(sacc[1]), "v"(sacc[2]));
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(b) : "v"(sacc[3]), "v"(sacc[4]), "v"(sacc[5]));
+        asm("v_max3_f32 %0, %1, %2, %0" : "+v"(a) : "v"(sacc[6]), "v"(sacc[7]));
+        asm("v_max3_f32 %0, %1, %2, %0" : "+v"(b) : "v"(sacc[8]), "v"(sacc[9]));
+        asm("v_max3_f32 %0, %1, %2, %0" : "+v"(a) : "v"(sacc[10]), "v"(sacc[11]));
+        asm("v_max3_f32 %0, %1, %2, %0" : "+v"(b) : "v"(sacc[12]), "v"(sacc[13]));
+        asm("v_max3_f32 %0, %1, %2, %0" : "+v"(a) : "v"(sacc[14]), "v"(sacc[15]));
+        asm("v_max_f32 %0, %1, %2" : "=v"(tmax) : "v"(a), "v"(b));
+    } else {
+        float a;
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(a) : "v"(sacc[0]), "v"(sacc[1]), "v"(sacc[2]));
+        asm("v_max_f32 %0, %1, %2" : "=v"(tmax) : "v"(a), "v"(sacc[3]));
+    }
+    {
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+        asm("v_max_f32 %0, %1, %2" : "=v"(tmax) : "v"(r[0]), "v"(r[1]));
+    }
     if (__builtin_amdgcn_ballot_w64(tmax > ATS_DEFER) != 0) {
         const float dm = fmaxf(tmax, 0.f);                                   // m_new - m_run
         const float alpha = __builtin_amdgcn_exp2f(-dm);
@@ -2272,14 +2291,20 @@ __device__ __forceinline__ void ats_softmax(f32x16 &sacc, f32x16 &o0, f32x16 &o1
         m_run += dm;
     }
     if constexpr (NR == 16) {
-        typedef float f32x8 __attribute__((ext_vector_type(8)));
-        typedef float f32x4 __attribute__((ext_vector_type(4)));
         typedef float f32x2 __attribute__((ext_vector_type(2)));
+        // the exponentials land in aligned register PAIRS (the empty asm ties each pair to a 64-bit register) so that the row sum is seven
+        // v_pk_add_f32 + two adds instead of thirteen
+        f32x2 pr[8];
 #pragma unroll
-        for (int r = 0; r < 16; r++) sacc[r] = __builtin_amdgcn_exp2f(sacc[r]);
-        const f32x8 s8 = sacc.lo + sacc.hi;
-        const f32x4 s4 = s8.lo + s8.hi;
-        const f32x2 s2 = s4.lo + s4.hi;
+        for (int q = 0; q < 8; q++) {
+            pr[q] = f32x2{__builtin_amdgcn_exp2f(sacc[2 * q]), __builtin_amdgcn_exp2f(sacc[2 * q + 1])};
+            asm volatile("" : "+v"(pr[q]));
+            sacc[2 * q] = pr[q].x;
+            sacc[2 * q + 1] = pr[q].y;
+        }
+        const f32x2 a0 = pr[0] + pr[4], a1 = pr[1] + pr[5], a2 = pr[2] + pr[6], a3 = pr[3] + pr[7];
+        const f32x2 b0 = a0 + a2, b1 = a1 + a3;
+        const f32x2 s2 = b0 + b1;
         l_run += s2.x + s2.y;
     } else {
 #pragma unroll
@@ -2323,7 +2348,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void k_attention_s(const 
 #if (D2R_ATTN_ABLATE & 512)
     const bool active = qt < n_kt && (qt + 1) * 32 <= T;  // ablation: the partial last query tile (5 of 32 queries at 197 tokens) computes nothing — the upper bound of what a cheaper tail tile can return
 #else
-    const bool active = qt < n_kt;                        // query tiles = key tiles = ceil(T / 32)
+    const bool active = __builtin_amdgcn_readfirstlane(qt < n_kt ? 1u : 0u) != 0u;     // query tiles = key tiles = ceil(T / 32); a SCALAR condition (hipcc kept it in a lane mask and rebuilt it with two VALU per key tile)
 #endif
     const uint32_t qrow = qt * 32 + li;
     const uint16_t *Qg = QKV + ((size_t)head * M_pad + row_base) * 64;
@@ -2401,10 +2426,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void k_attention_s(const 
     // K fragments of the tile about to be used: read one tile ahead, under the previous tile's softmax
     uint4 ka[4];
     auto read_k = [&]() {                                 // the tile in slot_k, then on to the next slot
-        if (active) {
+        // (every wave reads, a wave without a query tile too: the condition cost two VALU and a branch per key tile, the reads of one idle wave in eight cost nothing that is short)
 #pragma unroll
-            for (int s = 0; s < 4; s++) ka[s] = *(const uint4 *)(lds_cptr)(size_t)(smem0 + slot_k + koff[s]);
-        }
+        for (int s = 0; s < 4; s++) ka[s] = *(const uint4 *)(lds_cptr)(size_t)(smem0 + slot_k + koff[s]);
         advance(slot_k);
     };
     read_k();
@@ -2478,7 +2502,20 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void k_attention_s(const 
         // no faster and costs ten registers)
         if constexpr (!LAST) {
 #pragma unroll
-            for (int r = 0; r < 16; r++) sacc[r] = (D2R_ATTN_ABLATE & 128) ? __uint_as_float(ka[r & 3].x) : -m_run;     // the MFMAs subtract the running maximum
+            for (int r = 0; r < 16; r++) sacc[r] = (D2R_ATTN_ABLATE & 128) ? __uint_as_float(ka[r & 3].x) : 0.f;
+            if (!(D2R_ATTN_ABLATE & 128)) {
+                // the accumulator starts at -m_run (the MFMAs subtract the running maximum): eight 64-bit moves (hipcc emits sixteen v_mov_b32
+                // for the plain assignment; volatile: identical statements must not be merged)
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                f32x2 nm = {-m_run, -m_run}, pr[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) asm volatile("v_mov_b64 %0, %1" : "=v"(pr[q]) : "v"(nm));
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    sacc[2 * q] = pr[q].x;
+                    sacc[2 * q + 1] = pr[q].y;
+                }
+            }
 #pragma unroll
             for (int s = 0; s < ((D2R_ATTN_ABLATE & 128) ? 0 : 4); s++) s_mfma(sacc, s);
         }

@@ -7,7 +7,8 @@ from dream2real_amd.clip_model import CLIP_CONFIGS, random_clip_state_dict
 ctx = engine.Context(0)
 cfg = dict(CLIP_CONFIGS[os.environ.get("ATTN_PROBE_MODEL", "vit_b16")], num_layers=int(os.environ.get("ATTN_PROBE_LAYERS", "2")))
 sc = engine.ClipScorer(ctx, cfg, random_clip_state_dict(cfg, seed=6, text=False))
-pv = np.random.default_rng(0).standard_normal((2048, 3, 224, 224), dtype=np.float32)
+n_img = int(os.environ.get("ATTN_PROBE_IMAGES", "2048"))
+pv = np.random.default_rng(0).standard_normal((n_img, 3, cfg["image_size"], cfg["image_size"]), dtype=np.float32)
 ctx.set_option("chunk", 4096)
 sc.embed_pixels(pv)
 sc.embed_pixels(pv)
