@@ -1,7 +1,7 @@
 // Where do the waves of an eight-wave workgroup land?  (round 6: k_attention_s<8> runs 7 query tiles on 8 waves at 197 tokens; if wave i of
-// every workgroup goes to SIMD i mod 4, the idle wave and the 5-query tail wave of all four co-resident workgroups share two SIMDs and the
-// other two carry a third more work.)  Launches k_attention_s's geometry (grid (12, n, 1), 512 threads, 40 KiB dynamic LDS, four workgroups
-// per CU) with a kernel that spins for a while and records HW_ID / XCC_ID of every wave and its start time.
+// every workgroup goes to SIMD i mod 4, the idle wave and the 5-query tail wave of the co-resident workgroups (two per CU for the real kernel's 120 VGPRs) share two SIMDs and the
+// other two carry a third more work.)  Launches k_attention_s's geometry (grid (12, n, 1), 512 threads, 40 KiB dynamic LDS; this probe has few registers, so four workgroups
+// fit a CU) with a kernel that spins for a while and records HW_ID / XCC_ID of every wave and its start time.
 //   hipcc --offload-arch=gfx950 -O2 tools/probes/wave_placement_probe.hip -o /tmp/wpp && /tmp/wpp
 #include <hip/hip_runtime.h>
 #include <cstdio>
