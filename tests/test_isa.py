@@ -114,3 +114,30 @@ def test_fp8_k_loop_owns_its_fragment_registers(clip_isa):
             assert not any(re.search(r"\b%s\b" % r, t) for r in scale_regs), f"{name}: compiler instruction on a scale register: {t}"
         seen += 1
     assert seen == 3
+
+
+def test_attention_q_registers_are_not_touched_before_their_wait(clip_isa):
+    """k_attention_s loads its Q fragments from inline asm (so that hipcc does not drain the request ring for them inside the
+    key-tile loop) and waits for them by hand.  hipcc believes the registers are ready the moment the asm statement ends: any
+    instruction it places between the loads and the first vmcnt wait that touches them reads stale data (round 6 saw exactly
+    that — v_mov_b64 copies hoisted above the wait — when a branch sat between the two)."""
+    seen = 0
+    for name, lines in kernels(clip_isa, "k_attention_s"):
+        L = [l.strip() for l in lines]
+        q = [i for i, l in enumerate(L) if l.startswith("global_load_dwordx4") and "lds" not in l][:4]
+        assert len(q) == 4, name
+        regs = set()
+        for i in q:
+            m = re.search(r"global_load_dwordx4 v\[(\d+):(\d+)\]", L[i])
+            regs.update(range(int(m.group(1)), int(m.group(2)) + 1))
+        assert len(regs) == 16, name
+        wait = next(i for i in range(q[-1] + 1, len(L)) if L[i].startswith("s_waitcnt") and "vmcnt" in L[i])
+        for i in range(q[-1] + 1, wait):
+            l = L[i]
+            if not l or l.startswith((";", ".")):
+                continue
+            touched = any(int(a) <= r <= int(b) for a, b in re.findall(r"v\[(\d+):(\d+)\]", l) for r in regs) or \
+                any(int(a) in regs for a in re.findall(r"\bv(\d+)\b", l))
+            assert not touched, f"{name}: `{l}` touches a Q register before the first vmcnt wait"
+        seen += 1
+    assert seen >= 4
